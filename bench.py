@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""bench.py -- registrations/sec of the MI355X-native TEASER++ solve() hot path.
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on): synthetic
+N = 10 000 correspondences, 95 % outliers, noise_bound 0.01, estimate_scaling = false, GNC-TLS
+(SURVEY.md 8(d)).  One STEP = one batched pass of the whole hot path (TIM build + pruning ->
+adjacency bitmap -> max clique -> GNC-TLS rotation -> TLS translation) over `--batch` independent
+problems whose point arrays are already resident in HBM; every step sees different problems
+(a pool of seeded problems is cycled).  Multi-GPU: problems are independent, so each rank owns
+its own problems (weak scaling, no data-path collective); the fixed-size result records are
+all-gathered over RCCL at the end, inside the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline     -- K1 (tim_graph_kernel), from HIP events recorded on the solver's stream during
+                  the timed region: algorithmic bytes 48 n + 8 n ceil(n/64) per problem.
+  cpu_baseline -- the CPU oracle (a port of the reference path; the reference itself cannot be
+                  built here: no Eigen3 / pmc) timed on a bounded sample of the same workload.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+FP64_VEC_PEAK_TF = 78.6    # FP64 vector peak, FMA = 2 flops
+K1_FLOPS_PER_PAIR = 20.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="independent problems per step and per GPU")
+    ap.add_argument("--n", type=int, default=10000)
+    ap.add_argument("--outlier-ratio", type=float, default=0.95)
+    ap.add_argument("--noise-bound", type=float, default=0.01)
+    ap.add_argument("--pool", type=int, default=4, help="distinct batches cycled through the steps")
+    ap.add_argument("--seed", type=int, default=20250523)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-solves", type=int, default=16)
+    return ap.parse_args()
+
+
+def solver_params(tp, nb):
+    return tp.RobustRegistrationSolver.Params(
+        noise_bound=nb, cbar2=1.0, estimate_scaling=False, rotation_gnc_factor=1.4,
+        rotation_max_iterations=100, rotation_cost_threshold=0.005)
+
+
+def cpu_baseline(tp, args):
+    """Oracle (kind = port) on a bounded sample of the same workload, all host cores."""
+    from oracle import oracle
+
+    cores = os.cpu_count() or 1
+    times = []
+    t_all = time.perf_counter()
+    for i in range(args.cpu_solves):
+        pr = tp.synth_problem(args.seed + 100000 + i, args.n, args.outlier_ratio, args.noise_bound)
+        t0 = time.perf_counter()
+        o = oracle.solve(pr["src"], pr["dst"], noise_bound=args.noise_bound, cbar2=1.0,
+                         estimate_scaling=0, rotation_gnc_factor=1.4, rotation_max_iterations=100,
+                         rotation_cost_threshold=0.005, max_clique_num_threads=cores)
+        times.append(time.perf_counter() - t0)
+        assert o["valid"]
+        if time.perf_counter() - t_all > 25.0:
+            break
+    med = float(np.median(times))
+    return {"value": 1.0 / med, "unit": "registrations/s", "cores": cores, "kind": "port",
+            "sample": "%d solves of the bench workload (N=%d, %.0f%% outliers), median %.1f ms each, "
+                      "oracle built gcc -O2 -fopenmp without -march=native, OMP threads = %d"
+                      % (len(times), args.n, 100 * args.outlier_ratio, 1e3 * med, cores)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no HIP device visible); the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if dist is not None:
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    tp = importlib.import_module("teaser-plusplus_amd")
+    B, n = args.batch, args.n
+    solver = tp.RobustRegistrationSolver(solver_params(tp, args.noise_bound), device=local_rank)
+
+    # problem pool, resident in HBM before the timed region (packed [B*n, 3] doubles per batch)
+    pool = []
+    truth = []
+    for k in range(args.pool):
+        src = np.empty((B * n, 3))
+        dst = np.empty((B * n, 3))
+        tr = []
+        for b in range(B):
+            seed = args.seed + ((rank * args.pool + k) * B + b)
+            pr = tp.synth_problem(seed, n, args.outlier_ratio, args.noise_bound)
+            src[b * n:(b + 1) * n] = pr["src"].T
+            dst[b * n:(b + 1) * n] = pr["dst"].T
+            tr.append((pr["R"], pr["t"], int(pr["inliers"].sum())))
+        pool.append((torch.from_numpy(src).to(dev), torch.from_numpy(dst).to(dev)))
+        truth.append(tr)
+    offsets = np.arange(B, dtype=np.int64) * n
+    sizes = np.full(B, n, dtype=np.int32)
+    records = torch.zeros((B, 16), dtype=torch.float64, device=dev)
+
+    def step(k):
+        s_t, d_t = pool[k % args.pool]
+        out = solver.solve_batch_device(s_t.data_ptr(), d_t.data_ptr(), offsets, sizes)
+        return out
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    # correctness guard on the last warm-up batch: the work is not skipped and is right
+    out = step(args.warmup)
+    for b in range(B):
+        R, t, n_in = truth[args.warmup % args.pool][b]
+        o = out[b]
+        assert o.valid == 1 and o.clique_size == n_in, (o.valid, o.clique_size, n_in)
+        assert np.linalg.norm(np.array(o.rotation[:]).reshape(3, 3) - R) < 0.05
+        assert np.linalg.norm(np.array(o.translation[:]) - t) < 0.05
+
+    solver.set_profiling(True)  # HIP events around K1 on the solver's stream, inside the timed region
+    k1_ms, k1_launches, k1_bytes, k1_pairs = 0.0, 0, 0, 0
+    sync_all()
+    t0 = time.perf_counter()
+    last = None
+    for k in range(args.steps):
+        last = step(k)
+        pf = solver.get_profile()
+        k1_ms += pf["tim_graph_ms"]
+        k1_launches += pf["tim_graph_launches"]
+        k1_bytes += pf["tim_graph_bytes"]
+        k1_pairs += pf["tim_graph_pairs"]
+    # final gather of the fixed-size result records (RCCL over xGMI when N > 1)
+    rec = np.zeros((B, 16))
+    for b in range(B):
+        o = last[b]
+        rec[b, 0] = o.valid
+        rec[b, 1] = o.scale
+        rec[b, 2:11] = o.rotation[:]
+        rec[b, 11:14] = o.translation[:]
+        rec[b, 14] = o.clique_size
+        rec[b, 15] = o.n_translation_inliers
+    records.copy_(torch.from_numpy(rec))
+    if dist is not None:
+        gathered = [torch.empty_like(records) for _ in range(world)]
+        dist.all_gather(gathered, records)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+    elapsed = float(t_max.item())
+    solver.set_profiling(False)
+
+    # single-problem latency (not the headline value; reported for the ms/solve half of the metric)
+    lat = []
+    s_t, d_t = pool[0]
+    one_off, one_n = np.zeros(1, dtype=np.int64), np.array([n], dtype=np.int32)
+    for _ in range(10):
+        torch.cuda.synchronize()
+        a = time.perf_counter()
+        solver.solve_batch_device(s_t.data_ptr(), d_t.data_ptr(), one_off, one_n)
+        lat.append(time.perf_counter() - a)
+    lat_ms = 1e3 * float(np.median(lat))
+
+    if rank == 0:
+        total_regs = world * B * args.steps
+        value = total_regs / elapsed
+        k1_avg_s = (k1_ms / max(k1_launches, 1)) * 1e-3
+        bytes_per_launch = k1_bytes / max(k1_launches, 1)
+        flops_per_launch = K1_FLOPS_PER_PAIR * k1_pairs / max(k1_launches, 1)
+        hbm_gbs = bytes_per_launch / k1_avg_s / 1e9 if k1_avg_s > 0 else 0.0
+        fp64_tf = flops_per_launch / k1_avg_s / 1e12 if k1_avg_s > 0 else 0.0
+        line = {
+            "metric": "registrations/sec at N=%d correspondences, %.0f%% outliers" % (n, 100 * args.outlier_ratio),
+            "value": value, "unit": "registrations/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "synthetic N=%d correspondences, %.0f%% outliers, single-MI355X config "
+                                   "(BASELINE configs[1]); noise_bound=%g, estimate_scaling=false, GNC-TLS, "
+                                   "PMC_EXACT, CHAIN" % (n, 100 * args.outlier_ratio, args.noise_bound),
+                       "problems_per_step_per_gpu": B, "ms_per_registration": 1e3 * elapsed / (args.steps * B),
+                       "single_problem_latency_ms": lat_ms, "inputs": "resident in HBM",
+                       "parallelism": "independent problems per GPU, RCCL all_gather of result records"},
+            "roofline": {"kernel": "tim_graph_kernel<0> (K1: TIM norms + prune + adjacency bitmap)",
+                         "bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": 1e3 * k1_avg_s, "launches": k1_launches,
+                         "algorithmic_bytes_per_launch": bytes_per_launch,
+                         "fp64_valu": {"achieved": fp64_tf, "peak": FP64_VEC_PEAK_TF, "unit": "TFLOP/s",
+                                       "frac": fp64_tf / FP64_VEC_PEAK_TF,
+                                       "note": "K1 is FP64-VALU bound (SURVEY.md F6): 20 flops/pair "
+                                               "algorithmic, n(n-1)/2 pairs"}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(tp, args)
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

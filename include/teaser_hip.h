@@ -1,0 +1,221 @@
+/*
+ * teaser_hip.h -- C ABI of the MI355X-native TEASER++ registration hot path.
+ *
+ * This is the drop-in boundary for teaser::RobustRegistrationSolver::solve() and nothing else
+ * (TIM build + scale pruning -> inlier graph -> maximum clique -> GNC-TLS rotation -> TLS
+ * translation).  Plain pointers and sizes only; no C++/torch/Eigen types.  The reference has no
+ * FFI layer of its own: its boundary is the C++ class in teaser/include/teaser/registration.h,
+ * which pybind11 (python/teaserpp_python/teaserpp_python.cc:82-177) and MEX
+ * (matlab/teaser_mex.cc:207-218) wrap.  Each entry point below cites the reference interface it
+ * replaces (paths relative to the reference checkout).  INTEGRATION.md shows the bindings.
+ *
+ * Layout conventions
+ *   - point clouds: `3 x N` column-major doubles, i.e. x0 y0 z0 x1 y1 z1 ... -- exactly
+ *     Eigen::Matrix<double,3,Eigen::Dynamic>::data() (registration.h:576-577), zero-copy.
+ *   - rotation: 9 doubles, ROW-major (R(r,c) = rotation[3*r+c]).
+ *   - index lists: int32, ascending, in the reference's meaning (see each getter).
+ *   - adjacency bitmap: n rows of W = (n+63)/64 uint64 words, bit j of row i = edge (i,j).
+ *
+ * Threading: one handle = one device + one HIP stream; a handle is NOT re-entrant, distinct
+ * handles are independent (same contract as one RobustRegistrationSolver object).  Unlike the
+ * reference object (registration.cc:702-704 mutates the rotation solver), a handle is reusable.
+ *
+ * Errors: every call returns a teaser_hip_status; solve never throws.  A valid==0 solution with
+ * status OK is the reference's soft failure (clique size <= 1, registration.cc:643-647).
+ */
+#ifndef TEASER_HIP_H_
+#define TEASER_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TEASER_HIP_ABI_VERSION 1
+
+#if defined(__GNUC__)
+#define TEASER_HIP_API __attribute__((visibility("default")))
+#else
+#define TEASER_HIP_API
+#endif
+
+typedef enum teaser_hip_status {
+  TEASER_HIP_OK = 0,
+  TEASER_HIP_ERR_BAD_ARG = 1,
+  TEASER_HIP_ERR_HIP = 2,          /* a HIP runtime call failed: teaser_hip_last_error() */
+  TEASER_HIP_ERR_NO_DEVICE = 3,    /* no gfx950 device visible: the product never falls back to CPU */
+  TEASER_HIP_ERR_UNSUPPORTED = 4,  /* parameter combination outside the hot path (FGR/QUATRO) */
+  TEASER_HIP_ERR_TIME_LIMIT = 5,   /* max_clique_time_limit hit; incumbent returned (graph.cc:44) */
+  TEASER_HIP_ERR_SCRATCH = 6,      /* exact clique search ran out of device scratch */
+  TEASER_HIP_ERR_OOM = 7
+} teaser_hip_status;
+
+/* enums: registration.h:382-412 (same numeric values) */
+enum { TEASER_ROT_GNC_TLS = 0, TEASER_ROT_FGR = 1, TEASER_ROT_QUATRO = 2 };
+enum { TEASER_INLIER_PMC_EXACT = 0, TEASER_INLIER_PMC_HEU = 1, TEASER_INLIER_KCORE_HEU = 2,
+       TEASER_INLIER_NONE = 3 };
+enum { TEASER_TIM_CHAIN = 0, TEASER_TIM_COMPLETE = 1 };
+
+/* POD mirror of teaser::RobustRegistrationSolver::Params (registration.h:419-514): same fields,
+ * same order, same defaults (teaser_hip_params_default). */
+typedef struct teaser_params_c {
+  double noise_bound;                    /* 0.01 */
+  double cbar2;                          /* 1 */
+  int32_t estimate_scaling;              /* 1 */
+  int32_t rotation_estimation_algorithm; /* TEASER_ROT_GNC_TLS */
+  double rotation_gnc_factor;            /* 1.4 */
+  int64_t rotation_max_iterations;       /* 100 */
+  double rotation_cost_threshold;        /* 1e-6 */
+  int32_t rotation_tim_graph;            /* TEASER_TIM_CHAIN */
+  int32_t inlier_selection_mode;         /* TEASER_INLIER_PMC_EXACT */
+  double kcore_heuristic_threshold;      /* 0.5 */
+  int32_t use_max_clique;                /* deprecated, 1 */
+  int32_t max_clique_exact_solution;     /* deprecated, 1 */
+  double max_clique_time_limit;          /* 3600 s */
+  int32_t max_clique_num_threads;        /* accepted, ignored on the GPU */
+} teaser_params_c;
+
+/* teaser::RegistrationSolution (registration.h:32-39) + the scalars behind the getters. */
+typedef struct teaser_solution_c {
+  int32_t valid;                 /* RegistrationSolution::valid */
+  int32_t status;                /* teaser_hip_status of this problem */
+  double scale;
+  double rotation[9];            /* row-major */
+  double translation[3];
+  int32_t n;                     /* correspondences of this problem */
+  int32_t clique_size;           /* getInlierMaxClique().size() */
+  int32_t n_rotation_inliers;    /* getRotationInliers().size() */
+  int32_t n_translation_inliers; /* getTranslationInliers().size() */
+  double gnc_cost;               /* getGNCRotationCostAtTermination(), registration.h:609-611 */
+  int32_t gnc_iterations;
+  int32_t clique_exact_run;      /* 1 iff the device B&B had to run (bounds did not close) */
+  int32_t heuristic_size;        /* lower bound found by the greedy stage */
+  int32_t reserved0;
+  int64_t num_edges;             /* edges of the inlier graph */
+} teaser_solution_c;
+
+/* Per-stage device time of the last solve call (HIP events on the handle's stream), enabled by
+ * teaser_hip_set_profiling(h, 1).  Milliseconds, summed over the launches of that stage. */
+typedef struct teaser_profile_c {
+  float h2d_ms;
+  float tim_graph_ms;    /* K1: TIM norms + prune + adjacency bitmap */
+  int32_t tim_graph_launches;
+  float degree_ms;
+  float heuristic_ms;
+  float peel_ms;
+  float exact_ms;
+  float rotation_ms;
+  float translation_ms;
+  float d2h_ms;
+  float total_ms;
+  int64_t tim_graph_pairs; /* unordered pairs evaluated by K1 in the last call */
+  int64_t tim_graph_bytes; /* algorithmic bytes of K1: 48 n + 8 n ceil(n/64), summed over problems */
+} teaser_profile_c;
+
+typedef struct teaser_hip_solver teaser_hip_solver;
+
+/* Fills the defaults of registration.h:419-514. */
+TEASER_HIP_API int32_t teaser_hip_params_default(teaser_params_c* params);
+
+/* RobustRegistrationSolver(const Params&) (registration.h:548, registration.cc:507-510).
+ * device < 0: current device.  Fails with TEASER_HIP_ERR_NO_DEVICE when no GPU is visible. */
+TEASER_HIP_API int32_t teaser_hip_solver_create(const teaser_params_c* params, int32_t device,
+                                 teaser_hip_solver** out);
+TEASER_HIP_API int32_t teaser_hip_solver_destroy(teaser_hip_solver* h);
+
+/* reset(const Params&) (registration.h:891) / getParams() (registration.h:914). */
+TEASER_HIP_API int32_t teaser_hip_solver_reset(teaser_hip_solver* h, const teaser_params_c* params);
+TEASER_HIP_API int32_t teaser_hip_solver_get_params(const teaser_hip_solver* h, teaser_params_c* params);
+
+/* RegistrationSolution solve(const Matrix<double,3,Dyn>& src, const Matrix<double,3,Dyn>& dst)
+ * (registration.h:576-577, registration.cc:568-737).  src/dst are HOST pointers, 3 x n
+ * column-major; borrowed for the duration of the call.  n < 2 gives valid = 0. */
+TEASER_HIP_API int32_t teaser_hip_solve(teaser_hip_solver* h, const double* src, const double* dst, int32_t n,
+                         teaser_solution_c* out);
+
+/* Same contract with DEVICE pointers (inputs already resident in HBM, on h's device). */
+TEASER_HIP_API int32_t teaser_hip_solve_device(teaser_hip_solver* h, const double* d_src, const double* d_dst,
+                                int32_t n, teaser_solution_c* out);
+
+/* solve(const PointCloud&, const PointCloud&, std::vector<std::pair<int,int>>)
+ * (registration.h:567-569, registration.cc:553-566): float xyz clouds (geometry.h:15-23) and
+ * index pairs; gathers with float -> double widening, then solves. */
+TEASER_HIP_API int32_t teaser_hip_solve_correspondences(teaser_hip_solver* h, const float* src_cloud_xyz,
+                                         int32_t n_src, const float* dst_cloud_xyz, int32_t n_dst,
+                                         const int32_t* corr_pairs /* 2*C: src_idx,dst_idx */,
+                                         int32_t n_corr, teaser_solution_c* out);
+
+/* Batched mode (no reference equivalent; the reference solves one problem per object):
+ * `batch` independent problems, problem b has n[b] correspondences.  Host pointers per problem. */
+TEASER_HIP_API int32_t teaser_hip_solve_batch(teaser_hip_solver* h, const double* const* src,
+                               const double* const* dst, const int32_t* n, int32_t batch,
+                               teaser_solution_c* out /* [batch] */);
+
+/* Batched, inputs packed and device-resident: problem b occupies points
+ * [offset[b], offset[b]+n[b]) of d_src/d_dst (3 doubles per point); offsets are HOST arrays. */
+TEASER_HIP_API int32_t teaser_hip_solve_batch_device(teaser_hip_solver* h, const double* d_src,
+                                      const double* d_dst, const int64_t* point_offset,
+                                      const int32_t* n, int32_t batch, teaser_solution_c* out);
+
+/* Getters on the last solve call; `problem` indexes the batch (0 for single solves).  Each copies
+ * into buf when buf != NULL and *len (capacity in elements on entry) suffices, and always writes
+ * the required length to *len.
+ *   max_clique           getInlierMaxClique()        (registration.h:770)  sorted input indices
+ *   rotation_inliers     getRotationInliers()        (registration.h:713)  indices of rotation TIMs
+ *   translation_inliers  getTranslationInliers()     (registration.h:744)  positions in the clique
+ *   input_ordered_translation_inliers  getInputOrderedTranslationInliers() (registration.h:752-763)
+ *   inlier_graph_bitmap  the adjacency behind getInlierGraph() (registration.h:772), as bitmap
+ *   degrees              vertex degrees of the inlier graph */
+TEASER_HIP_API int32_t teaser_hip_get_max_clique(teaser_hip_solver* h, int32_t problem, int32_t* buf, int64_t* len);
+TEASER_HIP_API int32_t teaser_hip_get_rotation_inliers(teaser_hip_solver* h, int32_t problem, int32_t* buf,
+                                        int64_t* len);
+TEASER_HIP_API int32_t teaser_hip_get_translation_inliers(teaser_hip_solver* h, int32_t problem, int32_t* buf,
+                                           int64_t* len);
+TEASER_HIP_API int32_t teaser_hip_get_input_ordered_translation_inliers(teaser_hip_solver* h, int32_t problem,
+                                                         int32_t* buf, int64_t* len);
+TEASER_HIP_API int32_t teaser_hip_get_inlier_graph_bitmap(teaser_hip_solver* h, int32_t problem, uint64_t* buf,
+                                           int64_t* len /* words */);
+TEASER_HIP_API int32_t teaser_hip_get_degrees(teaser_hip_solver* h, int32_t problem, int32_t* buf, int64_t* len);
+
+/* Stage entry points (registration.h:584-601), host pointers, 3 x K column-major TIMs/points:
+ *   solveForRotation   -> GNCTLSRotationSolver::solveForRotation (registration.cc:764-866);
+ *                         noise_bound is the value the rotation solver holds.
+ *   solveForTranslation-> TLSTranslationSolver::solveForTranslation (registration.cc:445-471)
+ *   scalar TLS         -> ScalarTLSEstimator::estimate (registration.cc:21-88)
+ * inlier masks are one byte per element (0/1); may be NULL. */
+TEASER_HIP_API int32_t teaser_hip_solve_for_rotation(teaser_hip_solver* h, const double* src, const double* dst,
+                                      int32_t k, double noise_bound, double* rotation_rowmajor,
+                                      uint8_t* inlier_mask, double* cost, int32_t* iterations);
+TEASER_HIP_API int32_t teaser_hip_solve_for_translation(teaser_hip_solver* h, const double* src,
+                                         const double* dst, int32_t k, double* translation,
+                                         uint8_t* inlier_mask);
+TEASER_HIP_API int32_t teaser_hip_scalar_tls(teaser_hip_solver* h, const double* x, const double* ranges,
+                              int32_t n, double* estimate, uint8_t* inlier_mask);
+
+/* MaxCliqueSolver::findMaxClique (graph.cc:12-125) on a caller-supplied adjacency bitmap
+ * (host pointer, n rows of (n+63)/64 words).  clique: capacity n; sorted on return. */
+TEASER_HIP_API int32_t teaser_hip_max_clique(teaser_hip_solver* h, const uint64_t* bitmap, int32_t n,
+                              int32_t* clique, int32_t* clique_size, int32_t* exact_run);
+
+/* Profiling / diagnostics. */
+TEASER_HIP_API int32_t teaser_hip_set_profiling(teaser_hip_solver* h, int32_t enable);
+TEASER_HIP_API int32_t teaser_hip_get_profile(const teaser_hip_solver* h, teaser_profile_c* out);
+/* The HIP stream (hipStream_t) all kernels of this handle are launched on. */
+TEASER_HIP_API void* teaser_hip_get_stream(teaser_hip_solver* h);
+TEASER_HIP_API const char* teaser_hip_last_error(const teaser_hip_solver* h);
+TEASER_HIP_API int32_t teaser_hip_abi_version(void);
+TEASER_HIP_API int32_t teaser_hip_device_count(void);
+
+/* Deterministic synthetic problem generator (the reference has none that is
+ * seeded -- registration-test.cc:398-431 and teaser_cpp_ply.cc:21-40 use random_device).
+ * Host-only (no GPU needed).  src/dst: 3 x n column-major; R row-major 9; t 3; inlier_mask n
+ * bytes (1 = inlier); any output pointer except src/dst may be NULL. */
+TEASER_HIP_API int32_t teaser_hip_synth_problem(uint64_t seed, int32_t n, double outlier_ratio,
+                                 double noise_bound, double* src, double* dst, double* R,
+                                 double* t, uint8_t* inlier_mask);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TEASER_HIP_H_ */

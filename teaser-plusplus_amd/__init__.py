@@ -1,0 +1,525 @@
+"""MI355X-native TEASER++ registration hot path -- Python host side.
+
+A thin ctypes layer over the C ABI (include/teaser_hip.h, built into libteaser_hip.so by
+csrc/Makefile) that mirrors the reference's Python surface (reference
+python/teaserpp_python/teaserpp_python.cc:82-177): ``RobustRegistrationSolver``, its ``Params``,
+the enums, ``RegistrationSolution`` and the getters, with the same names and meanings.
+
+There is no CPU fallback: constructing a solver without a visible gfx950 device raises.
+Nothing here imports the oracle.
+
+The directory name contains a hyphen, so import it with
+``importlib.import_module("teaser-plusplus_amd")`` (see __graft_entry__.py).
+"""
+import ctypes as C
+import enum
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(_HERE, "libteaser_hip.so")
+
+STATUS_NAMES = {0: "OK", 1: "BAD_ARG", 2: "HIP", 3: "NO_DEVICE", 4: "UNSUPPORTED", 5: "TIME_LIMIT",
+                6: "SCRATCH", 7: "OOM"}
+
+
+class TeaserHipError(RuntimeError):
+    def __init__(self, status, msg=""):
+        self.status = status
+        super().__init__("teaser_hip status %d (%s) %s" % (status, STATUS_NAMES.get(status, "?"), msg))
+
+
+class RotationEstimationAlgorithm(enum.IntEnum):  # registration.h:389-393
+    GNC_TLS = 0
+    FGR = 1
+    QUATRO = 2
+
+
+class InlierSelectionMode(enum.IntEnum):  # registration.h:403-408
+    PMC_EXACT = 0
+    PMC_HEU = 1
+    KCORE_HEU = 2
+    NONE = 3
+
+
+class InlierGraphFormulation(enum.IntEnum):  # registration.h:416-419
+    CHAIN = 0
+    COMPLETE = 1
+
+
+class ParamsC(C.Structure):
+    """teaser_params_c (include/teaser_hip.h) == Params of registration.h:419-514."""
+    _fields_ = [
+        ("noise_bound", C.c_double),
+        ("cbar2", C.c_double),
+        ("estimate_scaling", C.c_int32),
+        ("rotation_estimation_algorithm", C.c_int32),
+        ("rotation_gnc_factor", C.c_double),
+        ("rotation_max_iterations", C.c_int64),
+        ("rotation_cost_threshold", C.c_double),
+        ("rotation_tim_graph", C.c_int32),
+        ("inlier_selection_mode", C.c_int32),
+        ("kcore_heuristic_threshold", C.c_double),
+        ("use_max_clique", C.c_int32),
+        ("max_clique_exact_solution", C.c_int32),
+        ("max_clique_time_limit", C.c_double),
+        ("max_clique_num_threads", C.c_int32),
+    ]
+
+
+class SolutionC(C.Structure):
+    _fields_ = [
+        ("valid", C.c_int32),
+        ("status", C.c_int32),
+        ("scale", C.c_double),
+        ("rotation", C.c_double * 9),
+        ("translation", C.c_double * 3),
+        ("n", C.c_int32),
+        ("clique_size", C.c_int32),
+        ("n_rotation_inliers", C.c_int32),
+        ("n_translation_inliers", C.c_int32),
+        ("gnc_cost", C.c_double),
+        ("gnc_iterations", C.c_int32),
+        ("clique_exact_run", C.c_int32),
+        ("heuristic_size", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("num_edges", C.c_int64),
+    ]
+
+
+class ProfileC(C.Structure):
+    _fields_ = [
+        ("h2d_ms", C.c_float),
+        ("tim_graph_ms", C.c_float),
+        ("tim_graph_launches", C.c_int32),
+        ("degree_ms", C.c_float),
+        ("heuristic_ms", C.c_float),
+        ("peel_ms", C.c_float),
+        ("exact_ms", C.c_float),
+        ("rotation_ms", C.c_float),
+        ("translation_ms", C.c_float),
+        ("d2h_ms", C.c_float),
+        ("total_ms", C.c_float),
+        ("tim_graph_pairs", C.c_int64),
+        ("tim_graph_bytes", C.c_int64),
+    ]
+
+
+EXPORTED_SYMBOLS = [
+    "teaser_hip_params_default", "teaser_hip_solver_create", "teaser_hip_solver_destroy",
+    "teaser_hip_solver_reset", "teaser_hip_solver_get_params", "teaser_hip_solve",
+    "teaser_hip_solve_device", "teaser_hip_solve_correspondences", "teaser_hip_solve_batch",
+    "teaser_hip_solve_batch_device", "teaser_hip_get_max_clique", "teaser_hip_get_rotation_inliers",
+    "teaser_hip_get_translation_inliers", "teaser_hip_get_input_ordered_translation_inliers",
+    "teaser_hip_get_inlier_graph_bitmap", "teaser_hip_get_degrees", "teaser_hip_solve_for_rotation",
+    "teaser_hip_solve_for_translation", "teaser_hip_scalar_tls", "teaser_hip_max_clique",
+    "teaser_hip_set_profiling", "teaser_hip_get_profile", "teaser_hip_get_stream",
+    "teaser_hip_last_error", "teaser_hip_abi_version", "teaser_hip_device_count",
+    "teaser_hip_synth_problem",
+]
+
+
+def build(force=False):
+    """Compile the HIP library for gfx950 (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-C", _CSRC, "-j8"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+_vp, _ip, _dp = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_double)
+_u8p, _i64p, _u64p = C.POINTER(C.c_uint8), C.POINTER(C.c_int64), C.POINTER(C.c_uint64)
+
+
+def lib():
+    """Load libteaser_hip.so; fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s is missing: run __graft_entry__.build() (make -C %s)" % (LIB_PATH, _CSRC))
+    L = C.CDLL(LIB_PATH)
+    L.teaser_hip_params_default.argtypes = [C.POINTER(ParamsC)]
+    L.teaser_hip_solver_create.argtypes = [C.POINTER(ParamsC), C.c_int32, C.POINTER(_vp)]
+    L.teaser_hip_solver_destroy.argtypes = [_vp]
+    L.teaser_hip_solver_reset.argtypes = [_vp, C.POINTER(ParamsC)]
+    L.teaser_hip_solver_get_params.argtypes = [_vp, C.POINTER(ParamsC)]
+    L.teaser_hip_solve.argtypes = [_vp, _dp, _dp, C.c_int32, C.POINTER(SolutionC)]
+    L.teaser_hip_solve_device.argtypes = [_vp, _vp, _vp, C.c_int32, C.POINTER(SolutionC)]
+    L.teaser_hip_solve_correspondences.argtypes = [_vp, C.POINTER(C.c_float), C.c_int32,
+                                                   C.POINTER(C.c_float), C.c_int32, _ip, C.c_int32,
+                                                   C.POINTER(SolutionC)]
+    L.teaser_hip_solve_batch.argtypes = [_vp, C.POINTER(_dp), C.POINTER(_dp), _ip, C.c_int32,
+                                         C.POINTER(SolutionC)]
+    L.teaser_hip_solve_batch_device.argtypes = [_vp, _vp, _vp, _i64p, _ip, C.c_int32,
+                                                C.POINTER(SolutionC)]
+    for nm in ("teaser_hip_get_max_clique", "teaser_hip_get_rotation_inliers",
+               "teaser_hip_get_translation_inliers",
+               "teaser_hip_get_input_ordered_translation_inliers", "teaser_hip_get_degrees"):
+        getattr(L, nm).argtypes = [_vp, C.c_int32, _ip, _i64p]
+    L.teaser_hip_get_inlier_graph_bitmap.argtypes = [_vp, C.c_int32, _u64p, _i64p]
+    L.teaser_hip_solve_for_rotation.argtypes = [_vp, _dp, _dp, C.c_int32, C.c_double, _dp, _u8p, _dp, _ip]
+    L.teaser_hip_solve_for_translation.argtypes = [_vp, _dp, _dp, C.c_int32, _dp, _u8p]
+    L.teaser_hip_scalar_tls.argtypes = [_vp, _dp, _dp, C.c_int32, _dp, _u8p]
+    L.teaser_hip_max_clique.argtypes = [_vp, _u64p, C.c_int32, _ip, _ip, _ip]
+    L.teaser_hip_set_profiling.argtypes = [_vp, C.c_int32]
+    L.teaser_hip_get_profile.argtypes = [_vp, C.POINTER(ProfileC)]
+    L.teaser_hip_get_stream.argtypes = [_vp]
+    L.teaser_hip_get_stream.restype = _vp
+    L.teaser_hip_last_error.argtypes = [_vp]
+    L.teaser_hip_last_error.restype = C.c_char_p
+    L.teaser_hip_synth_problem.argtypes = [C.c_uint64, C.c_int32, C.c_double, C.c_double, _dp, _dp,
+                                           _dp, _dp, _u8p]
+    _lib = L
+    return L
+
+
+def device_count():
+    return int(lib().teaser_hip_device_count())
+
+
+def _colmajor(points, what="points"):
+    """3xN matrix (the reference's Eigen::Matrix<double,3,Dynamic>) -> contiguous N x 3 float64,
+    whose memory is that matrix in column-major order (what the C ABI takes, zero-copy)."""
+    a = np.asarray(points, dtype=np.float64)
+    if a.ndim != 2 or a.shape[0] != 3:
+        raise ValueError("%s must be a 3xN matrix" % what)
+    return np.ascontiguousarray(a.T)
+
+
+def _ptr(a, ty=_dp):
+    return a.ctypes.data_as(ty)
+
+
+def synth_problem(seed, n, outlier_ratio, noise_bound=0.01):
+    """Deterministic synthetic problem; returns dict(src 3xN, dst 3xN, R, t, inliers)."""
+    src = np.empty((max(n, 0), 3))
+    dst = np.empty((max(n, 0), 3))
+    R = np.empty(9)
+    t = np.empty(3)
+    mask = np.zeros(max(n, 1), dtype=np.uint8)
+    rc = lib().teaser_hip_synth_problem(int(seed), int(n), float(outlier_ratio), float(noise_bound),
+                                        _ptr(src), _ptr(dst), _ptr(R), _ptr(t), _ptr(mask, _u8p))
+    if rc != 0:
+        raise TeaserHipError(rc)
+    return dict(src=src.T, dst=dst.T, R=R.reshape(3, 3), t=t, inliers=mask[:n].astype(bool))
+
+
+class RegistrationSolution:
+    """teaser::RegistrationSolution (registration.h:32-39)."""
+
+    def __init__(self, c):
+        self.valid = bool(c.valid)
+        self.scale = float(c.scale)
+        self.rotation = np.array(c.rotation[:], dtype=np.float64).reshape(3, 3)
+        self.translation = np.array(c.translation[:], dtype=np.float64)
+        self.status = int(c.status)
+
+    def __repr__(self):
+        return "<RegistrationSolution with scale=%r\ntranslation=\n%r\nrotation=\n%r\n>" % (
+            self.scale, self.translation, self.rotation)
+
+
+class RobustRegistrationSolver:
+    """Mirror of teaser::RobustRegistrationSolver (registration.h:361-957) on one MI355X.
+
+    ``solve(src, dst)`` takes two 3xN float64 matrices like the reference binding
+    (teaserpp_python.cc:104-106); every getter keeps the reference's name and meaning.
+    """
+
+    ROTATION_ESTIMATION_ALGORITHM = RotationEstimationAlgorithm
+    INLIER_SELECTION_MODE = InlierSelectionMode
+    INLIER_GRAPH_FORMULATION = InlierGraphFormulation
+
+    class Params:
+        """registration.h:419-514 -- same field names and defaults."""
+
+        def __init__(self, **kw):
+            c = ParamsC()
+            lib().teaser_hip_params_default(C.byref(c))
+            for name, _ in ParamsC._fields_:
+                setattr(self, name, getattr(c, name))
+            self.estimate_scaling = bool(self.estimate_scaling)
+            self.use_max_clique = bool(self.use_max_clique)
+            self.max_clique_exact_solution = bool(self.max_clique_exact_solution)
+            self.rotation_estimation_algorithm = RotationEstimationAlgorithm(self.rotation_estimation_algorithm)
+            self.rotation_tim_graph = InlierGraphFormulation(self.rotation_tim_graph)
+            self.inlier_selection_mode = InlierSelectionMode(self.inlier_selection_mode)
+            for k, v in kw.items():
+                if not hasattr(self, k):
+                    raise AttributeError(k)
+                setattr(self, k, v)
+
+        def to_c(self):
+            c = ParamsC()
+            for name, _ in ParamsC._fields_:
+                setattr(c, name, type(getattr(c, name))(getattr(self, name)))
+            return c
+
+    def __init__(self, params=None, device=-1, **kw):
+        if params is None:
+            params = RobustRegistrationSolver.Params(**kw)
+        self._params = params
+        self._h = _vp()
+        self._lib = lib()
+        c = params.to_c()
+        rc = self._lib.teaser_hip_solver_create(C.byref(c), int(device), C.byref(self._h))
+        if rc != 0:
+            self._h = _vp()
+            raise TeaserHipError(rc, "(no MI355X visible: the product has no CPU path)" if rc == 3 else "")
+        self._sol = None
+        self._sols = []
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.teaser_hip_solver_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc not in (0, 5):  # TIME_LIMIT still returns the incumbent (graph.cc:44)
+            raise TeaserHipError(rc, self._lib.teaser_hip_last_error(self._h).decode())
+
+    # --- reference API -------------------------------------------------------------------
+    def reset(self, params):  # registration.h:891
+        self._params = params
+        c = params.to_c()
+        self._check(self._lib.teaser_hip_solver_reset(self._h, C.byref(c)))
+        self._sol = None
+        self._sols = []
+
+    def getParams(self):  # registration.h:914
+        return self._params
+
+    def solve(self, src, dst):  # registration.h:576-577
+        s, d = _colmajor(src, "src"), _colmajor(dst, "dst")
+        if s.shape != d.shape:
+            raise ValueError("src and dst must have the same shape")
+        out = SolutionC()
+        self._check(self._lib.teaser_hip_solve(self._h, _ptr(s), _ptr(d), s.shape[0], C.byref(out)))
+        self._sols = [out]
+        self._sol = RegistrationSolution(out)
+        return self._sol
+
+    def solve_correspondences(self, src_cloud, dst_cloud, correspondences):  # registration.h:567-569
+        sc = np.ascontiguousarray(np.asarray(src_cloud, dtype=np.float32).reshape(-1, 3))
+        dc = np.ascontiguousarray(np.asarray(dst_cloud, dtype=np.float32).reshape(-1, 3))
+        cp = np.ascontiguousarray(np.asarray(correspondences, dtype=np.int32).reshape(-1, 2))
+        out = SolutionC()
+        fp = C.POINTER(C.c_float)
+        self._check(self._lib.teaser_hip_solve_correspondences(
+            self._h, _ptr(sc, fp), sc.shape[0], _ptr(dc, fp), dc.shape[0], _ptr(cp, _ip), cp.shape[0],
+            C.byref(out)))
+        self._sols = [out]
+        self._sol = RegistrationSolution(out)
+        return self._sol
+
+    def solve_batch(self, srcs, dsts):
+        """Batched mode: lists of 3xN_b matrices; returns a list of RegistrationSolution."""
+        ss = [_colmajor(s, "src") for s in srcs]
+        ds = [_colmajor(d, "dst") for d in dsts]
+        B = len(ss)
+        if B != len(ds):
+            raise ValueError("srcs and dsts differ in length")
+        sp = (_dp * B)(*[_ptr(a) for a in ss])
+        dp = (_dp * B)(*[_ptr(a) for a in ds])
+        n = np.array([a.shape[0] for a in ss], dtype=np.int32)
+        out = (SolutionC * B)()
+        self._check(self._lib.teaser_hip_solve_batch(self._h, sp, dp, _ptr(n, _ip), B, out))
+        self._sols = list(out)
+        self._sol = RegistrationSolution(out[0]) if B else None
+        return [RegistrationSolution(o) for o in out]
+
+    def solve_batch_device(self, d_src_ptr, d_dst_ptr, point_offsets, n):
+        """Batched, inputs packed and resident in HBM (raw device pointers, e.g. tensor.data_ptr())."""
+        off = np.ascontiguousarray(point_offsets, dtype=np.int64)
+        nn = np.ascontiguousarray(n, dtype=np.int32)
+        B = nn.size
+        out = (SolutionC * B)()
+        self._check(self._lib.teaser_hip_solve_batch_device(self._h, _vp(d_src_ptr), _vp(d_dst_ptr),
+                                                            _ptr(off, _i64p), _ptr(nn, _ip), B, out))
+        self._sols = list(out)
+        self._sol = RegistrationSolution(out[0]) if B else None
+        return out
+
+    def getSolution(self):  # registration.h:617
+        return self._sol
+
+    solution = property(getSolution)
+
+    def raw_solution(self, problem=0):
+        return self._sols[problem]
+
+    def getGNCRotationCostAtTermination(self, problem=0):  # registration.h:609-611
+        return float(self._sols[problem].gnc_cost)
+
+    gnc_rotation_cost_at_termination = property(getGNCRotationCostAtTermination)
+
+    def _get_list(self, fn, problem=0, dtype=np.int32, ptr=_ip):
+        ln = C.c_int64(0)
+        self._check(fn(self._h, problem, None, C.byref(ln)))
+        buf = np.zeros(max(ln.value, 1), dtype=dtype)
+        ln2 = C.c_int64(buf.size)
+        self._check(fn(self._h, problem, _ptr(buf, ptr), C.byref(ln2)))
+        return buf[:ln2.value]
+
+    def getInlierMaxClique(self, problem=0):  # registration.h:770
+        return self._get_list(self._lib.teaser_hip_get_max_clique, problem).tolist()
+
+    inlier_max_clique = property(getInlierMaxClique)
+
+    def getRotationInliers(self, problem=0):  # registration.h:713
+        return self._get_list(self._lib.teaser_hip_get_rotation_inliers, problem).tolist()
+
+    rotation_inliers = property(getRotationInliers)
+
+    def getRotationInliersMask(self, problem=0):  # registration.h:689
+        k = self._n_rotation_tims(problem)
+        m = np.zeros(k, dtype=bool)
+        m[self.getRotationInliers(problem)] = True
+        return m
+
+    rotation_inliers_mask = property(getRotationInliersMask)
+
+    def _n_rotation_tims(self, problem=0):
+        K = int(self._sols[problem].clique_size)
+        if int(self._params.rotation_tim_graph) == 0:
+            return K
+        return K * (K - 1) // 2
+
+    def getRotationInliersMap(self, problem=0):  # registration.h:698-702: the max clique
+        return np.array(self.getInlierMaxClique(problem), dtype=np.int32).reshape(1, -1)
+
+    def getTranslationInliers(self, problem=0):  # registration.h:744
+        return self._get_list(self._lib.teaser_hip_get_translation_inliers, problem).tolist()
+
+    translation_inliers = property(getTranslationInliers)
+
+    def getTranslationInliersMask(self, problem=0):  # registration.h:723-725
+        m = np.zeros(int(self._sols[problem].clique_size), dtype=bool)
+        m[self.getTranslationInliers(problem)] = True
+        return m
+
+    translation_inliers_mask = property(getTranslationInliersMask)
+
+    def getTranslationInliersMap(self, problem=0):  # registration.h:733-737: the max clique
+        return np.array(self.getInlierMaxClique(problem), dtype=np.int32).reshape(1, -1)
+
+    translation_inliers_map = property(getTranslationInliersMap)
+
+    def getInputOrderedTranslationInliers(self, problem=0):  # registration.h:752-763
+        return self._get_list(self._lib.teaser_hip_get_input_ordered_translation_inliers, problem).tolist()
+
+    def getInlierGraphBitmap(self, problem=0):
+        n = int(self._sols[problem].n)
+        W = (n + 63) // 64
+        flat = self._get_list(self._lib.teaser_hip_get_inlier_graph_bitmap, problem, np.uint64, _u64p)
+        if flat.size != n * W:
+            return np.zeros((n, W), dtype=np.uint64)
+        return flat.reshape(n, W)
+
+    def getInlierGraph(self, problem=0):  # registration.h:772: adjacency list
+        n = int(self._sols[problem].n)
+        bm = self.getInlierGraphBitmap(problem)
+        bits = np.unpackbits(bm.view(np.uint8), axis=1, bitorder="little")[:, :n]
+        return [np.flatnonzero(r).tolist() for r in bits]
+
+    inlier_graph = property(getInlierGraph)
+
+    def getDegrees(self, problem=0):
+        return self._get_list(self._lib.teaser_hip_get_degrees, problem)
+
+    # --- lazily regenerated M-sized products (never stored on the device) ------------------
+    def getScaleInliersMask(self, problem=0):  # registration.h:652: 1 x M, pair order of registration.cc:531
+        n = int(self._sols[problem].n)
+        bm = self.getInlierGraphBitmap(problem)
+        bits = np.unpackbits(bm.view(np.uint8), axis=1, bitorder="little")[:, :n].astype(bool)
+        iu = np.triu_indices(n, 1)
+        return bits[iu]
+
+    scale_inliers_mask = property(getScaleInliersMask)
+
+    def getScaleInliersMap(self, problem=0):  # registration.h:662: 2 x M (i, j)
+        n = int(self._sols[problem].n)
+        iu = np.triu_indices(n, 1)
+        return np.vstack([iu[0], iu[1]]).astype(np.int32)
+
+    scale_inliers_map = property(getScaleInliersMap)
+    getSrcTIMsMap = getScaleInliersMap
+    getDstTIMsMap = getScaleInliersMap
+
+    def getScaleInliers(self, problem=0):  # registration.h:671-679
+        mp = self.getScaleInliersMap(problem)
+        mk = self.getScaleInliersMask(problem)
+        return [(int(a), int(b)) for a, b in zip(mp[0][mk], mp[1][mk])]
+
+    # --- stage entry points (registration.h:584-601) ---------------------------------------
+    def solveForRotation(self, v1, v2, noise_bound=None):
+        a, b = _colmajor(v1, "v1"), _colmajor(v2, "v2")
+        R = np.zeros(9)
+        mask = np.zeros(a.shape[0], dtype=np.uint8)
+        cost, iters = C.c_double(), C.c_int32()
+        nb = self._params.noise_bound if noise_bound is None else noise_bound
+        self._check(self._lib.teaser_hip_solve_for_rotation(self._h, _ptr(a), _ptr(b), a.shape[0], nb,
+                                                            _ptr(R), _ptr(mask, _u8p), C.byref(cost),
+                                                            C.byref(iters)))
+        self._last_rotation = dict(R=R.reshape(3, 3), inliers=mask.astype(bool), cost=cost.value,
+                                   iterations=iters.value)
+        return self._last_rotation["R"]
+
+    def solveForTranslation(self, v1, v2):
+        a, b = _colmajor(v1, "v1"), _colmajor(v2, "v2")
+        t = np.zeros(3)
+        mask = np.zeros(a.shape[0], dtype=np.uint8)
+        self._check(self._lib.teaser_hip_solve_for_translation(self._h, _ptr(a), _ptr(b), a.shape[0],
+                                                               _ptr(t), _ptr(mask, _u8p)))
+        self._last_translation = dict(t=t, inliers=mask.astype(bool))
+        return t
+
+    def scalarTLS(self, x, ranges):
+        """ScalarTLSEstimator::estimate (registration.cc:21-88): returns (estimate, inlier mask)."""
+        xx = np.ascontiguousarray(x, dtype=np.float64)
+        rr = np.ascontiguousarray(ranges, dtype=np.float64)
+        est = C.c_double()
+        mask = np.zeros(xx.size, dtype=np.uint8)
+        self._check(self._lib.teaser_hip_scalar_tls(self._h, _ptr(xx), _ptr(rr), xx.size, C.byref(est),
+                                                    _ptr(mask, _u8p)))
+        return est.value, mask.astype(bool)
+
+    def maxClique(self, bitmap, n):
+        """MaxCliqueSolver::findMaxClique (graph.cc:12-125) on an adjacency bitmap [n, ceil(n/64)]."""
+        bm = np.ascontiguousarray(bitmap, dtype=np.uint64)
+        out = np.zeros(max(n, 1), dtype=np.int32)
+        size, er = C.c_int32(), C.c_int32()
+        self._check(self._lib.teaser_hip_max_clique(self._h, _ptr(bm, _u64p), n, _ptr(out, _ip),
+                                                    C.byref(size), C.byref(er)))
+        return out[:size.value].tolist(), bool(er.value)
+
+    # --- diagnostics ---------------------------------------------------------------------
+    def set_profiling(self, on=True):
+        self._check(self._lib.teaser_hip_set_profiling(self._h, 1 if on else 0))
+
+    def get_profile(self):
+        p = ProfileC()
+        self._check(self._lib.teaser_hip_get_profile(self._h, C.byref(p)))
+        return {k: getattr(p, k) for k, _ in ProfileC._fields_}
+
+    @property
+    def stream(self):
+        return self._lib.teaser_hip_get_stream(self._h)
+
+
+__all__ = ["RobustRegistrationSolver", "RegistrationSolution", "RotationEstimationAlgorithm",
+           "InlierSelectionMode", "InlierGraphFormulation", "TeaserHipError", "synth_problem",
+           "device_count", "build", "lib", "LIB_PATH", "EXPORTED_SYMBOLS"]

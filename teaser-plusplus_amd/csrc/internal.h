@@ -1,0 +1,112 @@
+// internal.h -- structures shared by the host orchestration and the gfx950 kernels.
+// Product code: never includes anything from oracle/.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "teaser_hip.h"
+
+namespace thip {
+
+constexpr int kWave = 64;          // CDNA4 wavefront
+constexpr int kMaxStarts = 16;     // greedy start vertices per problem
+constexpr int kPeelRounds = 3;     // k-core style peel launches before the host decision
+constexpr int kDynThreshold = 1024;  // |P| below which the greedy uses candidate-degree votes
+
+// One registration problem inside a (possibly ragged) batch.  Packed layouts in HBM:
+//   points   : src/dst  [sum n][3] doubles        (offset pt_off points)
+//   bitmap   : [sum n*W] uint64                   (offset bm_off words)
+//   per-vertex int arrays (deg, clique, ...) share pt_off
+//   per-row-word arrays (alive masks) use w_off words
+struct ProbDesc {
+  int32_t n;
+  int32_t W;
+  int64_t pt_off;
+  int64_t bm_off;
+  int64_t w_off;
+};
+
+// Mutable per-problem device state.
+struct ProbState {
+  int32_t lb;            // best greedy clique size
+  int32_t best_start;    // which start produced it
+  int32_t alive_count;   // vertices surviving the peel
+  int32_t peel_done;     // 1: peel reached a fixpoint (or emptied)
+  int32_t proven;        // 1: lb proven maximum by the peel (alive_count <= lb)
+  int32_t clique_size;   // final clique size (after exact stage if any)
+  int32_t n_rot;         // rotation inliers
+  int32_t n_trans;       // translation inliers
+  int32_t gnc_iters;
+  int32_t pad0;
+  int32_t start_vertex[kMaxStarts];
+  int32_t start_size[kMaxStarts];
+  unsigned long long deg_sum;  // sum of degrees = 2 * edges
+  double scale;
+  double R[9];
+  double t[3];
+  double gnc_cost;
+};
+
+// Scalar solver parameters the kernels need.
+struct EstParams {
+  double noise_bound;
+  double cbar2;
+  double gnc_factor;
+  double cost_threshold;
+  int64_t max_iterations;
+  int32_t tim_graph;  // 0 chain, 1 complete
+  int32_t pad;
+};
+
+// ---- kernel launchers (implemented in the .hip files) -------------------------------------
+// K1: fused TIM norms + scale pruning + symmetric adjacency bitmap (kernels_graph.hip)
+void launch_tim_graph(hipStream_t s, const ProbDesc* d_desc, int batch, int max_n,
+                      const double* d_src, const double* d_dst, uint64_t* d_bitmap,
+                      double noise_bound, double cbar2, int mode, const ProbState* d_state);
+// row popcounts -> degrees (+ per-problem degree sum), start vertex selection
+void launch_degrees(hipStream_t s, const ProbDesc* d_desc, int batch, int max_n,
+                    const uint64_t* d_bitmap, int32_t* d_deg, ProbState* d_state);
+void launch_pick_starts(hipStream_t s, const ProbDesc* d_desc, int batch, const int32_t* d_deg,
+                        ProbState* d_state);
+// greedy multi-start clique heuristic; writes per-start cliques, then the per-problem best
+void launch_heuristic(hipStream_t s, const ProbDesc* d_desc, int batch, int max_W,
+                      const uint64_t* d_bitmap, const int32_t* d_deg, ProbState* d_state,
+                      int32_t* d_start_cliques /* [kMaxStarts][sum n] */, int64_t total_n,
+                      int32_t* d_cand /* [kMaxStarts][sum n] */, int32_t* d_clique /* [sum n] */);
+// k-core style peel at threshold lb
+void launch_peel(hipStream_t s, const ProbDesc* d_desc, int batch, int max_n, int max_W,
+                 const uint64_t* d_bitmap, const int32_t* d_deg, ProbState* d_state,
+                 uint64_t* d_alive_a, uint64_t* d_alive_b);
+
+// exact B&B (kernels_clique.hip).  Works on ONE compact problem: n vertices already renumbered
+// in search order, bitmap rows of W words.
+struct ExactArgs {
+  const uint64_t* bitmap;
+  int32_t n;
+  int32_t W;
+  int32_t* best_size;       // device, initialised to the incumbent size
+  int32_t* best_clique;     // device [n]
+  int32_t* root_counter;    // device, zeroed
+  int32_t* status;          // device, 0 ok / 1 scratch overflow / 2 time limit
+  char* arena;              // device scratch, n_waves * arena_bytes
+  int64_t arena_bytes;      // per wave
+  int32_t n_waves;
+  int64_t deadline_ticks;   // wall_clock64 ticks allowed (0 = unlimited)
+};
+void launch_exact_clique(hipStream_t s, const ExactArgs& a);
+
+// K5/K6 (kernels_estimate.hip)
+void launch_gnc_tls(hipStream_t s, const ProbDesc* d_desc, int batch, const double* d_src,
+                    const double* d_dst, const int32_t* d_clique, ProbState* d_state,
+                    EstParams ep, double* d_weights /* [sum nT] */, int32_t* d_rot_inliers,
+                    const int64_t* d_tim_off);
+void launch_tls_translation(hipStream_t s, const ProbDesc* d_desc, int batch, const double* d_src,
+                            const double* d_dst, const int32_t* d_clique, ProbState* d_state,
+                            EstParams ep, char* d_scratch, int64_t scratch_stride,
+                            int32_t* d_trans_inliers);
+// generic scalar TLS on device arrays (one workgroup)
+void launch_scalar_tls(hipStream_t s, const double* d_x, const double* d_r, int32_t n,
+                       char* d_scratch, double* d_est, uint8_t* d_mask);
+
+}  // namespace thip

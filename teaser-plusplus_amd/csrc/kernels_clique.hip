@@ -1,0 +1,306 @@
+// kernels_clique.hip -- exact maximum-clique branch and bound on gfx950.
+//
+// Replaces pmc::pmcx_maxclique::search / search_dense behind
+// teaser::MaxCliqueSolver::findMaxClique (reference teaser/src/graph.cc:104-122).  pmc itself is
+// an un-vendored third-party library (reference teaser/CMakeLists.txt:6-13); this is an
+// independent design: one wavefront per root vertex, candidate sets as bitsets whose words are
+// spread over the 64 lanes, greedy sequential colouring for the bound (the rows of the bitmap
+// are streamed through the lanes, the two working sets Q/Qc live in LDS), an explicit DFS stack in
+// a per-wave HBM arena, and a device-wide incumbent shared with atomicMax.
+//
+// The host hands over a COMPACT problem: vertices already restricted to the peel survivors and
+// renumbered in search order (ascending degree), so "later neighbours of v" is simply the bits
+// above v in row v.
+#include "internal.h"
+
+namespace thip {
+
+struct LevelHdr {
+  int32_t pcount;   // |P| when the level was created
+  int32_t m;        // listed (branchable) vertices
+  int32_t idx;      // next listed vertex to branch on (descending)
+  int32_t pad;
+  int64_t prev_off; // arena offset of the parent level
+  int64_t bytes;    // size of this level record
+};
+
+__device__ __forceinline__ int64_t align16(int64_t x) { return (x + 15) & ~(int64_t)15; }
+
+__device__ __forceinline__ int wsum(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Greedy sequential colouring of P (BBMC-style).  Lists, in non-decreasing colour order, only
+// the vertices whose colour exceeds `need` (the others can never lead to an improvement from
+// this node).  Stops as soon as colours_used + uncoloured <= need (nothing will be listed).
+__device__ int colour_sort(const uint64_t* __restrict__ bitmap, int W, const uint64_t* P,
+                           int pcount, int need, uint64_t* Q, uint64_t* Qc, int32_t* order,
+                           int32_t* colour) {
+  const int lane = threadIdx.x;
+  for (int w = lane; w < W; w += 64) Q[w] = P[w];
+  __syncthreads();
+  int remaining = pcount, k = 0, m = 0;
+  while (remaining > 0) {
+    if (k + remaining <= need) break;
+    ++k;
+    for (int w = lane; w < W; w += 64) Qc[w] = Q[w];
+    __syncthreads();
+    int wcur = 0;
+    while (true) {
+      // first set bit of Qc at or after word wcur
+      int u = -1, wsel = 0, bit = 0;
+      for (int base = wcur; base < W; base += 64) {
+        const int w = base + lane;
+        const uint64_t word = (w < W) ? Qc[w] : 0ull;
+        const uint64_t mask = __ballot(word != 0ull);
+        if (mask) {
+          const int fl = __builtin_ctzll(mask);
+          const uint64_t ws = __shfl(word, fl, 64);
+          wsel = base + fl;
+          bit = __builtin_ctzll(ws);
+          u = wsel * 64 + bit;
+          break;
+        }
+      }
+      if (u < 0) break;
+      wcur = wsel;
+      const uint64_t* ru = bitmap + (int64_t)u * W;
+      for (int w = wcur + lane; w < W; w += 64) {
+        uint64_t x = Qc[w] & ~ru[w];
+        if (w == wsel) {
+          x &= ~(1ull << bit);
+          Q[w] &= ~(1ull << bit);
+        }
+        Qc[w] = x;
+      }
+      __syncthreads();
+      --remaining;
+      if (k > need) {
+        if (lane == 0) {
+          order[m] = u;
+          colour[m] = k;
+        }
+        ++m;
+      }
+    }
+  }
+  __syncthreads();
+  return m;
+}
+
+__global__ __launch_bounds__(64) void exact_clique_kernel(ExactArgs a, int32_t* recorded_size,
+                                                          int32_t* lock) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int n = a.n, W = a.W;
+  const int lane = threadIdx.x;
+  uint64_t* Q = reinterpret_cast<uint64_t*>(smem);
+  uint64_t* Qc = Q + ((W + 1) & ~1);
+  char* arena = a.arena + (int64_t)blockIdx.x * a.arena_bytes;
+  int32_t* C = reinterpret_cast<int32_t*>(arena);
+  const int64_t stack0 = align16((int64_t)(n + 1) * 4);
+  const long long t_start = wall_clock64();
+
+  while (true) {
+    int r = 0;
+    if (lane == 0) r = atomicAdd(a.root_counter, 1);
+    r = __builtin_amdgcn_readfirstlane(r);
+    if (r >= n) break;
+    if (a.deadline_ticks > 0 && wall_clock64() - t_start > a.deadline_ticks) {
+      if (lane == 0) atomicMax(a.status, 2);
+      break;
+    }
+    const int v = r;
+    int best = __hip_atomic_load(a.best_size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // level 0: P = later neighbours of v
+    int64_t off = stack0;
+    {
+      const int64_t need_bytes = align16(sizeof(LevelHdr)) + align16((int64_t)W * 8);
+      if (off + need_bytes > a.arena_bytes) {
+        if (lane == 0) atomicMax(a.status, 1);
+        break;
+      }
+    }
+    LevelHdr* L = reinterpret_cast<LevelHdr*>(arena + off);
+    uint64_t* P = reinterpret_cast<uint64_t*>(arena + off + align16(sizeof(LevelHdr)));
+    const uint64_t* rv = a.bitmap + (int64_t)v * W;
+    int pc = 0;
+    for (int w = lane; w < W; w += 64) {
+      uint64_t x = rv[w];
+      const int lo = w * 64;
+      if (lo + 63 <= v) x = 0;
+      else if (lo <= v) x &= ~((2ull << (v - lo)) - 1ull);  // keep bits > v
+      P[w] = x;
+      pc += __popcll(x);
+    }
+    pc = wsum(pc);
+    if (pc < best) continue;  // |C|+|P| = 1+pc must exceed best
+    int csize = 1;
+    if (lane == 0) C[0] = v;
+    // finish level 0
+    int64_t lvl_bytes = align16(sizeof(LevelHdr)) + align16((int64_t)W * 8) + 2 * align16((int64_t)pc * 4);
+    if (off + lvl_bytes > a.arena_bytes) {
+      if (lane == 0) atomicMax(a.status, 1);
+      break;
+    }
+    int32_t* order = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(P) + align16((int64_t)W * 8));
+    int32_t* colour = order + (align16((int64_t)pc * 4) / 4);
+    __syncthreads();
+    int m = colour_sort(a.bitmap, W, P, pc, best - csize, Q, Qc, order, colour);
+    if (lane == 0) {
+      L->pcount = pc;
+      L->m = m;
+      L->idx = m - 1;
+      L->prev_off = -1;
+      L->bytes = lvl_bytes;
+    }
+    __syncthreads();
+    int depth = 0;
+    bool overflow = false;
+    while (depth >= 0) {
+      L = reinterpret_cast<LevelHdr*>(arena + off);
+      P = reinterpret_cast<uint64_t*>(arena + off + align16(sizeof(LevelHdr)));
+      const int lpc = L->pcount;
+      order = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(P) + align16((int64_t)W * 8));
+      colour = order + (align16((int64_t)lpc * 4) / 4);
+      const int idx = L->idx;
+      best = __hip_atomic_load(a.best_size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      bool pop = idx < 0;
+      if (!pop && colour[idx] <= best - csize) pop = true;
+      if (pop) {
+        off = L->prev_off;
+        --depth;
+        --csize;
+        __syncthreads();
+        continue;
+      }
+      const int u = order[idx];
+      __syncthreads();
+      if (lane == 0) L->idx = idx - 1;
+      // child candidate set NP = P & N(u), built in place at the next arena slot
+      const int64_t noff = off + L->bytes;
+      const int64_t hdr_b = align16(sizeof(LevelHdr)), p_b = align16((int64_t)W * 8);
+      if (noff + hdr_b + p_b > a.arena_bytes) {
+        overflow = true;
+        break;
+      }
+      LevelHdr* NL = reinterpret_cast<LevelHdr*>(arena + noff);
+      uint64_t* NP = reinterpret_cast<uint64_t*>(arena + noff + hdr_b);
+      const uint64_t* ru = a.bitmap + (int64_t)u * W;
+      int cnt = 0;
+      for (int w = lane; w < W; w += 64) {
+        const uint64_t x = P[w] & ru[w];
+        NP[w] = x;
+        cnt += __popcll(x);
+      }
+      cnt = wsum(cnt);
+      if (lane == 0) {
+        P[u >> 6] &= ~(1ull << (u & 63));
+        C[csize] = u;
+      }
+      __syncthreads();
+      if (cnt == 0) {
+        const int size = csize + 1;
+        if (size > best) {
+          if (lane == 0) {
+            atomicMax(a.best_size, size);
+            while (atomicCAS(lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(2);
+            __threadfence();
+            const int rec = __hip_atomic_load(recorded_size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (size > rec) {
+              for (int k = 0; k < size; ++k)
+                __hip_atomic_store(a.best_clique + k, C[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(recorded_size, size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __threadfence();
+            atomicExch(lock, 0);
+          }
+          __syncthreads();
+        }
+      } else if (csize + 1 + cnt > best) {
+        const int64_t nbytes = hdr_b + p_b + 2 * align16((int64_t)cnt * 4);
+        if (noff + nbytes > a.arena_bytes) {
+          overflow = true;
+          break;
+        }
+        int32_t* norder = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(NP) + p_b);
+        int32_t* ncolour = norder + (align16((int64_t)cnt * 4) / 4);
+        ++csize;
+        const int nm = colour_sort(a.bitmap, W, NP, cnt, best - csize, Q, Qc, norder, ncolour);
+        if (lane == 0) {
+          NL->pcount = cnt;
+          NL->m = nm;
+          NL->idx = nm - 1;
+          NL->prev_off = off;
+          NL->bytes = nbytes;
+        }
+        __syncthreads();
+        off = noff;
+        ++depth;
+      }
+    }
+    if (overflow) {
+      if (lane == 0) atomicMax(a.status, 1);
+      break;
+    }
+  }
+}
+
+void launch_exact_clique(hipStream_t s, const ExactArgs& a) {
+  // best_size[0] = incumbent, best_size[1] = recorded size, best_size[2] = lock
+  const size_t lds = (size_t)2 * ((a.W + 1) & ~1) * 8;
+  hipLaunchKernelGGL(exact_clique_kernel, dim3(a.n_waves), dim3(64), lds, s, a, a.best_size + 1,
+                     a.best_size + 2);
+}
+
+// ------------------------------------------------------------------------------------------
+// helpers for the compact problem: gather points in search order
+// ------------------------------------------------------------------------------------------
+__global__ void gather_points_kernel(const double* __restrict__ src, const double* __restrict__ dst,
+                                     const int32_t* __restrict__ order, int n,
+                                     double* __restrict__ osrc, double* __restrict__ odst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t v = order[i];
+  for (int r = 0; r < 3; ++r) {
+    osrc[3 * (int64_t)i + r] = src[3 * v + r];
+    odst[3 * (int64_t)i + r] = dst[3 * v + r];
+  }
+}
+
+void launch_gather_points(hipStream_t s, const double* d_src, const double* d_dst,
+                          const int32_t* d_order, int n, double* d_osrc, double* d_odst) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(gather_points_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_src, d_dst,
+                     d_order, n, d_osrc, d_odst);
+}
+
+// gather rows/columns of a bitmap into a compact renumbered bitmap (used when the caller supplied
+// the adjacency itself, teaser_hip_max_clique): out[i][j] = in[order[i]][order[j]]
+__global__ __launch_bounds__(64) void gather_bitmap_kernel(const uint64_t* __restrict__ in, int W_in,
+                                                           const int32_t* __restrict__ order, int n,
+                                                           uint64_t* __restrict__ out, int W_out) {
+  const int i = blockIdx.x;
+  const int lane = threadIdx.x;
+  const uint64_t* row = in + (int64_t)order[i] * W_in;
+  for (int wo = 0; wo < W_out; ++wo) {
+    const int j = wo * 64 + lane;
+    bool e = false;
+    if (j < n) {
+      const int v = order[j];
+      e = (row[v >> 6] >> (v & 63)) & 1ull;
+    }
+    const uint64_t m = __ballot(e);
+    if (lane == 0) out[(int64_t)i * W_out + wo] = m;
+  }
+}
+
+void launch_gather_bitmap(hipStream_t s, const uint64_t* d_in, int W_in, const int32_t* d_order,
+                          int n, uint64_t* d_out, int W_out) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(gather_bitmap_kernel, dim3(n), dim3(64), 0, s, d_in, W_in, d_order, n, d_out,
+                     W_out);
+}
+
+}  // namespace thip

@@ -1,0 +1,646 @@
+// kernels_estimate.hip -- K5 (GNC-TLS rotation) and K6 (scalar TLS / translation) for gfx950.
+//
+// These stages run on K = |max clique| columns only (reference registration.cc:657-731): they
+// are latency-bound, so each is ONE launch with one workgroup per problem and the whole GNC loop,
+// including the 3x3 SVD, inside the kernel (no host round trips).
+//   K5: GNCTLSRotationSolver::solveForRotation, reference registration.cc:764-866, with
+//       utils::svdRot, reference utils.h:121-136.
+//   K6: ScalarTLSEstimator::estimate, reference registration.cc:21-88, and
+//       TLSTranslationSolver::solveForTranslation, reference registration.cc:445-471.
+#include <math.h>
+
+#include "internal.h"
+
+namespace thip {
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_max_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    double t = __shfl_xor(v, o, 64);
+    v = t > v ? t : v;
+  }
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------
+// 3x3 SVD rotation (utils.h:121-136): R = V diag(1,1,det(U)det(V)) U^T, H = U S V^T.
+// One-sided (Hestenes) Jacobi on the columns of H; row-major 3x3 arrays; run by one thread.
+// ------------------------------------------------------------------------------------------
+__device__ double det3(const double* M) {
+  return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) +
+         M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
+__device__ void svd_rot3(const double* H, double* R) {
+  double B[9], V[9];
+  for (int i = 0; i < 9; ++i) {
+    B[i] = H[i];
+    V[i] = (i % 4 == 0) ? 1.0 : 0.0;
+  }
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    bool rotated = false;
+    for (int p = 0; p < 2; ++p) {
+      for (int q = p + 1; q < 3; ++q) {
+        double alpha = 0, beta = 0, gamma = 0;
+        for (int r = 0; r < 3; ++r) {
+          alpha += B[3 * r + p] * B[3 * r + p];
+          beta += B[3 * r + q] * B[3 * r + q];
+          gamma += B[3 * r + p] * B[3 * r + q];
+        }
+        if (gamma == 0.0 || fabs(gamma) <= 1e-17 * sqrt(alpha * beta)) continue;
+        rotated = true;
+        const double zeta = (beta - alpha) / (2.0 * gamma);
+        const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+        for (int r = 0; r < 3; ++r) {
+          const double bp = B[3 * r + p], bq = B[3 * r + q];
+          B[3 * r + p] = c * bp - s * bq;
+          B[3 * r + q] = s * bp + c * bq;
+          const double vp = V[3 * r + p], vq = V[3 * r + q];
+          V[3 * r + p] = c * vp - s * vq;
+          V[3 * r + q] = s * vp + c * vq;
+        }
+      }
+    }
+    if (!rotated) break;
+  }
+  double sig[3];
+  for (int c = 0; c < 3; ++c)
+    sig[c] = sqrt(B[c] * B[c] + B[3 + c] * B[3 + c] + B[6 + c] * B[6 + c]);
+  // order columns by descending singular value
+  int i0 = 0, i1 = 1, i2 = 2;
+  if (sig[i1] > sig[i0]) { int t = i0; i0 = i1; i1 = t; }
+  if (sig[i2] > sig[i0]) { int t = i0; i0 = i2; i2 = t; }
+  if (sig[i2] > sig[i1]) { int t = i1; i1 = i2; i2 = t; }
+  const double s0 = sig[i0], s1 = sig[i1], s2 = sig[i2];
+  double u0[3], u1[3], u2[3], v0[3], v1[3], v2[3];
+  for (int r = 0; r < 3; ++r) {
+    v0[r] = V[3 * r + i0];
+    v1[r] = V[3 * r + i1];
+    v2[r] = V[3 * r + i2];
+  }
+  const double tiny = 1e-300;
+  if (s0 > tiny) {
+    for (int r = 0; r < 3; ++r) u0[r] = B[3 * r + i0] / s0;
+  } else {
+    u0[0] = 1; u0[1] = 0; u0[2] = 0;
+  }
+  if (s1 > tiny && s1 > 1e-15 * s0) {
+    for (int r = 0; r < 3; ++r) u1[r] = B[3 * r + i1] / s1;
+  } else {
+    const int k = (fabs(u0[0]) <= fabs(u0[1]) && fabs(u0[0]) <= fabs(u0[2])) ? 0
+                  : (fabs(u0[1]) <= fabs(u0[2]) ? 1 : 2);
+    double nn = 0;
+    for (int r = 0; r < 3; ++r) {
+      u1[r] = (r == k ? 1.0 : 0.0) - u0[k] * u0[r];
+      nn += u1[r] * u1[r];
+    }
+    nn = sqrt(nn);
+    for (int r = 0; r < 3; ++r) u1[r] /= nn;
+  }
+  if (s2 > tiny && s2 > 1e-15 * s0) {
+    for (int r = 0; r < 3; ++r) u2[r] = B[3 * r + i2] / s2;
+  } else {
+    u2[0] = u0[1] * u1[2] - u0[2] * u1[1];
+    u2[1] = u0[2] * u1[0] - u0[0] * u1[2];
+    u2[2] = u0[0] * u1[1] - u0[1] * u1[0];
+  }
+  double U[9], Vs[9];
+  for (int r = 0; r < 3; ++r) {
+    U[3 * r] = u0[r]; U[3 * r + 1] = u1[r]; U[3 * r + 2] = u2[r];
+    Vs[3 * r] = v0[r]; Vs[3 * r + 1] = v1[r]; Vs[3 * r + 2] = v2[r];
+  }
+  if (det3(U) * det3(Vs) < 0) {  // utils.h:131-133
+    Vs[2] = -Vs[2]; Vs[5] = -Vs[5]; Vs[8] = -Vs[8];
+  }
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c)
+      R[3 * r + c] = Vs[3 * r] * U[3 * c] + Vs[3 * r + 1] * U[3 * c + 1] + Vs[3 * r + 2] * U[3 * c + 2];
+}
+
+// ------------------------------------------------------------------------------------------
+// TIMs handed to the rotation solver (registration.cc:657-697), generated on the fly.
+// mode 0 CHAIN over the sorted clique, 1 COMPLETE (computeTIMs pair order), 2 raw columns.
+// ------------------------------------------------------------------------------------------
+struct TimSource {
+  const double* ps;
+  const double* pd;
+  const int32_t* c;
+  int K;
+  int mode;
+  double inv_scale;
+  __device__ __forceinline__ void get(int64_t j, double* x, double* y) const {
+    if (mode == 2) {
+      for (int r = 0; r < 3; ++r) {
+        x[r] = ps[3 * j + r];
+        y[r] = pd[3 * j + r];
+      }
+      return;
+    }
+    int a, b;  // TIM = v_b - v_a
+    if (mode == 0) {
+      a = (int)j;
+      b = (j + 1 == K) ? 0 : (int)j + 1;  // registration.cc:665-671: leaf - root
+    } else {
+      // invert k = a*K - a(a+1)/2 + (b-a-1), registration.cc:531
+      const double kk = 2.0 * K - 1.0;
+      int aa = (int)floor((kk - sqrt(kk * kk - 8.0 * (double)j)) * 0.5);
+      if (aa < 0) aa = 0;
+      while ((int64_t)(aa + 1) * K - (int64_t)(aa + 1) * (aa + 2) / 2 <= j) ++aa;
+      while ((int64_t)aa * K - (int64_t)aa * (aa + 1) / 2 > j) --aa;
+      a = aa;
+      b = (int)(j - ((int64_t)aa * K - (int64_t)aa * (aa + 1) / 2)) + aa + 1;
+    }
+    const int64_t ia = c[a], ib = c[b];
+    for (int r = 0; r < 3; ++r) {
+      x[r] = ps[3 * ib + r] - ps[3 * ia + r];
+      y[r] = (pd[3 * ib + r] - pd[3 * ia + r]) * inv_scale;  // registration.cc:697
+    }
+  }
+};
+
+__device__ __forceinline__ double residual_sq(const double* R, const double* x, const double* y) {
+  double s = 0;  // registration.cc:812-813
+  for (int r = 0; r < 3; ++r) {
+    const double d = y[r] - (R[3 * r] * x[0] + R[3 * r + 1] * x[1] + R[3 * r + 2] * x[2]);
+    s += d * d;
+  }
+  return s;
+}
+
+// The GNC-TLS loop for one problem, executed by a 256-thread workgroup.
+__device__ void gnc_tls_block(const TimSource& ts, int64_t KT, double noise_bound,
+                              double gnc_factor, int64_t max_iterations, double cost_threshold,
+                              double* w, double* R_out, double* cost_out, int* iters_out,
+                              double* sh /* LDS: 64 doubles */) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double* sH = sh;        // [4][9] partials -> H in sH[0..8]
+  double* sR = sh + 36;   // 9
+  double* sS = sh + 45;   // 4 partials + scalars
+  double noise_bound_sq = noise_bound * noise_bound;  // registration.cc:793-796
+  if (noise_bound_sq < 1e-16) noise_bound_sq = 1e-2;
+  for (int64_t j = tid; j < KT; j += 256) w[j] = 1.0;
+  double mu = 1, prev_cost = INFINITY, cost = INFINITY;
+  int iters = 0;
+  __syncthreads();
+  for (int64_t it = 0; it < max_iterations; ++it) {
+    ++iters;
+    // H = X diag(w) Y^T   (utils.h:125)
+    double h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t j = tid; j < KT; j += 256) {
+      double x[3], y[3];
+      ts.get(j, x, y);
+      const double wj = w[j];
+      for (int r = 0; r < 3; ++r) {
+        const double xw = x[r] * wj;
+        h[3 * r] += xw * y[0];
+        h[3 * r + 1] += xw * y[1];
+        h[3 * r + 2] += xw * y[2];
+      }
+    }
+    for (int k = 0; k < 9; ++k) {
+      const double v = wave_sum_d(h[k]);
+      if (lane == 0) sH[wave * 9 + k] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double H[9];
+      for (int k = 0; k < 9; ++k) H[k] = (sH[k] + sH[9 + k]) + (sH[18 + k] + sH[27 + k]);
+      svd_rot3(H, sR);  // registration.cc:809
+    }
+    __syncthreads();
+    double R[9];
+    for (int k = 0; k < 9; ++k) R[k] = sR[k];
+    if (it == 0) {  // registration.cc:814-825
+      double mx = -INFINITY;
+      for (int64_t j = tid; j < KT; j += 256) {
+        double x[3], y[3];
+        ts.get(j, x, y);
+        const double r2 = residual_sq(R, x, y);
+        mx = r2 > mx ? r2 : mx;
+      }
+      mx = wave_max_d(mx);
+      if (lane == 0) sS[wave] = mx;
+      __syncthreads();
+      const double m01 = sS[0] > sS[1] ? sS[0] : sS[1];
+      const double m23 = sS[2] > sS[3] ? sS[2] : sS[3];
+      const double max_residual = m01 > m23 ? m01 : m23;
+      mu = 1 / (2 * max_residual / noise_bound_sq - 1);
+      __syncthreads();
+      if (mu <= 0) break;
+    }
+    const double th1 = (mu + 1) / mu * noise_bound_sq;  // registration.cc:828-829
+    const double th2 = mu / (mu + 1) * noise_bound_sq;
+    double c = 0;
+    for (int64_t j = tid; j < KT; j += 256) {  // registration.cc:831-844
+      double x[3], y[3];
+      ts.get(j, x, y);
+      const double r2 = residual_sq(R, x, y);
+      c += w[j] * r2;
+      double nw;
+      if (r2 >= th1) {
+        nw = 0;
+      } else if (r2 <= th2) {
+        nw = 1;
+      } else {
+        nw = sqrt(noise_bound_sq * mu * (mu + 1) / r2) - mu;
+      }
+      w[j] = nw;
+    }
+    c = wave_sum_d(c);
+    if (lane == 0) sS[wave] = c;
+    __syncthreads();
+    cost = (sS[0] + sS[1]) + (sS[2] + sS[3]);
+    __syncthreads();
+    const double cost_diff = fabs(cost - prev_cost);  // registration.cc:847-858
+    mu = mu * gnc_factor;
+    prev_cost = cost;
+    if (cost_diff < cost_threshold) break;
+  }
+  if (tid == 0) {
+    for (int k = 0; k < 9; ++k) R_out[k] = sR[k];
+    *cost_out = cost;
+    *iters_out = iters;
+  }
+  __syncthreads();
+}
+
+// Ordered compaction of { j : pred(j) } into out[] by the first 256 threads of the workgroup
+// (every thread of the block must call: the barriers are block-wide); returns the count.
+template <typename Pred>
+__device__ int block_compact(int64_t n, Pred pred, int32_t* out, int* scan /* LDS 257 ints */) {
+  const int tid = threadIdx.x;
+  const bool active = tid < 256;
+  const int64_t L = (n + 255) / 256;
+  const int64_t b = active ? tid * L : n, e = (b + L < n) ? b + L : n;
+  int cnt = 0;
+  for (int64_t j = b; j < e; ++j) cnt += pred(j) ? 1 : 0;
+  if (active) scan[tid] = cnt;
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int t = 0; t < 256; ++t) {
+      const int v = scan[t];
+      scan[t] = acc;
+      acc += v;
+    }
+    scan[256] = acc;
+  }
+  __syncthreads();
+  if (active && out) {
+    int pos = scan[tid];
+    for (int64_t j = b; j < e; ++j)
+      if (pred(j)) out[pos++] = (int32_t)j;
+  }
+  const int total = scan[256];
+  __syncthreads();
+  return total;
+}
+
+__global__ __launch_bounds__(256) void gnc_tls_kernel(const ProbDesc* __restrict__ descs,
+                                                      const double* __restrict__ src,
+                                                      const double* __restrict__ dst,
+                                                      const int32_t* __restrict__ clique,
+                                                      ProbState* __restrict__ states, EstParams ep,
+                                                      double* __restrict__ weights,
+                                                      int32_t* __restrict__ rot_inliers,
+                                                      const int64_t* __restrict__ tim_off) {
+  __shared__ double sh[64];
+  __shared__ int scan[257];
+  const ProbDesc d = descs[blockIdx.x];
+  ProbState* st = states + blockIdx.x;
+  const int K = st->clique_size;
+  if (K <= 1) {  // registration.cc:643-647: invalid, rotation untouched
+    if (threadIdx.x == 0) {
+      st->n_rot = 0;
+      st->gnc_iters = 0;
+    }
+    return;
+  }
+  TimSource ts;
+  ts.ps = src + 3 * d.pt_off;
+  ts.pd = dst + 3 * d.pt_off;
+  ts.c = clique + d.pt_off;
+  ts.K = K;
+  ts.mode = ep.tim_graph;
+  const double scale = st->scale;
+  ts.inv_scale = 1 / scale;
+  const int64_t KT = ep.tim_graph == 0 ? (int64_t)K : (int64_t)K * (K - 1) / 2;
+  double* w = weights + tim_off[blockIdx.x];
+  const double nb = ep.noise_bound * (2 / scale);  // registration.cc:702-704
+  gnc_tls_block(ts, KT, nb, ep.gnc_factor, ep.max_iterations, ep.cost_threshold, w, st->R,
+                &st->gnc_cost, &st->gnc_iters, sh);
+  // registration.cc:861-865 + :712-716: inliers = weights >= 0.5
+  const int cnt = block_compact(KT, [&](int64_t j) { return w[j] >= 0.5; },
+                                rot_inliers + tim_off[blockIdx.x], scan);
+  if (threadIdx.x == 0) st->n_rot = cnt;
+}
+
+void launch_gnc_tls(hipStream_t s, const ProbDesc* d_desc, int batch, const double* d_src,
+                    const double* d_dst, const int32_t* d_clique, ProbState* d_state,
+                    EstParams ep, double* d_weights, int32_t* d_rot_inliers,
+                    const int64_t* d_tim_off) {
+  if (batch <= 0) return;
+  hipLaunchKernelGGL(gnc_tls_kernel, dim3(batch), dim3(256), 0, s, d_desc, d_src, d_dst, d_clique,
+                     d_state, ep, d_weights, d_rot_inliers, d_tim_off);
+}
+
+// Stand-alone rotation stage (solveForRotation entry point): src/dst are raw 3xK TIMs on device.
+__global__ __launch_bounds__(256) void gnc_tls_raw_kernel(const double* __restrict__ src,
+                                                          const double* __restrict__ dst, int K,
+                                                          double noise_bound, EstParams ep,
+                                                          double* __restrict__ w,
+                                                          double* __restrict__ out /* R9,cost */,
+                                                          int32_t* __restrict__ iters) {
+  __shared__ double sh[64];
+  TimSource ts;
+  ts.ps = src;
+  ts.pd = dst;
+  ts.c = nullptr;
+  ts.K = K;
+  ts.mode = 2;
+  ts.inv_scale = 1;
+  gnc_tls_block(ts, K, noise_bound, ep.gnc_factor, ep.max_iterations, ep.cost_threshold, w, out,
+                out + 9, iters, sh);
+}
+
+void launch_gnc_tls_raw(hipStream_t s, const double* d_src, const double* d_dst, int K,
+                        double noise_bound, EstParams ep, double* d_w, double* d_out,
+                        int32_t* d_iters) {
+  hipLaunchKernelGGL(gnc_tls_raw_kernel, dim3(1), dim3(256), 0, s, d_src, d_dst, K, noise_bound,
+                     ep, d_w, d_out, d_iters);
+}
+
+// ------------------------------------------------------------------------------------------
+// Scalar TLS (registration.cc:21-88) by a group of 256 threads (`gt` = thread index in the
+// group).  Endpoints (value, tag) with tag = +(i+1) for x_i - r_i, -(i+1) for x_i + r_i
+// (registration.cc:35-38) are bitonic-sorted ascending by (value, insertion index) -- the
+// reference's std::sort leaves tie order unspecified; insertion order is what a stable sort
+// gives.  The sweep (registration.cc:58-75) becomes a blocked prefix sum: each thread owns a
+// contiguous run of endpoints, run totals are combined sequentially in run order.
+// All __syncthreads() are block-wide: every group of the block must call with the same n.
+// ------------------------------------------------------------------------------------------
+struct TlsScratch {
+  double* val;   // [P2]
+  int32_t* tag;  // [P2]
+  double* tot;   // [6][256] run totals / prefixes
+  double* best;  // [256] cost, [256] x_hat
+  int32_t* bpos; // [256]
+};
+
+__device__ __forceinline__ bool ep_less(double va, int ta, double vb, int tb) {
+  if (va < vb) return true;
+  if (va > vb) return false;
+  // insertion index: 2*i for the opening endpoint, 2*i+1 for the closing one
+  const unsigned int oa = ta > 0 ? 2u * (unsigned)(ta - 1) : 2u * (unsigned)(-ta - 1) + 1u;
+  const unsigned int ob = tb > 0 ? 2u * (unsigned)(tb - 1) : 2u * (unsigned)(-tb - 1) + 1u;
+  return oa < ob;
+}
+
+__device__ double scalar_tls_group(const double* X, const double* Rg, double r_const, int n,
+                                   const TlsScratch& sc, int gt) {
+  const int m = 2 * n;
+  int P2 = 2;
+  while (P2 < m) P2 <<= 1;
+  for (int e = gt; e < P2; e += 256) {
+    if (e < m) {
+      const int i = e >> 1;
+      const double r = Rg ? Rg[i] : r_const;
+      sc.val[e] = (e & 1) ? X[i] + r : X[i] - r;
+      sc.tag[e] = (e & 1) ? -(i + 1) : (i + 1);
+    } else {
+      sc.val[e] = INFINITY;
+      sc.tag[e] = 0x7fffffff;
+    }
+  }
+  __syncthreads();
+  for (int k = 2; k <= P2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = gt; i < P2; i += 256) {
+        const int l = i ^ j;
+        if (l > i) {
+          const double vi = sc.val[i], vl = sc.val[l];
+          const int ti = sc.tag[i], tl = sc.tag[l];
+          const bool up = (i & k) == 0;
+          const bool l_lt_i = ep_less(vl, tl, vi, ti);
+          if (l_lt_i == up) {
+            sc.val[i] = vl; sc.val[l] = vi;
+            sc.tag[i] = tl; sc.tag[l] = ti;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // run totals
+  const int L = (m + 255) / 256;
+  const int b = gt * L, e_end = min(m, b + L);
+  double t_dwc = 0, t_dxw = 0, t_ris = 0, t_sx = 0, t_sxx = 0, t_card = 0;
+  for (int e = b; e < e_end; ++e) {
+    const int tg = sc.tag[e];
+    const int idx = (tg > 0 ? tg : -tg) - 1;
+    const double eps = tg > 0 ? 1.0 : -1.0;
+    const double x = X[idx], r = Rg ? Rg[idx] : r_const;
+    const double w = 1.0 / (r * r);
+    t_card += eps;
+    t_dwc += eps * w;
+    t_dxw += eps * w * x;
+    t_ris += eps * r;
+    t_sx += eps * x;
+    t_sxx += eps * x * x;
+  }
+  // sum of all ranges (registration.cc:51) as a run-ordered sum too
+  double rsum = 0;
+  {
+    const int Ln = (n + 255) / 256;
+    const int bn = gt * Ln, en = min(n, bn + Ln);
+    for (int i = bn; i < en; ++i) rsum += Rg ? Rg[i] : r_const;
+  }
+  sc.tot[0 * 256 + gt] = t_card;
+  sc.tot[1 * 256 + gt] = t_dwc;
+  sc.tot[2 * 256 + gt] = t_dxw;
+  sc.tot[3 * 256 + gt] = t_ris;
+  sc.tot[4 * 256 + gt] = t_sx;
+  sc.tot[5 * 256 + gt] = t_sxx;
+  sc.best[gt] = rsum;
+  __syncthreads();
+  if (gt < 6) {  // exclusive prefix over the runs, in run order
+    double acc = 0;
+    for (int t = 0; t < 256; ++t) {
+      const double v = sc.tot[gt * 256 + t];
+      sc.tot[gt * 256 + t] = acc;
+      acc += v;
+    }
+  } else if (gt == 6) {
+    double acc = 0;
+    for (int t = 0; t < 256; ++t) acc += sc.best[t];
+    sc.best[256] = acc;  // total of the ranges
+  }
+  __syncthreads();
+  const double ranges_sum = sc.best[256];
+  double card = sc.tot[gt], dwc = sc.tot[256 + gt], dxw = sc.tot[512 + gt];
+  double ris = ranges_sum - sc.tot[768 + gt];
+  double sx = sc.tot[1024 + gt], sxx = sc.tot[1280 + gt];
+  __syncthreads();
+  double bcost = INFINITY, bhat = NAN;
+  int bp = 0x7fffffff;
+  for (int e = b; e < e_end; ++e) {
+    const int tg = sc.tag[e];
+    const int idx = (tg > 0 ? tg : -tg) - 1;
+    const double eps = tg > 0 ? 1.0 : -1.0;
+    const double x = X[idx], r = Rg ? Rg[idx] : r_const;
+    const double w = 1.0 / (r * r);
+    card += eps;
+    dwc += eps * w;
+    dxw += eps * w * x;
+    ris -= eps * r;
+    sx += eps * x;
+    sxx += eps * x * x;
+    const double x_hat = dxw / dwc;
+    const double residual = card * x_hat * x_hat + sxx - 2 * sx * x_hat;
+    const double cost = residual + ris;
+    if (cost < bcost) {  // first minimum; NaN never wins (registration.cc:77-78)
+      bcost = cost;
+      bhat = x_hat;
+      bp = e;
+    }
+  }
+  sc.best[gt] = bcost;
+  sc.best[257 + gt] = bhat;
+  sc.bpos[gt] = bp;
+  __syncthreads();
+  // runs are in endpoint order, so the first strictly-smaller run wins
+  double est = NAN;
+  {
+    double c = INFINITY;
+    for (int t = 0; t < 256; ++t) {
+      if (sc.best[t] < c) {
+        c = sc.best[t];
+        est = sc.best[257 + t];
+      }
+    }
+    if (!(c < INFINITY)) {  // no finite cost anywhere: fall back to the first endpoint's x_hat
+      est = sc.best[257];
+    }
+  }
+  __syncthreads();
+  return est;
+}
+
+constexpr int kTlsLdsEndpoints = 2048;  // per group; larger problems sort in global scratch
+constexpr int kTlsGroupLds = kTlsLdsEndpoints * 12 + (6 * 256 + 514) * 8 + 256 * 4;
+
+__device__ __forceinline__ TlsScratch tls_scratch(char* lds_group, char* glob_group, int n) {
+  TlsScratch sc;
+  int P2 = 2;
+  while (P2 < 2 * n) P2 <<= 1;
+  char* base = lds_group;
+  sc.tot = reinterpret_cast<double*>(base);
+  sc.best = sc.tot + 6 * 256;
+  sc.bpos = reinterpret_cast<int32_t*>(sc.best + 514);
+  char* ep_area = reinterpret_cast<char*>(sc.bpos + 256);
+  if (P2 <= kTlsLdsEndpoints) {
+    sc.val = reinterpret_cast<double*>(ep_area);
+    sc.tag = reinterpret_cast<int32_t*>(sc.val + kTlsLdsEndpoints);
+  } else {
+    sc.val = reinterpret_cast<double*>(glob_group);
+    sc.tag = reinterpret_cast<int32_t*>(sc.val + P2);
+  }
+  return sc;
+}
+
+// K6: translation.  Block = 3 groups of 256 threads, group a estimates axis a.
+// Global scratch per problem: X[3][K] doubles, mask[3][K] bytes, then 3 endpoint areas.
+__global__ __launch_bounds__(768) void tls_translation_kernel(
+    const ProbDesc* __restrict__ descs, const double* __restrict__ src,
+    const double* __restrict__ dst, const int32_t* __restrict__ clique,
+    ProbState* __restrict__ states, EstParams ep, char* __restrict__ scratch,
+    int64_t scratch_stride, int32_t* __restrict__ trans_inliers) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int scan[257];
+  const ProbDesc d = descs[blockIdx.x];
+  ProbState* st = states + blockIdx.x;
+  const int K = st->clique_size;
+  if (K <= 1) {
+    if (threadIdx.x == 0) st->n_trans = 0;
+    return;
+  }
+  const int g = threadIdx.x >> 8, gt = threadIdx.x & 255;
+  char* ps = scratch + (int64_t)blockIdx.x * scratch_stride;
+  const int64_t Kp = (K + 1) & ~1;
+  double* X = reinterpret_cast<double*>(ps) + g * Kp;
+  uint8_t* mask = reinterpret_cast<uint8_t*>(ps + 3 * Kp * 8) + (int64_t)g * Kp;
+  int P2 = 2;
+  while (P2 < 2 * K) P2 <<= 1;
+  char* glob_ep = ps + 3 * Kp * 8 + 3 * Kp + 16 + (int64_t)g * ((int64_t)P2 * 12 + 16);
+  glob_ep = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(glob_ep) + 15) & ~(uintptr_t)15);
+
+  const double* psrc = src + 3 * d.pt_off;
+  const double* pdst = dst + 3 * d.pt_off;
+  const int32_t* c = clique + d.pt_off;
+  const double scale = st->scale;
+  // raw translation, registration.cc:726 + :455: dst - (scale * R) * src
+  const double r0 = scale * st->R[3 * g], r1 = scale * st->R[3 * g + 1], r2 = scale * st->R[3 * g + 2];
+  for (int j = gt; j < K; j += 256) {
+    const int64_t v = c[j];
+    const double a = r0 * psrc[3 * v] + r1 * psrc[3 * v + 1] + r2 * psrc[3 * v + 2];
+    X[j] = pdst[3 * v + g] - a;
+  }
+  __syncthreads();
+  const double beta = ep.noise_bound * sqrt(ep.cbar2);  // registration.cc:459 (not doubled)
+  TlsScratch sc = tls_scratch(smem + g * kTlsGroupLds, glob_ep, K);
+  const double est = scalar_tls_group(X, nullptr, beta, K, sc, gt);
+  for (int j = gt; j < K; j += 256) mask[j] = fabs(X[j] - est) <= beta ? 1 : 0;  // :86
+  if (gt == 0) st->t[g] = est;
+  __syncthreads();
+  // AND of the three axis masks (registration.cc:463-470), then findNonzero (:731)
+  const uint8_t* m0 = reinterpret_cast<uint8_t*>(ps + 3 * Kp * 8);
+  const uint8_t* m1 = m0 + Kp;
+  const uint8_t* m2 = m1 + Kp;
+  const int cnt = block_compact(K, [&](int64_t j) { return (m0[j] & m1[j] & m2[j]) != 0; },
+                                trans_inliers + d.pt_off, scan);
+  if (threadIdx.x == 0) st->n_trans = cnt;
+}
+
+void launch_tls_translation(hipStream_t s, const ProbDesc* d_desc, int batch, const double* d_src,
+                            const double* d_dst, const int32_t* d_clique, ProbState* d_state,
+                            EstParams ep, char* d_scratch, int64_t scratch_stride,
+                            int32_t* d_trans_inliers) {
+  if (batch <= 0) return;
+  static bool attr_set = false;
+  if (!attr_set) {  // 3 groups x 42 KB of dynamic LDS exceed the 64 KB default
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tls_translation_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 3 * kTlsGroupLds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(tls_translation_kernel, dim3(batch), dim3(768), 3 * kTlsGroupLds, s, d_desc,
+                     d_src, d_dst, d_clique, d_state, ep, d_scratch, scratch_stride,
+                     d_trans_inliers);
+}
+
+// Stand-alone scalar TLS on device arrays x[n], r[n] (one group).
+__global__ __launch_bounds__(256) void scalar_tls_kernel(const double* __restrict__ x,
+                                                         const double* __restrict__ r, int n,
+                                                         char* __restrict__ scratch,
+                                                         double* __restrict__ est_out,
+                                                         uint8_t* __restrict__ mask) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  TlsScratch sc = tls_scratch(smem, scratch, n);
+  const double est = scalar_tls_group(x, r, 0.0, n, sc, threadIdx.x);
+  if (mask)
+    for (int j = threadIdx.x; j < n; j += 256) mask[j] = fabs(x[j] - est) <= r[j] ? 1 : 0;
+  if (threadIdx.x == 0) *est_out = est;
+}
+
+void launch_scalar_tls(hipStream_t s, const double* d_x, const double* d_r, int32_t n,
+                       char* d_scratch, double* d_est, uint8_t* d_mask) {
+  hipLaunchKernelGGL(scalar_tls_kernel, dim3(1), dim3(256), kTlsGroupLds, s, d_x, d_r, n, d_scratch,
+                     d_est, d_mask);
+}
+
+}  // namespace thip

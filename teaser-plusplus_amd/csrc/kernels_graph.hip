@@ -1,0 +1,673 @@
+// kernels_graph.hip -- gfx950 kernels for the O(N^2) stage and the greedy/peel clique stages.
+//
+//   K1  tim_graph_kernel   fused computeTIMs (reference registration.cc:512-551) +
+//                          ScaleInliersSelector / TLS-scale consensus test (registration.cc:427-443,
+//                          410-425) + mask->graph loop (registration.cc:614-619): the TIMs are
+//                          never materialised; output is the symmetric adjacency bitmap.
+//   K2  degrees / starts / greedy clique / peel: stand in for pmc's compute_cores + pmc_heu
+//                          (reference graph.cc:58-59, 88-102).
+//
+// Compiled with -ffp-contract=off: the pruning predicate must round every product and add
+// individually, as the reference's default (non-FMA) build does.  FMAs below are explicit.
+#include "internal.h"
+
+namespace thip {
+
+// ------------------------------------------------------------------------------------------
+// small wave / block helpers (wave = 64 lanes)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    unsigned long long t = __shfl_xor(v, o, 64);
+    v = t > v ? t : v;
+  }
+  return v;
+}
+// block-wide (256 threads = 4 waves) reductions through a 4-entry LDS scratch
+__device__ __forceinline__ int block_sum_i(int v, int* red4) {
+  v = wave_sum_i(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red4[0] + red4[1] + red4[2] + red4[3];
+}
+__device__ __forceinline__ unsigned long long block_max_u64(unsigned long long v,
+                                                            unsigned long long* red4) {
+  v = wave_max_u64(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  unsigned long long a = red4[0] > red4[1] ? red4[0] : red4[1];
+  unsigned long long b = red4[2] > red4[3] ? red4[2] : red4[3];
+  return a > b ? a : b;
+}
+
+// ------------------------------------------------------------------------------------------
+// K1 predicate
+// ------------------------------------------------------------------------------------------
+// Reference semantics (registration.cc:434-442): with a = src_j - src_i, b = dst_j - dst_i,
+//   edge <=> | sqrt((ax^2+ay^2)+az^2) - sqrt((bx^2+by^2)+bz^2) | <= beta      (all IEEE double).
+// A = |a|^2 and B = |b|^2 are computed exactly as the reference rounds them.  The two square
+// roots are avoided by the algebraically equivalent test on S = A + B - beta^2:
+//   edge <=> S <= 0  or  S^2 <= 4AB,
+// decided from d = S^2 - 4AB only when |d| clears a guard band of 1e-12 (A+B+beta^2)^2 -- three
+// orders of magnitude above both the rounding error of d (<= ~7e-16 (A+B+beta^2)^2) and the
+// gap between the reference's rounded predicate and the exact one (<= ~4e-15 (A+B+beta^2)^2).
+// Inside the band (a vanishing fraction of pairs, and any NaN) the reference expression itself
+// is evaluated with correctly rounded sqrt, so the bitmap is bit-identical by construction.
+__device__ __forceinline__ bool tim_edge_fixed(double ax, double ay, double az, double bx,
+                                               double by, double bz, double beta, double beta2) {
+  const double A = (ax * ax + ay * ay) + az * az;
+  const double B = (bx * bx + by * by) + bz * bz;
+  const double t = A + B;
+  const double S = t - beta2;
+  const double d = __builtin_fma(S, S, -4.0 * (A * B));
+  const double u = t + beta2;
+  const double band = (u * u) * 1e-12;
+  bool res = (S <= 0.0) | (d <= 0.0);
+  if (!(__builtin_fabs(d) > band)) {  // rare: guard band or NaN
+    res = __builtin_fabs(__builtin_sqrt(A) - __builtin_sqrt(B)) <= beta;
+  }
+  return res;
+}
+
+// TLS-scale consensus (registration.cc:415-424 + :86): raw = |b|/|a|, alpha = beta * (1/|a|),
+// edge <=> |raw - s_hat| <= alpha.  Evaluated literally (IEEE sqrt / div).
+__device__ __forceinline__ bool tim_edge_scaled(double ax, double ay, double az, double bx,
+                                                double by, double bz, double beta, double s_hat) {
+  const double v1 = __builtin_sqrt((ax * ax + ay * ay) + az * az);
+  const double v2 = __builtin_sqrt((bx * bx + by * by) + bz * bz);
+  const double raw = v2 / v1;
+  const double alpha = beta * (1.0 / v1);
+  return __builtin_fabs(raw - s_hat) <= alpha;
+}
+
+// Tiling: a wave owns 64 rows (lane = row) and walks 64-column tiles of the upper triangle.
+// The column point is wave-uniform (scalar loads, SGPR operands); per column the 64 row lanes
+// evaluate the predicate, the lane keeps its own bit (row word) and the wave ballot IS the
+// transposed word (row j, word I) -- so each unordered pair is evaluated once and both halves of
+// the symmetric bitmap are written.  kColTilesPerWave consecutive column tiles per wave give each
+// lane kColTilesPerWave contiguous words of its row.
+constexpr int kColTilesPerWave = 4;
+constexpr int kWavesPerBlock = 4;
+constexpr int kColTilesPerBlock = kColTilesPerWave * kWavesPerBlock;
+
+template <int MODE>
+__global__ __launch_bounds__(256) void tim_graph_kernel(const ProbDesc* __restrict__ descs,
+                                                        const double* __restrict__ src,
+                                                        const double* __restrict__ dst,
+                                                        uint64_t* __restrict__ bitmap,
+                                                        double beta, double beta2,
+                                                        const ProbState* __restrict__ states) {
+  const ProbDesc d = descs[blockIdx.z];
+  const int n = d.n, W = d.W;
+  const int T = W;  // row/column tiles of 64
+  const int I = blockIdx.y;
+  if (I >= T) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int Jbase = (blockIdx.x * kWavesPerBlock + wave) * kColTilesPerWave;
+  if (Jbase + kColTilesPerWave - 1 < I || Jbase >= T) return;  // below the diagonal / outside
+
+  const double* __restrict__ ps = src + 3 * d.pt_off;
+  const double* __restrict__ pd = dst + 3 * d.pt_off;
+  uint64_t* __restrict__ bm = bitmap + d.bm_off;
+  double s_hat = 1.0;
+  if (MODE == 1) s_hat = states[blockIdx.z].scale;
+
+  const int i = I * 64 + lane;
+  const bool vi = i < n;
+  const int ic = vi ? i : n - 1;
+  const double six = ps[3 * ic], siy = ps[3 * ic + 1], siz = ps[3 * ic + 2];
+  const double dix = pd[3 * ic], diy = pd[3 * ic + 1], diz = pd[3 * ic + 2];
+
+  for (int s = 0; s < kColTilesPerWave; ++s) {
+    const int J = Jbase + s;
+    if (J < I || J >= T) continue;
+    const int j0 = J * 64;
+    uint64_t own = 0, tr = 0;
+#pragma unroll 8
+    for (int b = 0; b < 64; ++b) {
+      const int j = j0 + b;
+      const int jc = j < n ? j : n - 1;  // wave-uniform
+      const double sjx = ps[3 * jc], sjy = ps[3 * jc + 1], sjz = ps[3 * jc + 2];
+      const double djx = pd[3 * jc], djy = pd[3 * jc + 1], djz = pd[3 * jc + 2];
+      bool e;
+      if (MODE == 0) {
+        e = tim_edge_fixed(sjx - six, sjy - siy, sjz - siz, djx - dix, djy - diy, djz - diz, beta,
+                           beta2);
+      } else {
+        // reference TIM is v_j - v_i with i < j; in the transposed direction the norms are equal
+        e = tim_edge_scaled(sjx - six, sjy - siy, sjz - siz, djx - dix, djy - diy, djz - diz,
+                            beta, s_hat);
+      }
+      e = e & vi & (j < n) & (j != i);
+      const uint64_t m = __ballot(e);
+      own |= (uint64_t)(e ? 1 : 0) << b;
+      tr = (lane == b) ? m : tr;
+    }
+    if (vi) bm[(int64_t)i * W + J] = own;
+    if (J != I && j0 + lane < n) bm[(int64_t)(j0 + lane) * W + I] = tr;
+  }
+}
+
+void launch_tim_graph(hipStream_t s, const ProbDesc* d_desc, int batch, int max_n,
+                      const double* d_src, const double* d_dst, uint64_t* d_bitmap,
+                      double noise_bound, double cbar2, int mode, const ProbState* d_state) {
+  if (batch <= 0 || max_n <= 0) return;
+  const int T = (max_n + 63) / 64;
+  const double beta = 2 * noise_bound * sqrt(cbar2);  // registration.cc:438 / :421
+  dim3 grid((T + kColTilesPerBlock - 1) / kColTilesPerBlock, T, batch);
+  if (mode == 0)
+    hipLaunchKernelGGL(tim_graph_kernel<0>, grid, dim3(256), 0, s, d_desc, d_src, d_dst, d_bitmap,
+                       beta, beta * beta, d_state);
+  else
+    hipLaunchKernelGGL(tim_graph_kernel<1>, grid, dim3(256), 0, s, d_desc, d_src, d_dst, d_bitmap,
+                       beta, beta * beta, d_state);
+}
+
+// ------------------------------------------------------------------------------------------
+// degrees: one wave per bitmap row
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void degree_kernel(const ProbDesc* __restrict__ descs,
+                                                     const uint64_t* __restrict__ bitmap,
+                                                     int32_t* __restrict__ deg) {
+  const ProbDesc d = descs[blockIdx.y];
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= d.n) return;
+  const int lane = threadIdx.x & 63;
+  const uint64_t* r = bitmap + d.bm_off + (int64_t)row * d.W;
+  int c = 0;
+  for (int w = lane; w < d.W; w += 64) c += __popcll(r[w]);
+  c = wave_sum_i(c);
+  if (lane == 0) deg[d.pt_off + row] = c;
+}
+
+void launch_degrees(hipStream_t s, const ProbDesc* d_desc, int batch, int max_n,
+                    const uint64_t* d_bitmap, int32_t* d_deg, ProbState* d_state) {
+  if (batch <= 0 || max_n <= 0) return;
+  dim3 grid((max_n + 3) / 4, batch);
+  hipLaunchKernelGGL(degree_kernel, grid, dim3(256), 0, s, d_desc, d_bitmap, d_deg);
+}
+
+// ------------------------------------------------------------------------------------------
+// start vertices: the max-(degree, lowest index) vertex of each residue class mod kMaxStarts;
+// also the degree sum (edge count) of the problem.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pick_starts_kernel(const ProbDesc* __restrict__ descs,
+                                                          const int32_t* __restrict__ deg,
+                                                          ProbState* __restrict__ states) {
+  __shared__ unsigned long long keys[256];
+  __shared__ unsigned long long sums[4];
+  const ProbDesc d = descs[blockIdx.x];
+  const int32_t* dg = deg + d.pt_off;
+  unsigned long long best = 0, sum = 0;
+  // 256 % kMaxStarts == 0, so thread t only ever sees class t % kMaxStarts
+  for (int v = threadIdx.x; v < d.n; v += 256) {
+    const unsigned long long dv = (unsigned int)dg[v];
+    sum += dv;
+    const unsigned long long key = ((dv + 1) << 32) | (0xffffffffu - (unsigned int)v);
+    best = key > best ? key : best;
+  }
+  keys[threadIdx.x] = best;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  if ((threadIdx.x & 63) == 0) sums[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  ProbState* st = states + blockIdx.x;
+  if (threadIdx.x < kMaxStarts) {
+    unsigned long long b = 0;
+    for (int t = threadIdx.x; t < 256; t += kMaxStarts) b = keys[t] > b ? keys[t] : b;
+    st->start_vertex[threadIdx.x] = b ? (int)(0xffffffffu - (unsigned int)(b & 0xffffffffu)) : -1;
+    st->start_size[threadIdx.x] = 0;
+  }
+  if (threadIdx.x == 0) {
+    st->deg_sum = sums[0] + sums[1] + sums[2] + sums[3];
+    st->lb = 0;
+    st->best_start = -1;
+    st->alive_count = 0;
+    st->peel_done = 0;
+    st->proven = 0;
+    st->clique_size = 0;
+  }
+}
+
+void launch_pick_starts(hipStream_t s, const ProbDesc* d_desc, int batch, const int32_t* d_deg,
+                        ProbState* d_state) {
+  if (batch <= 0) return;
+  hipLaunchKernelGGL(pick_starts_kernel, dim3(batch), dim3(256), 0, s, d_desc, d_deg, d_state);
+}
+
+// ------------------------------------------------------------------------------------------
+// greedy clique from one start vertex (one workgroup per (start, problem)).
+//   candidates P = common neighbourhood of the clique so far, as an LDS bitset;
+//   |P| > kDynThreshold : add the candidate of largest global degree;
+//   otherwise           : one vote round -- d_P(u) = |N(u) & P| for every candidate (a wave per
+//                         candidate over the bitmap row); every u with d_P(u) = |P|-1 is
+//                         adjacent to all other candidates and joins at once; then the
+//                         candidate with the largest d_P joins and P shrinks to its neighbours.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void greedy_clique_kernel(
+    const ProbDesc* __restrict__ descs, const uint64_t* __restrict__ bitmap,
+    const int32_t* __restrict__ deg, ProbState* __restrict__ states,
+    int32_t* __restrict__ start_cliques, int64_t total_n) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const ProbDesc d = descs[blockIdx.y];
+  const int n = d.n, W = d.W;
+  const int Wpad = (W + 1) & ~1;
+  uint64_t* P = reinterpret_cast<uint64_t*>(smem);
+  unsigned long long* red64 = reinterpret_cast<unsigned long long*>(P + Wpad);  // 4
+  int* cand = reinterpret_cast<int*>(red64 + 4);                                  // kDynThreshold
+  int* dP = cand + kDynThreshold;                                                 // kDynThreshold
+  int* red4 = dP + kDynThreshold;                                                 // 4
+  int* misc = red4 + 4;                                                           // 8
+  int* wcnt = misc + 8;                                                           // 256
+
+  ProbState* st = states + blockIdx.y;
+  const int sidx = blockIdx.x;
+  const int v0 = st->start_vertex[sidx];
+  if (v0 < 0 || n <= 0) {
+    if (threadIdx.x == 0) st->start_size[sidx] = 0;
+    return;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint64_t* bm = bitmap + d.bm_off;
+  const int32_t* dg = deg + d.pt_off;
+  int32_t* C = start_cliques + (int64_t)sidx * total_n + d.pt_off;
+
+  int csize = 1;
+  if (tid == 0) C[0] = v0;
+  int pc = 0;
+  for (int w = tid; w < W; w += 256) {
+    const uint64_t x = bm[(int64_t)v0 * W + w];
+    P[w] = x;
+    pc += __popcll(x);
+  }
+  pc = block_sum_i(pc, red4);
+
+  while (pc > 0) {
+    if (pc > kDynThreshold) {
+      // static pick: largest global degree, ties to the smallest index
+      unsigned long long key = 0;
+      for (int w = tid; w < W; w += 256) {
+        uint64_t bits = P[w];
+        while (bits) {
+          const int u = w * 64 + __builtin_ctzll(bits);
+          bits &= bits - 1;
+          const unsigned long long k =
+              ((unsigned long long)(unsigned int)dg[u] << 32) | (0xffffffffu - (unsigned int)u);
+          key = k > key ? k : key;
+        }
+      }
+      key = block_max_u64(key, red64);
+      const int u = (int)(0xffffffffu - (unsigned int)(key & 0xffffffffu));
+      if (tid == 0) C[csize] = u;
+      ++csize;
+      int c = 0;
+      __syncthreads();
+      for (int w = tid; w < W; w += 256) {
+        const uint64_t x = P[w] & bm[(int64_t)u * W + w];
+        P[w] = x;
+        c += __popcll(x);
+      }
+      pc = block_sum_i(c, red4);
+      continue;
+    }
+
+    // ---- vote round: enumerate candidates in index order (contiguous word chunks per thread)
+    const int wpt = (W + 255) / 256;
+    const int w0 = tid * wpt, w1 = min(W, w0 + wpt);
+    int mycnt = 0;
+    for (int w = w0; w < w1; ++w) mycnt += __popcll(P[w]);
+    wcnt[tid] = mycnt;
+    __syncthreads();
+    // exclusive scan over 256 entries by wave 0 (4 per lane)
+    if (wave == 0) {
+      int a0 = wcnt[4 * lane], a1 = wcnt[4 * lane + 1], a2 = wcnt[4 * lane + 2],
+          a3 = wcnt[4 * lane + 3];
+      int tot = a0 + a1 + a2 + a3, incl = tot;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+      }
+      int ex = incl - tot;
+      wcnt[4 * lane] = ex;
+      wcnt[4 * lane + 1] = ex + a0;
+      wcnt[4 * lane + 2] = ex + a0 + a1;
+      wcnt[4 * lane + 3] = ex + a0 + a1 + a2;
+    }
+    __syncthreads();
+    {
+      int pos = wcnt[tid];
+      for (int w = w0; w < w1; ++w) {
+        uint64_t bits = P[w];
+        while (bits) {
+          cand[pos++] = w * 64 + __builtin_ctzll(bits);
+          bits &= bits - 1;
+        }
+      }
+    }
+    __syncthreads();
+    // votes: a wave per candidate
+    for (int idx = wave; idx < pc; idx += 4) {
+      const int u = cand[idx];
+      const uint64_t* ru = bm + (int64_t)u * W;
+      int c = 0;
+      for (int w = lane; w < W; w += 64) c += __popcll(ru[w] & P[w]);
+      c = wave_sum_i(c);
+      if (lane == 0) dP[idx] = c;
+    }
+    __syncthreads();
+    // bookkeeping by wave 0: append universal candidates, find the best non-universal one
+    if (wave == 0) {
+      int cs = csize, nU = 0;
+      unsigned long long bestk = 0;
+      for (int base = 0; base < pc; base += 64) {
+        const int idx = base + lane;
+        const bool valid = idx < pc;
+        const int dv = valid ? dP[idx] : -1;
+        const int u = valid ? cand[idx] : 0;
+        const bool isU = valid && (dv == pc - 1);
+        const uint64_t m = __ballot(isU);
+        if (isU) {
+          C[cs + __popcll(m & ((1ull << lane) - 1ull))] = u;
+          atomicAnd(reinterpret_cast<unsigned long long*>(&P[u >> 6]), ~(1ull << (u & 63)));
+        }
+        const int k = __popcll(m);
+        cs += k;
+        nU += k;
+        if (valid && !isU) {
+          const unsigned long long kk =
+              ((unsigned long long)(unsigned int)(dv + 1) << 32) | (0xffffffffu - (unsigned int)u);
+          bestk = kk > bestk ? kk : bestk;
+        }
+      }
+      bestk = wave_max_u64(bestk);
+      if (lane == 0) {
+        misc[0] = cs;
+        misc[1] = nU;
+        misc[2] = bestk ? (int)(0xffffffffu - (unsigned int)(bestk & 0xffffffffu)) : -1;
+      }
+    }
+    __syncthreads();
+    csize = misc[0];
+    const int nU = misc[1];
+    const int ubest = misc[2];
+    pc -= nU;
+    if (pc > 0 && ubest >= 0) {
+      if (tid == 0) C[csize] = ubest;
+      ++csize;
+      int c = 0;
+      for (int w = tid; w < W; w += 256) {
+        const uint64_t x = P[w] & bm[(int64_t)ubest * W + w];
+        P[w] = x;
+        c += __popcll(x);
+      }
+      pc = block_sum_i(c, red4);
+    } else {
+      pc = 0;
+      __syncthreads();
+    }
+  }
+  if (tid == 0) st->start_size[sidx] = csize;
+}
+
+// Per problem: choose the best start (largest clique, ties to the lowest start), emit it SORTED
+// into d_clique via an LDS membership bitset, set lb, and initialise the peel: alive = deg >= lb.
+__global__ __launch_bounds__(256) void select_best_kernel(
+    const ProbDesc* __restrict__ descs, const int32_t* __restrict__ deg,
+    ProbState* __restrict__ states, const int32_t* __restrict__ start_cliques, int64_t total_n,
+    int32_t* __restrict__ clique, uint64_t* __restrict__ alive_a, int do_peel) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const ProbDesc d = descs[blockIdx.x];
+  const int n = d.n, W = d.W;
+  uint64_t* memb = reinterpret_cast<uint64_t*>(smem);  // W
+  int* wcnt = reinterpret_cast<int*>(memb + ((W + 1) & ~1));  // 256
+  int* red4 = wcnt + 256;
+  ProbState* st = states + blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int best = 0, bs = -1;
+  for (int s = 0; s < kMaxStarts; ++s) {
+    const int sz = st->start_size[s];
+    if (sz > best) {
+      best = sz;
+      bs = s;
+    }
+  }
+  if (n == 1 && best == 0) {  // single vertex: the clique is that vertex
+    if (tid == 0) {
+      clique[d.pt_off] = 0;
+      st->lb = 1;
+      st->clique_size = 1;
+      st->proven = 1;
+      st->peel_done = 1;
+    }
+    return;
+  }
+  for (int w = tid; w < W; w += 256) memb[w] = 0;
+  __syncthreads();
+  if (bs >= 0) {
+    const int32_t* C = start_cliques + (int64_t)bs * total_n + d.pt_off;
+    for (int k = tid; k < best; k += 256) {
+      const int u = C[k];
+      atomicOr(reinterpret_cast<unsigned long long*>(&memb[u >> 6]), 1ull << (u & 63));
+    }
+  }
+  __syncthreads();
+  // enumerate members in ascending order
+  const int wpt = (W + 255) / 256;
+  const int w0 = tid * wpt, w1 = min(W, w0 + wpt);
+  int mycnt = 0;
+  for (int w = w0; w < w1; ++w) mycnt += __popcll(memb[w]);
+  wcnt[tid] = mycnt;
+  __syncthreads();
+  if (wave == 0) {
+    int a0 = wcnt[4 * lane], a1 = wcnt[4 * lane + 1], a2 = wcnt[4 * lane + 2],
+        a3 = wcnt[4 * lane + 3];
+    int tot = a0 + a1 + a2 + a3, incl = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    int ex = incl - tot;
+    wcnt[4 * lane] = ex;
+    wcnt[4 * lane + 1] = ex + a0;
+    wcnt[4 * lane + 2] = ex + a0 + a1;
+    wcnt[4 * lane + 3] = ex + a0 + a1 + a2;
+  }
+  __syncthreads();
+  {
+    int pos = wcnt[tid];
+    int32_t* out = clique + d.pt_off;
+    for (int w = w0; w < w1; ++w) {
+      uint64_t bits = memb[w];
+      while (bits) {
+        out[pos++] = w * 64 + __builtin_ctzll(bits);
+        bits &= bits - 1;
+      }
+    }
+  }
+  // peel init: alive = { v : deg(v) >= lb }   (a clique of lb+1 needs degree >= lb)
+  int alive = 0;
+  if (do_peel) {
+    const int32_t* dg = deg + d.pt_off;
+    uint64_t* al = alive_a + d.w_off;
+    for (int w = tid; w < W; w += 256) {
+      uint64_t bits = 0;
+      const int vmax = min(64, n - w * 64);
+      for (int b = 0; b < vmax; ++b) bits |= (uint64_t)(dg[w * 64 + b] >= best ? 1 : 0) << b;
+      al[w] = bits;
+      alive += __popcll(bits);
+    }
+    alive = block_sum_i(alive, red4);
+  }
+  if (tid == 0) {
+    st->lb = best;
+    st->best_start = bs;
+    st->clique_size = best;
+    st->alive_count = alive;
+    const int closed = do_peel ? (alive <= best) : 0;
+    st->proven = closed;
+    st->peel_done = do_peel ? closed : 1;
+  }
+}
+
+void launch_heuristic(hipStream_t s, const ProbDesc* d_desc, int batch, int max_W,
+                      const uint64_t* d_bitmap, const int32_t* d_deg, ProbState* d_state,
+                      int32_t* d_start_cliques, int64_t total_n, int32_t* d_cand,
+                      int32_t* d_clique) {
+  if (batch <= 0) return;
+  const int Wpad = (max_W + 1) & ~1;
+  const size_t lds = (size_t)Wpad * 8 + 4 * 8 + (size_t)kDynThreshold * 4 * 2 + 4 * 4 + 8 * 4 +
+                     256 * 4;
+  hipLaunchKernelGGL(greedy_clique_kernel, dim3(kMaxStarts, batch), dim3(256), lds, s, d_desc,
+                     d_bitmap, d_deg, d_state, d_start_cliques, total_n);
+}
+
+// ------------------------------------------------------------------------------------------
+// peel rounds at threshold lb: a vertex stays alive iff it has >= lb alive neighbours.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void peel_round_kernel(const ProbDesc* __restrict__ descs,
+                                                         const uint64_t* __restrict__ bitmap,
+                                                         ProbState* __restrict__ states,
+                                                         const uint64_t* __restrict__ cur_mask,
+                                                         uint64_t* __restrict__ nxt_mask,
+                                                         int32_t* __restrict__ next_count) {
+  __shared__ unsigned long long neww;
+  const ProbDesc d = descs[blockIdx.y];
+  const int tile = blockIdx.x;
+  if (tile >= d.W) return;
+  const ProbState* st = states + blockIdx.y;
+  if (st->peel_done) return;
+  const uint64_t* cur = cur_mask + d.w_off;
+  const uint64_t aw = cur[tile];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) neww = 0;
+  __syncthreads();
+  if (aw) {
+    const int lb = st->lb;
+    const uint64_t* bm = bitmap + d.bm_off;
+    for (int r = wave; r < 64; r += 4) {
+      if (!((aw >> r) & 1ull)) continue;
+      const uint64_t* row = bm + (int64_t)(tile * 64 + r) * d.W;
+      int c = 0;
+      for (int w = lane; w < d.W; w += 64) c += __popcll(row[w] & cur[w]);
+      c = wave_sum_i(c);
+      if (lane == 0 && c >= lb) atomicOr(&neww, 1ull << r);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    nxt_mask[d.w_off + tile] = neww;
+    if (neww) atomicAdd(next_count + blockIdx.y, __popcll(neww));
+  }
+}
+
+__global__ void peel_finish_kernel(ProbState* __restrict__ states, int32_t* __restrict__ next_count,
+                                   int batch) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= batch) return;
+  ProbState* st = states + p;
+  if (!st->peel_done) {
+    const int c = next_count[p];
+    if (c == st->alive_count) st->peel_done = 1;  // fixpoint
+    st->alive_count = c;
+    if (c <= st->lb) {
+      st->proven = 1;
+      st->peel_done = 1;
+    }
+  }
+  next_count[p] = 0;
+}
+
+void launch_select_best(hipStream_t s, const ProbDesc* d_desc, int batch, int max_W,
+                        const int32_t* d_deg, ProbState* d_state, const int32_t* d_start_cliques,
+                        int64_t total_n, int32_t* d_clique, uint64_t* d_alive_a, int do_peel) {
+  if (batch <= 0) return;
+  const size_t lds = (size_t)((max_W + 1) & ~1) * 8 + 256 * 4 + 4 * 4;
+  hipLaunchKernelGGL(select_best_kernel, dim3(batch), dim3(256), lds, s, d_desc, d_deg, d_state,
+                     d_start_cliques, total_n, d_clique, d_alive_a, do_peel);
+}
+
+void launch_peel_rounds(hipStream_t s, const ProbDesc* d_desc, int batch, int max_W,
+                        const uint64_t* d_bitmap, ProbState* d_state, uint64_t* d_alive_a,
+                        uint64_t* d_alive_b, int32_t* d_next_count, int rounds) {
+  if (batch <= 0) return;
+  uint64_t* cur = d_alive_a;
+  uint64_t* nxt = d_alive_b;
+  for (int r = 0; r < rounds; ++r) {
+    hipLaunchKernelGGL(peel_round_kernel, dim3(max_W, batch), dim3(256), 0, s, d_desc, d_bitmap,
+                       d_state, cur, nxt, d_next_count);
+    hipLaunchKernelGGL(peel_finish_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, d_state,
+                       d_next_count, batch);
+    uint64_t* t = cur;
+    cur = nxt;
+    nxt = t;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// estimate_scaling = true, first half of TLSScaleSolver::solveForScale (registration.cc:415-422):
+// raw_scales[k] = |b_k| / |a_k|, alphas[k] = beta * (1/|a_k|) for every TIM k in the reference's
+// pair order k = i*n - i(i+1)/2 + (j-i-1) (registration.cc:531).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void trims_kernel(const double* __restrict__ src,
+                                                    const double* __restrict__ dst, int n,
+                                                    double beta, double* __restrict__ raw,
+                                                    double* __restrict__ alpha) {
+  const int i = blockIdx.x;
+  if (i >= n - 1) return;
+  const int64_t seg = (int64_t)i * n - (int64_t)i * (i + 1) / 2;
+  const double six = src[3 * i], siy = src[3 * i + 1], siz = src[3 * i + 2];
+  const double dix = dst[3 * i], diy = dst[3 * i + 1], diz = dst[3 * i + 2];
+  for (int j = i + 1 + threadIdx.x; j < n; j += 256) {
+    const double ax = src[3 * j] - six, ay = src[3 * j + 1] - siy, az = src[3 * j + 2] - siz;
+    const double bx = dst[3 * j] - dix, by = dst[3 * j + 1] - diy, bz = dst[3 * j + 2] - diz;
+    const double v1 = __builtin_sqrt((ax * ax + ay * ay) + az * az);
+    const double v2 = __builtin_sqrt((bx * bx + by * by) + bz * bz);
+    const int64_t k = seg + (j - i - 1);
+    raw[k] = v2 / v1;
+    alpha[k] = beta * (1.0 / v1);
+  }
+}
+
+void launch_trims(hipStream_t s, const double* d_src, const double* d_dst, int n, double beta,
+                  double* d_raw, double* d_alpha) {
+  if (n < 2) return;
+  hipLaunchKernelGGL(trims_kernel, dim3(n - 1), dim3(256), 0, s, d_src, d_dst, n, beta, d_raw,
+                     d_alpha);
+}
+
+// inlier_selection_mode = NONE (registration.cc:648-654): every measurement is in the "clique"
+__global__ void fill_identity_clique_kernel(const ProbDesc* __restrict__ descs,
+                                            int32_t* __restrict__ clique,
+                                            ProbState* __restrict__ states) {
+  const ProbDesc d = descs[blockIdx.y];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < d.n) clique[d.pt_off + i] = i;
+  if (i == 0) {
+    ProbState* st = states + blockIdx.y;
+    st->lb = d.n;
+    st->clique_size = d.n;
+    st->proven = 1;
+    st->peel_done = 1;
+  }
+}
+
+void launch_fill_identity_clique(hipStream_t s, const ProbDesc* d_desc, int batch, int max_n,
+                                 int32_t* d_clique, ProbState* d_state) {
+  if (batch <= 0) return;
+  const int bx = max_n > 0 ? (max_n + 255) / 256 : 1;
+  hipLaunchKernelGGL(fill_identity_clique_kernel, dim3(bx, batch), dim3(256), 0, s, d_desc,
+                     d_clique, d_state);
+}
+
+}  // namespace thip

@@ -1,0 +1,1041 @@
+// solver.hip -- host orchestration + C ABI (include/teaser_hip.h) of the MI355X-native
+// TEASER++ solve() hot path.  Mirrors the stage order of
+// teaser::RobustRegistrationSolver::solve (reference teaser/src/registration.cc:568-737):
+//   TIMs + scale stage  ->  inlier graph  ->  maximum clique  ->  rotation  ->  translation.
+// Everything numeric runs in HIP kernels on the handle's stream; there is no CPU fallback:
+// without a GPU teaser_hip_solver_create fails with TEASER_HIP_ERR_NO_DEVICE.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "internal.h"
+
+namespace thip {
+// launchers defined in the kernel files but not declared in internal.h
+void launch_select_best(hipStream_t s, const ProbDesc* d_desc, int batch, int max_W,
+                        const int32_t* d_deg, ProbState* d_state, const int32_t* d_start_cliques,
+                        int64_t total_n, int32_t* d_clique, uint64_t* d_alive_a, int do_peel);
+void launch_peel_rounds(hipStream_t s, const ProbDesc* d_desc, int batch, int max_W,
+                        const uint64_t* d_bitmap, ProbState* d_state, uint64_t* d_alive_a,
+                        uint64_t* d_alive_b, int32_t* d_next_count, int rounds);
+void launch_gather_points(hipStream_t s, const double* d_src, const double* d_dst,
+                          const int32_t* d_order, int n, double* d_osrc, double* d_odst);
+void launch_gather_bitmap(hipStream_t s, const uint64_t* d_in, int W_in, const int32_t* d_order,
+                          int n, uint64_t* d_out, int W_out);
+void launch_gnc_tls_raw(hipStream_t s, const double* d_src, const double* d_dst, int K,
+                        double noise_bound, EstParams ep, double* d_w, double* d_out,
+                        int32_t* d_iters);
+void launch_trims(hipStream_t s, const double* d_src, const double* d_dst, int n, double beta,
+                  double* d_raw, double* d_alpha);
+void launch_fill_identity_clique(hipStream_t s, const ProbDesc* d_desc, int batch, int max_n,
+                                 int32_t* d_clique, ProbState* d_state);
+}  // namespace thip
+
+using namespace thip;
+
+namespace {
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+      e = hipMalloc(&p, bytes);
+      want = bytes;
+    }
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <typename T>
+  T* as() const {
+    return reinterpret_cast<T*>(p);
+  }
+};
+
+enum Stage { ST_H2D = 0, ST_TIM, ST_DEG, ST_HEU, ST_PEEL, ST_EXACT, ST_ROT, ST_TRANS, ST_D2H, ST_COUNT };
+
+}  // namespace
+
+struct teaser_hip_solver {
+  teaser_params_c params;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  bool profiling = false;
+  teaser_profile_c prof;
+  std::vector<hipEvent_t> ev_pool;
+  struct Span { int stage; hipEvent_t a, b; };
+  std::vector<Span> spans;
+  size_t ev_used = 0;
+
+  // last batch
+  int batch = 0;
+  int max_n = 0, max_W = 0;
+  int64_t total_n = 0, total_bm = 0, total_w = 0, total_tims = 0;
+  std::vector<ProbDesc> descs;
+  std::vector<ProbState> states;
+  std::vector<int64_t> tim_off;
+  std::vector<int32_t> exact_run;
+  std::vector<int32_t> heu_size;
+  std::vector<int32_t> prob_status;
+  const double* cur_src = nullptr;  // device pointers of the current inputs
+  const double* cur_dst = nullptr;
+  bool have_graph = false;
+
+  DevBuf d_desc, d_state, d_src, d_dst, d_bitmap, d_deg, d_clique, d_start_cliques, d_alive_a,
+      d_alive_b, d_next_count, d_weights, d_rot_inl, d_trans_inl, d_tls_scratch, d_tim_off;
+  // exact stage
+  DevBuf x_order, x_src, x_dst, x_bitmap, x_desc, x_state, x_ctrl, x_clique, x_arena;
+  // stand-alone stages
+  DevBuf s_a, s_b, s_c, s_d, s_e;
+};
+
+namespace {
+
+#define HIPCHK(h, call)                                                                     \
+  do {                                                                                      \
+    hipError_t _e = (call);                                                                 \
+    if (_e != hipSuccess) {                                                                 \
+      (h)->err = std::string(#call) + ": " + hipGetErrorString(_e);                         \
+      return _e == hipErrorOutOfMemory ? TEASER_HIP_ERR_OOM : TEASER_HIP_ERR_HIP;           \
+    }                                                                                       \
+  } while (0)
+
+struct StageScope {
+  teaser_hip_solver* h;
+  bool on;
+  hipEvent_t a = nullptr, b = nullptr;
+  int stage;
+  StageScope(teaser_hip_solver* hh, int st) : h(hh), on(hh->profiling), stage(st) {
+    if (!on) return;
+    if (h->ev_used + 2 > h->ev_pool.size()) {
+      for (int i = 0; i < 16; ++i) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) {
+          on = false;
+          return;
+        }
+        h->ev_pool.push_back(e);
+      }
+    }
+    a = h->ev_pool[h->ev_used++];
+    b = h->ev_pool[h->ev_used++];
+    (void)hipEventRecord(a, h->stream);
+  }
+  ~StageScope() {
+    if (!on) return;
+    (void)hipEventRecord(b, h->stream);
+    h->spans.push_back({stage, a, b});
+  }
+};
+
+void profile_begin(teaser_hip_solver* h) {
+  memset(&h->prof, 0, sizeof(h->prof));
+  h->spans.clear();
+  h->ev_used = 0;
+}
+
+void profile_end(teaser_hip_solver* h) {
+  if (!h->profiling) return;
+  float* slot[ST_COUNT] = {&h->prof.h2d_ms,  &h->prof.tim_graph_ms, &h->prof.degree_ms,
+                           &h->prof.heuristic_ms, &h->prof.peel_ms, &h->prof.exact_ms,
+                           &h->prof.rotation_ms, &h->prof.translation_ms, &h->prof.d2h_ms};
+  for (auto& s : h->spans) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+      *slot[s.stage] += ms;
+      h->prof.total_ms += ms;
+      if (s.stage == ST_TIM) h->prof.tim_graph_launches++;
+    }
+  }
+}
+
+bool params_supported(const teaser_params_c& p) {
+  return p.rotation_estimation_algorithm == TEASER_ROT_GNC_TLS;
+}
+
+int effective_mode(const teaser_params_c& p) {
+  int mode = p.inlier_selection_mode;
+  if (!p.use_max_clique) mode = TEASER_INLIER_NONE;            // registration.cc:574-578
+  if (!p.max_clique_exact_solution) mode = TEASER_INLIER_PMC_HEU;  // registration.cc:579-583
+  return mode;
+}
+
+EstParams est_params(const teaser_params_c& p) {
+  EstParams ep;
+  ep.noise_bound = p.noise_bound;
+  ep.cbar2 = p.cbar2;
+  ep.gnc_factor = p.rotation_gnc_factor;
+  ep.cost_threshold = p.rotation_cost_threshold;
+  ep.max_iterations = p.rotation_max_iterations;
+  ep.tim_graph = p.rotation_tim_graph;
+  ep.pad = 0;
+  return ep;
+}
+
+int64_t tls_scratch_bytes(int n) {
+  const int64_t Kp = (n + 1) & ~1;
+  int64_t P2 = 2;
+  while (P2 < 2 * (int64_t)n) P2 <<= 1;
+  return 3 * Kp * 8 + 3 * Kp + 16 + 3 * (P2 * 12 + 16) + 64;
+}
+
+// --------------------------------------------------------------------------------------------
+// Exact stage for one problem whose greedy bound the peel could not close (graph.cc:104-122).
+// --------------------------------------------------------------------------------------------
+int32_t run_exact_on_compact(teaser_hip_solver* h, const uint64_t* d_cbitmap, int n2, int W2,
+                             int lb, int max_deg, std::vector<int32_t>& best_local,
+                             int* status_out) {
+  hipStream_t s = h->stream;
+  // control words: [0] incumbent size, [1] recorded size, [2] lock, [3] root counter, [4] status
+  int32_t ctrl[8] = {lb, lb, 0, 0, 0, 0, 0, 0};
+  HIPCHK(h, h->x_ctrl.ensure(sizeof(ctrl)));
+  HIPCHK(h, h->x_clique.ensure((size_t)(n2 + 1) * 4));
+  int n_waves = 2048;
+  int64_t depth_guess = std::min<int64_t>((int64_t)lb + 96, (int64_t)n2 + 1);
+  int64_t arena = (int64_t)(n2 + 1) * 4 + depth_guess * (64 + (int64_t)W2 * 8 + 16) +
+                  8 * (int64_t)max_deg * 8 + (1 << 16);
+  arena = (arena + 255) & ~(int64_t)255;
+  const int64_t kTotalCap = (int64_t)24 << 30;
+  best_local.clear();
+  *status_out = 0;
+  for (int attempt = 0; attempt < 8; ++attempt) {
+    while ((int64_t)n_waves * arena > kTotalCap && n_waves > 64) n_waves /= 2;
+    if ((int64_t)n_waves * arena > kTotalCap) {
+      *status_out = 1;
+      break;
+    }
+    HIPCHK(h, h->x_arena.ensure((size_t)n_waves * (size_t)arena));
+    ctrl[3] = 0;
+    ctrl[4] = 0;
+    HIPCHK(h, hipMemcpyAsync(h->x_ctrl.p, ctrl, sizeof(ctrl), hipMemcpyHostToDevice, s));
+    ExactArgs a;
+    a.bitmap = d_cbitmap;
+    a.n = n2;
+    a.W = W2;
+    a.best_size = h->x_ctrl.as<int32_t>();
+    a.best_clique = h->x_clique.as<int32_t>();
+    a.root_counter = h->x_ctrl.as<int32_t>() + 3;
+    a.status = h->x_ctrl.as<int32_t>() + 4;
+    a.arena = h->x_arena.as<char>();
+    a.arena_bytes = arena;
+    a.n_waves = n_waves;
+    const double lim = h->params.max_clique_time_limit;
+    a.deadline_ticks = (lim > 0 && lim < 1e7) ? (int64_t)(lim * 1e8) : 0;  // 100 MHz counter
+    launch_exact_clique(s, a);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(ctrl, h->x_ctrl.p, sizeof(ctrl), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    if (ctrl[4] == 1) {  // arena overflow: keep the incumbent, retry with a larger arena
+      arena *= 4;
+      ctrl[0] = ctrl[1];
+      ctrl[2] = 0;
+      continue;
+    }
+    *status_out = ctrl[4];
+    break;
+  }
+  if (ctrl[1] > lb) {
+    best_local.resize((size_t)ctrl[1]);
+    HIPCHK(h, hipMemcpy(best_local.data(), h->x_clique.p, (size_t)ctrl[1] * 4, hipMemcpyDeviceToHost));
+  }
+  return TEASER_HIP_OK;
+}
+
+int32_t exact_stage(teaser_hip_solver* h, int p, const uint64_t* d_final_alive) {
+  hipStream_t s = h->stream;
+  const ProbDesc d = h->descs[(size_t)p];
+  ProbState& st = h->states[(size_t)p];
+  const int n = d.n, W = d.W;
+  std::vector<int32_t> deg((size_t)n);
+  std::vector<uint64_t> alive((size_t)W);
+  HIPCHK(h, hipMemcpy(deg.data(), h->d_deg.as<int32_t>() + d.pt_off, (size_t)n * 4, hipMemcpyDeviceToHost));
+  HIPCHK(h, hipMemcpy(alive.data(), d_final_alive + d.w_off, (size_t)W * 8, hipMemcpyDeviceToHost));
+  std::vector<int32_t> order;
+  order.reserve((size_t)st.alive_count);
+  int max_deg = 0;
+  for (int v = 0; v < n; ++v)
+    if ((alive[(size_t)(v >> 6)] >> (v & 63)) & 1ull) {
+      order.push_back(v);
+      max_deg = std::max(max_deg, deg[(size_t)v]);
+    }
+  std::stable_sort(order.begin(), order.end(),
+                   [&](int32_t a, int32_t b) { return deg[(size_t)a] < deg[(size_t)b]; });
+  const int n2 = (int)order.size();
+  if (n2 <= st.lb) return TEASER_HIP_OK;
+  const int W2 = (n2 + 63) / 64;
+  HIPCHK(h, h->x_order.ensure((size_t)n2 * 4));
+  HIPCHK(h, h->x_src.ensure((size_t)n2 * 24));
+  HIPCHK(h, h->x_dst.ensure((size_t)n2 * 24));
+  HIPCHK(h, h->x_bitmap.ensure((size_t)n2 * (size_t)W2 * 8));
+  HIPCHK(h, h->x_desc.ensure(sizeof(ProbDesc)));
+  HIPCHK(h, h->x_state.ensure(sizeof(ProbState)));
+  HIPCHK(h, hipMemcpyAsync(h->x_order.p, order.data(), (size_t)n2 * 4, hipMemcpyHostToDevice, s));
+  launch_gather_points(s, h->cur_src + 3 * d.pt_off, h->cur_dst + 3 * d.pt_off,
+                       h->x_order.as<int32_t>(), n2, h->x_src.as<double>(), h->x_dst.as<double>());
+  ProbDesc d2;
+  d2.n = n2;
+  d2.W = W2;
+  d2.pt_off = 0;
+  d2.bm_off = 0;
+  d2.w_off = 0;
+  HIPCHK(h, hipMemcpyAsync(h->x_desc.p, &d2, sizeof(d2), hipMemcpyHostToDevice, s));
+  HIPCHK(h, hipMemcpyAsync(h->x_state.p, &st, sizeof(st), hipMemcpyHostToDevice, s));
+  {
+    StageScope sc(h, ST_TIM);
+    launch_tim_graph(s, h->x_desc.as<ProbDesc>(), 1, n2, h->x_src.as<double>(), h->x_dst.as<double>(),
+                     h->x_bitmap.as<uint64_t>(), h->params.noise_bound, h->params.cbar2,
+                     h->params.estimate_scaling ? 1 : 0, h->x_state.as<ProbState>());
+  }
+  std::vector<int32_t> best_local;
+  int xstatus = 0;
+  int32_t rc = run_exact_on_compact(h, h->x_bitmap.as<uint64_t>(), n2, W2, st.lb, max_deg,
+                                    best_local, &xstatus);
+  if (rc != TEASER_HIP_OK) return rc;
+  if (xstatus == 1) h->prob_status[(size_t)p] = TEASER_HIP_ERR_SCRATCH;
+  if (xstatus == 2) h->prob_status[(size_t)p] = TEASER_HIP_ERR_TIME_LIMIT;
+  if (!best_local.empty()) {
+    std::vector<int32_t> cl(best_local.size());
+    for (size_t k = 0; k < best_local.size(); ++k) cl[k] = order[(size_t)best_local[k]];
+    std::sort(cl.begin(), cl.end());  // registration.cc:636
+    HIPCHK(h, hipMemcpy(h->d_clique.as<int32_t>() + d.pt_off, cl.data(), cl.size() * 4,
+                        hipMemcpyHostToDevice));
+    st.clique_size = (int32_t)cl.size();
+  }
+  return TEASER_HIP_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// estimate_scaling = true: TRIMs + scalar TLS over all M pairs (registration.cc:410-425)
+// --------------------------------------------------------------------------------------------
+constexpr int kMaxScaledN = 724;  // M = n(n-1)/2 <= 2^18 pairs sorted by one workgroup (round 1)
+
+int32_t scale_stage(teaser_hip_solver* h, int p) {
+  hipStream_t s = h->stream;
+  const ProbDesc d = h->descs[(size_t)p];
+  const int n = d.n;
+  const int64_t M = (int64_t)n * (n - 1) / 2;
+  if (M < 1) return TEASER_HIP_OK;
+  if (n > kMaxScaledN) {
+    h->err = "estimate_scaling=true is limited to n <= 724 correspondences in this build";
+    return TEASER_HIP_ERR_UNSUPPORTED;
+  }
+  int64_t P2 = 2;
+  while (P2 < 2 * M) P2 <<= 1;
+  HIPCHK(h, h->s_a.ensure((size_t)M * 8));
+  HIPCHK(h, h->s_b.ensure((size_t)M * 8));
+  HIPCHK(h, h->s_c.ensure((size_t)P2 * 12 + 64));
+  const double beta = 2 * h->params.noise_bound * std::sqrt(h->params.cbar2);
+  launch_trims(s, h->cur_src + 3 * d.pt_off, h->cur_dst + 3 * d.pt_off, n, beta,
+               h->s_a.as<double>(), h->s_b.as<double>());
+  double* d_scale = &(h->d_state.as<ProbState>()[p].scale);
+  launch_scalar_tls(s, h->s_a.as<double>(), h->s_b.as<double>(), (int32_t)M, h->s_c.as<char>(),
+                    d_scale, nullptr);
+  return TEASER_HIP_OK;
+}
+
+// --------------------------------------------------------------------------------------------
+// the batched pipeline; inputs are device-resident and packed
+// --------------------------------------------------------------------------------------------
+int32_t solve_packed(teaser_hip_solver* h, const double* d_src, const double* d_dst,
+                     const int64_t* pt_off, const int32_t* n, int batch, teaser_solution_c* out) {
+  hipStream_t s = h->stream;
+  const teaser_params_c& P = h->params;
+  if (!params_supported(P)) {
+    h->err = "only rotation_estimation_algorithm = GNC_TLS is on the MI355X hot path";
+    return TEASER_HIP_ERR_UNSUPPORTED;
+  }
+  const int mode = effective_mode(P);
+  h->batch = batch;
+  h->descs.assign((size_t)batch, ProbDesc());
+  h->states.assign((size_t)batch, ProbState());
+  h->tim_off.assign((size_t)batch, 0);
+  h->exact_run.assign((size_t)batch, 0);
+  h->heu_size.assign((size_t)batch, 0);
+  h->prob_status.assign((size_t)batch, TEASER_HIP_OK);
+  h->cur_src = d_src;
+  h->cur_dst = d_dst;
+  h->have_graph = false;
+  int64_t bm = 0, wo = 0, tims = 0, maxpt = 0;
+  int max_n = 0;
+  for (int b = 0; b < batch; ++b) {
+    if (n[b] < 0) return TEASER_HIP_ERR_BAD_ARG;
+    ProbDesc& d = h->descs[(size_t)b];
+    d.n = n[b];
+    d.W = (n[b] + 63) / 64;
+    d.pt_off = pt_off[b];
+    d.bm_off = bm;
+    d.w_off = wo;
+    bm += (int64_t)d.n * d.W;
+    wo += d.W;
+    h->tim_off[(size_t)b] = tims;
+    const int64_t kt = P.rotation_tim_graph == TEASER_TIM_CHAIN ? (int64_t)d.n
+                                                                : (int64_t)d.n * (d.n - 1) / 2;
+    tims += kt + 2;
+    max_n = std::max(max_n, d.n);
+    maxpt = std::max<int64_t>(maxpt, d.pt_off + d.n);
+    ProbState& st = h->states[(size_t)b];
+    memset(&st, 0, sizeof(st));
+    st.scale = 1.0;
+    st.R[0] = st.R[4] = st.R[8] = 1.0;
+    st.gnc_cost = INFINITY;
+    for (int k = 0; k < kMaxStarts; ++k) st.start_vertex[k] = -1;
+  }
+  if (tims > ((int64_t)1 << 31)) {
+    h->err = "rotation_tim_graph = COMPLETE needs too many TIMs for this batch";
+    return TEASER_HIP_ERR_UNSUPPORTED;
+  }
+  h->max_n = max_n;
+  h->max_W = (max_n + 63) / 64;
+  h->total_n = maxpt;
+  h->total_bm = bm;
+  h->total_w = wo;
+  h->total_tims = tims;
+  const int max_W = h->max_W;
+  const int64_t total_n = std::max<int64_t>(maxpt, 1);
+
+  HIPCHK(h, h->d_desc.ensure(sizeof(ProbDesc) * (size_t)batch));
+  HIPCHK(h, h->d_state.ensure(sizeof(ProbState) * (size_t)batch));
+  HIPCHK(h, h->d_tim_off.ensure(8 * (size_t)batch));
+  HIPCHK(h, h->d_clique.ensure(4 * (size_t)total_n));
+  HIPCHK(h, h->d_weights.ensure(8 * (size_t)std::max<int64_t>(tims, 1)));
+  HIPCHK(h, h->d_rot_inl.ensure(4 * (size_t)std::max<int64_t>(tims, 1)));
+  HIPCHK(h, h->d_trans_inl.ensure(4 * (size_t)total_n));
+  const int64_t tls_stride = tls_scratch_bytes(std::max(max_n, 1));
+  HIPCHK(h, h->d_tls_scratch.ensure((size_t)tls_stride * (size_t)batch));
+  const bool need_graph = (mode != TEASER_INLIER_NONE) && max_n >= 1;
+  if (need_graph) {
+    HIPCHK(h, h->d_bitmap.ensure(8 * (size_t)std::max<int64_t>(bm, 1)));
+    HIPCHK(h, h->d_deg.ensure(4 * (size_t)total_n));
+    HIPCHK(h, h->d_start_cliques.ensure(4 * (size_t)total_n * kMaxStarts));
+    HIPCHK(h, h->d_alive_a.ensure(8 * (size_t)std::max<int64_t>(wo, 1)));
+    HIPCHK(h, h->d_alive_b.ensure(8 * (size_t)std::max<int64_t>(wo, 1)));
+    HIPCHK(h, h->d_next_count.ensure(4 * (size_t)batch));
+  }
+  {
+    StageScope sc(h, ST_H2D);
+    HIPCHK(h, hipMemcpyAsync(h->d_desc.p, h->descs.data(), sizeof(ProbDesc) * (size_t)batch,
+                             hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(h->d_state.p, h->states.data(), sizeof(ProbState) * (size_t)batch,
+                             hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(h->d_tim_off.p, h->tim_off.data(), 8 * (size_t)batch,
+                             hipMemcpyHostToDevice, s));
+    if (need_graph) HIPCHK(h, hipMemsetAsync(h->d_next_count.p, 0, 4 * (size_t)batch, s));
+  }
+  const ProbDesc* dd = h->d_desc.as<ProbDesc>();
+  ProbState* ds = h->d_state.as<ProbState>();
+  const EstParams ep = est_params(P);
+
+  if (P.estimate_scaling) {
+    StageScope sc(h, ST_TIM);
+    for (int b = 0; b < batch; ++b) {
+      int32_t rc = scale_stage(h, b);
+      if (rc != TEASER_HIP_OK) return rc;
+    }
+  }
+  if (need_graph) {
+    {
+      StageScope sc(h, ST_TIM);
+      launch_tim_graph(s, dd, batch, max_n, d_src, d_dst, h->d_bitmap.as<uint64_t>(), P.noise_bound,
+                       P.cbar2, P.estimate_scaling ? 1 : 0, ds);
+    }
+    for (int b = 0; b < batch; ++b) {
+      const int64_t nn = h->descs[(size_t)b].n;
+      h->prof.tim_graph_pairs += nn * (nn - 1) / 2;
+      h->prof.tim_graph_bytes += 48 * nn + 8 * nn * ((nn + 63) / 64);
+    }
+    {
+      StageScope sc(h, ST_DEG);
+      launch_degrees(s, dd, batch, max_n, h->d_bitmap.as<uint64_t>(), h->d_deg.as<int32_t>(), ds);
+      launch_pick_starts(s, dd, batch, h->d_deg.as<int32_t>(), ds);
+    }
+    {
+      StageScope sc(h, ST_HEU);
+      launch_heuristic(s, dd, batch, max_W, h->d_bitmap.as<uint64_t>(), h->d_deg.as<int32_t>(), ds,
+                       h->d_start_cliques.as<int32_t>(), total_n, nullptr, h->d_clique.as<int32_t>());
+      launch_select_best(s, dd, batch, max_W, h->d_deg.as<int32_t>(), ds,
+                         h->d_start_cliques.as<int32_t>(), total_n, h->d_clique.as<int32_t>(),
+                         h->d_alive_a.as<uint64_t>(), mode == TEASER_INLIER_PMC_EXACT ? 1 : 0);
+    }
+    if (mode == TEASER_INLIER_PMC_EXACT) {
+      StageScope sc(h, ST_PEEL);
+      launch_peel_rounds(s, dd, batch, max_W, h->d_bitmap.as<uint64_t>(), ds,
+                         h->d_alive_a.as<uint64_t>(), h->d_alive_b.as<uint64_t>(),
+                         h->d_next_count.as<int32_t>(), kPeelRounds);
+    }
+    h->have_graph = true;
+  } else {
+    launch_fill_identity_clique(s, dd, batch, max_n, h->d_clique.as<int32_t>(), ds);
+  }
+  HIPCHK(h, hipGetLastError());
+
+  auto run_estimators = [&]() -> int32_t {
+    {
+      StageScope sc(h, ST_ROT);
+      launch_gnc_tls(s, dd, batch, d_src, d_dst, h->d_clique.as<int32_t>(), ds, ep,
+                     h->d_weights.as<double>(), h->d_rot_inl.as<int32_t>(),
+                     h->d_tim_off.as<int64_t>());
+    }
+    {
+      StageScope sc(h, ST_TRANS);
+      launch_tls_translation(s, dd, batch, d_src, d_dst, h->d_clique.as<int32_t>(), ds, ep,
+                             h->d_tls_scratch.as<char>(), tls_stride, h->d_trans_inl.as<int32_t>());
+    }
+    HIPCHK(h, hipGetLastError());
+    {
+      StageScope sc(h, ST_D2H);
+      HIPCHK(h, hipMemcpyAsync(h->states.data(), h->d_state.p, sizeof(ProbState) * (size_t)batch,
+                               hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(h, hipStreamSynchronize(s));
+    return TEASER_HIP_OK;
+  };
+  // speculative: the greedy clique is almost always the maximum one, so the estimators are
+  // enqueued before the host learns whether the peel closed the bound (one sync per solve)
+  int32_t rc = run_estimators();
+  if (rc != TEASER_HIP_OK) return rc;
+
+  for (int b = 0; b < batch; ++b) h->heu_size[(size_t)b] = h->states[(size_t)b].lb;
+  if (need_graph && mode == TEASER_INLIER_PMC_EXACT) {
+    bool changed = false;
+    const uint64_t* final_alive =
+        (kPeelRounds % 2 == 0) ? h->d_alive_a.as<uint64_t>() : h->d_alive_b.as<uint64_t>();
+    for (int b = 0; b < batch; ++b) {
+      ProbState& st = h->states[(size_t)b];
+      if (st.proven || h->descs[(size_t)b].n < 2) continue;
+      h->exact_run[(size_t)b] = 1;
+      const int before = st.clique_size;
+      {
+        StageScope sc(h, ST_EXACT);
+        rc = exact_stage(h, b, final_alive);
+      }
+      if (rc != TEASER_HIP_OK) return rc;
+      if (st.clique_size != before) {
+        changed = true;
+        HIPCHK(h, hipMemcpy(&ds[b].clique_size, &st.clique_size, 4, hipMemcpyHostToDevice));
+      }
+    }
+    if (changed) {
+      rc = run_estimators();
+      if (rc != TEASER_HIP_OK) return rc;
+    }
+  }
+
+  for (int b = 0; b < batch; ++b) {
+    const ProbState& st = h->states[(size_t)b];
+    teaser_solution_c& o = out[b];
+    memset(&o, 0, sizeof(o));
+    o.n = h->descs[(size_t)b].n;
+    o.status = h->prob_status[(size_t)b];
+    o.scale = st.scale;
+    o.clique_size = st.clique_size;
+    o.heuristic_size = h->heu_size[(size_t)b];
+    o.clique_exact_run = h->exact_run[(size_t)b];
+    o.num_edges = (int64_t)(st.deg_sum / 2);
+    if (st.clique_size <= 1) {  // registration.cc:643-647
+      o.valid = 0;
+      o.rotation[0] = o.rotation[4] = o.rotation[8] = 1.0;
+      o.gnc_cost = INFINITY;
+      continue;
+    }
+    o.valid = 1;
+    memcpy(o.rotation, st.R, sizeof(o.rotation));
+    memcpy(o.translation, st.t, sizeof(o.translation));
+    o.n_rotation_inliers = st.n_rot;
+    o.n_translation_inliers = st.n_trans;
+    o.gnc_cost = st.gnc_cost;
+    o.gnc_iterations = st.gnc_iters;
+  }
+  return TEASER_HIP_OK;
+}
+
+int32_t upload_and_solve(teaser_hip_solver* h, const double* const* src, const double* const* dst,
+                         const int32_t* n, int batch, teaser_solution_c* out) {
+  std::vector<int64_t> off((size_t)batch);
+  int64_t tot = 0;
+  for (int b = 0; b < batch; ++b) {
+    if (n[b] < 0 || (n[b] > 0 && (!src[b] || !dst[b]))) return TEASER_HIP_ERR_BAD_ARG;
+    off[(size_t)b] = tot;
+    tot += n[b];
+  }
+  profile_begin(h);
+  HIPCHK(h, h->d_src.ensure((size_t)std::max<int64_t>(tot, 1) * 24));
+  HIPCHK(h, h->d_dst.ensure((size_t)std::max<int64_t>(tot, 1) * 24));
+  {
+    StageScope sc(h, ST_H2D);
+    for (int b = 0; b < batch; ++b) {
+      if (n[b] == 0) continue;
+      HIPCHK(h, hipMemcpyAsync(h->d_src.as<double>() + 3 * off[(size_t)b], src[b], (size_t)n[b] * 24,
+                               hipMemcpyHostToDevice, h->stream));
+      HIPCHK(h, hipMemcpyAsync(h->d_dst.as<double>() + 3 * off[(size_t)b], dst[b], (size_t)n[b] * 24,
+                               hipMemcpyHostToDevice, h->stream));
+    }
+  }
+  int32_t rc = solve_packed(h, h->d_src.as<double>(), h->d_dst.as<double>(), off.data(), n, batch, out);
+  profile_end(h);
+  return rc;
+}
+
+template <typename T>
+int32_t copy_out(teaser_hip_solver* h, const T* d_ptr, int64_t count, T* buf, int64_t* len) {
+  if (!len) return TEASER_HIP_ERR_BAD_ARG;
+  const int64_t cap = *len;
+  *len = count;
+  if (!buf) return TEASER_HIP_OK;
+  if (cap < count) return TEASER_HIP_ERR_BAD_ARG;
+  if (count > 0) HIPCHK(h, hipMemcpy(buf, d_ptr, (size_t)count * sizeof(T), hipMemcpyDeviceToHost));
+  return TEASER_HIP_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+int32_t teaser_hip_abi_version(void) { return TEASER_HIP_ABI_VERSION; }
+
+int32_t teaser_hip_device_count(void) {
+  int c = 0;
+  if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+  return c;
+}
+
+int32_t teaser_hip_params_default(teaser_params_c* p) {
+  if (!p) return TEASER_HIP_ERR_BAD_ARG;
+  p->noise_bound = 0.01;  // registration.h:419-514
+  p->cbar2 = 1;
+  p->estimate_scaling = 1;
+  p->rotation_estimation_algorithm = TEASER_ROT_GNC_TLS;
+  p->rotation_gnc_factor = 1.4;
+  p->rotation_max_iterations = 100;
+  p->rotation_cost_threshold = 1e-6;
+  p->rotation_tim_graph = TEASER_TIM_CHAIN;
+  p->inlier_selection_mode = TEASER_INLIER_PMC_EXACT;
+  p->kcore_heuristic_threshold = 0.5;
+  p->use_max_clique = 1;
+  p->max_clique_exact_solution = 1;
+  p->max_clique_time_limit = 3600;
+  p->max_clique_num_threads = 0;
+  return TEASER_HIP_OK;
+}
+
+int32_t teaser_hip_solver_create(const teaser_params_c* params, int32_t device,
+                                 teaser_hip_solver** out) {
+  if (!out) return TEASER_HIP_ERR_BAD_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return TEASER_HIP_ERR_NO_DEVICE;
+  if (device < 0) {
+    if (hipGetDevice(&device) != hipSuccess) return TEASER_HIP_ERR_NO_DEVICE;
+  }
+  if (device >= count) return TEASER_HIP_ERR_BAD_ARG;
+  if (hipSetDevice(device) != hipSuccess) return TEASER_HIP_ERR_HIP;
+  teaser_hip_solver* h = new teaser_hip_solver();
+  h->device = device;
+  if (params)
+    h->params = *params;
+  else
+    teaser_hip_params_default(&h->params);
+  memset(&h->prof, 0, sizeof(h->prof));
+  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+    delete h;
+    return TEASER_HIP_ERR_HIP;
+  }
+  *out = h;
+  return TEASER_HIP_OK;
+}
+
+int32_t teaser_hip_solver_destroy(teaser_hip_solver* h) {
+  if (!h) return TEASER_HIP_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  DevBuf* bufs[] = {&h->d_desc, &h->d_state, &h->d_src, &h->d_dst, &h->d_bitmap, &h->d_deg,
+                    &h->d_clique, &h->d_start_cliques, &h->d_alive_a, &h->d_alive_b,
+                    &h->d_next_count, &h->d_weights, &h->d_rot_inl, &h->d_trans_inl,
+                    &h->d_tls_scratch, &h->d_tim_off, &h->x_order, &h->x_src, &h->x_dst,
+                    &h->x_bitmap, &h->x_desc, &h->x_state, &h->x_ctrl, &h->x_clique, &h->x_arena,
+                    &h->s_a, &h->s_b, &h->s_c, &h->s_d, &h->s_e};
+  for (DevBuf* b : bufs) b->release();
+  for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return TEASER_HIP_OK;
+}
+
+int32_t teaser_hip_solver_reset(teaser_hip_solver* h, const teaser_params_c* params) {
+  if (!h || !params) return TEASER_HIP_ERR_BAD_ARG;
+  h->params = *params;
+  h->batch = 0;  // reset() clears max_clique_/inliers/graph, registration.h:881-885
+  h->have_graph = false;
+  return TEASER_HIP_OK;
+}
+
+int32_t teaser_hip_solver_get_params(const teaser_hip_solver* h, teaser_params_c* params) {
+  if (!h || !params) return TEASER_HIP_ERR_BAD_ARG;
+  *params = h->params;
+  return TEASER_HIP_OK;
+}
+
+int32_t teaser_hip_solve(teaser_hip_solver* h, const double* src, const double* dst, int32_t n,
+                         teaser_solution_c* out) {
+  if (!h || !out || n < 0 || (n > 0 && (!src || !dst))) return TEASER_HIP_ERR_BAD_ARG;
+  (void)hipSetDevice(h->device);
+  const double* sp[1] = {src};
+  const double* dp[1] = {dst};
+  return upload_and_solve(h, sp, dp, &n, 1, out);
+}
+
+int32_t teaser_hip_solve_device(teaser_hip_solver* h, const double* d_src, const double* d_dst,
+                                int32_t n, teaser_solution_c* out) {
+  if (!h || !out || n < 0 || (n > 0 && (!d_src || !d_dst))) return TEASER_HIP_ERR_BAD_ARG;
+  (void)hipSetDevice(h->device);
+  int64_t off = 0;
+  profile_begin(h);
+  int32_t rc = solve_packed(h, d_src, d_dst, &off, &n, 1, out);
+  profile_end(h);
+  return rc;
+}
+
+int32_t teaser_hip_solve_correspondences(teaser_hip_solver* h, const float* src_cloud,
+                                         int32_t n_src, const float* dst_cloud, int32_t n_dst,
+                                         const int32_t* corr, int32_t n_corr,
+                                         teaser_solution_c* out) {
+  if (!h || !out || n_corr < 0 || (n_corr > 0 && (!src_cloud || !dst_cloud || !corr)))
+    return TEASER_HIP_ERR_BAD_ARG;
+  // registration.cc:557-565: gather + float -> double widening (O(C), done on the host)
+  std::vector<double> s((size_t)n_corr * 3), d((size_t)n_corr * 3);
+  for (int32_t i = 0; i < n_corr; ++i) {
+    const int32_t a = corr[2 * i], b = corr[2 * i + 1];
+    if (a < 0 || a >= n_src || b < 0 || b >= n_dst) return TEASER_HIP_ERR_BAD_ARG;
+    for (int r = 0; r < 3; ++r) {
+      s[3 * (size_t)i + r] = (double)src_cloud[3 * (size_t)a + r];
+      d[3 * (size_t)i + r] = (double)dst_cloud[3 * (size_t)b + r];
+    }
+  }
+  return teaser_hip_solve(h, s.data(), d.data(), n_corr, out);
+}
+
+int32_t teaser_hip_solve_batch(teaser_hip_solver* h, const double* const* src,
+                               const double* const* dst, const int32_t* n, int32_t batch,
+                               teaser_solution_c* out) {
+  if (!h || batch < 0 || (batch > 0 && (!src || !dst || !n || !out))) return TEASER_HIP_ERR_BAD_ARG;
+  if (batch == 0) return TEASER_HIP_OK;
+  (void)hipSetDevice(h->device);
+  return upload_and_solve(h, src, dst, n, batch, out);
+}
+
+int32_t teaser_hip_solve_batch_device(teaser_hip_solver* h, const double* d_src,
+                                      const double* d_dst, const int64_t* point_offset,
+                                      const int32_t* n, int32_t batch, teaser_solution_c* out) {
+  if (!h || batch < 0 || (batch > 0 && (!d_src || !d_dst || !point_offset || !n || !out)))
+    return TEASER_HIP_ERR_BAD_ARG;
+  if (batch == 0) return TEASER_HIP_OK;
+  (void)hipSetDevice(h->device);
+  profile_begin(h);
+  int32_t rc = solve_packed(h, d_src, d_dst, point_offset, n, batch, out);
+  profile_end(h);
+  return rc;
+}
+
+#define CHECK_PROBLEM(h, problem)                                            \
+  if (!(h) || (problem) < 0 || (problem) >= (h)->batch) return TEASER_HIP_ERR_BAD_ARG; \
+  (void)hipSetDevice((h)->device)
+
+int32_t teaser_hip_get_max_clique(teaser_hip_solver* h, int32_t problem, int32_t* buf, int64_t* len) {
+  CHECK_PROBLEM(h, problem);
+  const ProbDesc& d = h->descs[(size_t)problem];
+  return copy_out(h, h->d_clique.as<int32_t>() + d.pt_off, h->states[(size_t)problem].clique_size,
+                  buf, len);
+}
+
+int32_t teaser_hip_get_rotation_inliers(teaser_hip_solver* h, int32_t problem, int32_t* buf,
+                                        int64_t* len) {
+  CHECK_PROBLEM(h, problem);
+  const ProbState& st = h->states[(size_t)problem];
+  return copy_out(h, h->d_rot_inl.as<int32_t>() + h->tim_off[(size_t)problem],
+                  st.clique_size > 1 ? st.n_rot : 0, buf, len);
+}
+
+int32_t teaser_hip_get_translation_inliers(teaser_hip_solver* h, int32_t problem, int32_t* buf,
+                                           int64_t* len) {
+  CHECK_PROBLEM(h, problem);
+  const ProbDesc& d = h->descs[(size_t)problem];
+  const ProbState& st = h->states[(size_t)problem];
+  return copy_out(h, h->d_trans_inl.as<int32_t>() + d.pt_off, st.clique_size > 1 ? st.n_trans : 0,
+                  buf, len);
+}
+
+int32_t teaser_hip_get_input_ordered_translation_inliers(teaser_hip_solver* h, int32_t problem,
+                                                         int32_t* buf, int64_t* len) {
+  CHECK_PROBLEM(h, problem);
+  if (!len) return TEASER_HIP_ERR_BAD_ARG;
+  const ProbDesc& d = h->descs[(size_t)problem];
+  const ProbState& st = h->states[(size_t)problem];
+  const int64_t cnt = st.clique_size > 1 ? st.n_trans : 0;
+  const int64_t cap = *len;
+  *len = cnt;
+  if (!buf) return TEASER_HIP_OK;
+  if (cap < cnt) return TEASER_HIP_ERR_BAD_ARG;
+  std::vector<int32_t> ti((size_t)cnt), cl((size_t)st.clique_size);
+  if (cnt > 0) {
+    HIPCHK(h, hipMemcpy(ti.data(), h->d_trans_inl.as<int32_t>() + d.pt_off, (size_t)cnt * 4, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(cl.data(), h->d_clique.as<int32_t>() + d.pt_off, (size_t)st.clique_size * 4, hipMemcpyDeviceToHost));
+  }
+  for (int64_t k = 0; k < cnt; ++k) buf[k] = cl[(size_t)ti[(size_t)k]];  // registration.h:757-762
+  return TEASER_HIP_OK;
+}
+
+int32_t teaser_hip_get_inlier_graph_bitmap(teaser_hip_solver* h, int32_t problem, uint64_t* buf,
+                                           int64_t* len) {
+  CHECK_PROBLEM(h, problem);
+  if (!h->have_graph) {
+    if (len) *len = 0;
+    return len ? TEASER_HIP_OK : TEASER_HIP_ERR_BAD_ARG;
+  }
+  const ProbDesc& d = h->descs[(size_t)problem];
+  return copy_out(h, h->d_bitmap.as<uint64_t>() + d.bm_off, (int64_t)d.n * d.W, buf, len);
+}
+
+int32_t teaser_hip_get_degrees(teaser_hip_solver* h, int32_t problem, int32_t* buf, int64_t* len) {
+  CHECK_PROBLEM(h, problem);
+  if (!h->have_graph) {
+    if (len) *len = 0;
+    return len ? TEASER_HIP_OK : TEASER_HIP_ERR_BAD_ARG;
+  }
+  const ProbDesc& d = h->descs[(size_t)problem];
+  return copy_out(h, h->d_deg.as<int32_t>() + d.pt_off, (int64_t)d.n, buf, len);
+}
+
+int32_t teaser_hip_solve_for_rotation(teaser_hip_solver* h, const double* src, const double* dst,
+                                      int32_t k, double noise_bound, double* rotation,
+                                      uint8_t* inlier_mask, double* cost, int32_t* iterations) {
+  if (!h || !src || !dst || k <= 0 || !rotation) return TEASER_HIP_ERR_BAD_ARG;
+  (void)hipSetDevice(h->device);
+  hipStream_t s = h->stream;
+  HIPCHK(h, h->s_a.ensure((size_t)k * 24));
+  HIPCHK(h, h->s_b.ensure((size_t)k * 24));
+  HIPCHK(h, h->s_c.ensure((size_t)k * 8));
+  HIPCHK(h, h->s_d.ensure(128));
+  HIPCHK(h, hipMemcpyAsync(h->s_a.p, src, (size_t)k * 24, hipMemcpyHostToDevice, s));
+  HIPCHK(h, hipMemcpyAsync(h->s_b.p, dst, (size_t)k * 24, hipMemcpyHostToDevice, s));
+  launch_gnc_tls_raw(s, h->s_a.as<double>(), h->s_b.as<double>(), k, noise_bound, est_params(h->params),
+                     h->s_c.as<double>(), h->s_d.as<double>(), reinterpret_cast<int32_t*>(h->s_d.as<double>() + 12));
+  HIPCHK(h, hipGetLastError());
+  double outv[13];
+  HIPCHK(h, hipMemcpyAsync(outv, h->s_d.p, sizeof(outv), hipMemcpyDeviceToHost, s));
+  std::vector<double> w((size_t)k);
+  HIPCHK(h, hipMemcpyAsync(w.data(), h->s_c.p, (size_t)k * 8, hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  memcpy(rotation, outv, 9 * sizeof(double));
+  if (cost) *cost = outv[9];
+  if (iterations) memcpy(iterations, &outv[12], 4);
+  if (inlier_mask)
+    for (int32_t j = 0; j < k; ++j) inlier_mask[j] = w[(size_t)j] >= 0.5;  // registration.cc:861-865
+  return TEASER_HIP_OK;
+}
+
+int32_t teaser_hip_solve_for_translation(teaser_hip_solver* h, const double* src,
+                                         const double* dst, int32_t k, double* translation,
+                                         uint8_t* inlier_mask) {
+  if (!h || !src || !dst || k <= 1 || !translation) return TEASER_HIP_ERR_BAD_ARG;
+  (void)hipSetDevice(h->device);
+  // one-problem batch whose clique is the identity and whose rotation/scale are the identity:
+  // raw translation = dst - src (registration.cc:455)
+  hipStream_t s = h->stream;
+  ProbDesc d;
+  d.n = k;
+  d.W = (k + 63) / 64;
+  d.pt_off = 0;
+  d.bm_off = 0;
+  d.w_off = 0;
+  ProbState st;
+  memset(&st, 0, sizeof(st));
+  st.scale = 1;
+  st.R[0] = st.R[4] = st.R[8] = 1;
+  st.clique_size = k;
+  std::vector<int32_t> ident((size_t)k);
+  for (int32_t i = 0; i < k; ++i) ident[(size_t)i] = i;
+  const int64_t stride = tls_scratch_bytes(k);
+  HIPCHK(h, h->s_a.ensure((size_t)k * 24));
+  HIPCHK(h, h->s_b.ensure((size_t)k * 24));
+  HIPCHK(h, h->s_c.ensure((size_t)k * 4));
+  HIPCHK(h, h->s_d.ensure(sizeof(ProbDesc) + sizeof(ProbState) + 64));
+  HIPCHK(h, h->s_e.ensure((size_t)k * 4));
+  HIPCHK(h, h->d_tls_scratch.ensure((size_t)stride));
+  char* dp = h->s_d.as<char>();
+  HIPCHK(h, hipMemcpyAsync(h->s_a.p, src, (size_t)k * 24, hipMemcpyHostToDevice, s));
+  HIPCHK(h, hipMemcpyAsync(h->s_b.p, dst, (size_t)k * 24, hipMemcpyHostToDevice, s));
+  HIPCHK(h, hipMemcpyAsync(h->s_c.p, ident.data(), (size_t)k * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(h, hipMemcpyAsync(dp, &d, sizeof(d), hipMemcpyHostToDevice, s));
+  HIPCHK(h, hipMemcpyAsync(dp + 64, &st, sizeof(st), hipMemcpyHostToDevice, s));
+  launch_tls_translation(s, reinterpret_cast<ProbDesc*>(dp), 1, h->s_a.as<double>(), h->s_b.as<double>(),
+                         h->s_c.as<int32_t>(), reinterpret_cast<ProbState*>(dp + 64),
+                         est_params(h->params), h->d_tls_scratch.as<char>(), stride, h->s_e.as<int32_t>());
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(&st, dp + 64, sizeof(st), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  memcpy(translation, st.t, 3 * sizeof(double));
+  if (inlier_mask) {
+    std::vector<int32_t> inl((size_t)std::max(st.n_trans, 1));
+    if (st.n_trans > 0)
+      HIPCHK(h, hipMemcpy(inl.data(), h->s_e.p, (size_t)st.n_trans * 4, hipMemcpyDeviceToHost));
+    memset(inlier_mask, 0, (size_t)k);
+    for (int32_t j = 0; j < st.n_trans; ++j) inlier_mask[inl[(size_t)j]] = 1;
+  }
+  h->batch = 0;
+  return TEASER_HIP_OK;
+}
+
+int32_t teaser_hip_scalar_tls(teaser_hip_solver* h, const double* x, const double* ranges,
+                              int32_t n, double* estimate, uint8_t* inlier_mask) {
+  if (!h || !x || !ranges || n <= 0 || !estimate) return TEASER_HIP_ERR_BAD_ARG;
+  (void)hipSetDevice(h->device);
+  hipStream_t s = h->stream;
+  int64_t P2 = 2;
+  while (P2 < 2 * (int64_t)n) P2 <<= 1;
+  HIPCHK(h, h->s_a.ensure((size_t)n * 8));
+  HIPCHK(h, h->s_b.ensure((size_t)n * 8));
+  HIPCHK(h, h->s_c.ensure((size_t)P2 * 12 + 64));
+  HIPCHK(h, h->s_d.ensure(64));
+  HIPCHK(h, h->s_e.ensure((size_t)n + 16));
+  HIPCHK(h, hipMemcpyAsync(h->s_a.p, x, (size_t)n * 8, hipMemcpyHostToDevice, s));
+  HIPCHK(h, hipMemcpyAsync(h->s_b.p, ranges, (size_t)n * 8, hipMemcpyHostToDevice, s));
+  launch_scalar_tls(s, h->s_a.as<double>(), h->s_b.as<double>(), n, h->s_c.as<char>(),
+                    h->s_d.as<double>(), h->s_e.as<uint8_t>());
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(estimate, h->s_d.p, 8, hipMemcpyDeviceToHost, s));
+  if (inlier_mask) HIPCHK(h, hipMemcpyAsync(inlier_mask, h->s_e.p, (size_t)n, hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  return TEASER_HIP_OK;
+}
+
+int32_t teaser_hip_max_clique(teaser_hip_solver* h, const uint64_t* bitmap, int32_t n,
+                              int32_t* clique, int32_t* clique_size, int32_t* exact_run) {
+  if (!h || !bitmap || n <= 0 || !clique || !clique_size) return TEASER_HIP_ERR_BAD_ARG;
+  (void)hipSetDevice(h->device);
+  hipStream_t s = h->stream;
+  const int W = (n + 63) / 64;
+  const int mode = effective_mode(h->params);
+  ProbDesc d;
+  d.n = n;
+  d.W = W;
+  d.pt_off = 0;
+  d.bm_off = 0;
+  d.w_off = 0;
+  ProbState st;
+  memset(&st, 0, sizeof(st));
+  for (int k = 0; k < kMaxStarts; ++k) st.start_vertex[k] = -1;
+  h->batch = 0;
+  HIPCHK(h, h->d_desc.ensure(sizeof(ProbDesc)));
+  HIPCHK(h, h->d_state.ensure(sizeof(ProbState)));
+  HIPCHK(h, h->d_bitmap.ensure((size_t)n * W * 8));
+  HIPCHK(h, h->d_deg.ensure((size_t)n * 4));
+  HIPCHK(h, h->d_clique.ensure((size_t)n * 4));
+  HIPCHK(h, h->d_start_cliques.ensure((size_t)n * 4 * kMaxStarts));
+  HIPCHK(h, h->d_alive_a.ensure((size_t)W * 8));
+  HIPCHK(h, h->d_alive_b.ensure((size_t)W * 8));
+  HIPCHK(h, h->d_next_count.ensure(4));
+  HIPCHK(h, hipMemcpyAsync(h->d_desc.p, &d, sizeof(d), hipMemcpyHostToDevice, s));
+  HIPCHK(h, hipMemcpyAsync(h->d_state.p, &st, sizeof(st), hipMemcpyHostToDevice, s));
+  HIPCHK(h, hipMemcpyAsync(h->d_bitmap.p, bitmap, (size_t)n * W * 8, hipMemcpyHostToDevice, s));
+  HIPCHK(h, hipMemsetAsync(h->d_next_count.p, 0, 4, s));
+  const ProbDesc* dd = h->d_desc.as<ProbDesc>();
+  ProbState* ds = h->d_state.as<ProbState>();
+  const bool exact = (mode == TEASER_INLIER_PMC_EXACT);
+  launch_degrees(s, dd, 1, n, h->d_bitmap.as<uint64_t>(), h->d_deg.as<int32_t>(), ds);
+  launch_pick_starts(s, dd, 1, h->d_deg.as<int32_t>(), ds);
+  launch_heuristic(s, dd, 1, W, h->d_bitmap.as<uint64_t>(), h->d_deg.as<int32_t>(), ds,
+                   h->d_start_cliques.as<int32_t>(), n, nullptr, h->d_clique.as<int32_t>());
+  launch_select_best(s, dd, 1, W, h->d_deg.as<int32_t>(), ds, h->d_start_cliques.as<int32_t>(), n,
+                     h->d_clique.as<int32_t>(), h->d_alive_a.as<uint64_t>(), exact ? 1 : 0);
+  if (exact)
+    launch_peel_rounds(s, dd, 1, W, h->d_bitmap.as<uint64_t>(), ds, h->d_alive_a.as<uint64_t>(),
+                       h->d_alive_b.as<uint64_t>(), h->d_next_count.as<int32_t>(), kPeelRounds);
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(&st, h->d_state.p, sizeof(st), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  std::vector<int32_t> cl((size_t)st.clique_size);
+  if (st.clique_size > 0)
+    HIPCHK(h, hipMemcpy(cl.data(), h->d_clique.p, (size_t)st.clique_size * 4, hipMemcpyDeviceToHost));
+  if (exact_run) *exact_run = 0;
+  if (exact && !st.proven && n >= 2) {
+    if (exact_run) *exact_run = 1;
+    const uint64_t* final_alive =
+        (kPeelRounds % 2 == 0) ? h->d_alive_a.as<uint64_t>() : h->d_alive_b.as<uint64_t>();
+    std::vector<int32_t> deg((size_t)n);
+    std::vector<uint64_t> alive((size_t)W);
+    HIPCHK(h, hipMemcpy(deg.data(), h->d_deg.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(h, hipMemcpy(alive.data(), final_alive, (size_t)W * 8, hipMemcpyDeviceToHost));
+    std::vector<int32_t> order;
+    int max_deg = 0;
+    for (int v = 0; v < n; ++v)
+      if ((alive[(size_t)(v >> 6)] >> (v & 63)) & 1ull) {
+        order.push_back(v);
+        max_deg = std::max(max_deg, deg[(size_t)v]);
+      }
+    std::stable_sort(order.begin(), order.end(),
+                     [&](int32_t a, int32_t b) { return deg[(size_t)a] < deg[(size_t)b]; });
+    const int n2 = (int)order.size();
+    if (n2 > st.lb) {
+      const int W2 = (n2 + 63) / 64;
+      HIPCHK(h, h->x_order.ensure((size_t)n2 * 4));
+      HIPCHK(h, h->x_bitmap.ensure((size_t)n2 * W2 * 8));
+      HIPCHK(h, hipMemcpyAsync(h->x_order.p, order.data(), (size_t)n2 * 4, hipMemcpyHostToDevice, s));
+      launch_gather_bitmap(s, h->d_bitmap.as<uint64_t>(), W, h->x_order.as<int32_t>(), n2,
+                           h->x_bitmap.as<uint64_t>(), W2);
+      std::vector<int32_t> best_local;
+      int xstatus = 0;
+      int32_t rc = run_exact_on_compact(h, h->x_bitmap.as<uint64_t>(), n2, W2, st.lb, max_deg,
+                                        best_local, &xstatus);
+      if (rc != TEASER_HIP_OK) return rc;
+      if (!best_local.empty()) {
+        cl.resize(best_local.size());
+        for (size_t k = 0; k < best_local.size(); ++k) cl[k] = order[(size_t)best_local[k]];
+        std::sort(cl.begin(), cl.end());
+      }
+      if (xstatus == 1) return TEASER_HIP_ERR_SCRATCH;
+      if (xstatus == 2) {
+        *clique_size = (int32_t)cl.size();
+        memcpy(clique, cl.data(), cl.size() * 4);
+        return TEASER_HIP_ERR_TIME_LIMIT;
+      }
+    }
+  }
+  *clique_size = (int32_t)cl.size();
+  if (!cl.empty()) memcpy(clique, cl.data(), cl.size() * 4);
+  return TEASER_HIP_OK;
+}
+
+int32_t teaser_hip_set_profiling(teaser_hip_solver* h, int32_t enable) {
+  if (!h) return TEASER_HIP_ERR_BAD_ARG;
+  h->profiling = enable != 0;
+  return TEASER_HIP_OK;
+}
+
+int32_t teaser_hip_get_profile(const teaser_hip_solver* h, teaser_profile_c* out) {
+  if (!h || !out) return TEASER_HIP_ERR_BAD_ARG;
+  *out = h->prof;
+  return TEASER_HIP_OK;
+}
+
+void* teaser_hip_get_stream(teaser_hip_solver* h) { return h ? (void*)h->stream : nullptr; }
+
+const char* teaser_hip_last_error(const teaser_hip_solver* h) { return h ? h->err.c_str() : ""; }
+
+}  // extern "C"

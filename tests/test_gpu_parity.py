@@ -1,0 +1,462 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the committed
+golden vectors.  Run on a real MI355X with `pytest -m gpu`.
+
+Parity bar (BASELINE.json north_star): bit-exact adjacency bitmap / clique / inlier index sets,
+rotation within 1e-4 Frobenius, translation within 1e-4 m.
+"""
+import importlib
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from util import angular_error, golden, is_clique
+
+pytestmark = pytest.mark.gpu
+
+tp = importlib.import_module("teaser-plusplus_amd")
+G = golden()
+
+R_TOL = 1e-4  # Frobenius, north_star
+T_TOL = 1e-4  # metres, north_star
+
+
+def make_solver(**kw):
+    return tp.RobustRegistrationSolver(tp.RobustRegistrationSolver.Params(**kw))
+
+
+def bench_params(**kw):
+    """SURVEY.md 8(d) synthetic-config parameters (example values teaser_cpp_ply.cc:79-87)."""
+    p = dict(noise_bound=0.01, cbar2=1.0, estimate_scaling=False, rotation_gnc_factor=1.4,
+             rotation_max_iterations=100, rotation_cost_threshold=0.005)
+    p.update(kw)
+    return p
+
+
+def oracle_params(p):
+    q = dict(p)
+    q["estimate_scaling"] = int(q.get("estimate_scaling", True))
+    return q
+
+
+def check_solution_parity(solver, sol, o, problem=0, check_clique=True):
+    assert sol.valid == o["valid"]
+    clique = solver.getInlierMaxClique(problem)
+    assert len(clique) == len(o["max_clique"])
+    if check_clique and o["clique_unique"]:
+        assert clique == o["max_clique"].tolist()
+    if not o["valid"]:
+        return
+    if o["clique_unique"]:
+        assert abs(sol.scale - o["scale"]) <= 1e-9 * max(1, abs(o["scale"]))
+        assert np.linalg.norm(sol.rotation - o["rotation"]) <= R_TOL
+        assert np.linalg.norm(sol.translation - o["translation"]) <= T_TOL
+        assert solver.getRotationInliers(problem) == o["rotation_inliers"].tolist()
+        assert solver.getTranslationInliers(problem) == o["translation_inliers"].tolist()
+
+
+# ---------------------------------------------------------------------------------------------
+# K1: adjacency bitmap, bit-exact
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,rho,seed", [(64, 0.5, 1), (65, 0.3, 2), (200, 0.9, 3), (1000, 0.9, 4),
+                                        (3000, 0.95, 5), (4097, 0.8, 6)])
+def test_k1_bitmap_bit_exact_synthetic(n, rho, seed):
+    pr = tp.synth_problem(20250523 + seed, n, rho, 0.01)
+    s = make_solver(**bench_params())
+    s.solve(pr["src"], pr["dst"])
+    bm = s.getInlierGraphBitmap()
+    _, ref = oracle.inlier_bitmap(pr["src"], pr["dst"], 0.01, 1.0, False)
+    assert bm.shape == ref.shape
+    assert (bm == ref).all()
+    deg = s.getDegrees()
+    assert (deg == oracle.bitmap_to_dense(ref, n).sum(1)).all()
+
+
+def test_k1_bitmap_bit_exact_fixtures():
+    for src, dst, nb in [(G["object_in"], G["scene_in"], float(G["object_noise_bound"])),
+                         (G["model1000"].astype(np.float64).T, G["scene1000"].astype(np.float64).T, 0.0067364)]:
+        s = make_solver(**bench_params(noise_bound=nb))
+        s.solve(src, dst)
+        _, ref = oracle.inlier_bitmap(src, dst, nb, 1.0, False)
+        assert (s.getInlierGraphBitmap() == ref).all()
+
+
+def test_k1_guard_band_exact_path():
+    """Pairs sitting exactly on the pruning boundary force the in-band (IEEE sqrt) path:
+    src on a line at distance a, dst at a + beta (+- a few ulps)."""
+    rng = np.random.default_rng(11)
+    nb = 0.01
+    beta = 2 * nb
+    n = 512
+    a = rng.uniform(0.1, 3.0, size=n)
+    src = np.zeros((3, n))
+    dst = np.zeros((3, n))
+    src[0] = np.cumsum(a)
+    gaps = a + beta
+    # perturb a quarter of the gaps by a few ulps either way
+    k = rng.integers(-3, 4, size=n)
+    gaps = np.where(rng.uniform(size=n) < 0.5, gaps, np.nextafter(gaps, gaps + k))
+    dst[0] = np.cumsum(gaps)
+    s = make_solver(**bench_params(noise_bound=nb))
+    s.solve(src, dst)
+    _, ref = oracle.inlier_bitmap(src, dst, nb, 1.0, False)
+    assert (s.getInlierGraphBitmap() == ref).all()
+    # duplicates / zero-length TIMs (A = 0 or B = 0)
+    src2 = np.repeat(rng.uniform(size=(3, 40)), 4, axis=1)
+    dst2 = src2 + rng.uniform(-0.03, 0.03, size=src2.shape)
+    s.solve(src2, dst2)
+    _, ref2 = oracle.inlier_bitmap(src2, dst2, nb, 1.0, False)
+    assert (s.getInlierGraphBitmap() == ref2).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# stage solvers: the reference's own known answers (through the HIP kernels)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", [1, 2, 3])
+def test_scalar_tls_known_answers(case):
+    s = make_solver()
+    est, mask = s.scalarTLS(G["tls%d_x" % case], G["tls%d_r" % case])
+    assert abs(est - float(G["tls%d_est" % case])) < float(G["tls_tol"])
+    assert (mask == G["tls%d_mask" % case].astype(bool)).all()
+    oe, om = oracle.scalar_tls(G["tls%d_x" % case], G["tls%d_r" % case])
+    assert abs(est - oe) < 1e-12 and (mask == om).all()
+
+
+def test_scalar_tls_random_vs_oracle():
+    rng = np.random.default_rng(12)
+    s = make_solver()
+    for n in (2, 3, 17, 100, 500, 1023, 1025, 5000):
+        x = np.concatenate([rng.normal(0.7, 0.01, size=n // 2), rng.uniform(-5, 5, size=n - n // 2)])
+        r = rng.uniform(0.01, 0.05, size=n)
+        est, mask = s.scalarTLS(x, r)
+        oe, om = oracle.scalar_tls(x, r)
+        assert abs(est - oe) < 1e-10
+        assert (mask == om).all()
+
+
+def test_translation_known_answer():
+    s = make_solver(noise_bound=float(G["trans_noise_bound"]))
+    t = s.solveForTranslation(G["trans_v1"], G["trans_v2"])
+    assert np.linalg.norm(t - G["trans_expected_t"]) < float(G["trans_tol"])
+    ot, om = oracle.tls_translation(G["trans_v1"], G["trans_v2"], float(G["trans_noise_bound"]))
+    assert np.linalg.norm(t - ot) < 1e-12
+    assert (s._last_translation["inliers"] == om).all()
+
+
+def test_rotation_known_answer():
+    src = G["rot_src"].T
+    R_exp = G["rot_expected_R"]
+    dst = R_exp @ src
+    mi, thr, fac, nb = G["rot_params"]
+    s = make_solver(rotation_max_iterations=int(mi), rotation_cost_threshold=float(thr),
+                    rotation_gnc_factor=float(fac))
+    R = s.solveForRotation(src, dst, noise_bound=float(nb))
+    assert angular_error(R_exp, R) < float(G["rot_tol"])
+    assert np.linalg.norm(R - R_exp) < 1e-9
+
+
+def test_rotation_with_outliers_vs_oracle():
+    rng = np.random.default_rng(13)
+    for trial in range(5):
+        k = 300
+        src = rng.normal(size=(3, k))
+        R0 = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+        if np.linalg.det(R0) < 0:
+            R0[:, 0] *= -1
+        dst = R0 @ src + 0.005 * rng.normal(size=(3, k))
+        bad = rng.choice(k, size=60, replace=False)
+        dst[:, bad] = rng.normal(size=(3, 60))
+        s = make_solver(rotation_cost_threshold=1e-12)
+        R = s.solveForRotation(src, dst, noise_bound=0.02)
+        o = oracle.gnc_tls_rotation(src, dst, 0.02, 1.4, 100, 1e-12)
+        assert np.linalg.norm(R - o["R"]) < 1e-8
+        assert (s._last_rotation["inliers"] == o["inliers"]).all()
+        assert s._last_rotation["iterations"] == o["iterations"]
+        assert abs(s._last_rotation["cost"] - o["cost"]) <= 1e-9 * max(1.0, abs(o["cost"]))
+
+
+# ---------------------------------------------------------------------------------------------
+# clique stage
+# ---------------------------------------------------------------------------------------------
+def test_toy_graph_cliques():
+    s = make_solver()
+    c, _ = s.maxClique(oracle.bitmap_from_edges(5, G["graph_k5_edges"]), 5)
+    assert c == [0, 1, 2, 3, 4]
+    c, _ = s.maxClique(oracle.bitmap_from_edges(4, G["graph_4node_edges"]), 4)
+    assert c == [0, 2, 3]
+    c, _ = s.maxClique(oracle.bitmap_from_edges(4, []), 4)
+    assert len(c) == 1
+
+
+def test_random_graph_cliques_vs_oracle():
+    rng = np.random.default_rng(14)
+    s = make_solver()
+    n_exact = 0
+    for trial in range(30):
+        n = int(rng.integers(5, 300))
+        p = float(rng.uniform(0.05, 0.8))
+        if n > 150:
+            p = min(p, 0.5)
+        A = np.triu(rng.uniform(size=(n, n)) < p, 1)
+        bm = oracle.bitmap_from_edges(n, np.argwhere(A))
+        c, er = s.maxClique(bm, n)
+        o = oracle.max_clique(bm, n)
+        n_exact += int(er)
+        assert len(c) == len(o["clique"])
+        assert is_clique(A | A.T, c)
+        assert c == sorted(c)
+        if o["unique"]:
+            assert c == o["clique"].tolist()
+    assert n_exact > 0  # the device B&B was actually exercised
+
+
+def test_planted_clique_needs_exact():
+    """A planted clique hidden among higher-degree decoys: greedy start vertices miss it, the
+    exact stage must find it."""
+    rng = np.random.default_rng(15)
+    n, k = 400, 30
+    A = np.triu(rng.uniform(size=(n, n)) < 0.35, 1)
+    members = np.sort(rng.choice(n, size=k, replace=False))
+    for i in members:
+        for j in members:
+            if i < j:
+                A[i, j] = True
+    bm = oracle.bitmap_from_edges(n, np.argwhere(A))
+    s = make_solver()
+    c, er = s.maxClique(bm, n)
+    o = oracle.max_clique(bm, n)
+    assert len(c) == len(o["clique"]) >= k
+    assert is_clique(A | A.T, c)
+    if o["unique"]:
+        assert c == o["clique"].tolist()
+
+
+# ---------------------------------------------------------------------------------------------
+# end-to-end
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,rho,seed", [(100, 0.5, 21), (500, 0.9, 22), (2000, 0.9, 23), (5000, 0.9, 24)])
+def test_solve_parity_synthetic(n, rho, seed):
+    pr = tp.synth_problem(20250523 + seed, n, rho, 0.01)
+    p = bench_params()
+    s = make_solver(**p)
+    sol = s.solve(pr["src"], pr["dst"])
+    o = oracle.solve(pr["src"], pr["dst"], **oracle_params(p))
+    check_solution_parity(s, sol, o)
+    assert o["clique_unique"]
+    assert set(s.getInlierMaxClique()) == set(np.flatnonzero(pr["inliers"]).tolist())
+    assert angular_error(pr["R"], sol.rotation) < 0.05
+    assert np.linalg.norm(pr["t"] - sol.translation) < 0.05
+    # input-ordered translation inliers (registration.h:752-763)
+    cl = s.getInlierMaxClique()
+    assert s.getInputOrderedTranslationInliers() == [cl[i] for i in s.getTranslationInliers()]
+
+
+def test_solve_parity_config2_10k():
+    """BASELINE config 2: N = 10 000, 95 % outliers (the bench workload)."""
+    pr = tp.synth_problem(20250523, 10000, 0.95, 0.01)
+    p = bench_params()
+    s = make_solver(**p)
+    sol = s.solve(pr["src"], pr["dst"])
+    o = oracle.solve(pr["src"], pr["dst"], **oracle_params(p))
+    check_solution_parity(s, sol, o)
+    assert len(s.getInlierMaxClique()) == 500
+    _, ref = oracle.inlier_bitmap(pr["src"], pr["dst"], 0.01, 1.0, False)
+    assert (s.getInlierGraphBitmap() == ref).all()
+    assert s.raw_solution().num_edges == o["num_edges"]
+
+
+def test_solve_object_scene_fixed_scale():
+    """Hard clique fixture (max_core+1 > omega): registration-test.cc:313-391 bounds."""
+    obj, scn = G["object_in"], G["scene_in"]
+    p = bench_params(noise_bound=float(G["object_noise_bound"]))
+    s = make_solver(**p)
+    sol = s.solve(obj, scn)
+    o = oracle.solve(obj, scn, **oracle_params(p))
+    check_solution_parity(s, sol, o)
+    assert len(s.getInlierMaxClique()) == 34
+    assert s.raw_solution().clique_exact_run == 1
+    bR1, bt1, bR2, bt2 = G["object_bounds"]
+    assert angular_error(G["object_expected_R"], sol.rotation) <= bR2
+    assert np.linalg.norm(sol.translation - G["object_expected_t"]) <= bt2
+    adj = oracle.bitmap_to_dense(s.getInlierGraphBitmap(), obj.shape[1])
+    assert is_clique(adj, s.getInlierMaxClique())
+
+
+def test_solve_object_scene_estimate_scaling():
+    obj, scn = G["object_in"], G["scene_in"]
+    p = dict(noise_bound=float(G["object_noise_bound"]), estimate_scaling=True,
+             rotation_cost_threshold=0.005)
+    s = make_solver(**p)
+    sol = s.solve(obj, scn)
+    o = oracle.solve(obj, scn, **oracle_params(p))
+    assert abs(sol.scale - float(G["object_expected_scale"])) < 1e-4
+    assert abs(sol.scale - o["scale"]) < 1e-9
+    _, ref = oracle.inlier_bitmap(obj, scn, p["noise_bound"], 1.0, True)
+    assert (s.getInlierGraphBitmap() == ref).all()
+    check_solution_parity(s, sol, o)
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 6])
+def test_benchmark_fixtures(k):
+    """reference test/benchmark/registration-benchmark.cc:180-374 thresholds, on the GPU path."""
+    src = G["bench%d_src" % k].astype(np.float64).T
+    dst = G["bench%d_dst" % k].astype(np.float64).T
+    p = dict(noise_bound=float(G["bench%d_noise_bound" % k]), cbar2=1.0, estimate_scaling=True,
+             rotation_max_iterations=100, rotation_gnc_factor=1.4, rotation_cost_threshold=1e-12)
+    s = make_solver(**p)
+    sol = s.solve(src, dst)
+    assert sol.valid
+    sg, Rg, tg, se, Re, te = G["bench%d_thresholds" % k]
+    assert abs(sol.scale - float(G["bench%d_s_ref" % k])) <= sg
+    assert angular_error(G["bench%d_R_ref" % k], sol.rotation) <= Rg
+    assert np.linalg.norm(sol.translation - G["bench%d_t_ref" % k]) <= tg
+    assert abs(sol.scale - float(G["bench%d_s_est" % k])) <= se
+    assert angular_error(G["bench%d_R_est" % k], sol.rotation) <= Re
+    assert np.linalg.norm(sol.translation - G["bench%d_t_est" % k]) <= te
+    o = oracle.solve(src, dst, **oracle_params(p))
+    check_solution_parity(s, sol, o)
+
+
+def test_bunny_config1():
+    """BASELINE config 1 (plumbing): bun_zipper_res3 with the example's T, noise and outlier model
+    (teaser_cpp_ply.cc:12-40,62-68) driven by a seeded generator."""
+    rng = np.random.default_rng(20250523)
+    src = G["bunny"].astype(np.float64).T  # 3 x 1889
+    T = G["bunny_T"]
+    n = src.shape[1]
+    NB = 0.001
+    dst = T[:3, :3] @ src + T[:3, 3:4]
+    dst += (rng.uniform(-1, 1, size=dst.shape)) * NB / 2
+    for _ in range(1700):  # with replacement, like the example
+        i = int(rng.integers(0, n))
+        dst[:, i] += float(rng.integers(5, 11))
+    p = bench_params(noise_bound=NB)
+    s = make_solver(**p)
+    sol = s.solve(src, dst)
+    o = oracle.solve(src, dst, **oracle_params(p))
+    check_solution_parity(s, sol, o)
+    assert angular_error(T[:3, :3], sol.rotation) < 0.02
+    assert np.linalg.norm(T[:3, 3] - sol.translation) < 0.005
+
+
+def test_outlier_detection():
+    """registration-test.cc:394-467: clique == exact inlier set for far outliers."""
+    rng = np.random.default_rng(17)
+    for n_out in range(1, 6):
+        src = rng.uniform(-1, 1, size=(3, 20))
+        R = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+        if np.linalg.det(R) < 0:
+            R[:, 0] *= -1
+        t = rng.uniform(-1, 1, size=(3, 1))
+        dst = R @ src + t
+        out_idx = rng.choice(20, size=n_out, replace=False)
+        dst[:, out_idx] += rng.uniform(5, 10, size=(3, n_out))
+        s = make_solver(**bench_params(rotation_cost_threshold=1e-12))
+        sol = s.solve(src, dst)
+        assert s.getInlierMaxClique() == sorted(set(range(20)) - set(out_idx.tolist()))
+        assert angular_error(R, sol.rotation) < 1e-6
+        assert np.linalg.norm(sol.translation - t.ravel()) < 1e-6
+
+
+def test_edge_cases():
+    s = make_solver(**bench_params())
+    # empty and single-point inputs: valid = false, no crash (registration.cc:643-647)
+    for n in (0, 1):
+        sol = s.solve(np.zeros((3, n)), np.zeros((3, n)))
+        assert not sol.valid
+    # two consistent points: clique of 2
+    src = np.array([[0, 1.0], [0, 0], [0, 0]])
+    sol = s.solve(src, src + 0.5)
+    assert sol.valid and s.getInlierMaxClique() == [0, 1]
+    assert np.linalg.norm(sol.translation - 0.5) < 1e-9
+    # all outliers: two far-inconsistent points -> clique size 1 -> invalid
+    dst = np.array([[0, 9.0], [0, 0], [0, 0]])
+    sol = s.solve(src, dst)
+    assert not sol.valid and len(s.getInlierMaxClique()) == 1
+    # handle reuse after an invalid solve (the reference object is single-use; ours is not)
+    pr = tp.synth_problem(5, 300, 0.5, 0.01)
+    a = s.solve(pr["src"], pr["dst"])
+    b = s.solve(pr["src"], pr["dst"])
+    assert a.valid and (a.rotation == b.rotation).all() and (a.translation == b.translation).all()
+    # no outliers at all
+    pr = tp.synth_problem(6, 700, 0.0, 0.01)
+    sol = s.solve(pr["src"], pr["dst"])
+    assert len(s.getInlierMaxClique()) == 700
+
+
+def test_inlier_selection_modes():
+    pr = tp.synth_problem(31, 400, 0.8, 0.01)
+    truth = np.flatnonzero(pr["inliers"]).tolist()
+    for mode in (tp.InlierSelectionMode.PMC_EXACT, tp.InlierSelectionMode.PMC_HEU,
+                 tp.InlierSelectionMode.KCORE_HEU):
+        s = make_solver(**bench_params(inlier_selection_mode=mode))
+        s.solve(pr["src"], pr["dst"])
+        assert s.getInlierMaxClique() == truth
+    s = make_solver(**bench_params(inlier_selection_mode=tp.InlierSelectionMode.NONE))
+    sol = s.solve(pr["src"], pr["dst"])
+    assert s.getInlierMaxClique() == list(range(400))
+    o = oracle.solve(pr["src"], pr["dst"], **oracle_params(bench_params(inlier_selection_mode=3)))
+    assert np.linalg.norm(sol.rotation - o["rotation"]) < R_TOL
+    assert np.linalg.norm(sol.translation - o["translation"]) < T_TOL
+    # unsupported rotation algorithm: loud error, never a silent fallback
+    s = make_solver(**bench_params(rotation_estimation_algorithm=tp.RotationEstimationAlgorithm.FGR))
+    with pytest.raises(tp.TeaserHipError):
+        s.solve(pr["src"], pr["dst"])
+
+
+def test_complete_tim_graph():
+    pr = tp.synth_problem(32, 300, 0.7, 0.01)
+    p = bench_params(rotation_tim_graph=tp.InlierGraphFormulation.COMPLETE)
+    s = make_solver(**p)
+    sol = s.solve(pr["src"], pr["dst"])
+    o = oracle.solve(pr["src"], pr["dst"], **oracle_params(dict(p, rotation_tim_graph=1)))
+    check_solution_parity(s, sol, o)
+
+
+def test_correspondence_overload():
+    """solve(PointCloud, PointCloud, correspondences), registration.cc:553-566."""
+    pr = tp.synth_problem(33, 500, 0.6, 0.01)
+    rng = np.random.default_rng(33)
+    src_cloud = pr["src"].T.astype(np.float32)
+    dst_cloud = pr["dst"].T.astype(np.float32)
+    perm = rng.permutation(500)
+    dst_shuffled = dst_cloud[perm]
+    inv = np.argsort(perm)
+    corr = np.stack([np.arange(500), inv], axis=1)
+    s = make_solver(**bench_params())
+    sol = s.solve_correspondences(src_cloud, dst_shuffled, corr)
+    s2 = make_solver(**bench_params())
+    sol2 = s2.solve(src_cloud.astype(np.float64).T, dst_cloud.astype(np.float64).T)
+    assert (sol.rotation == sol2.rotation).all() and (sol.translation == sol2.translation).all()
+    assert s.getInlierMaxClique() == s2.getInlierMaxClique()
+
+
+def test_batch_matches_single():
+    """Batched mode: ragged batch, each problem identical to its single-solve result."""
+    sizes = [300, 1000, 64, 777, 1, 500]
+    probs = [tp.synth_problem(40 + i, n, 0.8, 0.01) for i, n in enumerate(sizes)]
+    sb = make_solver(**bench_params())
+    sols = sb.solve_batch([p["src"] for p in probs], [p["dst"] for p in probs])
+    for i, pr in enumerate(probs):
+        s1 = make_solver(**bench_params())
+        one = s1.solve(pr["src"], pr["dst"])
+        assert sols[i].valid == one.valid
+        assert sb.getInlierMaxClique(i) == s1.getInlierMaxClique()
+        if one.valid:
+            assert (sols[i].rotation == one.rotation).all()
+            assert (sols[i].translation == one.translation).all()
+            assert sb.getRotationInliers(i) == s1.getRotationInliers()
+            assert sb.getTranslationInliers(i) == s1.getTranslationInliers()
+
+
+def test_determinism():
+    pr = tp.synth_problem(50, 3000, 0.9, 0.01)
+    s = make_solver(**bench_params())
+    first = s.solve(pr["src"], pr["dst"])
+    c0 = s.getInlierMaxClique()
+    b0 = s.getInlierGraphBitmap().copy()
+    for _ in range(5):
+        sol = s.solve(pr["src"], pr["dst"])
+        assert (sol.rotation == first.rotation).all() and (sol.translation == first.translation).all()
+        assert s.getInlierMaxClique() == c0
+        assert (s.getInlierGraphBitmap() == b0).all()
