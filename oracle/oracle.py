@@ -217,18 +217,20 @@ def solve(src, dst, params=None, **kw):
     n = s.shape[0]
     sol = OracleSolution()
     clique = np.zeros(max(n, 1), dtype=np.int32)
-    rot = np.zeros(max(n, 1), dtype=np.int32)
+    rot_cap = max(n, 1) if p.rotation_tim_graph == 0 else max(n * (n - 1) // 2, 1)
+    rot = np.zeros(rot_cap, dtype=np.int32)
     tr = np.zeros(max(n, 1), dtype=np.int32)
     ip = C.POINTER(C.c_int32)
     rc = lib().oracle_solve(C.byref(p), _dp(s), _dp(d), C.c_int32(n), C.byref(sol),
-                            clique.ctypes.data_as(ip), rot.ctypes.data_as(ip), tr.ctypes.data_as(ip))
+                            clique.ctypes.data_as(ip), rot.ctypes.data_as(ip), C.c_int64(rot_cap),
+                            tr.ctypes.data_as(ip))
     if rc != 0:
         raise RuntimeError("oracle_solve rc=%d" % rc)
     return dict(
         valid=bool(sol.valid), scale=sol.scale,
         rotation=np.array(sol.rotation[:]).reshape(3, 3), translation=np.array(sol.translation[:]),
         max_clique=clique[:sol.clique_size].copy(),
-        rotation_inliers=rot[:min(sol.n_rotation_inliers, n)].copy(),
+        rotation_inliers=rot[:min(sol.n_rotation_inliers, rot_cap)].copy(),
         translation_inliers=tr[:sol.n_translation_inliers].copy(),
         gnc_cost=sol.gnc_cost, gnc_iterations=sol.gnc_iterations,
         clique_unique=bool(sol.clique_unique), clique_exact_run=bool(sol.clique_exact_run),

@@ -888,7 +888,8 @@ ORACLE_API int oracle_tls_translation(const double* src, const double* dst, int6
 /* ------------------------------------------------------------------------------------------- */
 ORACLE_API int oracle_solve(const oracle_params* p, const double* src, const double* dst,
                             int32_t n, oracle_solution* sol, int32_t* clique_out,
-                            int32_t* rot_inliers_out, int32_t* trans_inliers_out) {
+                            int32_t* rot_inliers_out, int64_t rot_capacity,
+                            int32_t* trans_inliers_out) {
   memset(sol, 0, sizeof(*sol));
   sol->valid = 1; /* registration.h:33 */
   for (int i = 0; i < 3; ++i) sol->rotation[4 * i] = 1.0;
@@ -982,7 +983,7 @@ ORACLE_API int oracle_solve(const oracle_params* p, const double* src, const dou
   int nr = 0;
   for (int64_t i = 0; i < KT; ++i) /* :712-716 */
     if (rmask[i]) {
-      if (rot_inliers_out && nr < n) rot_inliers_out[nr] = (int32_t)i;
+      if (rot_inliers_out && nr < rot_capacity) rot_inliers_out[nr] = (int32_t)i;
       ++nr;
     }
   sol->n_rotation_inliers = nr;
