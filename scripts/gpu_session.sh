@@ -1,9 +1,21 @@
+#!/bin/bash
+# One GPU-box session: parity tests, bench, rocprofv3 kernel stats + PMC passes.
+# Usage (from the repo root, on the GPU box via gpurun): bash scripts/gpu_session.sh <tag>
 set -x
+TAG=${1:-r1}
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q --timeout=300 -k "complete" > gpurun_out/t3.log 2>&1; echo "t3 rc=$?"; tail -5 gpurun_out/t3.log
-timeout 600 python scripts/profile_stages.py > gpurun_out/stages.log 2>&1; echo "stages rc=$?"; cat gpurun_out/stages.log
-timeout 900 python scripts/profile_stages.py big > gpurun_out/stages_big.log 2>&1; echo "big rc=$?"; cat gpurun_out/stages_big.log
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_r1 -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_bench.log 2>&1; echo "prof rc=$?"
-cd $GRAFT_REPO_ROOT; ls -R gpurun_out/prof_r1 | head -20
-find gpurun_out/prof_r1 -name "*kernel_stats*" | head -2 | xargs -I{} head -30 {}
+OUT=$GRAFT_REPO_ROOT/gpurun_out
+python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke_$TAG.log 2>&1; echo "smoke rc=$?"
+timeout 1200 python -m pytest tests -m gpu -q --timeout=600 > $OUT/tests_$TAG.log 2>&1; echo "tests rc=$?"
+tail -15 $OUT/tests_$TAG.log
+timeout 600 python bench.py > $OUT/bench_$TAG.log 2>&1; echo "bench rc=$?"
+tail -2 $OUT/bench_$TAG.log
+timeout 600 python scripts/profile_stages.py > $OUT/stages_$TAG.log 2>&1; cat $OUT/stages_$TAG.log
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/prof_bench_$TAG.log 2>&1; echo "prof rc=$?"
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$TAG -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $OUT/pmc_fetch_$TAG.log 2>&1; echo "pmc fetch rc=$?"
+timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$TAG -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 1 --no-cpu-baseline > $OUT/pmc_write_$TAG.log 2>&1; echo "pmc write rc=$?"
+cd $GRAFT_REPO_ROOT
+find gpurun_out/prof_$TAG gpurun_out/pmc_fetch_$TAG gpurun_out/pmc_write_$TAG -type f | head -40
+find gpurun_out/prof_$TAG -name "*kernel_stats*" | head -1 | xargs -I{} head -30 {}

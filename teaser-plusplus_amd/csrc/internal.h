@@ -12,7 +12,6 @@ namespace thip {
 constexpr int kWave = 64;          // CDNA4 wavefront
 constexpr int kMaxStarts = 16;     // greedy start vertices per problem
 constexpr int kPeelRounds = 3;     // k-core style peel launches before the host decision
-constexpr int kDynThreshold = 1024;  // |P| below which the greedy uses candidate-degree votes
 
 // One registration problem inside a (possibly ragged) batch.  Packed layouts in HBM:
 //   points   : src/dst  [sum n][3] doubles        (offset pt_off points)

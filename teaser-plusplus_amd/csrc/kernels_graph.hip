@@ -245,15 +245,48 @@ void launch_pick_starts(hipStream_t s, const ProbDesc* d_desc, int batch, const 
 }
 
 // ------------------------------------------------------------------------------------------
-// greedy clique from one start vertex (one workgroup per (start, problem)).
-//   candidates P = common neighbourhood of the clique so far, as an LDS bitset;
-//   |P| > kDynThreshold : add the candidate of largest global degree;
-//   otherwise           : one vote round -- d_P(u) = |N(u) & P| for every candidate (a wave per
-//                         candidate over the bitmap row); every u with d_P(u) = |P|-1 is
-//                         adjacent to all other candidates and joins at once; then the
-//                         candidate with the largest d_P joins and P shrinks to its neighbours.
+// greedy clique from one start vertex (one 512-thread workgroup per (start, problem)).
+//   candidates P = common neighbourhood of the clique so far, an LDS bitset over all vertices.
+//   |P| > kCap  : shrink P.  Cheap "static" picks (candidate of largest global degree) while they
+//                 shrink P by >10 %; when they stop doing so P is close to a clique, and a
+//                 streaming vote round (a wave per candidate over its bitmap row in HBM/L2) adds
+//                 every candidate adjacent to all others at once.
+//   |P| <= kCap : the candidates' induced subgraph is gathered ONCE into a compact |P| x |P| bit
+//                 matrix in LDS (lane = candidate column, one ballot per 64 columns); all further
+//                 vote rounds run out of LDS:  d(u) = |N(u) & P|;  every u with d(u) = |P|-1 is
+//                 adjacent to all other candidates and joins at once;  then the candidate with the
+//                 largest d joins and P shrinks to its neighbours.
+// Deterministic: every tie is broken towards the smallest vertex index.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void greedy_clique_kernel(
+constexpr int kGreedyThreads = 512;
+constexpr int kGreedyWaves = kGreedyThreads / 64;
+constexpr int kCap = 640;            // compact-mode candidate cap
+constexpr int kCapW = kCap / 64;     // words per compact row
+constexpr int kCapStride = kCapW + 1;  // odd row stride (in 8-byte words): conflict-free ds_read_b64
+
+__device__ __forceinline__ int blockN_sum_i(int v, int* red /* kGreedyWaves */) {
+  v = wave_sum_i(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  int s = 0;
+#pragma unroll
+  for (int k = 0; k < kGreedyWaves; ++k) s += red[k];
+  return s;
+}
+__device__ __forceinline__ unsigned long long blockN_max_u64(unsigned long long v,
+                                                             unsigned long long* red) {
+  v = wave_max_u64(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  unsigned long long m = 0;
+#pragma unroll
+  for (int k = 0; k < kGreedyWaves; ++k) m = red[k] > m ? red[k] : m;
+  return m;
+}
+
+__global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
     const ProbDesc* __restrict__ descs, const uint64_t* __restrict__ bitmap,
     const int32_t* __restrict__ deg, ProbState* __restrict__ states,
     int32_t* __restrict__ start_cliques, int64_t total_n) {
@@ -261,13 +294,15 @@ __global__ __launch_bounds__(256) void greedy_clique_kernel(
   const ProbDesc d = descs[blockIdx.y];
   const int n = d.n, W = d.W;
   const int Wpad = (W + 1) & ~1;
-  uint64_t* P = reinterpret_cast<uint64_t*>(smem);
-  unsigned long long* red64 = reinterpret_cast<unsigned long long*>(P + Wpad);  // 4
-  int* cand = reinterpret_cast<int*>(red64 + 4);                                  // kDynThreshold
-  int* dP = cand + kDynThreshold;                                                 // kDynThreshold
-  int* red4 = dP + kDynThreshold;                                                 // 4
-  int* misc = red4 + 4;                                                           // 8
-  int* wcnt = misc + 8;                                                           // 256
+  uint64_t* P = reinterpret_cast<uint64_t*>(smem);                      // Wpad
+  uint64_t* U = P + Wpad;                                               // Wpad (streaming rounds)
+  uint64_t* A = U + Wpad;                                               // kCap * kCapStride
+  uint64_t* Pc = A + kCap * kCapStride;                                 // 16
+  unsigned long long* red64 = reinterpret_cast<unsigned long long*>(Pc + 16);  // kGreedyWaves
+  int* cand = reinterpret_cast<int*>(red64 + kGreedyWaves);             // kCap
+  int* wcnt = cand + kCap;                                              // kGreedyThreads
+  int* red = wcnt + kGreedyThreads;                                     // kGreedyWaves
+  int* misc = red + kGreedyWaves;                                       // 8
 
   ProbState* st = states + blockIdx.y;
   const int sidx = blockIdx.x;
@@ -284,18 +319,20 @@ __global__ __launch_bounds__(256) void greedy_clique_kernel(
   int csize = 1;
   if (tid == 0) C[0] = v0;
   int pc = 0;
-  for (int w = tid; w < W; w += 256) {
+  for (int w = tid; w < W; w += kGreedyThreads) {
     const uint64_t x = bm[(int64_t)v0 * W + w];
     P[w] = x;
     pc += __popcll(x);
   }
-  pc = block_sum_i(pc, red4);
+  pc = blockN_sum_i(pc, red);
 
-  while (pc > 0) {
-    if (pc > kDynThreshold) {
+  // ---- phase 1: shrink P to at most kCap candidates --------------------------------------
+  bool prefer_vote = false;
+  while (pc > kCap) {
+    if (!prefer_vote) {
       // static pick: largest global degree, ties to the smallest index
       unsigned long long key = 0;
-      for (int w = tid; w < W; w += 256) {
+      for (int w = tid; w < W; w += kGreedyThreads) {
         uint64_t bits = P[w];
         while (bits) {
           const int u = w * 64 + __builtin_ctzll(bits);
@@ -305,43 +342,111 @@ __global__ __launch_bounds__(256) void greedy_clique_kernel(
           key = k > key ? k : key;
         }
       }
-      key = block_max_u64(key, red64);
+      key = blockN_max_u64(key, red64);
       const int u = (int)(0xffffffffu - (unsigned int)(key & 0xffffffffu));
       if (tid == 0) C[csize] = u;
       ++csize;
       int c = 0;
       __syncthreads();
-      for (int w = tid; w < W; w += 256) {
+      for (int w = tid; w < W; w += kGreedyThreads) {
         const uint64_t x = P[w] & bm[(int64_t)u * W + w];
         P[w] = x;
         c += __popcll(x);
       }
-      pc = block_sum_i(c, red4);
+      c = blockN_sum_i(c, red);
+      prefer_vote = (long long)c * 10 > (long long)pc * 9;
+      pc = c;
       continue;
     }
+    // streaming vote round over the set bits of P: wave `wave` owns words wave, wave+8, ...
+    if (tid == 0) misc[0] = csize;
+    unsigned long long bestk = 0;
+    for (int w = wave; w < W; w += kGreedyWaves) {
+      uint64_t bits = P[w];
+      uint64_t uni = 0;
+      while (bits) {
+        const int b = __builtin_ctzll(bits);
+        bits &= bits - 1;
+        const int u = w * 64 + b;
+        const uint64_t* ru = bm + (int64_t)u * W;
+        int c = 0;
+        for (int x = lane; x < W; x += 64) c += __popcll(ru[x] & P[x]);
+        c = wave_sum_i(c);
+        if (c == pc - 1) {
+          uni |= 1ull << b;
+        } else {
+          const unsigned long long kk =
+              ((unsigned long long)(unsigned int)(c + 1) << 32) | (0xffffffffu - (unsigned int)u);
+          bestk = kk > bestk ? kk : bestk;
+        }
+      }
+      if (lane == 0) U[w] = uni;
+    }
+    bestk = blockN_max_u64(bestk, red64);  // (barriers inside: U and misc[0] are visible after)
+    // append the universal candidates (any order: the final clique is re-sorted) and drop them
+    int nU = 0;
+    for (int w = tid; w < W; w += kGreedyThreads) {
+      uint64_t bits = U[w];
+      if (bits) {
+        const int k = __popcll(bits);
+        int pos = atomicAdd(&misc[0], k);
+        nU += k;
+        P[w] &= ~bits;
+        while (bits) {
+          C[pos++] = w * 64 + __builtin_ctzll(bits);
+          bits &= bits - 1;
+        }
+      }
+    }
+    nU = blockN_sum_i(nU, red);
+    csize += nU;
+    const int left = pc - nU;
+    if (left > 0 && bestk) {
+      const int u = (int)(0xffffffffu - (unsigned int)(bestk & 0xffffffffu));
+      if (tid == 0) C[csize] = u;
+      ++csize;
+      int c = 0;
+      for (int w = tid; w < W; w += kGreedyThreads) {
+        const uint64_t x = P[w] & bm[(int64_t)u * W + w];
+        P[w] = x;
+        c += __popcll(x);
+      }
+      c = blockN_sum_i(c, red);
+      prefer_vote = (long long)c * 10 > (long long)left * 9;
+      pc = c;
+    } else {
+      pc = 0;
+      __syncthreads();
+    }
+  }
 
-    // ---- vote round: enumerate candidates in index order (contiguous word chunks per thread)
-    const int wpt = (W + 255) / 256;
+  if (pc > 0) {
+    // ---- phase 2: candidate list in index order (contiguous word chunks per thread) -------
+    const int wpt = (W + kGreedyThreads - 1) / kGreedyThreads;
     const int w0 = tid * wpt, w1 = min(W, w0 + wpt);
     int mycnt = 0;
     for (int w = w0; w < w1; ++w) mycnt += __popcll(P[w]);
     wcnt[tid] = mycnt;
     __syncthreads();
-    // exclusive scan over 256 entries by wave 0 (4 per lane)
-    if (wave == 0) {
-      int a0 = wcnt[4 * lane], a1 = wcnt[4 * lane + 1], a2 = wcnt[4 * lane + 2],
-          a3 = wcnt[4 * lane + 3];
-      int tot = a0 + a1 + a2 + a3, incl = tot;
+    if (wave == 0) {  // exclusive scan over 512 entries (8 per lane)
+      int a[8], tot = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        a[k] = wcnt[8 * lane + k];
+        tot += a[k];
+      }
+      int incl = tot;
 #pragma unroll
       for (int o = 1; o < 64; o <<= 1) {
         int t = __shfl_up(incl, o, 64);
         if (lane >= o) incl += t;
       }
       int ex = incl - tot;
-      wcnt[4 * lane] = ex;
-      wcnt[4 * lane + 1] = ex + a0;
-      wcnt[4 * lane + 2] = ex + a0 + a1;
-      wcnt[4 * lane + 3] = ex + a0 + a1 + a2;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        wcnt[8 * lane + k] = ex;
+        ex += a[k];
+      }
     }
     __syncthreads();
     {
@@ -355,65 +460,110 @@ __global__ __launch_bounds__(256) void greedy_clique_kernel(
       }
     }
     __syncthreads();
-    // votes: a wave per candidate
-    for (int idx = wave; idx < pc; idx += 4) {
-      const int u = cand[idx];
-      const uint64_t* ru = bm + (int64_t)u * W;
-      int c = 0;
-      for (int w = lane; w < W; w += 64) c += __popcll(ru[w] & P[w]);
-      c = wave_sum_i(c);
-      if (lane == 0) dP[idx] = c;
+
+    // ---- phase 3: compact adjacency A[r][k] bit l = edge(cand[r], cand[64k+l]) -------------
+    const int Wc = (pc + 63) >> 6;
+    int cw[kCapW], cb[kCapW];
+    unsigned int vmask = 0;
+#pragma unroll
+    for (int k = 0; k < kCapW; ++k) {
+      const int idx = 64 * k + lane;
+      const bool ok = idx < pc;
+      const int c = ok ? cand[idx] : 0;
+      cw[k] = c >> 6;
+      cb[k] = c & 63;
+      vmask |= ok ? (1u << k) : 0u;
     }
-    __syncthreads();
-    // bookkeeping by wave 0: append universal candidates, find the best non-universal one
-    if (wave == 0) {
-      int cs = csize, nU = 0;
-      unsigned long long bestk = 0;
-      for (int base = 0; base < pc; base += 64) {
-        const int idx = base + lane;
-        const bool valid = idx < pc;
-        const int dv = valid ? dP[idx] : -1;
-        const int u = valid ? cand[idx] : 0;
-        const bool isU = valid && (dv == pc - 1);
-        const uint64_t m = __ballot(isU);
-        if (isU) {
-          C[cs + __popcll(m & ((1ull << lane) - 1ull))] = u;
-          atomicAnd(reinterpret_cast<unsigned long long*>(&P[u >> 6]), ~(1ull << (u & 63)));
+    for (int r = wave; r < pc; r += 2 * kGreedyWaves) {
+      const int r2 = r + kGreedyWaves;
+      const bool has2 = r2 < pc;
+      const uint64_t* ru = bm + (int64_t)cand[r] * W;
+      const uint64_t* rv = bm + (int64_t)cand[has2 ? r2 : r] * W;
+      uint64_t x[kCapW], y[kCapW];
+#pragma unroll
+      for (int k = 0; k < kCapW; ++k) {
+        x[k] = (k < Wc) ? ru[cw[k]] : 0ull;
+        y[k] = (k < Wc) ? rv[cw[k]] : 0ull;
+      }
+      uint64_t mx = 0, my = 0;
+#pragma unroll
+      for (int k = 0; k < kCapW; ++k) {
+        const bool ok = (vmask >> k) & 1u;
+        const uint64_t bx = __ballot(ok && ((x[k] >> cb[k]) & 1ull));
+        const uint64_t by = __ballot(ok && ((y[k] >> cb[k]) & 1ull));
+        if (lane == k) {
+          mx = bx;
+          my = by;
         }
-        const int k = __popcll(m);
-        cs += k;
-        nU += k;
-        if (valid && !isU) {
+      }
+      if (lane < Wc) {
+        A[r * kCapStride + lane] = mx;
+        if (has2) A[r2 * kCapStride + lane] = my;
+      }
+    }
+    if (tid < 16) {
+      const int lo = tid * 64;
+      Pc[tid] = (lo + 64 <= pc) ? ~0ull : (lo < pc ? ((1ull << (pc - lo)) - 1ull) : 0ull);
+    }
+    if (tid == 0) misc[0] = csize;
+    __syncthreads();
+
+    // ---- phase 4: vote rounds on the compact matrix (all in LDS) ---------------------------
+    int pcnt = pc;
+    while (pcnt > 0) {
+      int dv[2];
+      bool in[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int c = tid + kGreedyThreads * j;
+        in[j] = c < pc && ((Pc[c >> 6] >> (c & 63)) & 1ull);
+        int dd = 0;
+        if (in[j]) {
+          for (int w = 0; w < Wc; ++w) dd += __popcll(A[c * kCapStride + w] & Pc[w]);
+        }
+        dv[j] = dd;
+      }
+      __syncthreads();  // all votes read Pc before it is modified
+      unsigned long long bestk = 0;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int c = tid + kGreedyThreads * j;
+        const bool isU = in[j] && dv[j] == pcnt - 1;
+        const uint64_t m = __ballot(isU);
+        if (m) {
+          int base = 0;
+          if (lane == 0) base = atomicAdd(&misc[0], __popcll(m));
+          base = __shfl(base, 0, 64);
+          if (isU) {
+            C[base + __popcll(m & ((1ull << lane) - 1ull))] = cand[c];
+            atomicAnd(reinterpret_cast<unsigned long long*>(&Pc[c >> 6]), ~(1ull << (c & 63)));
+          }
+        }
+        if (in[j] && !isU) {
           const unsigned long long kk =
-              ((unsigned long long)(unsigned int)(dv + 1) << 32) | (0xffffffffu - (unsigned int)u);
+              ((unsigned long long)(unsigned int)(dv[j] + 1) << 32) | (0xffffffffu - (unsigned int)c);
           bestk = kk > bestk ? kk : bestk;
         }
       }
-      bestk = wave_max_u64(bestk);
-      if (lane == 0) {
-        misc[0] = cs;
-        misc[1] = nU;
-        misc[2] = bestk ? (int)(0xffffffffu - (unsigned int)(bestk & 0xffffffffu)) : -1;
-      }
-    }
-    __syncthreads();
-    csize = misc[0];
-    const int nU = misc[1];
-    const int ubest = misc[2];
-    pc -= nU;
-    if (pc > 0 && ubest >= 0) {
-      if (tid == 0) C[csize] = ubest;
-      ++csize;
-      int c = 0;
-      for (int w = tid; w < W; w += 256) {
-        const uint64_t x = P[w] & bm[(int64_t)ubest * W + w];
-        P[w] = x;
-        c += __popcll(x);
-      }
-      pc = block_sum_i(c, red4);
-    } else {
-      pc = 0;
+      bestk = blockN_max_u64(bestk, red64);
+      csize = misc[0];
+      int left = 0;
+      for (int w = 0; w < Wc; ++w) left += __popcll(Pc[w]);
       __syncthreads();
+      if (left > 0 && bestk) {
+        const int bc = (int)(0xffffffffu - (unsigned int)(bestk & 0xffffffffu));
+        if (tid == 0) {
+          C[csize] = cand[bc];
+          misc[0] = csize + 1;
+        }
+        ++csize;
+        if (tid < Wc) Pc[tid] &= A[bc * kCapStride + tid];
+        __syncthreads();
+        pcnt = 0;
+        for (int w = 0; w < Wc; ++w) pcnt += __popcll(Pc[w]);
+      } else {
+        pcnt = 0;
+      }
     }
   }
   if (tid == 0) st->start_size[sidx] = csize;
@@ -520,16 +670,26 @@ __global__ __launch_bounds__(256) void select_best_kernel(
   }
 }
 
+size_t greedy_lds_bytes(int max_W) {
+  const size_t Wpad = (size_t)((max_W + 1) & ~1);
+  return Wpad * 8 * 2 + (size_t)kCap * kCapStride * 8 + 16 * 8 + kGreedyWaves * 8 + (size_t)kCap * 4 +
+         kGreedyThreads * 4 + kGreedyWaves * 4 + 8 * 4;
+}
+
 void launch_heuristic(hipStream_t s, const ProbDesc* d_desc, int batch, int max_W,
                       const uint64_t* d_bitmap, const int32_t* d_deg, ProbState* d_state,
                       int32_t* d_start_cliques, int64_t total_n, int32_t* d_cand,
                       int32_t* d_clique) {
   if (batch <= 0) return;
-  const int Wpad = (max_W + 1) & ~1;
-  const size_t lds = (size_t)Wpad * 8 + 4 * 8 + (size_t)kDynThreshold * 4 * 2 + 4 * 4 + 8 * 4 +
-                     256 * 4;
-  hipLaunchKernelGGL(greedy_clique_kernel, dim3(kMaxStarts, batch), dim3(256), lds, s, d_desc,
-                     d_bitmap, d_deg, d_state, d_start_cliques, total_n);
+  const size_t lds = greedy_lds_bytes(max_W);
+  static size_t lds_cap = 0;
+  if (lds > lds_cap) {  // beyond the 64 KB default dynamic-LDS limit
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(greedy_clique_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    lds_cap = lds;
+  }
+  hipLaunchKernelGGL(greedy_clique_kernel, dim3(kMaxStarts, batch), dim3(kGreedyThreads), lds, s,
+                     d_desc, d_bitmap, d_deg, d_state, d_start_cliques, total_n);
 }
 
 // ------------------------------------------------------------------------------------------
