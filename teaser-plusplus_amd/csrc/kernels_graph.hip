@@ -9,6 +9,8 @@
 //
 // Compiled with -ffp-contract=off: the pruning predicate must round every product and add
 // individually, as the reference's default (non-FMA) build does.  FMAs below are explicit.
+#include <utility>
+
 #include "internal.h"
 
 namespace thip {
@@ -53,107 +55,233 @@ __device__ __forceinline__ unsigned long long block_max_u64(unsigned long long v
 // ------------------------------------------------------------------------------------------
 // Reference semantics (registration.cc:434-442): with a = src_j - src_i, b = dst_j - dst_i,
 //   edge <=> | sqrt((ax^2+ay^2)+az^2) - sqrt((bx^2+by^2)+bz^2) | <= beta      (all IEEE double).
-// A = |a|^2 and B = |b|^2 are computed exactly as the reference rounds them.  The two square
-// roots are avoided by the algebraically equivalent test on S = A + B - beta^2:
-//   edge <=> S <= 0  or  S^2 <= 4AB,
-// decided from d = S^2 - 4AB only when |d| clears a guard band of 1e-12 (A+B+beta^2)^2 -- three
-// orders of magnitude above both the rounding error of d (<= ~7e-16 (A+B+beta^2)^2) and the
-// gap between the reference's rounded predicate and the exact one (<= ~4e-15 (A+B+beta^2)^2).
-// Inside the band (a vanishing fraction of pairs, and any NaN) the reference expression itself
-// is evaluated with correctly rounded sqrt, so the bitmap is bit-identical by construction.
-__device__ __forceinline__ bool tim_edge_fixed(double ax, double ay, double az, double bx,
-                                               double by, double bz, double beta, double beta2) {
+// Exact arithmetic: with A = |a|^2, B = |b|^2, t = A + B, D = A - B,
+//   edge <=> t <= beta^2  or  d := D^2 - 2 beta^2 t + beta^4 <= 0         (d = (t-beta^2)^2 - 4AB).
+// FAST PATH (per pair: 6 sub, 6 fma/mul for A and B, 2 add, 2 fma for d, 2 for the band, 3 cmp):
+// A, B, d are evaluated with FMAs -- NOT the reference's rounding -- and the sign of d is trusted
+// only when |d| clears a guard band of 2e-12 (t^2 + beta^4) >= 1e-12 (t + beta^2)^2: three
+// orders of magnitude above both the rounding error of the fast d (a few 1e-16 (t+beta^2)^2) and
+// the gap between the reference's rounded predicate and the exact one (<= ~4e-15 (t+beta^2)^2).
+// EXACT PATH (inside the band -- a vanishing fraction of pairs -- and for any NaN): the reference
+// expression itself, products and sums individually rounded (this file is compiled with
+// -ffp-contract=off) and correctly rounded sqrt, so the bitmap is bit-identical by construction.
+struct EdgeConst {
+  double beta;        // 2 noise_bound sqrt(cbar2)
+  double beta2;       // beta^2
+  double m2beta2;     // -2 beta^2
+  double beta4;       // beta^4
+  double s_hat;       // scale estimate (MODE 1)
+};
+
+__device__ __forceinline__ bool tim_edge_exact(double ax, double ay, double az, double bx,
+                                               double by, double bz, double beta) {
   const double A = (ax * ax + ay * ay) + az * az;
   const double B = (bx * bx + by * by) + bz * bz;
+  return __builtin_fabs(__builtin_sqrt(A) - __builtin_sqrt(B)) <= beta;
+}
+
+// fast path; *uncertain is set when the sign of d cannot be trusted (guard band or NaN)
+__device__ __forceinline__ bool tim_edge_fast(double ax, double ay, double az, double bx,
+                                              double by, double bz, const EdgeConst& k,
+                                              bool* uncertain, bool* short_pair) {
+  const double A = __builtin_fma(az, az, __builtin_fma(ay, ay, ax * ax));
+  const double B = __builtin_fma(bz, bz, __builtin_fma(by, by, bx * bx));
   const double t = A + B;
-  const double S = t - beta2;
-  const double d = __builtin_fma(S, S, -4.0 * (A * B));
-  const double u = t + beta2;
-  const double band = (u * u) * 1e-12;
-  bool res = (S <= 0.0) | (d <= 0.0);
-  if (!(__builtin_fabs(d) > band)) {  // rare: guard band or NaN
-    res = __builtin_fabs(__builtin_sqrt(A) - __builtin_sqrt(B)) <= beta;
-  }
-  return res;
+  const double D = A - B;
+  const double d = __builtin_fma(D, D, __builtin_fma(t, k.m2beta2, k.beta4));
+  const double band = __builtin_fma(t, t, k.beta4) * 2e-12;
+  *uncertain = !(__builtin_fabs(d) > band);
+  *short_pair = t <= k.beta2;
+  return d <= 0.0;
 }
 
 // TLS-scale consensus (registration.cc:415-424 + :86): raw = |b|/|a|, alpha = beta * (1/|a|),
 // edge <=> |raw - s_hat| <= alpha.  Evaluated literally (IEEE sqrt / div).
 __device__ __forceinline__ bool tim_edge_scaled(double ax, double ay, double az, double bx,
-                                                double by, double bz, double beta, double s_hat) {
+                                                double by, double bz, const EdgeConst& k) {
   const double v1 = __builtin_sqrt((ax * ax + ay * ay) + az * az);
   const double v2 = __builtin_sqrt((bx * bx + by * by) + bz * bz);
   const double raw = v2 / v1;
-  const double alpha = beta * (1.0 / v1);
-  return __builtin_fabs(raw - s_hat) <= alpha;
+  const double alpha = k.beta * (1.0 / v1);
+  return __builtin_fabs(raw - k.s_hat) <= alpha;
 }
 
 // Tiling: a wave owns 64 rows (lane = row) and walks 64-column tiles of the upper triangle.
-// The column point is wave-uniform (scalar loads, SGPR operands); per column the 64 row lanes
-// evaluate the predicate, the lane keeps its own bit (row word) and the wave ballot IS the
-// transposed word (row j, word I) -- so each unordered pair is evaluated once and both halves of
-// the symmetric bitmap are written.  kColTilesPerWave consecutive column tiles per wave give each
-// lane kColTilesPerWave contiguous words of its row.
+// The tile's 64 column points are staged once in a per-wave LDS buffer and read back as
+// broadcast ds_read_b128 (same address in every lane), software-pipelined three columns ahead;
+// per column the 64 row lanes evaluate the predicate, the lane keeps its own bit (row word) and
+// the wave ballot IS the transposed word (row j, word I, kept in lane j by v_writelane) -- so each
+// unordered pair is evaluated once and both halves of the symmetric bitmap are written.
+// A block = 4 waves x kColTilesPerWave consecutive column tiles of ONE row tile, so a row's words
+// from one block are contiguous (128 B).
 constexpr int kColTilesPerWave = 4;
 constexpr int kWavesPerBlock = 4;
 constexpr int kColTilesPerBlock = kColTilesPerWave * kWavesPerBlock;
+
+// One 64-row x 64-column tile, fully unrolled over the columns (B is a compile-time constant so
+// the own-bit constant and the v_writelane lane select are immediates).
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+template <int MODE>
+struct ColTile {
+  static constexpr int kPf = 3;         // software prefetch distance (columns)
+  const double* cb;                     // LDS: this wave's 64 column points, 6 doubles each
+  d2 pf[kPf][3];                        // prefetched column points (registers)
+  int cb_addr;                          // LDS byte address of cb
+
+  // 3 x ds_read_b128 of column C (48 B), broadcast: every lane reads the same address
+  template <int C>
+  __device__ __forceinline__ void load_col(d2 (&slot)[3]) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(slot[0]) : "v"(cb_addr), "n"(48 * C));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(slot[1]) : "v"(cb_addr), "n"(48 * C + 16));
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(slot[2]) : "v"(cb_addr), "n"(48 * C + 32));
+  }
+  double six, siy, siz, dix, diy, diz;  // row point (per lane)
+  unsigned int own_lo, own_hi;          // this lane's row word
+  int tr_lo, tr_hi;                     // lane b: ballot of column b (the transposed word)
+  uint64_t unc_cols;                    // wave-uniform: columns to redo with the exact predicate
+
+  template <int B>
+  __device__ __forceinline__ void step(const EdgeConst& kc) {
+    // Column point B was prefetched kPf steps ago into slot S; wait for it (LDS returns in order,
+    // so the younger prefetches stay in flight), then refill the slot with column B + kPf.
+    // The loads and waits are inline asm because the compiler otherwise sinks every LDS read to
+    // just before its use (no latency hiding); the "+v" operands order the uses after the wait.
+    constexpr int S = B % kPf;
+    constexpr int younger = 3 * ((63 - B) < (kPf - 1) ? (63 - B) : (kPf - 1));
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(pf[S][0]), "+v"(pf[S][1]), "+v"(pf[S][2]) : "n"(younger));
+    const double sjx = pf[S][0].x, sjy = pf[S][0].y, sjz = pf[S][1].x;
+    const double djx = pf[S][1].y, djy = pf[S][2].x, djz = pf[S][2].y;
+    if (B + kPf < 64) load_col<B + kPf>(pf[S]);
+    bool e;
+    uint64_t m;
+    if (MODE == 0) {
+      bool unc, shortp;
+      const bool neg = tim_edge_fast(sjx - six, sjy - siy, sjz - siz, djx - dix, djy - diy,
+                                     djz - diz, kc, &unc, &shortp);
+      // columns holding an uncertain lane are redone exactly after the tile (scalar bookkeeping)
+      unc_cols |= (__builtin_amdgcn_ballot_w64(unc) != 0ull) ? (1ull << B) : 0ull;
+      // each compare writes its lane mask straight to an SGPR pair; OR them as scalars
+      m = __builtin_amdgcn_ballot_w64(neg) | __builtin_amdgcn_ballot_w64(shortp);
+      e = neg | shortp;
+    } else {
+      // reference TIM is v_j - v_i with i < j; in the transposed direction the norms are equal
+      e = tim_edge_scaled(sjx - six, sjy - siy, sjz - siz, djx - dix, djy - diy, djz - diz, kc);
+      m = __builtin_amdgcn_ballot_w64(e);
+    }
+    // consume the mask NOW (the empty asm pins the accumulators in VGPRs; without it the
+    // compiler keeps all 64 masks live in SGPRs and spills them)
+    if (B < 32) {
+      own_lo |= e ? (1u << (B & 31)) : 0u;
+      asm volatile("" : "+v"(own_lo));
+    } else {
+      own_hi |= e ? (1u << (B & 31)) : 0u;
+      asm volatile("" : "+v"(own_hi));
+    }
+    // lane B keeps the ballot: v_writelane_b32 (no clang builtin on this toolchain)
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(tr_lo) : "s"((int)(unsigned int)m), "n"(B));
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(tr_hi) : "s"((int)(unsigned int)(m >> 32)), "n"(B));
+  }
+  template <int... Bs>
+  __device__ __forceinline__ void run(const EdgeConst& kc, std::integer_sequence<int, Bs...>) {
+    (step<Bs>(kc), ...);
+  }
+};
 
 template <int MODE>
 __global__ __launch_bounds__(256) void tim_graph_kernel(const ProbDesc* __restrict__ descs,
                                                         const double* __restrict__ src,
                                                         const double* __restrict__ dst,
                                                         uint64_t* __restrict__ bitmap,
-                                                        double beta, double beta2,
+                                                        double beta, int gx, int gy,
                                                         const ProbState* __restrict__ states) {
-  const ProbDesc d = descs[blockIdx.z];
+  const ProbDesc d = descs[blockIdx.y];
   const int n = d.n, W = d.W;
   const int T = W;  // row/column tiles of 64
-  const int I = blockIdx.y;
+  // Logical block order: row tile fastest, so the blocks in flight share a column group.
+  // XCD-aware remap (hardware deals consecutive workgroup ids round-robin over the 8 XCDs):
+  // inside every run of 128 ids, the 16 logical neighbours (16 consecutive row tiles of one column
+  // group = the writers of one 128-B line of transposed words) are given the same XCD, so their
+  // 8-byte partial writes merge in that XCD's L2; every XCD still gets 16 of each 128 blocks.
+  const int nblk = gx * gy;
+  const int pid = blockIdx.x;
+  int lid = pid;
+  if (pid < (nblk & ~127)) lid = (pid & ~127) | ((pid & 7) << 4) | ((pid >> 3) & 15);
+  const int I = lid % gy;
+  const int X = lid / gy;
   if (I >= T) return;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int Jbase = (blockIdx.x * kWavesPerBlock + wave) * kColTilesPerWave;
+  const int Jbase = (X * kWavesPerBlock + wave) * kColTilesPerWave;
   if (Jbase + kColTilesPerWave - 1 < I || Jbase >= T) return;  // below the diagonal / outside
 
   const double* __restrict__ ps = src + 3 * d.pt_off;
   const double* __restrict__ pd = dst + 3 * d.pt_off;
   uint64_t* __restrict__ bm = bitmap + d.bm_off;
-  double s_hat = 1.0;
-  if (MODE == 1) s_hat = states[blockIdx.z].scale;
+  __shared__ __attribute__((aligned(16))) double cbuf[kWavesPerBlock][64 * 6];
+  double* cbw = cbuf[wave];  // private to this wave: no block barrier needed
+  EdgeConst kc;
+  kc.beta = beta;
+  kc.beta2 = beta * beta;
+  kc.m2beta2 = -2.0 * kc.beta2;
+  kc.beta4 = kc.beta2 * kc.beta2;
+  kc.s_hat = 1.0;
+  if (MODE == 1) kc.s_hat = states[blockIdx.y].scale;
 
   const int i = I * 64 + lane;
   const bool vi = i < n;
   const int ic = vi ? i : n - 1;
   const double six = ps[3 * ic], siy = ps[3 * ic + 1], siz = ps[3 * ic + 2];
   const double dix = pd[3 * ic], diy = pd[3 * ic + 1], diz = pd[3 * ic + 2];
+  const uint64_t rowmask = (n - I * 64 >= 64) ? ~0ull : ((1ull << (n - I * 64)) - 1ull);
 
   for (int s = 0; s < kColTilesPerWave; ++s) {
     const int J = Jbase + s;
     if (J < I || J >= T) continue;
     const int j0 = J * 64;
-    uint64_t own = 0, tr = 0;
-#pragma unroll 8
-    for (int b = 0; b < 64; ++b) {
-      const int j = j0 + b;
-      const int jc = j < n ? j : n - 1;  // wave-uniform
-      const double sjx = ps[3 * jc], sjy = ps[3 * jc + 1], sjz = ps[3 * jc + 2];
-      const double djx = pd[3 * jc], djy = pd[3 * jc + 1], djz = pd[3 * jc + 2];
-      bool e;
-      if (MODE == 0) {
-        e = tim_edge_fixed(sjx - six, sjy - siy, sjz - siz, djx - dix, djy - diy, djz - diz, beta,
-                           beta2);
-      } else {
-        // reference TIM is v_j - v_i with i < j; in the transposed direction the norms are equal
-        e = tim_edge_scaled(sjx - six, sjy - siy, sjz - siz, djx - dix, djy - diy, djz - diz,
-                            beta, s_hat);
-      }
-      e = e & vi & (j < n) & (j != i);
-      const uint64_t m = __ballot(e);
-      own |= (uint64_t)(e ? 1 : 0) << b;
-      tr = (lane == b) ? m : tr;
+    // stage the tile's 64 column points in LDS (lane b -> column j0+b, clamped to n-1)
+    {
+      const int jc = min(j0 + lane, n - 1);
+      double* w = cbw + 6 * lane;
+      w[0] = ps[3 * jc]; w[1] = ps[3 * jc + 1]; w[2] = ps[3 * jc + 2];
+      w[3] = pd[3 * jc]; w[4] = pd[3 * jc + 1]; w[5] = pd[3 * jc + 2];
     }
+    ColTile<MODE> ct;
+    ct.cb = cbw;
+    ct.six = six; ct.siy = siy; ct.siz = siz; ct.dix = dix; ct.diy = diy; ct.diz = diz;
+    ct.own_lo = 0; ct.own_hi = 0; ct.tr_lo = 0; ct.tr_hi = 0; ct.unc_cols = 0;
+    ct.cb_addr = (int)(uintptr_t)cbw;  // LDS aperture: the low 32 bits are the LDS byte address
+    // every staging ds_write above must have been ISSUED before the asm reads (in-order LDS)
+    asm volatile("" ::: "memory");
+    ct.template load_col<0>(ct.pf[0]);
+    ct.template load_col<1>(ct.pf[1]);
+    ct.template load_col<2>(ct.pf[2]);
+    ct.run(kc, std::make_integer_sequence<int, 64>());
+    uint64_t own = ((uint64_t)ct.own_hi << 32) | ct.own_lo;
+    uint64_t trw = ((uint64_t)(unsigned int)ct.tr_hi << 32) | (unsigned int)ct.tr_lo;
+    if (MODE == 0) {
+      // exact redo of the (very rare) columns with a lane inside the guard band
+      uint64_t todo = ct.unc_cols;
+      while (todo) {
+        const int b = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const int jc = min(j0 + b, n - 1);
+        const bool e = tim_edge_exact(ps[3 * jc] - six, ps[3 * jc + 1] - siy, ps[3 * jc + 2] - siz,
+                                      pd[3 * jc] - dix, pd[3 * jc + 1] - diy, pd[3 * jc + 2] - diz,
+                                      kc.beta);
+        const uint64_t m = __ballot(e);
+        own = (own & ~(1ull << b)) | ((uint64_t)(e ? 1 : 0) << b);
+        trw = (lane == b) ? m : trw;
+      }
+    }
+    // masks applied once per tile: columns / rows beyond n, and the diagonal
+    const uint64_t colmask = (n - j0 >= 64) ? ~0ull : ((1ull << (n - j0)) - 1ull);
+    own &= colmask;
+    if (J == I) own &= ~(1ull << lane);
     if (vi) bm[(int64_t)i * W + J] = own;
-    if (J != I && j0 + lane < n) bm[(int64_t)(j0 + lane) * W + I] = tr;
+    if (J != I && j0 + lane < n) {
+      bm[(int64_t)(j0 + lane) * W + I] = trw & rowmask;
+    }
   }
 }
 
@@ -163,13 +291,14 @@ void launch_tim_graph(hipStream_t s, const ProbDesc* d_desc, int batch, int max_
   if (batch <= 0 || max_n <= 0) return;
   const int T = (max_n + 63) / 64;
   const double beta = 2 * noise_bound * sqrt(cbar2);  // registration.cc:438 / :421
-  dim3 grid((T + kColTilesPerBlock - 1) / kColTilesPerBlock, T, batch);
+  const int gx = (T + kColTilesPerBlock - 1) / kColTilesPerBlock, gy = T;
+  dim3 grid(gx * gy, batch);
   if (mode == 0)
     hipLaunchKernelGGL(tim_graph_kernel<0>, grid, dim3(256), 0, s, d_desc, d_src, d_dst, d_bitmap,
-                       beta, beta * beta, d_state);
+                       beta, gx, gy, d_state);
   else
     hipLaunchKernelGGL(tim_graph_kernel<1>, grid, dim3(256), 0, s, d_desc, d_src, d_dst, d_bitmap,
-                       beta, beta * beta, d_state);
+                       beta, gx, gy, d_state);
 }
 
 // ------------------------------------------------------------------------------------------
