@@ -124,7 +124,6 @@ def main():
         truth.append(tr)
     offsets = np.arange(B, dtype=np.int64) * n
     sizes = np.full(B, n, dtype=np.int32)
-    records = torch.zeros((B, 16), dtype=torch.float64, device=dev)
 
     def step(k):
         s_t, d_t = pool[k % args.pool]
@@ -160,20 +159,10 @@ def main():
         k1_launches += pf["tim_graph_launches"]
         k1_bytes += pf["tim_graph_bytes"]
         k1_pairs += pf["tim_graph_pairs"]
-    # final gather of the fixed-size result records (RCCL over xGMI when N > 1)
-    rec = np.zeros((B, 16))
-    for b in range(B):
-        o = last[b]
-        rec[b, 0] = o.valid
-        rec[b, 1] = o.scale
-        rec[b, 2:11] = o.rotation[:]
-        rec[b, 11:14] = o.translation[:]
-        rec[b, 14] = o.clique_size
-        rec[b, 15] = o.n_translation_inliers
-    records.copy_(torch.from_numpy(rec))
-    if dist is not None:
-        gathered = [torch.empty_like(records) for _ in range(world)]
-        dist.all_gather(gathered, records)
+    # final gather of the fixed-size result records (256 B each; RCCL over xGMI when N > 1)
+    rec = tp.batched.pack_records([last[b] for b in range(B)], first_index=rank * B)
+    allrec = tp.batched.gather_records(rec, world * B, dist if world > 1 else None, device=dev)
+    assert allrec.shape[0] == world * B
     sync_all()
     elapsed = time.perf_counter() - t0
     t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)

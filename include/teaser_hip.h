@@ -91,7 +91,9 @@ typedef struct teaser_solution_c {
   int32_t gnc_iterations;
   int32_t clique_exact_run;      /* 1 iff the device B&B had to run (bounds did not close) */
   int32_t heuristic_size;        /* lower bound found by the greedy stage */
-  int32_t reserved0;
+  int32_t colour_uncoloured;     /* global colouring bound: survivors left without one of the
+                                    heuristic_size colours (0: greedy clique proven maximum without
+                                    search; > 0: they were the only B&B roots; -1: stage not run) */
   int64_t num_edges;             /* edges of the inlier graph */
 } teaser_solution_c;
 
@@ -111,6 +113,8 @@ typedef struct teaser_profile_c {
   float total_ms;
   int64_t tim_graph_pairs; /* unordered pairs evaluated by K1 in the last call */
   int64_t tim_graph_bytes; /* algorithmic bytes of K1: 48 n + 8 n ceil(n/64), summed over problems */
+  float colour_ms;         /* global colouring bound (only for problems the peel did not close) */
+  int32_t reserved0;
 } teaser_profile_c;
 
 typedef struct teaser_hip_solver teaser_hip_solver;

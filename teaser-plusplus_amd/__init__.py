@@ -85,7 +85,7 @@ class SolutionC(C.Structure):
         ("gnc_iterations", C.c_int32),
         ("clique_exact_run", C.c_int32),
         ("heuristic_size", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("colour_uncoloured", C.c_int32),
         ("num_edges", C.c_int64),
     ]
 
@@ -105,6 +105,8 @@ class ProfileC(C.Structure):
         ("total_ms", C.c_float),
         ("tim_graph_pairs", C.c_int64),
         ("tim_graph_bytes", C.c_int64),
+        ("colour_ms", C.c_float),
+        ("reserved0", C.c_int32),
     ]
 
 
@@ -520,6 +522,8 @@ class RobustRegistrationSolver:
         return self._lib.teaser_hip_get_stream(self._h)
 
 
-__all__ = ["RobustRegistrationSolver", "RegistrationSolution", "RotationEstimationAlgorithm",
+from . import batched  # noqa: E402,F401  (sharding + record gather for the multi-GPU batched mode)
+
+__all__ = ["batched", "RobustRegistrationSolver", "RegistrationSolution", "RotationEstimationAlgorithm",
            "InlierSelectionMode", "InlierGraphFormulation", "TeaserHipError", "synth_problem",
            "device_count", "build", "lib", "LIB_PATH", "EXPORTED_SYMBOLS"]

@@ -37,7 +37,7 @@ struct ProbState {
   int32_t n_rot;         // rotation inliers
   int32_t n_trans;       // translation inliers
   int32_t gnc_iters;
-  int32_t pad0;
+  int32_t x_count;       // colouring bound: survivors left without a colour
   int32_t start_vertex[kMaxStarts];
   int32_t start_size[kMaxStarts];
   unsigned long long deg_sum;  // sum of degrees = 2 * edges
@@ -91,9 +91,17 @@ struct ExactArgs {
   char* arena;              // device scratch, n_waves * arena_bytes
   int64_t arena_bytes;      // per wave
   int32_t n_waves;
+  int32_t n_roots;          // roots 0..n_roots-1 are searched (n: all; colouring bound: |X|)
   int64_t deadline_ticks;   // wall_clock64 ticks allowed (0 = unlimited)
 };
 void launch_exact_clique(hipStream_t s, const ExactArgs& a);
+// global colouring bound on the peel survivors of the selected problems (kernels_clique.hip)
+constexpr int kColourMaxLb = 4096;  // palette limit (64 LDS words per wave)
+constexpr int kColourRounds = 10;
+void launch_colour_bound(hipStream_t s, const ProbDesc* d_desc, const int32_t* d_sel, int nsel,
+                         int max_n, const uint64_t* d_bitmap, const uint64_t* d_alive,
+                         const int32_t* d_clique, ProbState* d_state, int32_t* d_colour,
+                         int32_t* d_tent, int32_t* d_xlist, int rounds);
 
 // K5/K6 (kernels_estimate.hip)
 void launch_gnc_tls(hipStream_t s, const ProbDesc* d_desc, int batch, const double* d_src,

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64) void exact_clique_kernel(ExactArgs a, int32_t* 
     int r = 0;
     if (lane == 0) r = atomicAdd(a.root_counter, 1);
     r = __builtin_amdgcn_readfirstlane(r);
-    if (r >= n) break;
+    if (r >= a.n_roots) break;
     if (a.deadline_ticks > 0 && wall_clock64() - t_start > a.deadline_ticks) {
       if (lane == 0) atomicMax(a.status, 2);
       break;
@@ -301,6 +301,196 @@ void launch_gather_bitmap(hipStream_t s, const uint64_t* d_in, int W_in, const i
   if (n <= 0) return;
   hipLaunchKernelGGL(gather_bitmap_kernel, dim3(n), dim3(64), 0, s, d_in, W_in, d_order, n, d_out,
                      W_out);
+}
+
+// ------------------------------------------------------------------------------------------
+// Global colouring bound (runs only for problems whose greedy bound the peel did not close).
+// If the peel survivors can be properly coloured with lb colours, no clique larger than lb exists
+// (pigeonhole) and the greedy clique is proven maximum without any search.  Vertices that end up
+// without a colour form a (small) set X: every clique larger than lb must contain a vertex of X,
+// so the exact search only needs X as roots.  pmc has no such stage (it bounds every root
+// separately, reference graph.cc:104-122); this is what makes config 3 (outlier degree >> lb)
+// cheap on a GPU: ~7 data-parallel rounds instead of 50 000 sequential root colourings.
+//
+// Speculative parallel colouring with a fixed palette of lb colours:
+//   clique members take colours 0..lb-1 (mutually adjacent -> all different);
+//   round r, assign : every uncoloured survivor gathers the colours of its coloured neighbours
+//                     into an LDS bitset and picks the hash(v,r)-th FREE colour (none free ->
+//                     the vertex goes to X for good: its neighbours only gain colours);
+//   round r, resolve: among adjacent vertices that picked the same colour in this round only the
+//                     one with the highest hash priority keeps it; losers retry next round.
+// Every choice is a pure function of (v, r): the result is deterministic.
+// ------------------------------------------------------------------------------------------
+constexpr int kColourMaxWords = 64;  // palette up to 4096 colours
+
+__device__ __forceinline__ unsigned int mix32(unsigned int x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ unsigned int colour_hash(int v, int round, unsigned int salt) {
+  return mix32((unsigned int)v * 0x9E3779B9u + (unsigned int)round * 0x85EBCA6Bu + salt);
+}
+
+__global__ __launch_bounds__(256) void colour_init_kernel(const ProbDesc* __restrict__ descs,
+                                                          const int32_t* __restrict__ sel,
+                                                          const uint64_t* __restrict__ alive,
+                                                          const int32_t* __restrict__ clique,
+                                                          ProbState* __restrict__ states,
+                                                          int32_t* __restrict__ colour,
+                                                          int32_t* __restrict__ tent) {
+  const int p = sel[blockIdx.y];
+  const ProbDesc d = descs[p];
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= d.n) return;
+  const int lb = states[p].lb;
+  const bool al = (alive[d.w_off + (v >> 6)] >> (v & 63)) & 1ull;
+  int c = al ? -1 : -3;
+  if (al) {  // position of v in the sorted clique (binary search)
+    const int32_t* cl = clique + d.pt_off;
+    int lo = 0, hi = lb;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (cl[mid] < v) lo = mid + 1; else hi = mid;
+    }
+    if (lo < lb && cl[lo] == v) c = lo;
+  }
+  colour[d.pt_off + v] = c;
+  tent[d.pt_off + v] = -1;
+  if (v == 0) states[p].x_count = 0;
+}
+
+__global__ __launch_bounds__(256) void colour_assign_kernel(const ProbDesc* __restrict__ descs,
+                                                            const int32_t* __restrict__ sel,
+                                                            const uint64_t* __restrict__ bitmap,
+                                                            const uint64_t* __restrict__ alive,
+                                                            const ProbState* __restrict__ states,
+                                                            int32_t* __restrict__ colour,
+                                                            int32_t* __restrict__ tent, int round) {
+  __shared__ unsigned long long Fs[4][kColourMaxWords];
+  const int p = sel[blockIdx.y];
+  const ProbDesc d = descs[p];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int v = blockIdx.x * 4 + wave;
+  if (v >= d.n) return;
+  int32_t* col = colour + d.pt_off;
+  if (col[v] != -1) return;
+  const int lb = states[p].lb;
+  const int nw = (lb + 63) >> 6;
+  unsigned long long* F = Fs[wave];
+  F[lane] = 0ull;  // kColourMaxWords == 64 lanes
+  const uint64_t* row = bitmap + d.bm_off + (int64_t)v * d.W;
+  const uint64_t* al = alive + d.w_off;
+  for (int w = lane; w < d.W; w += 64) {
+    uint64_t bits = row[w] & al[w];
+    while (bits) {
+      const int u = w * 64 + __builtin_ctzll(bits);
+      bits &= bits - 1;
+      const int cu = col[u];
+      if (cu >= 0) atomicOr(&F[cu >> 6], 1ull << (cu & 63));
+    }
+  }
+  // wave-private LDS, same-wave ordering: no block barrier needed
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  unsigned long long freeb = 0ull;
+  if (lane < nw) {
+    freeb = ~F[lane];
+    const int rem = lb - lane * 64;
+    if (rem < 64) freeb &= (1ull << rem) - 1ull;
+  }
+  const int cnt = __popcll(freeb);
+  int incl = cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  const int total = __shfl(incl, 63, 64);
+  if (total == 0) {
+    if (lane == 0) {
+      col[v] = -2;
+      tent[d.pt_off + v] = -1;
+    }
+    return;
+  }
+  const int target = (int)(colour_hash(v, round, 0x1234567u) % (unsigned int)total);
+  const int excl = incl - cnt;
+  if (target >= excl && target < incl) {
+    int k = target - excl;
+    unsigned long long b = freeb;
+    while (k-- > 0) b &= b - 1;
+    tent[d.pt_off + v] = lane * 64 + __builtin_ctzll(b);
+  }
+}
+
+__global__ __launch_bounds__(256) void colour_resolve_kernel(const ProbDesc* __restrict__ descs,
+                                                             const int32_t* __restrict__ sel,
+                                                             const uint64_t* __restrict__ bitmap,
+                                                             const uint64_t* __restrict__ alive,
+                                                             int32_t* __restrict__ colour,
+                                                             const int32_t* __restrict__ tent,
+                                                             int round) {
+  const int p = sel[blockIdx.y];
+  const ProbDesc d = descs[p];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int v = blockIdx.x * 4 + wave;
+  if (v >= d.n) return;
+  int32_t* col = colour + d.pt_off;
+  const int32_t* tn = tent + d.pt_off;
+  if (col[v] != -1) return;
+  const int tv = tn[v];
+  if (tv < 0) return;
+  const unsigned int pv = colour_hash(v, round, 0xabcdef1u);
+  const uint64_t* row = bitmap + d.bm_off + (int64_t)v * d.W;
+  const uint64_t* al = alive + d.w_off;
+  bool lose = false;
+  for (int w = lane; w < d.W; w += 64) {
+    uint64_t bits = row[w] & al[w];
+    while (bits) {
+      const int u = w * 64 + __builtin_ctzll(bits);
+      bits &= bits - 1;
+      if (tn[u] == tv) {
+        const unsigned int pu = colour_hash(u, round, 0xabcdef1u);
+        lose |= (pu > pv) | ((pu == pv) & (u > v));
+      }
+    }
+  }
+  if (__ballot(lose) == 0ull && lane == 0) col[v] = tv;
+}
+
+// X = survivors left without a colour (-1: still contended after the last round, -2: palette
+// exhausted); unordered append, the host sorts.
+__global__ __launch_bounds__(256) void colour_collect_kernel(const ProbDesc* __restrict__ descs,
+                                                             const int32_t* __restrict__ sel,
+                                                             const int32_t* __restrict__ colour,
+                                                             ProbState* __restrict__ states,
+                                                             int32_t* __restrict__ xlist) {
+  const int p = sel[blockIdx.y];
+  const ProbDesc d = descs[p];
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= d.n) return;
+  const int c = colour[d.pt_off + v];
+  if (c == -1 || c == -2) {
+    const int idx = atomicAdd(&states[p].x_count, 1);
+    xlist[d.pt_off + idx] = v;
+  }
+}
+
+void launch_colour_bound(hipStream_t s, const ProbDesc* d_desc, const int32_t* d_sel, int nsel,
+                         int max_n, const uint64_t* d_bitmap, const uint64_t* d_alive,
+                         const int32_t* d_clique, ProbState* d_state, int32_t* d_colour,
+                         int32_t* d_tent, int32_t* d_xlist, int rounds) {
+  if (nsel <= 0 || max_n <= 0) return;
+  dim3 gv((max_n + 255) / 256, nsel), gw((max_n + 3) / 4, nsel);
+  hipLaunchKernelGGL(colour_init_kernel, gv, dim3(256), 0, s, d_desc, d_sel, d_alive, d_clique,
+                     d_state, d_colour, d_tent);
+  for (int r = 0; r < rounds; ++r) {
+    hipLaunchKernelGGL(colour_assign_kernel, gw, dim3(256), 0, s, d_desc, d_sel, d_bitmap, d_alive,
+                       d_state, d_colour, d_tent, r);
+    hipLaunchKernelGGL(colour_resolve_kernel, gw, dim3(256), 0, s, d_desc, d_sel, d_bitmap, d_alive,
+                       d_colour, d_tent, r);
+  }
+  hipLaunchKernelGGL(colour_collect_kernel, gv, dim3(256), 0, s, d_desc, d_sel, d_colour, d_state,
+                     d_xlist);
 }
 
 }  // namespace thip

@@ -66,7 +66,7 @@ struct DevBuf {
   }
 };
 
-enum Stage { ST_H2D = 0, ST_TIM, ST_DEG, ST_HEU, ST_PEEL, ST_EXACT, ST_ROT, ST_TRANS, ST_D2H, ST_COUNT };
+enum Stage { ST_H2D = 0, ST_TIM, ST_DEG, ST_HEU, ST_PEEL, ST_EXACT, ST_ROT, ST_TRANS, ST_D2H, ST_COLOUR, ST_COUNT };
 
 }  // namespace
 
@@ -98,6 +98,9 @@ struct teaser_hip_solver {
 
   DevBuf d_desc, d_state, d_src, d_dst, d_bitmap, d_deg, d_clique, d_start_cliques, d_alive_a,
       d_alive_b, d_next_count, d_weights, d_rot_inl, d_trans_inl, d_tls_scratch, d_tim_off;
+  // colouring bound
+  DevBuf c_sel, c_colour, c_tent, c_xlist;
+  std::vector<int32_t> colour_x;  // |X| per problem of the last solve (-1: stage not run)
   // exact stage
   DevBuf x_order, x_src, x_dst, x_bitmap, x_desc, x_state, x_ctrl, x_clique, x_arena;
   // stand-alone stages
@@ -151,9 +154,11 @@ void profile_begin(teaser_hip_solver* h) {
 
 void profile_end(teaser_hip_solver* h) {
   if (!h->profiling) return;
+  (void)hipStreamSynchronize(h->stream);  // the last span may still be in flight
   float* slot[ST_COUNT] = {&h->prof.h2d_ms,  &h->prof.tim_graph_ms, &h->prof.degree_ms,
                            &h->prof.heuristic_ms, &h->prof.peel_ms, &h->prof.exact_ms,
-                           &h->prof.rotation_ms, &h->prof.translation_ms, &h->prof.d2h_ms};
+                           &h->prof.rotation_ms, &h->prof.translation_ms, &h->prof.d2h_ms,
+                           &h->prof.colour_ms};
   for (auto& s : h->spans) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
@@ -199,13 +204,13 @@ int64_t tls_scratch_bytes(int n) {
 // --------------------------------------------------------------------------------------------
 int32_t run_exact_on_compact(teaser_hip_solver* h, const uint64_t* d_cbitmap, int n2, int W2,
                              int lb, int max_deg, std::vector<int32_t>& best_local,
-                             int* status_out) {
+                             int* status_out, int n_roots) {
   hipStream_t s = h->stream;
   // control words: [0] incumbent size, [1] recorded size, [2] lock, [3] root counter, [4] status
   int32_t ctrl[8] = {lb, lb, 0, 0, 0, 0, 0, 0};
   HIPCHK(h, h->x_ctrl.ensure(sizeof(ctrl)));
   HIPCHK(h, h->x_clique.ensure((size_t)(n2 + 1) * 4));
-  int n_waves = 2048;
+  int n_waves = std::min(2048, std::max(n_roots, 1));
   int64_t depth_guess = std::min<int64_t>((int64_t)lb + 96, (int64_t)n2 + 1);
   int64_t arena = (int64_t)(n2 + 1) * 4 + depth_guess * (64 + (int64_t)W2 * 8 + 16) +
                   8 * (int64_t)max_deg * 8 + (1 << 16);
@@ -234,6 +239,7 @@ int32_t run_exact_on_compact(teaser_hip_solver* h, const uint64_t* d_cbitmap, in
     a.arena = h->x_arena.as<char>();
     a.arena_bytes = arena;
     a.n_waves = n_waves;
+    a.n_roots = n_roots;
     const double lim = h->params.max_clique_time_limit;
     a.deadline_ticks = (lim > 0 && lim < 1e7) ? (int64_t)(lim * 1e8) : 0;  // 100 MHz counter
     launch_exact_clique(s, a);
@@ -256,7 +262,11 @@ int32_t run_exact_on_compact(teaser_hip_solver* h, const uint64_t* d_cbitmap, in
   return TEASER_HIP_OK;
 }
 
-int32_t exact_stage(teaser_hip_solver* h, int p, const uint64_t* d_final_alive) {
+// X (may be null): the survivors the colouring bound could not colour -- every clique larger
+// than lb contains one of them, so they are the only roots, and only X and its neighbourhood
+// enter the compact problem.
+int32_t exact_stage(teaser_hip_solver* h, int p, const uint64_t* d_final_alive,
+                    const std::vector<int32_t>* X, bool from_points) {
   hipStream_t s = h->stream;
   const ProbDesc d = h->descs[(size_t)p];
   ProbState& st = h->states[(size_t)p];
@@ -266,45 +276,68 @@ int32_t exact_stage(teaser_hip_solver* h, int p, const uint64_t* d_final_alive) 
   HIPCHK(h, hipMemcpy(deg.data(), h->d_deg.as<int32_t>() + d.pt_off, (size_t)n * 4, hipMemcpyDeviceToHost));
   HIPCHK(h, hipMemcpy(alive.data(), d_final_alive + d.w_off, (size_t)W * 8, hipMemcpyDeviceToHost));
   std::vector<int32_t> order;
-  order.reserve((size_t)st.alive_count);
-  int max_deg = 0;
-  for (int v = 0; v < n; ++v)
-    if ((alive[(size_t)(v >> 6)] >> (v & 63)) & 1ull) {
-      order.push_back(v);
-      max_deg = std::max(max_deg, deg[(size_t)v]);
+  int n_roots = -1;
+  if (X && !X->empty() && X->size() <= 512) {
+    // candidates = alive neighbours of X; rows of X fetched from the device bitmap
+    std::vector<uint64_t> un((size_t)W, 0), row((size_t)W);
+    for (int32_t x : *X) {
+      HIPCHK(h, hipMemcpy(row.data(), h->d_bitmap.as<uint64_t>() + d.bm_off + (int64_t)x * W,
+                          (size_t)W * 8, hipMemcpyDeviceToHost));
+      for (int w = 0; w < W; ++w) un[(size_t)w] |= row[(size_t)w] & alive[(size_t)w];
     }
-  std::stable_sort(order.begin(), order.end(),
-                   [&](int32_t a, int32_t b) { return deg[(size_t)a] < deg[(size_t)b]; });
+    for (int32_t x : *X) un[(size_t)(x >> 6)] &= ~(1ull << (x & 63));
+    order = *X;  // roots first, ascending
+    n_roots = (int)X->size();
+    std::vector<int32_t> rest;
+    for (int v = 0; v < n; ++v)
+      if ((un[(size_t)(v >> 6)] >> (v & 63)) & 1ull) rest.push_back(v);
+    std::stable_sort(rest.begin(), rest.end(),
+                     [&](int32_t a, int32_t b) { return deg[(size_t)a] < deg[(size_t)b]; });
+    order.insert(order.end(), rest.begin(), rest.end());
+  } else {
+    order.reserve((size_t)st.alive_count);
+    for (int v = 0; v < n; ++v)
+      if ((alive[(size_t)(v >> 6)] >> (v & 63)) & 1ull) order.push_back(v);
+    std::stable_sort(order.begin(), order.end(),
+                     [&](int32_t a, int32_t b) { return deg[(size_t)a] < deg[(size_t)b]; });
+    n_roots = (int)order.size();
+  }
+  int max_deg = 0;
+  for (int32_t v : order) max_deg = std::max(max_deg, deg[(size_t)v]);
   const int n2 = (int)order.size();
   if (n2 <= st.lb) return TEASER_HIP_OK;
   const int W2 = (n2 + 63) / 64;
   HIPCHK(h, h->x_order.ensure((size_t)n2 * 4));
-  HIPCHK(h, h->x_src.ensure((size_t)n2 * 24));
-  HIPCHK(h, h->x_dst.ensure((size_t)n2 * 24));
   HIPCHK(h, h->x_bitmap.ensure((size_t)n2 * (size_t)W2 * 8));
-  HIPCHK(h, h->x_desc.ensure(sizeof(ProbDesc)));
-  HIPCHK(h, h->x_state.ensure(sizeof(ProbState)));
   HIPCHK(h, hipMemcpyAsync(h->x_order.p, order.data(), (size_t)n2 * 4, hipMemcpyHostToDevice, s));
-  launch_gather_points(s, h->cur_src + 3 * d.pt_off, h->cur_dst + 3 * d.pt_off,
-                       h->x_order.as<int32_t>(), n2, h->x_src.as<double>(), h->x_dst.as<double>());
-  ProbDesc d2;
-  d2.n = n2;
-  d2.W = W2;
-  d2.pt_off = 0;
-  d2.bm_off = 0;
-  d2.w_off = 0;
-  HIPCHK(h, hipMemcpyAsync(h->x_desc.p, &d2, sizeof(d2), hipMemcpyHostToDevice, s));
-  HIPCHK(h, hipMemcpyAsync(h->x_state.p, &st, sizeof(st), hipMemcpyHostToDevice, s));
-  {
+  if (from_points) {
+    // the compact adjacency is recomputed from the gathered points (cheaper than a bit gather)
+    HIPCHK(h, h->x_src.ensure((size_t)n2 * 24));
+    HIPCHK(h, h->x_dst.ensure((size_t)n2 * 24));
+    HIPCHK(h, h->x_desc.ensure(sizeof(ProbDesc)));
+    HIPCHK(h, h->x_state.ensure(sizeof(ProbState)));
+    launch_gather_points(s, h->cur_src + 3 * d.pt_off, h->cur_dst + 3 * d.pt_off,
+                         h->x_order.as<int32_t>(), n2, h->x_src.as<double>(), h->x_dst.as<double>());
+    ProbDesc d2;
+    d2.n = n2;
+    d2.W = W2;
+    d2.pt_off = 0;
+    d2.bm_off = 0;
+    d2.w_off = 0;
+    HIPCHK(h, hipMemcpyAsync(h->x_desc.p, &d2, sizeof(d2), hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(h->x_state.p, &st, sizeof(st), hipMemcpyHostToDevice, s));
     StageScope sc(h, ST_TIM);
     launch_tim_graph(s, h->x_desc.as<ProbDesc>(), 1, n2, h->x_src.as<double>(), h->x_dst.as<double>(),
                      h->x_bitmap.as<uint64_t>(), h->params.noise_bound, h->params.cbar2,
                      h->params.estimate_scaling ? 1 : 0, h->x_state.as<ProbState>());
+  } else {
+    launch_gather_bitmap(s, h->d_bitmap.as<uint64_t>() + d.bm_off, W, h->x_order.as<int32_t>(), n2,
+                         h->x_bitmap.as<uint64_t>(), W2);
   }
   std::vector<int32_t> best_local;
   int xstatus = 0;
   int32_t rc = run_exact_on_compact(h, h->x_bitmap.as<uint64_t>(), n2, W2, st.lb, max_deg,
-                                    best_local, &xstatus);
+                                    best_local, &xstatus, n_roots);
   if (rc != TEASER_HIP_OK) return rc;
   if (xstatus == 1) h->prob_status[(size_t)p] = TEASER_HIP_ERR_SCRATCH;
   if (xstatus == 2) h->prob_status[(size_t)p] = TEASER_HIP_ERR_TIME_LIMIT;
@@ -349,6 +382,77 @@ int32_t scale_stage(teaser_hip_solver* h, int p) {
 }
 
 // --------------------------------------------------------------------------------------------
+// After the greedy + peel stages (host copies of the states are fresh): for every problem whose
+// bound is still open run the global colouring bound, then the exact search from the roots it
+// could not colour (graph.cc:104-122 is the reference's counterpart: pmc's exact search).
+// --------------------------------------------------------------------------------------------
+int32_t close_clique_bounds(teaser_hip_solver* h, int batch, int64_t total_n, bool from_points,
+                            bool* changed) {
+  hipStream_t s = h->stream;
+  const ProbDesc* dd = h->d_desc.as<ProbDesc>();
+  ProbState* ds = h->d_state.as<ProbState>();
+  int32_t rc = TEASER_HIP_OK;
+  {
+    const uint64_t* final_alive =
+        (kPeelRounds % 2 == 0) ? h->d_alive_a.as<uint64_t>() : h->d_alive_b.as<uint64_t>();
+    // problems whose greedy bound the peel did not close: first the global colouring bound
+    std::vector<int32_t> unproven, csel;
+    for (int b = 0; b < batch; ++b) {
+      const ProbState& st = h->states[(size_t)b];
+      if (st.proven || h->descs[(size_t)b].n < 2) continue;
+      unproven.push_back(b);
+      if (st.lb >= 2 && st.lb <= kColourMaxLb) csel.push_back(b);
+    }
+    h->colour_x.assign((size_t)batch, -1);
+    if (!csel.empty()) {
+      StageScope sc(h, ST_COLOUR);
+      HIPCHK(h, h->c_sel.ensure(4 * csel.size()));
+      HIPCHK(h, h->c_colour.ensure(4 * (size_t)total_n));
+      HIPCHK(h, h->c_tent.ensure(4 * (size_t)total_n));
+      HIPCHK(h, h->c_xlist.ensure(4 * (size_t)total_n));
+      HIPCHK(h, hipMemcpyAsync(h->c_sel.p, csel.data(), 4 * csel.size(), hipMemcpyHostToDevice, s));
+      int cmax_n = 0;
+      for (int32_t b : csel) cmax_n = std::max(cmax_n, h->descs[(size_t)b].n);
+      launch_colour_bound(s, dd, h->c_sel.as<int32_t>(), (int)csel.size(), cmax_n,
+                          h->d_bitmap.as<uint64_t>(), final_alive, h->d_clique.as<int32_t>(), ds,
+                          h->c_colour.as<int32_t>(), h->c_tent.as<int32_t>(),
+                          h->c_xlist.as<int32_t>(), kColourRounds);
+      HIPCHK(h, hipGetLastError());
+      for (int32_t b : csel)
+        HIPCHK(h, hipMemcpyAsync(&h->colour_x[(size_t)b], &ds[b].x_count, 4, hipMemcpyDeviceToHost, s));
+      HIPCHK(h, hipStreamSynchronize(s));
+    }
+    for (int32_t b : unproven) {
+      ProbState& st = h->states[(size_t)b];
+      std::vector<int32_t> X;
+      const int xc = h->colour_x[(size_t)b];
+      if (xc == 0) {  // lb colours suffice for every survivor: the greedy clique is maximum
+        st.proven = 1;
+        continue;
+      }
+      if (xc > 0) {
+        X.resize((size_t)xc);
+        HIPCHK(h, hipMemcpy(X.data(), h->c_xlist.as<int32_t>() + h->descs[(size_t)b].pt_off,
+                            (size_t)xc * 4, hipMemcpyDeviceToHost));
+        std::sort(X.begin(), X.end());
+      }
+      h->exact_run[(size_t)b] = 1;
+      const int before = st.clique_size;
+      {
+        StageScope sc(h, ST_EXACT);
+        rc = exact_stage(h, b, final_alive, xc > 0 ? &X : nullptr, from_points);
+      }
+      if (rc != TEASER_HIP_OK) return rc;
+      if (st.clique_size != before) {
+        *changed = true;
+        HIPCHK(h, hipMemcpy(&ds[b].clique_size, &st.clique_size, 4, hipMemcpyHostToDevice));
+      }
+    }
+  }
+  return TEASER_HIP_OK;
+}
+
+// --------------------------------------------------------------------------------------------
 // the batched pipeline; inputs are device-resident and packed
 // --------------------------------------------------------------------------------------------
 int32_t solve_packed(teaser_hip_solver* h, const double* d_src, const double* d_dst,
@@ -370,6 +474,7 @@ int32_t solve_packed(teaser_hip_solver* h, const double* d_src, const double* d_
   h->cur_src = d_src;
   h->cur_dst = d_dst;
   h->have_graph = false;
+  h->colour_x.assign((size_t)batch, -1);
   int64_t bm = 0, wo = 0, tims = 0, maxpt = 0;
   int max_n = 0;
   for (int b = 0; b < batch; ++b) {
@@ -512,23 +617,8 @@ int32_t solve_packed(teaser_hip_solver* h, const double* d_src, const double* d_
   for (int b = 0; b < batch; ++b) h->heu_size[(size_t)b] = h->states[(size_t)b].lb;
   if (need_graph && mode == TEASER_INLIER_PMC_EXACT) {
     bool changed = false;
-    const uint64_t* final_alive =
-        (kPeelRounds % 2 == 0) ? h->d_alive_a.as<uint64_t>() : h->d_alive_b.as<uint64_t>();
-    for (int b = 0; b < batch; ++b) {
-      ProbState& st = h->states[(size_t)b];
-      if (st.proven || h->descs[(size_t)b].n < 2) continue;
-      h->exact_run[(size_t)b] = 1;
-      const int before = st.clique_size;
-      {
-        StageScope sc(h, ST_EXACT);
-        rc = exact_stage(h, b, final_alive);
-      }
-      if (rc != TEASER_HIP_OK) return rc;
-      if (st.clique_size != before) {
-        changed = true;
-        HIPCHK(h, hipMemcpy(&ds[b].clique_size, &st.clique_size, 4, hipMemcpyHostToDevice));
-      }
-    }
+    rc = close_clique_bounds(h, batch, total_n, /*from_points=*/true, &changed);
+    if (rc != TEASER_HIP_OK) return rc;
     if (changed) {
       rc = run_estimators();
       if (rc != TEASER_HIP_OK) return rc;
@@ -545,6 +635,7 @@ int32_t solve_packed(teaser_hip_solver* h, const double* d_src, const double* d_
     o.clique_size = st.clique_size;
     o.heuristic_size = h->heu_size[(size_t)b];
     o.clique_exact_run = h->exact_run[(size_t)b];
+    o.colour_uncoloured = b < (int)h->colour_x.size() ? h->colour_x[(size_t)b] : -1;
     o.num_edges = (int64_t)(st.deg_sum / 2);
     if (st.clique_size <= 1) {  // registration.cc:643-647
       o.valid = 0;
@@ -670,6 +761,7 @@ int32_t teaser_hip_solver_destroy(teaser_hip_solver* h) {
                     &h->d_next_count, &h->d_weights, &h->d_rot_inl, &h->d_trans_inl,
                     &h->d_tls_scratch, &h->d_tim_off, &h->x_order, &h->x_src, &h->x_dst,
                     &h->x_bitmap, &h->x_desc, &h->x_state, &h->x_ctrl, &h->x_clique, &h->x_arena,
+                    &h->c_sel, &h->c_colour, &h->c_tent, &h->c_xlist,
                     &h->s_a, &h->s_b, &h->s_c, &h->s_d, &h->s_e};
   for (DevBuf* b : bufs) b->release();
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
@@ -932,16 +1024,23 @@ int32_t teaser_hip_max_clique(teaser_hip_solver* h, const uint64_t* bitmap, int3
   hipStream_t s = h->stream;
   const int W = (n + 63) / 64;
   const int mode = effective_mode(h->params);
-  ProbDesc d;
+  // a one-problem "batch" whose graph is the caller's bitmap
+  h->batch = 0;  // getters of a previous solve are invalidated
+  h->descs.assign(1, ProbDesc());
+  h->states.assign(1, ProbState());
+  h->exact_run.assign(1, 0);
+  h->heu_size.assign(1, 0);
+  h->prob_status.assign(1, TEASER_HIP_OK);
+  h->colour_x.assign(1, -1);
+  ProbDesc& d = h->descs[0];
   d.n = n;
   d.W = W;
   d.pt_off = 0;
   d.bm_off = 0;
   d.w_off = 0;
-  ProbState st;
+  ProbState& st = h->states[0];
   memset(&st, 0, sizeof(st));
   for (int k = 0; k < kMaxStarts; ++k) st.start_vertex[k] = -1;
-  h->batch = 0;
   HIPCHK(h, h->d_desc.ensure(sizeof(ProbDesc)));
   HIPCHK(h, h->d_state.ensure(sizeof(ProbState)));
   HIPCHK(h, h->d_bitmap.ensure((size_t)n * W * 8));
@@ -970,56 +1069,16 @@ int32_t teaser_hip_max_clique(teaser_hip_solver* h, const uint64_t* bitmap, int3
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipMemcpyAsync(&st, h->d_state.p, sizeof(st), hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipStreamSynchronize(s));
-  std::vector<int32_t> cl((size_t)st.clique_size);
-  if (st.clique_size > 0)
-    HIPCHK(h, hipMemcpy(cl.data(), h->d_clique.p, (size_t)st.clique_size * 4, hipMemcpyDeviceToHost));
-  if (exact_run) *exact_run = 0;
-  if (exact && !st.proven && n >= 2) {
-    if (exact_run) *exact_run = 1;
-    const uint64_t* final_alive =
-        (kPeelRounds % 2 == 0) ? h->d_alive_a.as<uint64_t>() : h->d_alive_b.as<uint64_t>();
-    std::vector<int32_t> deg((size_t)n);
-    std::vector<uint64_t> alive((size_t)W);
-    HIPCHK(h, hipMemcpy(deg.data(), h->d_deg.p, (size_t)n * 4, hipMemcpyDeviceToHost));
-    HIPCHK(h, hipMemcpy(alive.data(), final_alive, (size_t)W * 8, hipMemcpyDeviceToHost));
-    std::vector<int32_t> order;
-    int max_deg = 0;
-    for (int v = 0; v < n; ++v)
-      if ((alive[(size_t)(v >> 6)] >> (v & 63)) & 1ull) {
-        order.push_back(v);
-        max_deg = std::max(max_deg, deg[(size_t)v]);
-      }
-    std::stable_sort(order.begin(), order.end(),
-                     [&](int32_t a, int32_t b) { return deg[(size_t)a] < deg[(size_t)b]; });
-    const int n2 = (int)order.size();
-    if (n2 > st.lb) {
-      const int W2 = (n2 + 63) / 64;
-      HIPCHK(h, h->x_order.ensure((size_t)n2 * 4));
-      HIPCHK(h, h->x_bitmap.ensure((size_t)n2 * W2 * 8));
-      HIPCHK(h, hipMemcpyAsync(h->x_order.p, order.data(), (size_t)n2 * 4, hipMemcpyHostToDevice, s));
-      launch_gather_bitmap(s, h->d_bitmap.as<uint64_t>(), W, h->x_order.as<int32_t>(), n2,
-                           h->x_bitmap.as<uint64_t>(), W2);
-      std::vector<int32_t> best_local;
-      int xstatus = 0;
-      int32_t rc = run_exact_on_compact(h, h->x_bitmap.as<uint64_t>(), n2, W2, st.lb, max_deg,
-                                        best_local, &xstatus);
-      if (rc != TEASER_HIP_OK) return rc;
-      if (!best_local.empty()) {
-        cl.resize(best_local.size());
-        for (size_t k = 0; k < best_local.size(); ++k) cl[k] = order[(size_t)best_local[k]];
-        std::sort(cl.begin(), cl.end());
-      }
-      if (xstatus == 1) return TEASER_HIP_ERR_SCRATCH;
-      if (xstatus == 2) {
-        *clique_size = (int32_t)cl.size();
-        memcpy(clique, cl.data(), cl.size() * 4);
-        return TEASER_HIP_ERR_TIME_LIMIT;
-      }
-    }
+  if (exact && n >= 2) {
+    bool changed = false;
+    int32_t rc = close_clique_bounds(h, 1, n, /*from_points=*/false, &changed);
+    if (rc != TEASER_HIP_OK) return rc;
   }
-  *clique_size = (int32_t)cl.size();
-  if (!cl.empty()) memcpy(clique, cl.data(), cl.size() * 4);
-  return TEASER_HIP_OK;
+  if (exact_run) *exact_run = h->exact_run[0];
+  *clique_size = st.clique_size;
+  if (st.clique_size > 0)
+    HIPCHK(h, hipMemcpy(clique, h->d_clique.p, (size_t)st.clique_size * 4, hipMemcpyDeviceToHost));
+  return h->prob_status[0];
 }
 
 int32_t teaser_hip_set_profiling(teaser_hip_solver* h, int32_t enable) {
