@@ -98,6 +98,8 @@ void launch_exact_clique(hipStream_t s, const ExactArgs& a);
 // global colouring bound on the peel survivors of the selected problems (kernels_clique.hip)
 constexpr int kColourMaxLb = 4096;  // palette limit (64 LDS words per wave)
 constexpr int kColourRounds = 10;
+constexpr int kRootPruneCap = 512;   // leftover roots tested by root_prune_kernel (counts in d_tent)
+constexpr int kRootPruneSlices = 32; // workgroups per root
 void launch_colour_bound(hipStream_t s, const ProbDesc* d_desc, const int32_t* d_sel, int nsel,
                          int max_n, const uint64_t* d_bitmap, const uint64_t* d_alive,
                          const int32_t* d_clique, ProbState* d_state, int32_t* d_colour,

@@ -463,15 +463,67 @@ __global__ __launch_bounds__(256) void colour_collect_kernel(const ProbDesc* __r
                                                              const int32_t* __restrict__ sel,
                                                              const int32_t* __restrict__ colour,
                                                              ProbState* __restrict__ states,
-                                                             int32_t* __restrict__ xlist) {
+                                                             int32_t* __restrict__ xlist,
+                                                             int32_t* __restrict__ tent) {
   const int p = sel[blockIdx.y];
   const ProbDesc d = descs[p];
   const int v = blockIdx.x * 256 + threadIdx.x;
   if (v >= d.n) return;
+  tent[d.pt_off + v] = 0;  // reused as the root_prune counters
   const int c = colour[d.pt_off + v];
   if (c == -1 || c == -2) {
     const int idx = atomicAdd(&states[p].x_count, 1);
     xlist[d.pt_off + idx] = v;
+  }
+}
+
+// Neighbourhood test for the few roots X the colouring left over.  If x lies in a clique Q with
+// |Q| >= lb+1, every other member y of Q has at least |Q|-2 >= lb-1 common (surviving) neighbours
+// with x, and there are at least lb such y.  So x is discarded when fewer than lb of its surviving
+// neighbours y have |N(y) & N(x)| >= lb-1.  kRootPruneSlices workgroups per root, each counting
+// the qualifying y of its slice of N(x) into count[i] (zeroed by colour_collect_kernel).
+
+
+__global__ __launch_bounds__(256) void root_prune_kernel(const ProbDesc* __restrict__ descs,
+                                                         const int32_t* __restrict__ sel,
+                                                         const uint64_t* __restrict__ bitmap,
+                                                         const uint64_t* __restrict__ alive,
+                                                         const ProbState* __restrict__ states,
+                                                         const int32_t* __restrict__ xlist,
+                                                         int32_t* __restrict__ count) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int wsum_[4];
+  const int p = sel[blockIdx.z];
+  const ProbDesc d = descs[p];
+  const int xc = states[p].x_count;
+  if (xc > kRootPruneCap || (int)blockIdx.y >= xc) return;
+  const int lb = states[p].lb;
+  const int x = xlist[d.pt_off + blockIdx.y];
+  uint64_t* Rx = reinterpret_cast<uint64_t*>(smem);
+  const uint64_t* bm = bitmap + d.bm_off;
+  const uint64_t* al = alive + d.w_off;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int w = threadIdx.x; w < d.W; w += 256) Rx[w] = bm[(int64_t)x * d.W + w] & al[w];
+  __syncthreads();
+  // this block's slice of x's neighbours: words blockIdx.x*4+wave, stride 4*gridDim.x
+  int cnt = 0;
+  for (int w = blockIdx.x * 4 + wave; w < d.W; w += 4 * gridDim.x) {
+    uint64_t bits = Rx[w];
+    while (bits) {
+      const int y = w * 64 + __builtin_ctzll(bits);
+      bits &= bits - 1;
+      const uint64_t* ry = bm + (int64_t)y * d.W;
+      int c = 0;
+      for (int k = lane; k < d.W; k += 64) c += __popcll(ry[k] & Rx[k]);
+      c = wsum(c);
+      cnt += (c >= lb - 1) ? 1 : 0;
+    }
+  }
+  if (lane == 0) wsum_[wave] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int t = wsum_[0] + wsum_[1] + wsum_[2] + wsum_[3];
+    if (t) atomicAdd(&count[d.pt_off + blockIdx.y], t);
   }
 }
 
@@ -490,7 +542,11 @@ void launch_colour_bound(hipStream_t s, const ProbDesc* d_desc, const int32_t* d
                        d_colour, d_tent, r);
   }
   hipLaunchKernelGGL(colour_collect_kernel, gv, dim3(256), 0, s, d_desc, d_sel, d_colour, d_state,
-                     d_xlist);
+                     d_xlist, d_tent);
+  // d_tent is free again (zeroed by the collect kernel): per-root counts of qualifying neighbours
+  const int max_W = (max_n + 63) / 64;
+  hipLaunchKernelGGL(root_prune_kernel, dim3(kRootPruneSlices, kRootPruneCap, nsel), dim3(256),
+                     (size_t)max_W * 8, s, d_desc, d_sel, d_bitmap, d_alive, d_state, d_xlist, d_tent);
 }
 
 }  // namespace thip

@@ -434,6 +434,20 @@ int32_t close_clique_bounds(teaser_hip_solver* h, int batch, int64_t total_n, bo
         X.resize((size_t)xc);
         HIPCHK(h, hipMemcpy(X.data(), h->c_xlist.as<int32_t>() + h->descs[(size_t)b].pt_off,
                             (size_t)xc * 4, hipMemcpyDeviceToHost));
+        if (xc <= kRootPruneCap) {  // drop the roots the neighbourhood test discarded
+          std::vector<int32_t> keep((size_t)xc);
+          HIPCHK(h, hipMemcpy(keep.data(), h->c_tent.as<int32_t>() + h->descs[(size_t)b].pt_off,
+                              (size_t)xc * 4, hipMemcpyDeviceToHost));
+          size_t m = 0;
+          for (size_t k = 0; k < X.size(); ++k)
+            if (keep[k] >= st.lb) X[m++] = X[k];  // >= lb qualifying neighbours: still a root
+          X.resize(m);
+          if (X.empty()) {  // no root can lie in a clique larger than lb
+            h->colour_x[(size_t)b] = 0;
+            st.proven = 1;
+            continue;
+          }
+        }
         std::sort(X.begin(), X.end());
       }
       h->exact_run[(size_t)b] = 1;
