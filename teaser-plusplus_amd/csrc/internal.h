@@ -118,4 +118,12 @@ void launch_tls_translation(hipStream_t s, const ProbDesc* d_desc, int batch, co
 void launch_scalar_tls(hipStream_t s, const double* d_x, const double* d_r, int32_t n,
                        char* d_scratch, double* d_est, uint8_t* d_mask);
 
+// scalar TLS over many measurements: device radix sort + blocked sweep (kernels_scale.hip)
+int64_t scalar_tls_large_workspace_bytes(int64_t n);
+hipError_t launch_scalar_tls_large(hipStream_t s, const double* d_x, const double* d_r, int64_t n,
+                                   char* d_workspace, double* d_est, uint8_t* d_mask);
+hipError_t launch_tls_scale_large(hipStream_t s, const double* d_src, const double* d_dst, int n,
+                                  double beta, double* d_raw, double* d_alpha, char* d_workspace,
+                                  double* d_scale);
+
 }  // namespace thip

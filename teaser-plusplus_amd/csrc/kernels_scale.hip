@@ -1,0 +1,436 @@
+// kernels_scale.hip -- scalar TLS over MANY measurements (the estimate_scaling = true stage for
+// any n): TLSScaleSolver::solveForScale (reference teaser/src/registration.cc:410-425) feeding
+// ScalarTLSEstimator::estimate (registration.cc:21-88) with M = n(n-1)/2 TRIMs.
+//
+//   1. trim_endpoints_kernel   raw_k = |b_k|/|a_k|, alpha_k = beta/|a_k| for every pair in the
+//                              reference's pair order (registration.cc:531) and, fused, the 2M
+//                              interval endpoints (value, tag = +-(k+1)) of registration.cc:35-38
+//   2. device radix sort       ascending by value only (registration.cc:41-42).  The sort is stable
+//                              and the endpoints are generated in insertion order, so ties resolve
+//                              exactly like the single-workgroup path and the oracle's merge sort.
+//   3. the sweep of registration.cc:58-75 as a three-pass blocked prefix sum over the sorted
+//      endpoints (chunk totals -> exclusive scan of the totals -> per-endpoint cost + arg-min),
+//      first minimum wins, NaN never wins (registration.cc:77-78).
+// The running sums are therefore associated differently from the reference's sequential loop
+// (~1e-16 relative); the estimate is compared against the oracle at 1e-9.
+#include <cstring>
+#include <cstdint>
+
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include "internal.h"
+
+namespace thip {
+
+namespace {
+
+constexpr int kSwThreads = 256;
+constexpr int kSwPer = 8;                         // consecutive endpoints per thread
+constexpr int kSwChunk = kSwThreads * kSwPer;     // endpoints per workgroup
+constexpr int kNumAcc = 7;                        // card, dwc, dxw, ris, sx, sxx, opening ranges
+
+struct Acc {
+  double v[kNumAcc];
+};
+
+__device__ __forceinline__ void acc_add(Acc& a, int tag, const double* __restrict__ x,
+                                        const double* __restrict__ r) {
+  const int idx = (tag > 0 ? tag : -tag) - 1;
+  const double eps = tag > 0 ? 1.0 : -1.0;
+  const double xv = x[idx], rv = r[idx];
+  const double w = 1.0 / (rv * rv);  // weights = ranges^-2, registration.cc:45-46
+  a.v[0] += eps;
+  a.v[1] += eps * w;
+  a.v[2] += eps * w * xv;
+  a.v[3] += eps * rv;
+  a.v[4] += eps * xv;
+  a.v[5] += eps * xv * xv;
+  a.v[6] += tag > 0 ? rv : 0.0;
+}
+
+__device__ __forceinline__ double shfl_up_d(double v, int d) { return __shfl_up(v, d, 64); }
+__device__ __forceinline__ double shfl_down_d(double v, int d) { return __shfl_down(v, d, 64); }
+
+// One row of pairs per workgroup (row i, columns j > i), like trims_kernel, plus the endpoints.
+__global__ __launch_bounds__(256) void trim_endpoints_kernel(
+    const double* __restrict__ src, const double* __restrict__ dst, int n, double beta,
+    double* __restrict__ raw, double* __restrict__ alpha, double* __restrict__ keys,
+    int32_t* __restrict__ tags) {
+  const int i = blockIdx.x;
+  if (i >= n - 1) return;
+  const int64_t seg = (int64_t)i * n - (int64_t)i * (i + 1) / 2;
+  const double six = src[3 * i], siy = src[3 * i + 1], siz = src[3 * i + 2];
+  const double dix = dst[3 * i], diy = dst[3 * i + 1], diz = dst[3 * i + 2];
+  for (int j = i + 1 + threadIdx.x; j < n; j += 256) {
+    const double ax = src[3 * j] - six, ay = src[3 * j + 1] - siy, az = src[3 * j + 2] - siz;
+    const double bx = dst[3 * j] - dix, by = dst[3 * j + 1] - diy, bz = dst[3 * j + 2] - diz;
+    const double v1 = __builtin_sqrt((ax * ax + ay * ay) + az * az);  // registration.cc:415-418
+    const double v2 = __builtin_sqrt((bx * bx + by * by) + bz * bz);
+    const int64_t k = seg + (j - i - 1);
+    const double s = v2 / v1;              // registration.cc:420
+    const double a = beta * (1.0 / v1);    // registration.cc:422
+    raw[k] = s;
+    alpha[k] = a;
+    // registration.cc:35-38
+    *reinterpret_cast<double2*>(keys + 2 * k) = make_double2(s - a, s + a);
+    *reinterpret_cast<int2*>(tags + 2 * k) = make_int2((int)(k + 1), -(int)(k + 1));
+  }
+}
+
+__global__ __launch_bounds__(256) void tls_endpoints_kernel(const double* __restrict__ x,
+                                                            const double* __restrict__ r, int64_t n,
+                                                            double* __restrict__ keys,
+                                                            int32_t* __restrict__ tags) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= n) return;
+  const double s = x[k], a = r[k];
+  *reinterpret_cast<double2*>(keys + 2 * k) = make_double2(s - a, s + a);
+  *reinterpret_cast<int2*>(tags + 2 * k) = make_int2((int)(k + 1), -(int)(k + 1));
+}
+
+// pass A: totals of every chunk of kSwChunk sorted endpoints.  partials is SoA [kNumAcc][nblk].
+__global__ __launch_bounds__(kSwThreads) void tls_sweep_totals_kernel(
+    const int32_t* __restrict__ tags, const double* __restrict__ x, const double* __restrict__ r,
+    int64_t m, int64_t nblk, double* __restrict__ partials) {
+  __shared__ double red[kSwThreads / 64][kNumAcc];
+  const int64_t base = (int64_t)blockIdx.x * kSwChunk + (int64_t)threadIdx.x * kSwPer;
+  Acc a;
+  for (int q = 0; q < kNumAcc; ++q) a.v[q] = 0;
+  for (int e = 0; e < kSwPer; ++e)
+    if (base + e < m) acc_add(a, tags[base + e], x, r);
+  // fixed-shape tree inside the wave, then the waves in order
+  for (int q = 0; q < kNumAcc; ++q) {
+    double v = a.v[q];
+    for (int off = 32; off > 0; off >>= 1) v += shfl_down_d(v, off);
+    a.v[q] = v;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0)
+    for (int q = 0; q < kNumAcc; ++q) red[wave][q] = a.v[q];
+  __syncthreads();
+  if (threadIdx.x < kNumAcc) {
+    double v = 0;
+    for (int w = 0; w < kSwThreads / 64; ++w) v += red[w][threadIdx.x];
+    partials[(int64_t)threadIdx.x * nblk + blockIdx.x] = v;
+  }
+}
+
+// pass B: exclusive scan of the chunk totals in chunk order (one workgroup); total of the
+// opening ranges (= sum of all ranges, registration.cc:51) -> out[0].
+__global__ __launch_bounds__(1024) void tls_sweep_scan_kernel(double* __restrict__ partials,
+                                                              int64_t nblk,
+                                                              double* __restrict__ out) {
+  __shared__ double tot[kNumAcc][1024];
+  const int t = threadIdx.x;
+  const int64_t L = (nblk + 1023) / 1024;
+  const int64_t b0 = (int64_t)t * L, b1 = b0 + L < nblk ? b0 + L : nblk;
+  for (int q = 0; q < kNumAcc; ++q) {
+    double s = 0;
+    for (int64_t b = b0; b < b1; ++b) s += partials[(int64_t)q * nblk + b];
+    tot[q][t] = s;
+  }
+  __syncthreads();
+  if (t < kNumAcc) {
+    double acc = 0;
+    for (int k = 0; k < 1024; ++k) {
+      const double v = tot[t][k];
+      tot[t][k] = acc;
+      acc += v;
+    }
+    if (t == 6) out[0] = acc;
+  }
+  __syncthreads();
+  for (int q = 0; q < kNumAcc; ++q) {
+    double acc = tot[q][t];
+    for (int64_t b = b0; b < b1; ++b) {
+      const double v = partials[(int64_t)q * nblk + b];
+      partials[(int64_t)q * nblk + b] = acc;
+      acc += v;
+    }
+  }
+}
+
+struct Best {
+  double cost, hat;
+  int64_t pos;
+};
+
+__device__ __forceinline__ bool best_less(double ca, int64_t pa, double cb, int64_t pb) {
+  return ca < cb || (ca == cb && pa < pb);  // first minimum (registration.cc:78); NaN never wins
+}
+
+// pass C: per-endpoint cost (registration.cc:58-75) and the chunk's first minimum.
+__global__ __launch_bounds__(kSwThreads) void tls_sweep_cost_kernel(
+    const int32_t* __restrict__ tags, const double* __restrict__ x, const double* __restrict__ r,
+    int64_t m, int64_t nblk, const double* __restrict__ partials,
+    const double* __restrict__ ranges_sum_p, double* __restrict__ best_cost,
+    double* __restrict__ best_hat, int64_t* __restrict__ best_pos, double* __restrict__ first_hat) {
+  __shared__ double wtot[kSwThreads / 64][6];
+  __shared__ double bc[kSwThreads / 64], bh[kSwThreads / 64];
+  __shared__ int64_t bp[kSwThreads / 64];
+  const int64_t base = (int64_t)blockIdx.x * kSwChunk + (int64_t)threadIdx.x * kSwPer;
+  int tg[kSwPer];
+  double xv[kSwPer], rv[kSwPer];
+  double loc[6] = {0, 0, 0, 0, 0, 0};
+  for (int e = 0; e < kSwPer; ++e) {
+    tg[e] = 0;
+    xv[e] = 0;
+    rv[e] = 1;
+    if (base + e < m) {
+      const int tag = tags[base + e];
+      const int idx = (tag > 0 ? tag : -tag) - 1;
+      tg[e] = tag;
+      xv[e] = x[idx];
+      rv[e] = r[idx];
+      const double eps = tag > 0 ? 1.0 : -1.0, w = 1.0 / (rv[e] * rv[e]);
+      loc[0] += eps;
+      loc[1] += eps * w;
+      loc[2] += eps * w * xv[e];
+      loc[3] += eps * rv[e];
+      loc[4] += eps * xv[e];
+      loc[5] += eps * xv[e] * xv[e];
+    }
+  }
+  // exclusive prefix of the thread totals inside the workgroup (wave scan + wave offsets)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double pre[6];
+  for (int q = 0; q < 6; ++q) {
+    double inc = loc[q];
+    for (int off = 1; off < 64; off <<= 1) {
+      const double up = shfl_up_d(inc, off);
+      if (lane >= off) inc += up;
+    }
+    if (lane == 63) wtot[wave][q] = inc;
+    pre[q] = inc - loc[q];
+  }
+  __syncthreads();
+  const double ranges_sum = ranges_sum_p[0];
+  double run[6];
+  for (int q = 0; q < 6; ++q) {
+    double off = partials[(int64_t)q * nblk + blockIdx.x];
+    for (int w = 0; w < wave; ++w) off += wtot[w][q];
+    run[q] = off + pre[q];
+  }
+  double bcost = INFINITY, bhat = NAN;
+  int64_t bpos = INT64_MAX;
+  for (int e = 0; e < kSwPer; ++e) {
+    if (tg[e] == 0) continue;
+    const double eps = tg[e] > 0 ? 1.0 : -1.0, w = 1.0 / (rv[e] * rv[e]);
+    run[0] += eps;
+    run[1] += eps * w;
+    run[2] += eps * w * xv[e];
+    run[3] += eps * rv[e];
+    run[4] += eps * xv[e];
+    run[5] += eps * xv[e] * xv[e];
+    const double x_hat = run[2] / run[1];
+    const double residual = run[0] * x_hat * x_hat + run[5] - 2 * run[4] * x_hat;
+    const double cost = residual + (ranges_sum - run[3]);
+    if (base + e == 0) first_hat[0] = x_hat;
+    if (cost < bcost) {
+      bcost = cost;
+      bhat = x_hat;
+      bpos = base + e;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const double oc = shfl_down_d(bcost, off), oh = shfl_down_d(bhat, off);
+    const int64_t op = __shfl_down((long long)bpos, off, 64);
+    if (best_less(oc, op, bcost, bpos)) {
+      bcost = oc;
+      bhat = oh;
+      bpos = op;
+    }
+  }
+  if (lane == 0) {
+    bc[wave] = bcost;
+    bh[wave] = bhat;
+    bp[wave] = bpos;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kSwThreads / 64; ++w)
+      if (best_less(bc[w], bp[w], bcost, bpos)) {
+        bcost = bc[w];
+        bhat = bh[w];
+        bpos = bp[w];
+      }
+    best_cost[blockIdx.x] = bcost;
+    best_hat[blockIdx.x] = bhat;
+    best_pos[blockIdx.x] = bpos;
+  }
+}
+
+// pass D: first minimum over the chunks -> estimate
+__global__ __launch_bounds__(1024) void tls_sweep_argmin_kernel(
+    const double* __restrict__ best_cost, const double* __restrict__ best_hat,
+    const int64_t* __restrict__ best_pos, int64_t nblk, const double* __restrict__ first_hat,
+    double* __restrict__ est) {
+  __shared__ double bc[16], bh[16];
+  __shared__ int64_t bp[16];
+  double c = INFINITY, h = NAN;
+  int64_t p = INT64_MAX;
+  for (int64_t b = threadIdx.x; b < nblk; b += 1024) {
+    const double oc = best_cost[b];
+    const int64_t op = best_pos[b];
+    if (best_less(oc, op, c, p)) {
+      c = oc;
+      h = best_hat[b];
+      p = op;
+    }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    const double oc = shfl_down_d(c, off), oh = shfl_down_d(h, off);
+    const int64_t op = __shfl_down((long long)p, off, 64);
+    if (best_less(oc, op, c, p)) {
+      c = oc;
+      h = oh;
+      p = op;
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    bc[wave] = c;
+    bh[wave] = h;
+    bp[wave] = p;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w)
+      if (best_less(bc[w], bp[w], c, p)) {
+        c = bc[w];
+        h = bh[w];
+        p = bp[w];
+      }
+    // no finite cost anywhere: the reference's minCoeff lands on index 0
+    est[0] = (c < INFINITY) ? h : first_hat[0];
+  }
+}
+
+__global__ __launch_bounds__(256) void tls_mask_kernel(const double* __restrict__ x,
+                                                       const double* __restrict__ r, int64_t n,
+                                                       const double* __restrict__ est,
+                                                       uint8_t* __restrict__ mask) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k < n) mask[k] = fabs(x[k] - est[0]) <= r[k] ? 1 : 0;  // registration.cc:86
+}
+
+inline size_t align_up(size_t v) { return (v + 255) & ~(size_t)255; }
+
+}  // namespace
+
+// Workspace layout (bytes, 256-aligned pieces): keys[2][2n] doubles, tags[2][2n] int32,
+// partials [7][nblk] doubles, best cost/hat [nblk] doubles, best pos [nblk] int64, 4 scalars,
+// the radix sort's temporary storage.
+static size_t sort_temp_bytes(int64_t m) {
+  size_t bytes = 0;
+  rocprim::double_buffer<double> k(nullptr, nullptr);
+  rocprim::double_buffer<int32_t> v(nullptr, nullptr);
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, k, v, (size_t)m, 0, 64, (hipStream_t)0);
+  return bytes;
+}
+
+int64_t scalar_tls_large_workspace_bytes(int64_t n) {
+  const int64_t m = 2 * n;
+  const int64_t nblk = (m + kSwChunk - 1) / kSwChunk;
+  size_t b = 0;
+  b += 2 * align_up((size_t)m * 8);
+  b += 2 * align_up((size_t)m * 4);
+  b += align_up((size_t)nblk * 8 * kNumAcc);
+  b += 3 * align_up((size_t)nblk * 8);
+  b += 256;
+  b += align_up(sort_temp_bytes(m));
+  return (int64_t)b;
+}
+
+namespace {
+struct Work {
+  double* keys[2];
+  int32_t* tags[2];
+  double* partials;
+  double* best_cost;
+  double* best_hat;
+  int64_t* best_pos;
+  double* scalars;  // [0] sum of ranges, [1] first x_hat
+  void* sort_tmp;
+  size_t sort_tmp_bytes;
+  int64_t nblk;
+};
+
+Work carve(char* ws, int64_t n) {
+  Work w;
+  const int64_t m = 2 * n;
+  w.nblk = (m + kSwChunk - 1) / kSwChunk;
+  char* p = ws;
+  for (int k = 0; k < 2; ++k) {
+    w.keys[k] = reinterpret_cast<double*>(p);
+    p += align_up((size_t)m * 8);
+  }
+  for (int k = 0; k < 2; ++k) {
+    w.tags[k] = reinterpret_cast<int32_t*>(p);
+    p += align_up((size_t)m * 4);
+  }
+  w.partials = reinterpret_cast<double*>(p);
+  p += align_up((size_t)w.nblk * 8 * kNumAcc);
+  w.best_cost = reinterpret_cast<double*>(p);
+  p += align_up((size_t)w.nblk * 8);
+  w.best_hat = reinterpret_cast<double*>(p);
+  p += align_up((size_t)w.nblk * 8);
+  w.best_pos = reinterpret_cast<int64_t*>(p);
+  p += align_up((size_t)w.nblk * 8);
+  w.scalars = reinterpret_cast<double*>(p);
+  p += 256;
+  w.sort_tmp = p;
+  w.sort_tmp_bytes = sort_temp_bytes(m);
+  return w;
+}
+
+// sort + sweep on endpoints already generated into w.keys[0] / w.tags[0]
+hipError_t sort_and_sweep(hipStream_t s, const Work& w, const double* d_x, const double* d_r,
+                          int64_t n, double* d_est) {
+  const int64_t m = 2 * n;
+  rocprim::double_buffer<double> kb(w.keys[0], w.keys[1]);
+  rocprim::double_buffer<int32_t> vb(w.tags[0], w.tags[1]);
+  size_t tmp = w.sort_tmp_bytes;
+  hipError_t e = rocprim::radix_sort_pairs(w.sort_tmp, tmp, kb, vb, (size_t)m, 0, 64, s);
+  if (e != hipSuccess) return e;
+  const int32_t* tags = vb.current();
+  hipLaunchKernelGGL(tls_sweep_totals_kernel, dim3((unsigned)w.nblk), dim3(kSwThreads), 0, s, tags,
+                     d_x, d_r, m, w.nblk, w.partials);
+  hipLaunchKernelGGL(tls_sweep_scan_kernel, dim3(1), dim3(1024), 0, s, w.partials, w.nblk,
+                     w.scalars);
+  hipLaunchKernelGGL(tls_sweep_cost_kernel, dim3((unsigned)w.nblk), dim3(kSwThreads), 0, s, tags,
+                     d_x, d_r, m, w.nblk, w.partials, w.scalars, w.best_cost, w.best_hat,
+                     w.best_pos, w.scalars + 1);
+  hipLaunchKernelGGL(tls_sweep_argmin_kernel, dim3(1), dim3(1024), 0, s, w.best_cost, w.best_hat,
+                     w.best_pos, w.nblk, w.scalars + 1, d_est);
+  return hipGetLastError();
+}
+}  // namespace
+
+// Scalar TLS of n measurements x[n] with ranges r[n] (device arrays) -> d_est (+ optional mask).
+hipError_t launch_scalar_tls_large(hipStream_t s, const double* d_x, const double* d_r, int64_t n,
+                                   char* d_workspace, double* d_est, uint8_t* d_mask) {
+  const Work w = carve(d_workspace, n);
+  hipLaunchKernelGGL(tls_endpoints_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_x,
+                     d_r, n, w.keys[0], w.tags[0]);
+  hipError_t e = sort_and_sweep(s, w, d_x, d_r, n, d_est);
+  if (e != hipSuccess) return e;
+  if (d_mask)
+    hipLaunchKernelGGL(tls_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d_x, d_r,
+                       n, d_est, d_mask);
+  return hipGetLastError();
+}
+
+// TLS scale estimate of one problem's n points: TRIMs + endpoints fused, then sort + sweep.
+// d_raw / d_alpha: [M] doubles (kept: the sweep gathers from them).
+hipError_t launch_tls_scale_large(hipStream_t s, const double* d_src, const double* d_dst, int n,
+                                  double beta, double* d_raw, double* d_alpha, char* d_workspace,
+                                  double* d_scale) {
+  const int64_t M = (int64_t)n * (n - 1) / 2;
+  const Work w = carve(d_workspace, M);
+  hipLaunchKernelGGL(trim_endpoints_kernel, dim3(n - 1), dim3(256), 0, s, d_src, d_dst, n, beta,
+                     d_raw, d_alpha, w.keys[0], w.tags[0]);
+  return sort_and_sweep(s, w, d_raw, d_alpha, M, d_scale);
+}
+
+}  // namespace thip

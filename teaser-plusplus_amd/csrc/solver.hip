@@ -355,7 +355,12 @@ int32_t exact_stage(teaser_hip_solver* h, int p, const uint64_t* d_final_alive,
 // --------------------------------------------------------------------------------------------
 // estimate_scaling = true: TRIMs + scalar TLS over all M pairs (registration.cc:410-425)
 // --------------------------------------------------------------------------------------------
-constexpr int kMaxScaledN = 724;  // M = n(n-1)/2 <= 2^18 pairs sorted by one workgroup (round 1)
+// Up to kSmallScaledN points the M <= 2^18 TRIMs are sorted by ONE workgroup (lowest latency; every
+// reference fixture is in this range); above, kernels_scale.hip: fused TRIM/endpoint kernel ->
+// device radix sort -> three-pass sweep.  The reference's `int nr_centers = 2*N`
+// (registration.cc:47) overflows for M > 2^30, i.e. n > 46341: refused here rather than undefined.
+constexpr int kSmallScaledN = 724;
+constexpr int kMaxScaledN = 46341;
 
 int32_t scale_stage(teaser_hip_solver* h, int p) {
   hipStream_t s = h->stream;
@@ -364,18 +369,25 @@ int32_t scale_stage(teaser_hip_solver* h, int p) {
   const int64_t M = (int64_t)n * (n - 1) / 2;
   if (M < 1) return TEASER_HIP_OK;
   if (n > kMaxScaledN) {
-    h->err = "estimate_scaling=true is limited to n <= 724 correspondences in this build";
+    h->err = "estimate_scaling=true needs 2*n(n-1)/2 < 2^31 endpoints (n <= 46341), as the reference";
     return TEASER_HIP_ERR_UNSUPPORTED;
+  }
+  const double beta = 2 * h->params.noise_bound * std::sqrt(h->params.cbar2);
+  double* d_scale = &(h->d_state.as<ProbState>()[p].scale);
+  HIPCHK(h, h->s_a.ensure((size_t)M * 8));
+  HIPCHK(h, h->s_b.ensure((size_t)M * 8));
+  if (n > kSmallScaledN) {
+    HIPCHK(h, h->s_c.ensure((size_t)scalar_tls_large_workspace_bytes(M)));
+    HIPCHK(h, launch_tls_scale_large(s, h->cur_src + 3 * d.pt_off, h->cur_dst + 3 * d.pt_off, n, beta,
+                                     h->s_a.as<double>(), h->s_b.as<double>(), h->s_c.as<char>(),
+                                     d_scale));
+    return TEASER_HIP_OK;
   }
   int64_t P2 = 2;
   while (P2 < 2 * M) P2 <<= 1;
-  HIPCHK(h, h->s_a.ensure((size_t)M * 8));
-  HIPCHK(h, h->s_b.ensure((size_t)M * 8));
   HIPCHK(h, h->s_c.ensure((size_t)P2 * 12 + 64));
-  const double beta = 2 * h->params.noise_bound * std::sqrt(h->params.cbar2);
   launch_trims(s, h->cur_src + 3 * d.pt_off, h->cur_dst + 3 * d.pt_off, n, beta,
                h->s_a.as<double>(), h->s_b.as<double>());
-  double* d_scale = &(h->d_state.as<ProbState>()[p].scale);
   launch_scalar_tls(s, h->s_a.as<double>(), h->s_b.as<double>(), (int32_t)M, h->s_c.as<char>(),
                     d_scale, nullptr);
   return TEASER_HIP_OK;
@@ -1013,17 +1025,22 @@ int32_t teaser_hip_scalar_tls(teaser_hip_solver* h, const double* x, const doubl
   if (!h || !x || !ranges || n <= 0 || !estimate) return TEASER_HIP_ERR_BAD_ARG;
   (void)hipSetDevice(h->device);
   hipStream_t s = h->stream;
+  const bool large = n > (1 << 18);  // beyond the single-workgroup sort: radix sort + blocked sweep
   int64_t P2 = 2;
   while (P2 < 2 * (int64_t)n) P2 <<= 1;
   HIPCHK(h, h->s_a.ensure((size_t)n * 8));
   HIPCHK(h, h->s_b.ensure((size_t)n * 8));
-  HIPCHK(h, h->s_c.ensure((size_t)P2 * 12 + 64));
+  HIPCHK(h, h->s_c.ensure(large ? (size_t)scalar_tls_large_workspace_bytes(n) : (size_t)P2 * 12 + 64));
   HIPCHK(h, h->s_d.ensure(64));
   HIPCHK(h, h->s_e.ensure((size_t)n + 16));
   HIPCHK(h, hipMemcpyAsync(h->s_a.p, x, (size_t)n * 8, hipMemcpyHostToDevice, s));
   HIPCHK(h, hipMemcpyAsync(h->s_b.p, ranges, (size_t)n * 8, hipMemcpyHostToDevice, s));
-  launch_scalar_tls(s, h->s_a.as<double>(), h->s_b.as<double>(), n, h->s_c.as<char>(),
-                    h->s_d.as<double>(), h->s_e.as<uint8_t>());
+  if (large)
+    HIPCHK(h, launch_scalar_tls_large(s, h->s_a.as<double>(), h->s_b.as<double>(), n, h->s_c.as<char>(),
+                                      h->s_d.as<double>(), h->s_e.as<uint8_t>()));
+  else
+    launch_scalar_tls(s, h->s_a.as<double>(), h->s_b.as<double>(), n, h->s_c.as<char>(),
+                      h->s_d.as<double>(), h->s_e.as<uint8_t>());
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipMemcpyAsync(estimate, h->s_d.p, 8, hipMemcpyDeviceToHost, s));
   if (inlier_mask) HIPCHK(h, hipMemcpyAsync(inlier_mask, h->s_e.p, (size_t)n, hipMemcpyDeviceToHost, s));

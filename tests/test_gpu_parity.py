@@ -134,6 +134,74 @@ def test_scalar_tls_random_vs_oracle():
         assert (mask == om).all()
 
 
+def test_scalar_tls_large_vs_oracle():
+    """n > 2^18 measurements: device radix sort + three-pass blocked sweep (kernels_scale.hip)
+    against the oracle's sequential sweep.  The running sums associate differently (~1e-16
+    relative), hence 1e-9 on the estimate; the consensus mask is identical."""
+    rng = np.random.default_rng(13)
+    s = make_solver()
+    for n in ((1 << 18) + 1, 400000, 1000003):
+        x = np.concatenate([rng.normal(1.3, 0.004, size=n // 10), rng.uniform(0.2, 4.0, size=n - n // 10)])
+        r = rng.uniform(0.005, 0.05, size=n)
+        est, mask = s.scalarTLS(x, r)
+        oe, om = oracle.scalar_tls(x, r)
+        assert abs(est - oe) < 1e-9
+        assert (mask == om).all()
+    # heavy ties: the stable sort must order tied endpoints like the oracle (insertion order)
+    n = 300000
+    x = np.round(rng.uniform(0, 2, size=n), 2)
+    r = np.full(n, 0.25)
+    est, mask = s.scalarTLS(x, r)
+    oe, om = oracle.scalar_tls(x, r)
+    assert abs(est - oe) < 1e-9 and (mask == om).all()
+
+
+@pytest.mark.parametrize("n,rho,scale,seed", [(725, 0.8, 1.7, 31), (1500, 0.9, 0.6, 32), (2500, 0.9, 2.25, 33)])
+def test_solve_estimate_scaling_large_vs_oracle(n, rho, scale, seed):
+    """estimate_scaling = true (the Params default) beyond the single-workgroup range
+    (registration.cc:410-425 with M = n(n-1)/2 up to 3.1e6 TRIMs here)."""
+    pr = tp.synth_problem(20250523 + seed, n, rho, 0.01)
+    dst = pr["dst"] * scale
+    nb = 0.01 * scale  # the generator's noise (within 0.01) is scaled with the cloud
+    p = bench_params(estimate_scaling=True, noise_bound=nb)
+    s = make_solver(**p)
+    sol = s.solve(pr["src"], dst)
+    o = oracle.solve(pr["src"], dst, **oracle_params(p))
+    assert sol.valid and o["valid"]
+    assert abs(sol.scale - o["scale"]) <= 1e-9
+    assert abs(sol.scale - scale) < 0.05 * scale
+    _, ref = oracle.inlier_bitmap(pr["src"], dst, nb, 1.0, True)
+    bm = s.getInlierGraphBitmap()
+    # the consensus test |s_k - s_hat| <= alpha_k uses s_hat, which may differ in the last ulps:
+    # allow a handful of boundary pairs, none in practice
+    diff = int(np.unpackbits((bm ^ ref).view(np.uint8)).sum())
+    assert diff <= 2, diff
+    if diff == 0:
+        check_solution_parity(s, sol, o)
+
+
+def test_solve_estimate_scaling_full_size_vs_oracle_fixture():
+    """Full-size estimate_scaling = true (N = 10 000: M = 5e7 TRIMs, 1e8 endpoints through the
+    radix sort) against the oracle's result committed in tests/golden/scale_golden.json (made by
+    tests/golden/make_scale_golden.py; 43 s of CPU there).  At 95 % outliers the reference's TLS
+    scale estimate does not recover the true scale -- parity is with the algorithm, not the truth."""
+    import json
+    import os
+
+    from util import ROOT
+    for g in json.load(open(os.path.join(ROOT, "tests", "golden", "scale_golden.json"))):
+        pr = tp.synth_problem(g["seed"], g["n"], g["outlier_ratio"], 0.01)
+        dst = pr["dst"] * g["dst_scale"]
+        s = make_solver(**bench_params(estimate_scaling=True, noise_bound=g["noise_bound"]))
+        sol = s.solve(pr["src"], dst)
+        assert abs(sol.scale - g["oracle_scale"]) <= 1e-9
+        assert abs(int(s.raw_solution().num_edges) - g["oracle_edges"]) <= 2
+        if g["outlier_ratio"] <= 0.6:  # here the estimate is good: the pose is the planted one
+            assert abs(sol.scale - g["dst_scale"]) < 5e-3
+            assert angular_error(pr["R"], sol.rotation) < 0.02
+            assert np.linalg.norm(sol.translation - g["dst_scale"] * pr["t"]) < 0.05
+
+
 def test_translation_known_answer():
     s = make_solver(noise_bound=float(G["trans_noise_bound"]))
     t = s.solveForTranslation(G["trans_v1"], G["trans_v2"])
