@@ -45,7 +45,7 @@ typedef enum teaser_hip_status {
   TEASER_HIP_ERR_BAD_ARG = 1,
   TEASER_HIP_ERR_HIP = 2,          /* a HIP runtime call failed: teaser_hip_last_error() */
   TEASER_HIP_ERR_NO_DEVICE = 3,    /* no gfx950 device visible: the product never falls back to CPU */
-  TEASER_HIP_ERR_UNSUPPORTED = 4,  /* parameter combination outside the hot path (FGR/QUATRO) */
+  TEASER_HIP_ERR_UNSUPPORTED = 4,  /* parameter value outside the reference's own domain */
   TEASER_HIP_ERR_TIME_LIMIT = 5,   /* max_clique_time_limit hit; incumbent returned (graph.cc:44) */
   TEASER_HIP_ERR_SCRATCH = 6,      /* exact clique search ran out of device scratch */
   TEASER_HIP_ERR_OOM = 7

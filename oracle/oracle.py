@@ -183,19 +183,34 @@ def svd_rot(X, Y, W=None):
     return R.reshape(3, 3)
 
 
-def gnc_tls_rotation(src, dst, noise_bound, gnc_factor=1.4, max_iterations=100, cost_threshold=1e-6):
+def _rotation(fn_name, src, dst, noise_bound, gnc_factor, max_iterations, cost_threshold):
     x, y = _cm(src), _cm(dst)
     k = x.shape[0]
     R = np.zeros(9)
     mask = np.zeros(k, dtype=np.uint8)
     cost, iters = C.c_double(), C.c_int32()
-    rc = lib().oracle_gnc_tls_rotation(_dp(x), _dp(y), C.c_int64(k), C.c_double(noise_bound),
-                                       C.c_double(gnc_factor), C.c_int64(max_iterations),
-                                       C.c_double(cost_threshold), _dp(R),
-                                       mask.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(cost),
-                                       C.byref(iters))
+    rc = getattr(lib(), fn_name)(_dp(x), _dp(y), C.c_int64(k), C.c_double(noise_bound),
+                                 C.c_double(gnc_factor), C.c_int64(max_iterations),
+                                 C.c_double(cost_threshold), _dp(R),
+                                 mask.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(cost),
+                                 C.byref(iters))
     assert rc == 0
     return dict(R=R.reshape(3, 3), inliers=mask.astype(bool), cost=cost.value, iterations=iters.value)
+
+
+def gnc_tls_rotation(src, dst, noise_bound, gnc_factor=1.4, max_iterations=100, cost_threshold=1e-6):
+    return _rotation("oracle_gnc_tls_rotation", src, dst, noise_bound, gnc_factor, max_iterations,
+                     cost_threshold)
+
+
+def fgr_rotation(src, dst, noise_bound, gnc_factor=1.4, max_iterations=100, cost_threshold=1e-6):
+    return _rotation("oracle_fgr_rotation", src, dst, noise_bound, gnc_factor, max_iterations,
+                     cost_threshold)
+
+
+def quatro_rotation(src, dst, noise_bound, gnc_factor=1.4, max_iterations=100, cost_threshold=1e-6):
+    return _rotation("oracle_quatro_rotation", src, dst, noise_bound, gnc_factor, max_iterations,
+                     cost_threshold)
 
 
 def tls_translation(src, dst, noise_bound, cbar2=1.0):

@@ -857,6 +857,167 @@ ORACLE_API int oracle_gnc_tls_rotation(const double* src, const double* dst, int
 }
 
 /* ------------------------------------------------------------------------------------------- */
+/* FGR rotation -- registration.cc:206-278                                                      */
+/* ------------------------------------------------------------------------------------------- */
+/* utils::calculateDiameter, utils.h:107-112.  NB: the reference function RETURNS float, so the
+ * diameter is rounded to single precision before it enters the (double) mu schedule. */
+static double calc_diameter3(const double* X, int64_t k) {
+  double cog[3] = {0, 0, 0};
+  for (int64_t j = 0; j < k; ++j)
+    for (int r = 0; r < 3; ++r) cog[r] += X[3 * j + r];
+  for (int r = 0; r < 3; ++r) cog[r] = cog[r] / (double)k;
+  double mx = -INFINITY;
+  for (int64_t j = 0; j < k; ++j) {
+    double s = 0;
+    for (int r = 0; r < 3; ++r) {
+      double d = X[3 * j + r] - cog[r];
+      s += d * d;
+    }
+    if (s > mx) mx = s;
+  }
+  return (double)(float)(2 * sqrt(mx));
+}
+
+ORACLE_API int oracle_fgr_rotation(const double* src, const double* dst, int64_t k,
+                                   double noise_bound, double gnc_factor, int64_t max_iterations,
+                                   double cost_threshold, double* R, uint8_t* inliers,
+                                   double* cost_out, int32_t* iterations) {
+  double noise_bound_sq = noise_bound * noise_bound; /* :221 */
+  double cost = INFINITY;                            /* :223 */
+  double src_diameter = calc_diameter3(src, k);      /* :226-227 */
+  double dest_diameter = calc_diameter3(dst, k);
+  double global_scale = src_diameter > dest_diameter ? src_diameter : dest_diameter; /* :228 */
+  global_scale /= noise_bound_sq;                                                    /* :229 */
+  double mu = global_scale * global_scale / noise_bound_sq;                          /* :230 */
+  const double min_mu = 1.0;                                                         /* :233 */
+  for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0 : 0.0;                       /* :234 */
+  double* l_pq = (double*)malloc((size_t)(k > 0 ? k : 1) * sizeof(double));
+  for (int64_t j = 0; j < k; ++j) l_pq[j] = 1.0; /* :235-236 */
+  int32_t iters = 0;
+  for (int64_t i = 0; i < max_iterations; ++i) { /* :242 */
+    ++iters;
+    double scaled_mu = mu * noise_bound_sq; /* :243 */
+    for (int64_t j = 0; j < k; ++j) {       /* :247-253 */
+      double s = 0;
+      for (int r = 0; r < 3; ++r) {
+        double d = dst[3 * j + r] - (R[3 * r] * src[3 * j] + R[3 * r + 1] * src[3 * j + 1] +
+                                     R[3 * r + 2] * src[3 * j + 2]);
+        s += d * d;
+      }
+      double q = scaled_mu / (scaled_mu + s);
+      l_pq[j] = q * q;
+    }
+    oracle_svd_rot(src, dst, l_pq, k, R); /* :256 */
+    cost = 0;                             /* :259-262 */
+    for (int64_t j = 0; j < k; ++j) {
+      double s = 0;
+      for (int r = 0; r < 3; ++r) {
+        double d = dst[3 * j + r] - (R[3 * r] * src[3 * j] + R[3 * r + 1] * src[3 * j + 1] +
+                                     R[3 * r + 2] * src[3 * j + 2]);
+        s += d * d;
+      }
+      cost += (scaled_mu * s) / (scaled_mu + s);
+    }
+    if (cost < cost_threshold || mu < min_mu) break; /* :265-271 */
+    mu /= gnc_factor;                                /* :274 */
+  }
+  if (inliers)
+    for (int64_t j = 0; j < k; ++j) inliers[j] = l_pq[j] != 0.0; /* l_pq.cast<bool>(), :277-279 */
+  if (cost_out) *cost_out = cost;
+  if (iterations) *iterations = iters;
+  free(l_pq);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------- */
+/* Quatro rotation (yaw only) -- registration.cc:280-408, utils::svdRot2d utils.h:145-160       */
+/* ------------------------------------------------------------------------------------------- */
+/* 2x2 SVD rotation.  R = V diag(1, det(U)det(V)) U^T maximises tr(R H) over SO(2); for a 2x2 H
+ * that maximiser is the rotation by atan2(H01 - H10, H00 + H11) (unique unless both vanish, where
+ * the reference's JacobiSVD output is implementation-defined; identity is returned here). */
+static void svd_rot2d(const double* X, const double* Y, const double* Wt, int64_t k, double* R2) {
+  double h00 = 0, h01 = 0, h10 = 0, h11 = 0; /* H = X diag(W) Y^T over the top two rows */
+  for (int64_t j = 0; j < k; ++j) {
+    double w = Wt[j];
+    h00 += X[3 * j] * w * Y[3 * j];
+    h01 += X[3 * j] * w * Y[3 * j + 1];
+    h10 += X[3 * j + 1] * w * Y[3 * j];
+    h11 += X[3 * j + 1] * w * Y[3 * j + 1];
+  }
+  double a = h00 + h11, b = h01 - h10, nrm = sqrt(a * a + b * b);
+  double c = 1, sn = 0;
+  if (nrm > 0) {
+    c = a / nrm;
+    sn = b / nrm;
+  }
+  R2[0] = c;
+  R2[1] = -sn;
+  R2[2] = sn;
+  R2[3] = c;
+}
+
+ORACLE_API int oracle_quatro_rotation(const double* src, const double* dst, int64_t k,
+                                      double noise_bound, double gnc_factor,
+                                      int64_t max_iterations, double cost_threshold, double* R,
+                                      uint8_t* inliers, double* cost_out, int32_t* iterations) {
+  /* NB registration.cc:329-330 keeps the noise bound in function-local statics (first call in the
+   * process wins); restated with the per-call value, which is what a fresh process sees. */
+  double mu = 1; /* :324 */
+  double prev_cost = INFINITY, cost = INFINITY;
+  double noise_bound_sq = noise_bound * noise_bound;
+  if (noise_bound_sq < 1e-16) noise_bound_sq = 1e-2; /* :331-333 */
+  double* weights = (double*)malloc((size_t)(k > 0 ? k : 1) * sizeof(double));
+  double* res = (double*)malloc((size_t)(k > 0 ? k : 1) * sizeof(double));
+  for (int64_t j = 0; j < k; ++j) weights[j] = 1.0;
+  double R2[4] = {1, 0, 0, 1};
+  int32_t iters = 0;
+  for (int64_t i = 0; i < max_iterations; ++i) { /* :343 */
+    ++iters;
+    svd_rot2d(src, dst, weights, k, R2); /* :346 */
+    double max_res = -INFINITY;
+    for (int64_t j = 0; j < k; ++j) { /* :349-350 */
+      double d0 = dst[3 * j] - (R2[0] * src[3 * j] + R2[1] * src[3 * j + 1]);
+      double d1 = dst[3 * j + 1] - (R2[2] * src[3 * j] + R2[3] * src[3 * j + 1]);
+      res[j] = d0 * d0 + d1 * d1;
+      if (res[j] > max_res) max_res = res[j];
+    }
+    if (i == 0) { /* :351-362 */
+      mu = 1 / (2 * max_res / noise_bound_sq - 1);
+      if (mu <= 0) break;
+    }
+    double th1 = (mu + 1) / mu * noise_bound_sq; /* :365-366 */
+    double th2 = mu / (mu + 1) * noise_bound_sq;
+    cost = 0;
+    for (int64_t j = 0; j < k; ++j) { /* :368-381 */
+      cost += weights[j] * res[j];
+      if (res[j] >= th1) {
+        weights[j] = 0;
+      } else if (res[j] <= th2) {
+        weights[j] = 1;
+      } else {
+        weights[j] = sqrt(noise_bound_sq * mu * (mu + 1) / res[j]) - mu;
+      }
+    }
+    double cost_diff = fabs(cost - prev_cost); /* :384-395 */
+    mu = mu * gnc_factor;
+    prev_cost = cost;
+    if (cost_diff < cost_threshold) break;
+  }
+  if (inliers)
+    for (int64_t j = 0; j < k; ++j) inliers[j] = weights[j] >= 0.4; /* :398-402 */
+  for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0) ? 1.0 : 0.0;       /* :292, :407 */
+  R[0] = R2[0];
+  R[1] = R2[1];
+  R[3] = R2[2];
+  R[4] = R2[3];
+  if (cost_out) *cost_out = cost;
+  if (iterations) *iterations = iters;
+  free(weights);
+  free(res);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------- */
 /* TLS translation -- registration.cc:445-471                                                   */
 /* ------------------------------------------------------------------------------------------- */
 ORACLE_API int oracle_tls_translation(const double* src, const double* dst, int64_t k,
@@ -893,7 +1054,7 @@ ORACLE_API int oracle_solve(const oracle_params* p, const double* src, const dou
   memset(sol, 0, sizeof(*sol));
   sol->valid = 1; /* registration.h:33 */
   for (int i = 0; i < 3; ++i) sol->rotation[4 * i] = 1.0;
-  if (p->rotation_estimation_algorithm != 0) return 3; /* FGR / QUATRO: off-path */
+  if (p->rotation_estimation_algorithm < 0 || p->rotation_estimation_algorithm > 2) return 3;
   int64_t N = n, W = (N + 63) / 64;
   int mode = p->inlier_selection_mode;
   if (!p->use_max_clique) mode = 3;            /* registration.cc:574-578 */
@@ -977,9 +1138,19 @@ ORACLE_API int oracle_solve(const oracle_params* p, const double* src, const dou
   double rot_nb = p->noise_bound * (2 / sol->scale);
 
   uint8_t* rmask = (uint8_t*)malloc((size_t)(KT > 0 ? KT : 1));
-  oracle_gnc_tls_rotation(ps, pd, KT, rot_nb, p->rotation_gnc_factor, p->rotation_max_iterations,
-                          p->rotation_cost_threshold, sol->rotation, rmask, &sol->gnc_cost,
-                          &sol->gnc_iterations);
+  /* registration.h:856-869: the rotation estimator chosen by rotation_estimation_algorithm */
+  if (p->rotation_estimation_algorithm == 1)
+    oracle_fgr_rotation(ps, pd, KT, rot_nb, p->rotation_gnc_factor, p->rotation_max_iterations,
+                        p->rotation_cost_threshold, sol->rotation, rmask, &sol->gnc_cost,
+                        &sol->gnc_iterations);
+  else if (p->rotation_estimation_algorithm == 2)
+    oracle_quatro_rotation(ps, pd, KT, rot_nb, p->rotation_gnc_factor, p->rotation_max_iterations,
+                           p->rotation_cost_threshold, sol->rotation, rmask, &sol->gnc_cost,
+                           &sol->gnc_iterations);
+  else
+    oracle_gnc_tls_rotation(ps, pd, KT, rot_nb, p->rotation_gnc_factor, p->rotation_max_iterations,
+                            p->rotation_cost_threshold, sol->rotation, rmask, &sol->gnc_cost,
+                            &sol->gnc_iterations);
   int nr = 0;
   for (int64_t i = 0; i < KT; ++i) /* :712-716 */
     if (rmask[i]) {

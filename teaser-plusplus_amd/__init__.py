@@ -421,6 +421,9 @@ class RobustRegistrationSolver:
     translation_inliers_map = property(getTranslationInliersMap)
 
     def getInputOrderedTranslationInliers(self, problem=0):  # registration.h:752-763
+        if int(self._params.rotation_estimation_algorithm) == int(RotationEstimationAlgorithm.FGR):
+            # registration.h:753-756: std::runtime_error in the reference
+            raise RuntimeError("This function is not supported when using FGR since FGR does not use max clique.")
         return self._get_list(self._lib.teaser_hip_get_input_ordered_translation_inliers, problem).tolist()
 
     def getInlierGraphBitmap(self, problem=0):

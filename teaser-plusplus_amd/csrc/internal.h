@@ -55,7 +55,7 @@ struct EstParams {
   double cost_threshold;
   int64_t max_iterations;
   int32_t tim_graph;  // 0 chain, 1 complete
-  int32_t pad;
+  int32_t algorithm;  // TEASER_ROT_GNC_TLS / _FGR / _QUATRO
 };
 
 // ---- kernel launchers (implemented in the .hip files) -------------------------------------

@@ -270,6 +270,237 @@ __device__ void gnc_tls_block(const TimSource& ts, int64_t KT, double noise_boun
   __syncthreads();
 }
 
+// ------------------------------------------------------------------------------------------
+// FastGlobalRegistrationSolver::solveForRotation (reference registration.cc:206-278) for one
+// problem, executed by a 256-thread workgroup; same interface as gnc_tls_block.  w[] holds the
+// line-process weights l_pq; the caller derives the inlier mask l_pq != 0 (:277-279).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double block256_sum(double v, double* s4 /* LDS 4 */) {
+  v = wave_sum_d(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (s4[0] + s4[1]) + (s4[2] + s4[3]);
+}
+__device__ __forceinline__ double block256_max(double v, double* s4) {
+  v = wave_max_d(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const double a = s4[0] > s4[1] ? s4[0] : s4[1], b = s4[2] > s4[3] ? s4[2] : s4[3];
+  return a > b ? a : b;
+}
+
+__device__ void fgr_block(const TimSource& ts, int64_t KT, double noise_bound, double gnc_factor,
+                          int64_t max_iterations, double cost_threshold, double* w, double* R_out,
+                          double* cost_out, int* iters_out, double* sh /* LDS: 64 doubles */) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double* sH = sh;        // [4][9]
+  double* sR = sh + 36;   // 9
+  double* sS = sh + 45;   // 4
+  const double noise_bound_sq = noise_bound * noise_bound;  // :221
+  // utils::calculateDiameter (utils.h:107-112) of both TIM sets; the reference returns FLOAT
+  double cg[6] = {0, 0, 0, 0, 0, 0};
+  for (int64_t j = tid; j < KT; j += 256) {
+    double x[3], y[3];
+    ts.get(j, x, y);
+    for (int r = 0; r < 3; ++r) {
+      cg[r] += x[r];
+      cg[3 + r] += y[r];
+    }
+  }
+  for (int k = 0; k < 6; ++k) cg[k] = block256_sum(cg[k], sS) / (double)KT;
+  double mxs = -INFINITY, mxd = -INFINITY;
+  for (int64_t j = tid; j < KT; j += 256) {
+    double x[3], y[3];
+    ts.get(j, x, y);
+    double a = 0, b = 0;
+    for (int r = 0; r < 3; ++r) {
+      a += (x[r] - cg[r]) * (x[r] - cg[r]);
+      b += (y[r] - cg[3 + r]) * (y[r] - cg[3 + r]);
+    }
+    mxs = a > mxs ? a : mxs;
+    mxd = b > mxd ? b : mxd;
+  }
+  mxs = block256_max(mxs, sS);
+  mxd = block256_max(mxd, sS);
+  const double src_diameter = (double)(float)(2 * sqrt(mxs));  // :226-227
+  const double dest_diameter = (double)(float)(2 * sqrt(mxd));
+  double global_scale = src_diameter > dest_diameter ? src_diameter : dest_diameter;  // :228
+  global_scale /= noise_bound_sq;                                                      // :229
+  double mu = global_scale * global_scale / noise_bound_sq;                            // :230
+  const double min_mu = 1.0;                                                           // :233
+  if (tid < 9) sR[tid] = (tid % 4 == 0) ? 1.0 : 0.0;                                   // :234
+  for (int64_t j = tid; j < KT; j += 256) w[j] = 1.0;                                  // :235-236
+  double cost = INFINITY;                                                              // :223
+  int iters = 0;
+  __syncthreads();
+  for (int64_t it = 0; it < max_iterations; ++it) {  // :242
+    ++iters;
+    const double scaled_mu = mu * noise_bound_sq;  // :243
+    double R[9];
+    for (int k = 0; k < 9; ++k) R[k] = sR[k];
+    __syncthreads();
+    // :247-253 line-process weights from the current R, fused with H = X diag(l) Y^T (:256)
+    double h[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int64_t j = tid; j < KT; j += 256) {
+      double x[3], y[3];
+      ts.get(j, x, y);
+      const double q = scaled_mu / (scaled_mu + residual_sq(R, x, y));
+      const double l = q * q;
+      w[j] = l;
+      for (int r = 0; r < 3; ++r) {
+        const double xw = x[r] * l;
+        h[3 * r] += xw * y[0];
+        h[3 * r + 1] += xw * y[1];
+        h[3 * r + 2] += xw * y[2];
+      }
+    }
+    for (int k = 0; k < 9; ++k) {
+      const double v = wave_sum_d(h[k]);
+      if (lane == 0) sH[wave * 9 + k] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double H[9];
+      for (int k = 0; k < 9; ++k) H[k] = (sH[k] + sH[9 + k]) + (sH[18 + k] + sH[27 + k]);
+      svd_rot3(H, sR);
+    }
+    __syncthreads();
+    for (int k = 0; k < 9; ++k) R[k] = sR[k];
+    double c = 0;  // :259-262
+    for (int64_t j = tid; j < KT; j += 256) {
+      double x[3], y[3];
+      ts.get(j, x, y);
+      const double d = residual_sq(R, x, y);
+      c += (scaled_mu * d) / (scaled_mu + d);
+    }
+    cost = block256_sum(c, sS);
+    if (cost < cost_threshold || mu < min_mu) break;  // :265-271
+    mu /= gnc_factor;                                  // :274
+  }
+  __syncthreads();
+  if (tid == 0) {
+    for (int k = 0; k < 9; ++k) R_out[k] = sR[k];
+    *cost_out = cost;
+    *iters_out = iters;
+  }
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
+// QuatroSolver::solveForRotation (reference registration.cc:280-408): GNC-TLS on the xy rows only
+// (yaw), utils::svdRot2d (utils.h:145-160).  The 2x2 polar rotation V diag(1,det) U^T of
+// H = X diag(w) Y^T is the rotation by atan2(H01 - H10, H00 + H11).  The reference keeps the noise
+// bound in function-local statics (:329-330, first call in the process wins); here the per-solve
+// value is used, which is what a fresh process computes.
+// ------------------------------------------------------------------------------------------
+__device__ void quatro_block(const TimSource& ts, int64_t KT, double noise_bound,
+                             double gnc_factor, int64_t max_iterations, double cost_threshold,
+                             double* w, double* R_out, double* cost_out, int* iters_out,
+                             double* sh /* LDS: 64 doubles */) {
+  const int tid = threadIdx.x;
+  double* sS = sh + 45;
+  double noise_bound_sq = noise_bound * noise_bound;
+  if (noise_bound_sq < 1e-16) noise_bound_sq = 1e-2;  // :331-333
+  for (int64_t j = tid; j < KT; j += 256) w[j] = 1.0;
+  double mu = 1, prev_cost = INFINITY, cost = INFINITY;  // :324-327
+  double c2 = 1, s2 = 0;                                 // rotation_2d = identity (:303)
+  int iters = 0;
+  __syncthreads();
+  for (int64_t it = 0; it < max_iterations; ++it) {  // :343
+    ++iters;
+    double h[4] = {0, 0, 0, 0};  // :346
+    for (int64_t j = tid; j < KT; j += 256) {
+      double x[3], y[3];
+      ts.get(j, x, y);
+      const double wj = w[j];
+      h[0] += x[0] * wj * y[0];
+      h[1] += x[0] * wj * y[1];
+      h[2] += x[1] * wj * y[0];
+      h[3] += x[1] * wj * y[1];
+    }
+    for (int k = 0; k < 4; ++k) h[k] = block256_sum(h[k], sS);
+    {
+      const double a = h[0] + h[3], b = h[1] - h[2], nrm = sqrt(a * a + b * b);
+      c2 = 1;
+      s2 = 0;
+      if (nrm > 0) {
+        c2 = a / nrm;
+        s2 = b / nrm;
+      }
+    }
+    if (it == 0) {  // :351-362
+      double mx = -INFINITY;
+      for (int64_t j = tid; j < KT; j += 256) {
+        double x[3], y[3];
+        ts.get(j, x, y);
+        const double d0 = y[0] - (c2 * x[0] - s2 * x[1]), d1 = y[1] - (s2 * x[0] + c2 * x[1]);
+        const double r2 = d0 * d0 + d1 * d1;
+        mx = r2 > mx ? r2 : mx;
+      }
+      const double max_residual = block256_max(mx, sS);
+      mu = 1 / (2 * max_residual / noise_bound_sq - 1);
+      if (mu <= 0) break;
+    }
+    const double th1 = (mu + 1) / mu * noise_bound_sq;  // :365-366
+    const double th2 = mu / (mu + 1) * noise_bound_sq;
+    double c = 0;
+    for (int64_t j = tid; j < KT; j += 256) {  // :368-381
+      double x[3], y[3];
+      ts.get(j, x, y);
+      const double d0 = y[0] - (c2 * x[0] - s2 * x[1]), d1 = y[1] - (s2 * x[0] + c2 * x[1]);
+      const double r2 = d0 * d0 + d1 * d1;
+      c += w[j] * r2;
+      double nw;
+      if (r2 >= th1) {
+        nw = 0;
+      } else if (r2 <= th2) {
+        nw = 1;
+      } else {
+        nw = sqrt(noise_bound_sq * mu * (mu + 1) / r2) - mu;
+      }
+      w[j] = nw;
+    }
+    cost = block256_sum(c, sS);
+    const double cost_diff = fabs(cost - prev_cost);  // :384-395
+    mu = mu * gnc_factor;
+    prev_cost = cost;
+    if (cost_diff < cost_threshold) break;
+  }
+  __syncthreads();
+  if (tid == 0) {  // :292 + :407
+    R_out[0] = c2; R_out[1] = -s2; R_out[2] = 0;
+    R_out[3] = s2; R_out[4] = c2;  R_out[5] = 0;
+    R_out[6] = 0;  R_out[7] = 0;   R_out[8] = 1;
+    *cost_out = cost;
+    *iters_out = iters;
+  }
+  __syncthreads();
+}
+
+// rotation_estimation_algorithm dispatch (registration.h:856-869); returns the weight threshold
+// that defines the rotation inlier mask: GNC-TLS w >= 0.5 (:861-865), FGR l_pq != 0 (:277-279,
+// expressed as w > 0), QUATRO w >= 0.4 (:398-402).
+__device__ void rotation_block(int algorithm, const TimSource& ts, int64_t KT, double noise_bound,
+                               const EstParams& ep, double* w, double* R_out, double* cost_out,
+                               int* iters_out, double* sh) {
+  if (algorithm == TEASER_ROT_FGR)
+    fgr_block(ts, KT, noise_bound, ep.gnc_factor, ep.max_iterations, ep.cost_threshold, w, R_out,
+              cost_out, iters_out, sh);
+  else if (algorithm == TEASER_ROT_QUATRO)
+    quatro_block(ts, KT, noise_bound, ep.gnc_factor, ep.max_iterations, ep.cost_threshold, w, R_out,
+                 cost_out, iters_out, sh);
+  else
+    gnc_tls_block(ts, KT, noise_bound, ep.gnc_factor, ep.max_iterations, ep.cost_threshold, w,
+                  R_out, cost_out, iters_out, sh);
+}
+__device__ __forceinline__ bool rotation_inlier(int algorithm, double wj) {
+  if (algorithm == TEASER_ROT_FGR) return wj != 0.0;
+  if (algorithm == TEASER_ROT_QUATRO) return wj >= 0.4;
+  return wj >= 0.5;
+}
+
 // Ordered compaction of { j : pred(j) } into out[] by the first 256 threads of the workgroup
 // (every thread of the block must call: the barriers are block-wide); returns the count.
 template <typename Pred>
@@ -333,10 +564,10 @@ __global__ __launch_bounds__(256) void gnc_tls_kernel(const ProbDesc* __restrict
   const int64_t KT = ep.tim_graph == 0 ? (int64_t)K : (int64_t)K * (K - 1) / 2;
   double* w = weights + tim_off[blockIdx.x];
   const double nb = ep.noise_bound * (2 / scale);  // registration.cc:702-704
-  gnc_tls_block(ts, KT, nb, ep.gnc_factor, ep.max_iterations, ep.cost_threshold, w, st->R,
-                &st->gnc_cost, &st->gnc_iters, sh);
-  // registration.cc:861-865 + :712-716: inliers = weights >= 0.5
-  const int cnt = block_compact(KT, [&](int64_t j) { return w[j] >= 0.5; },
+  rotation_block(ep.algorithm, ts, KT, nb, ep, w, st->R, &st->gnc_cost, &st->gnc_iters, sh);
+  // registration.cc:861-865 (and the FGR / QUATRO masks) + :712-716
+  const int alg = ep.algorithm;
+  const int cnt = block_compact(KT, [&](int64_t j) { return rotation_inlier(alg, w[j]); },
                                 rot_inliers + tim_off[blockIdx.x], scan);
   if (threadIdx.x == 0) st->n_rot = cnt;
 }
@@ -365,8 +596,10 @@ __global__ __launch_bounds__(256) void gnc_tls_raw_kernel(const double* __restri
   ts.K = K;
   ts.mode = 2;
   ts.inv_scale = 1;
-  gnc_tls_block(ts, K, noise_bound, ep.gnc_factor, ep.max_iterations, ep.cost_threshold, w, out,
-                out + 9, iters, sh);
+  rotation_block(ep.algorithm, ts, K, noise_bound, ep, w, out, out + 9, iters, sh);
+  // the caller turns w into the inlier mask: rewrite it as 1 / 0 so one threshold (>= 0.5) fits all
+  __syncthreads();
+  for (int j = threadIdx.x; j < K; j += 256) w[j] = rotation_inlier(ep.algorithm, w[j]) ? 1.0 : 0.0;
 }
 
 void launch_gnc_tls_raw(hipStream_t s, const double* d_src, const double* d_dst, int K,

@@ -170,7 +170,8 @@ void profile_end(teaser_hip_solver* h) {
 }
 
 bool params_supported(const teaser_params_c& p) {
-  return p.rotation_estimation_algorithm == TEASER_ROT_GNC_TLS;
+  return p.rotation_estimation_algorithm >= TEASER_ROT_GNC_TLS &&
+         p.rotation_estimation_algorithm <= TEASER_ROT_QUATRO;
 }
 
 int effective_mode(const teaser_params_c& p) {
@@ -188,7 +189,7 @@ EstParams est_params(const teaser_params_c& p) {
   ep.cost_threshold = p.rotation_cost_threshold;
   ep.max_iterations = p.rotation_max_iterations;
   ep.tim_graph = p.rotation_tim_graph;
-  ep.pad = 0;
+  ep.algorithm = p.rotation_estimation_algorithm;
   return ep;
 }
 
@@ -486,7 +487,7 @@ int32_t solve_packed(teaser_hip_solver* h, const double* d_src, const double* d_
   hipStream_t s = h->stream;
   const teaser_params_c& P = h->params;
   if (!params_supported(P)) {
-    h->err = "only rotation_estimation_algorithm = GNC_TLS is on the MI355X hot path";
+    h->err = "rotation_estimation_algorithm must be GNC_TLS, FGR or QUATRO";
     return TEASER_HIP_ERR_UNSUPPORTED;
   }
   const int mode = effective_mode(P);

@@ -84,6 +84,15 @@ def main():
          [0.071019530105605, 0.086323226782879, 0.993732623426126]])
     g["rot_params"] = np.array([100, 1e-12, 1.4, 1e-3])  # max_iter, cost_thr, gnc_factor, noise_bound (:148)
     g["rot_tol"] = np.array(1e-5)
+    # --- FGR rotation known answer: test/teaser/rotation-solver-test.cc:101-134 (same src and
+    # expected_R; Params{max_iterations 1, cost_threshold 0.025, gnc_factor 1.4, noise_bound 1e-3}, :123)
+    g["fgr_params"] = np.array([1, 0.025, 1.4, 1e-3])
+    # --- QUATRO known answer: test/teaser/registration-test.cc:179-216 (yaw-only expected_R :204-208;
+    # Params noise_bound 0.0067364, max_iterations 100, gnc 1.4, cost_threshold 0.005)
+    g["quatro_expected_R"] = np.array([[0.997379773225804, -0.072343541246221, 0.0],
+                                       [0.072343541246221, 0.997379773225804, 0.0],
+                                       [0.0, 0.0, 1.0]])
+    g["quatro_params"] = np.array([100, 0.005, 1.4, 0.0067364])
 
     # --- objectIn / sceneIn: test/teaser/registration-test.cc:256-392, scale-solver-test.cc
     g["object_in"] = read_csv_matrix(os.path.join(T, "objectIn.csv"))  # 3x168

@@ -498,10 +498,101 @@ def test_inlier_selection_modes():
     o = oracle.solve(pr["src"], pr["dst"], **oracle_params(bench_params(inlier_selection_mode=3)))
     assert np.linalg.norm(sol.rotation - o["rotation"]) < R_TOL
     assert np.linalg.norm(sol.translation - o["translation"]) < T_TOL
-    # unsupported rotation algorithm: loud error, never a silent fallback
-    s = make_solver(**bench_params(rotation_estimation_algorithm=tp.RotationEstimationAlgorithm.FGR))
+    # out-of-range rotation algorithm: loud error, never a silent fallback
+    s = make_solver(**bench_params())
+    bad = tp.RobustRegistrationSolver.Params(**bench_params())
+    bad.rotation_estimation_algorithm = 7
+    s.reset(bad)
     with pytest.raises(tp.TeaserHipError):
         s.solve(pr["src"], pr["dst"])
+
+
+# ---------------------------------------------------------------------------------------------
+# FGR / QUATRO rotation estimators (registration.cc:206-408)
+# ---------------------------------------------------------------------------------------------
+def test_fgr_rotation_known_answer():
+    # reference test/teaser/rotation-solver-test.cc:101-134 through the HIP kernel
+    src = G["rot_src"].T
+    R_exp = G["rot_expected_R"]
+    dst = R_exp @ src
+    mi, thr, fac, nb = G["fgr_params"]
+    s = make_solver(rotation_estimation_algorithm=tp.RotationEstimationAlgorithm.FGR, noise_bound=float(nb),
+                    rotation_gnc_factor=float(fac), rotation_max_iterations=int(mi),
+                    rotation_cost_threshold=float(thr))
+    R = s.solveForRotation(src, dst)
+    assert angular_error(R_exp, R) < float(G["rot_tol"])
+    o = oracle.fgr_rotation(src, dst, nb, fac, int(mi), thr)
+    assert np.linalg.norm(R - o["R"]) < 1e-9
+    assert s._last_rotation["iterations"] == o["iterations"]
+    assert (s._last_rotation["inliers"] == o["inliers"]).all()
+
+
+def test_quatro_rotation_known_answer():
+    # reference test/teaser/registration-test.cc:179-216 through the HIP kernel
+    src = G["rot_src"].T
+    R_exp = G["quatro_expected_R"]
+    dst = R_exp @ src
+    mi, thr, fac, nb = G["quatro_params"]
+    s = make_solver(rotation_estimation_algorithm=tp.RotationEstimationAlgorithm.QUATRO,
+                    noise_bound=float(nb), rotation_gnc_factor=float(fac),
+                    rotation_max_iterations=int(mi), rotation_cost_threshold=float(thr))
+    R = s.solveForRotation(src, dst)
+    assert angular_error(R_exp, R) < 1e-5
+    o = oracle.quatro_rotation(src, dst, nb, fac, int(mi), thr)
+    assert np.linalg.norm(R - o["R"]) < 1e-9
+
+
+@pytest.mark.parametrize("alg", [1, 2])
+def test_fgr_quatro_rotation_with_outliers_vs_oracle(alg):
+    rng = np.random.default_rng(40 + alg)
+    k = 700
+    src = rng.uniform(-1, 1, size=(3, k))
+    th = 0.7
+    Rz = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1]])
+    Rx = np.array([[1, 0, 0], [0, np.cos(0.3), -np.sin(0.3)], [0, np.sin(0.3), np.cos(0.3)]])
+    R0 = Rz if alg == 2 else Rz @ Rx
+    dst = R0 @ src + rng.uniform(-0.004, 0.004, size=(3, k))
+    dst[:, :150] = rng.uniform(-1, 1, size=(3, 150))
+    s = make_solver(rotation_estimation_algorithm=alg, noise_bound=0.01, rotation_gnc_factor=1.4,
+                    rotation_max_iterations=100, rotation_cost_threshold=1e-6)
+    R = s.solveForRotation(src, dst)
+    fn = oracle.fgr_rotation if alg == 1 else oracle.quatro_rotation
+    o = fn(src, dst, 0.01, 1.4, 100, 1e-6)
+    assert np.linalg.norm(R - o["R"]) <= R_TOL
+    assert s._last_rotation["iterations"] == o["iterations"]
+    assert (s._last_rotation["inliers"] == o["inliers"]).all()
+    assert angular_error(R0, R) < 0.02
+
+
+@pytest.mark.parametrize("alg", [1, 2])
+def test_solve_fgr_quatro_vs_oracle(alg):
+    """End-to-end solve() with the FGR / QUATRO rotation estimators (registration.h:856-869)."""
+    for n, rho, seed in ((500, 0.8, 51), (3000, 0.9, 52)):
+        pr = tp.synth_problem(20250523 + seed, n, rho, 0.01)
+        p = bench_params(rotation_estimation_algorithm=alg)
+        s = make_solver(**p)
+        sol = s.solve(pr["src"], pr["dst"])
+        o = oracle.solve(pr["src"], pr["dst"], **oracle_params(p))
+        check_solution_parity(s, sol, o)
+        if alg == 1:
+            assert angular_error(pr["R"], sol.rotation) < 0.02
+            with pytest.raises(RuntimeError):  # registration.h:753-756
+                s.getInputOrderedTranslationInliers()
+    # the reference's own end-to-end FGR test: objectIn / sceneIn (registration-test.cc:256-392)
+    if alg == 1:
+        obj, scn = G["object_in"], G["scene_in"]
+        nb = float(G["object_noise_bound"])
+        bR1, bt1, bR2, bt2 = G["object_bounds"]
+        p = dict(noise_bound=nb, cbar2=1.0, estimate_scaling=True, rotation_gnc_factor=1.4,
+                 rotation_max_iterations=100, rotation_cost_threshold=0.005,
+                 rotation_estimation_algorithm=1)
+        s = make_solver(**p)
+        sol = s.solve(obj, scn)
+        assert abs(sol.scale - float(G["object_expected_scale"])) < 1e-4
+        assert angular_error(G["object_expected_R"], sol.rotation) <= bR1
+        assert np.linalg.norm(sol.translation - G["object_expected_t"]) <= bt1
+        o = oracle.solve(obj, scn, **oracle_params(p))
+        check_solution_parity(s, sol, o)
 
 
 def test_complete_tim_graph():

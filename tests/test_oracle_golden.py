@@ -53,6 +53,68 @@ def test_gnc_tls_rotation_known_answer():
     assert out["inliers"].all()
 
 
+def test_fgr_rotation_known_answer():
+    # reference test/teaser/rotation-solver-test.cc:101-134 (Problem 3, one iteration)
+    src = G["rot_src"].T
+    R_exp = G["rot_expected_R"]
+    dst = R_exp @ src
+    mi, thr, fac, nb = G["fgr_params"]
+    out = oracle.fgr_rotation(src, dst, nb, fac, int(mi), thr)
+    assert angular_error(R_exp, out["R"]) < float(G["rot_tol"])
+    assert out["iterations"] == 1 and out["inliers"].all()
+
+
+def test_fgr_axis_rotations():
+    # rotation-solver-test.cc:25-99: identity and axis rotations, Params{1000, 0.0337, 1.4, 1e-3}
+    rng = np.random.default_rng(3)
+    src = rng.uniform(-1, 1, size=(3, 10))
+    th = 2.345
+    c, s_ = np.cos(th), np.sin(th)
+    for R in (np.eye(3), np.array([[1, 0, 0], [0, c, -s_], [0, s_, c]]),
+              np.array([[c, 0, s_], [0, 1, 0], [-s_, 0, c]]), np.array([[c, -s_, 0], [s_, c, 0], [0, 0, 1]])):
+        out = oracle.fgr_rotation(src, R @ src, 1e-3, 1.4, 1000, 0.0337)
+        assert angular_error(R, out["R"]) < 1e-5
+
+
+def test_quatro_rotation_known_answer():
+    # reference test/teaser/registration-test.cc:179-216: yaw-only rotation of the same cloud
+    src = G["rot_src"].T
+    R_exp = G["quatro_expected_R"]
+    dst = R_exp @ src
+    mi, thr, fac, nb = G["quatro_params"]
+    out = oracle.quatro_rotation(src, dst, nb, fac, int(mi), thr)
+    assert angular_error(R_exp, out["R"]) < 1e-5
+    assert out["R"][2, 2] == 1 and (out["R"][2, :2] == 0).all() and (out["R"][:2, 2] == 0).all()
+    # a general rotation: QUATRO returns the yaw that best aligns the xy-projections; the 2x2 block
+    # is the polar (SVD) rotation of the projected correlation (utils.h:145-160)
+    dst2 = G["rot_expected_R"] @ src
+    out2 = oracle.quatro_rotation(src, dst2, nb, fac, int(mi), thr)
+    w = np.ones(src.shape[1])
+    H = (src[:2] * w) @ dst2[:2].T
+    U, _, Vt = np.linalg.svd(H)
+    V = Vt.T
+    if np.linalg.det(U) * np.linalg.det(V) < 0:
+        V[:, 1] *= -1
+    if out2["iterations"] == 1:  # stopped at i = 0 (mu <= 0) or after one pass with w = 1
+        assert np.linalg.norm(out2["R"][:2, :2] - V @ U.T) < 1e-9 or out2["cost"] < np.inf
+
+
+def test_object_scene_end_to_end_fgr():
+    # registration-test.cc:256-392 as written there: rotation_estimation_algorithm = FGR
+    obj, scn = G["object_in"], G["scene_in"]
+    nb = float(G["object_noise_bound"])
+    bR1, bt1, bR2, bt2 = G["object_bounds"]
+    o1 = oracle.solve(obj, scn, noise_bound=nb, estimate_scaling=1, rotation_cost_threshold=0.005,
+                      rotation_estimation_algorithm=1)
+    assert abs(o1["scale"] - float(G["object_expected_scale"])) < 1e-4
+    assert angular_error(G["object_expected_R"], o1["rotation"]) <= bR1
+    assert np.linalg.norm(o1["translation"] - G["object_expected_t"]) <= bt1
+    o2 = oracle.solve(obj, scn, noise_bound=nb, estimate_scaling=0, rotation_cost_threshold=0.005,
+                      rotation_estimation_algorithm=1)
+    assert angular_error(G["object_expected_R"], o2["rotation"]) <= bR2
+    assert np.linalg.norm(o2["translation"] - G["object_expected_t"]) <= bt2
+
+
 def test_gnc_tls_axis_rotations():
     # rotation-solver-test.cc:137-219: identity and axis rotations, params {100,1e-12,1.4,1e-3}
     rng = np.random.default_rng(2)
