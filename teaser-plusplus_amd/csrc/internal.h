@@ -63,6 +63,12 @@ struct EstParams {
 void launch_tim_graph(hipStream_t s, const ProbDesc* d_desc, int batch, int max_n,
                       const double* d_src, const double* d_dst, uint64_t* d_bitmap,
                       double noise_bound, double cbar2, int mode, const ProbState* d_state);
+// K1 on the matrix cores (fixed scale only): f32 Gram filter + FP64 exact fallback, same bitmap
+int64_t tim_prep_bytes(int batch);
+void launch_tim_graph_mfma(hipStream_t s, const ProbDesc* d_desc, int batch, int max_n,
+                           int64_t total_pts, const double* d_src, const double* d_dst,
+                           void* d_pk, void* d_prep, uint64_t* d_bitmap, double noise_bound,
+                           double cbar2);
 // row popcounts -> degrees (+ per-problem degree sum), start vertex selection
 void launch_degrees(hipStream_t s, const ProbDesc* d_desc, int batch, int max_n,
                     const uint64_t* d_bitmap, int32_t* d_deg, ProbState* d_state);

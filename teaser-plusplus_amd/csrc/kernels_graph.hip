@@ -11,6 +11,8 @@
 // individually, as the reference's default (non-FMA) build does.  FMAs below are explicit.
 #include <utility>
 
+#include <cstdlib>
+
 #include "internal.h"
 
 namespace thip {
@@ -188,46 +190,28 @@ struct ColTile {
   }
 };
 
-template <int MODE>
-__global__ __launch_bounds__(256) void tim_graph_kernel(const ProbDesc* __restrict__ descs,
-                                                        const double* __restrict__ src,
-                                                        const double* __restrict__ dst,
-                                                        uint64_t* __restrict__ bitmap,
-                                                        double beta, int gx, int gy,
-                                                        const ProbState* __restrict__ states) {
-  const ProbDesc d = descs[blockIdx.y];
-  const int n = d.n, W = d.W;
-  const int T = W;  // row/column tiles of 64
-  // Logical block order: row tile fastest, so the blocks in flight share a column group.
-  // XCD-aware remap (hardware deals consecutive workgroup ids round-robin over the 8 XCDs):
-  // inside every run of 128 ids, the 16 logical neighbours (16 consecutive row tiles of one column
-  // group = the writers of one 128-B line of transposed words) are given the same XCD, so their
-  // 8-byte partial writes merge in that XCD's L2; every XCD still gets 16 of each 128 blocks.
+// Logical block -> (row tile I, column group X).  Row tile fastest, so the blocks in flight share a
+// column group.  XCD-aware remap (hardware deals consecutive workgroup ids round-robin over the 8
+// XCDs): inside every run of 128 ids, the 16 logical neighbours (16 consecutive row tiles of one
+// column group = the writers of one 128-B line of transposed words) are given the same XCD, so
+// their 8-byte partial writes merge in that XCD's L2; every XCD still gets 16 of each 128 blocks.
+__device__ __forceinline__ void tim_block_coords(int gx, int gy, int* I, int* X) {
   const int nblk = gx * gy;
   const int pid = blockIdx.x;
   int lid = pid;
   if (pid < (nblk & ~127)) lid = (pid & ~127) | ((pid & 7) << 4) | ((pid >> 3) & 15);
-  const int I = lid % gy;
-  const int X = lid / gy;
-  if (I >= T) return;
+  *I = lid % gy;
+  *X = lid / gy;
+}
+
+// FP64 path of one wave: 64 rows (row tile I) x kColTilesPerWave column tiles from Jbase.
+template <int MODE>
+__device__ __forceinline__ void tim_wave_fp64(const double* __restrict__ ps,
+                                              const double* __restrict__ pd,
+                                              uint64_t* __restrict__ bm, int n, int W, int I,
+                                              int Jbase, const EdgeConst& kc, double* cbw) {
+  const int T = W;
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int Jbase = (X * kWavesPerBlock + wave) * kColTilesPerWave;
-  if (Jbase + kColTilesPerWave - 1 < I || Jbase >= T) return;  // below the diagonal / outside
-
-  const double* __restrict__ ps = src + 3 * d.pt_off;
-  const double* __restrict__ pd = dst + 3 * d.pt_off;
-  uint64_t* __restrict__ bm = bitmap + d.bm_off;
-  __shared__ __attribute__((aligned(16))) double cbuf[kWavesPerBlock][64 * 6];
-  double* cbw = cbuf[wave];  // private to this wave: no block barrier needed
-  EdgeConst kc;
-  kc.beta = beta;
-  kc.beta2 = beta * beta;
-  kc.m2beta2 = -2.0 * kc.beta2;
-  kc.beta4 = kc.beta2 * kc.beta2;
-  kc.s_hat = 1.0;
-  if (MODE == 1) kc.s_hat = states[blockIdx.y].scale;
-
   const int i = I * 64 + lane;
   const bool vi = i < n;
   const int ic = vi ? i : n - 1;
@@ -285,6 +269,448 @@ __global__ __launch_bounds__(256) void tim_graph_kernel(const ProbDesc* __restri
   }
 }
 
+template <int MODE>
+__global__ __launch_bounds__(256) void tim_graph_kernel(const ProbDesc* __restrict__ descs,
+                                                        const double* __restrict__ src,
+                                                        const double* __restrict__ dst,
+                                                        uint64_t* __restrict__ bitmap,
+                                                        double beta, int gx, int gy,
+                                                        const ProbState* __restrict__ states) {
+  const ProbDesc d = descs[blockIdx.y];
+  const int n = d.n, W = d.W;
+  const int T = W;  // row/column tiles of 64
+  int I, X;
+  tim_block_coords(gx, gy, &I, &X);
+  if (I >= T) return;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int Jbase = (X * kWavesPerBlock + wave) * kColTilesPerWave;
+  if (Jbase + kColTilesPerWave - 1 < I || Jbase >= T) return;  // below the diagonal / outside
+
+  __shared__ __attribute__((aligned(16))) double cbuf[kWavesPerBlock][64 * 6];
+  EdgeConst kc;
+  kc.beta = beta;
+  kc.beta2 = beta * beta;
+  kc.m2beta2 = -2.0 * kc.beta2;
+  kc.beta4 = kc.beta2 * kc.beta2;
+  kc.s_hat = 1.0;
+  if (MODE == 1) kc.s_hat = states[blockIdx.y].scale;
+  tim_wave_fp64<MODE>(src + 3 * d.pt_off, dst + 3 * d.pt_off, bitmap + d.bm_off, n, W, I, Jbase, kc,
+                      cbuf[wave]);  // cbuf[wave] is private to this wave: no block barrier needed
+}
+
+// ==========================================================================================
+// K1 on the matrix cores (fixed-scale predicate, MODE 0).
+//
+// |a|^2 = |s_j - s_i|^2 = n_i + n_j - 2 s_i.s_j is a rank-5 contraction, so the squared TIM norms
+// of a 32 x 32 tile of pairs are THREE v_mfma_f32_32x32x2_f32 per cloud (K = 6: x, y, z, n, 1, 0
+// against -2x', -2y', -2z', 1, n', 0) on points centred per problem and rounded to f32 (pre-pass).
+// The matrix pipe runs beside the VALU, which keeps only the epilogue: D = A - B, t = A + B,
+// d = D^2 - 2 beta^2 t + beta^4 (packed f32), two compares and one add-with-carry per pair.
+// The f32 result is a FILTER: its sign is trusted only outside a rigorous error band; everything
+// inside the band (a few 1e-6 of the pairs) is re-evaluated with the reference expression in
+// FP64 (tim_edge_exact), so the bitmap stays bit-identical to the oracle by construction.
+//
+// Error budget (u = 2^-24, R = max |centred point| over both clouds, eps = 32 u R^2):
+//   * centring + f32 rounding of the coordinates moves |a|^2 by <= 8 u R^2, the f32 norms n by
+//     2 u R^2, the MFMA's fmaf chain (5 roundings of partial sums <= 4 R^2) by 20 u R^2
+//     => |A~ - A*| <= eps (same for B);
+//   * propagating through D, t, e = beta^4 - 2 beta^2 t, d = D^2 + e with 4 eps |D| <=
+//     2 eps (D^2/lam + lam), lam = beta R, and D^2 <= 1.01 |d~| + 2 beta^2 t + beta^4:
+//       |d~ - d*| <= kappa |d~| + K2 t~ + K0,
+//       kappa = 3.04 u + 2.03 eps/lam,  K2 = 10.1 u beta^2 + 4.04 eps beta^2/lam,
+//       K0 = 4 eps^2 + 4 beta^2 eps + 4.1 u beta^4 + 2.02 eps beta^4/lam + 2.02 eps lam + G,
+//     G = 1.3e-13 beta R^3 + 8e-15 beta^2 R^2 covering the gap between the reference's rounded
+//     double predicate and the exact one (|x - beta| <= 4.5e-16 y + 1.1e-16 beta);
+//   * sign(d~) is trusted iff |d~| > (K2 t~ + K0) / (1 - kappa); pairs with t~ <= tau =
+//     beta^2 (1 + 8u) + 2.1 eps (the t <= beta^2 branch of the predicate) send their tile to FP64.
+// kappa > 1/4 (beta below ~2e-5 R: f32 cannot resolve the band) => the problem runs on the FP64
+// kernel body instead (tim_wave_fp64), chosen per problem on the device.
+// ==========================================================================================
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct TimPrep {         // per problem, zeroed then filled by the pre-pass
+  // bounding boxes as order-preserving uint images of the f32 coordinates (atomicMax only):
+  // hi[k] = max key(v), lo[k] = max ~key(v)  (k = 0..2 src xyz, 3..5 dst xyz)
+  unsigned int hi[6];
+  unsigned int lo[6];
+  unsigned int r2_bits;  // max |centred f32 point|^2 over both clouds (float bits, atomicMax)
+  unsigned int pad[3];
+};
+
+__device__ __forceinline__ unsigned int f32_key(float f) {  // monotone float -> uint
+  const unsigned int b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float f32_unkey(unsigned int k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+// centre of a problem's cloud c (0 src, 1 dst), axis k: any finite value is valid (the error
+// analysis uses the rounded CENTRED coordinates), so the f32 bounding box is enough
+__device__ __forceinline__ double prep_centre(const TimPrep* pr, int c, int k) {
+  const float hi = f32_unkey(pr->hi[3 * c + k]), lo = f32_unkey(~pr->lo[3 * c + k]);
+  const double mid = 0.5 * ((double)lo + (double)hi);
+  return (mid == mid && fabs(mid) < 1e300) ? mid : 0.0;
+}
+
+__global__ __launch_bounds__(256) void tim_prep_bbox_kernel(const ProbDesc* __restrict__ descs,
+                                                            const double* __restrict__ src,
+                                                            const double* __restrict__ dst,
+                                                            TimPrep* __restrict__ prep) {
+  const ProbDesc d = descs[blockIdx.y];
+  const double* ps = src + 3 * d.pt_off;
+  const double* pd = dst + 3 * d.pt_off;
+  unsigned int hi[6] = {0, 0, 0, 0, 0, 0}, lo[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = blockIdx.x * 1024 + threadIdx.x; i < min(d.n, (int)(blockIdx.x + 1) * 1024); i += 256)
+    for (int k = 0; k < 3; ++k) {
+      const unsigned int a = f32_key((float)ps[3 * i + k]), b = f32_key((float)pd[3 * i + k]);
+      hi[k] = max(hi[k], a);
+      lo[k] = max(lo[k], ~a);
+      hi[3 + k] = max(hi[3 + k], b);
+      lo[3 + k] = max(lo[3 + k], ~b);
+    }
+  for (int k = 0; k < 6; ++k) {
+    for (int o = 32; o > 0; o >>= 1) {
+      hi[k] = max(hi[k], (unsigned int)__shfl_xor((int)hi[k], o, 64));
+      lo[k] = max(lo[k], (unsigned int)__shfl_xor((int)lo[k], o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+      if (hi[k]) atomicMax(&prep[blockIdx.y].hi[k], hi[k]);
+      if (lo[k]) atomicMax(&prep[blockIdx.y].lo[k], lo[k]);
+    }
+  }
+}
+
+// centred f32 points + f32 squared norms: pk[i] = (x, y, z, n); atomicMax of n into r2_bits
+__global__ __launch_bounds__(256) void tim_prep_pack_kernel(const ProbDesc* __restrict__ descs,
+                                                            const double* __restrict__ src,
+                                                            const double* __restrict__ dst,
+                                                            TimPrep* __restrict__ prep,
+                                                            float4* __restrict__ pk_src,
+                                                            float4* __restrict__ pk_dst) {
+  const ProbDesc d = descs[blockIdx.y];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float m = 0.f;
+  if (i < d.n) {
+    const TimPrep* pr = prep + blockIdx.y;
+    const double* a = src + 3 * (d.pt_off + i);
+    const double* b = dst + 3 * (d.pt_off + i);
+    const float ax = (float)(a[0] - prep_centre(pr, 0, 0)), ay = (float)(a[1] - prep_centre(pr, 0, 1)),
+                az = (float)(a[2] - prep_centre(pr, 0, 2));
+    const float bx = (float)(b[0] - prep_centre(pr, 1, 0)), by = (float)(b[1] - prep_centre(pr, 1, 1)),
+                bz = (float)(b[2] - prep_centre(pr, 1, 2));
+    // exact in double (24-bit inputs), one rounding to f32
+    const float na = (float)(((double)ax * ax + (double)ay * ay) + (double)az * az);
+    const float nb = (float)(((double)bx * bx + (double)by * by) + (double)bz * bz);
+    pk_src[d.pt_off + i] = make_float4(ax, ay, az, na);
+    pk_dst[d.pt_off + i] = make_float4(bx, by, bz, nb);
+    m = na > nb ? na : nb;
+    if (!(m == m)) m = INFINITY;  // NaN coordinates: force the FP64 path
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const float t = __shfl_xor(m, o, 64);
+    m = t > m ? t : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(&prep[blockIdx.y].r2_bits, __float_as_uint(m));
+}
+
+struct MfmaConst {
+  f32x2 m2b2, b4, K2, K0;  // both halves equal (operands of the packed ops)
+  float tau;
+  int use_mfma;
+};
+
+__device__ __forceinline__ float f32_up(double v) {  // a float >= v (v >= 0)
+  float f = (float)v;
+  if ((double)f < v) f = __uint_as_float(__float_as_uint(f) + 1u);
+  return f;
+}
+
+// Band constants in f32, every step rounded towards "wider" by a relative 2^-20 inflation (f32
+// arithmetic here errs by a few 2^-24 per operation, far inside the 1.001 safety factor).
+__device__ __forceinline__ MfmaConst mfma_consts(double beta_d, unsigned int r2_bits) {
+  MfmaConst c;
+  const float u = 5.9604644775390625e-8f;  // 2^-24
+  const float up = 1.000001f;
+  const float beta = (float)beta_d * up;
+  const float R2 = __uint_as_float(r2_bits) * up;
+  const float R = __builtin_sqrtf(R2) * up;
+  const float b2 = beta * beta * up, b4 = b2 * b2 * up;
+  const float eps = 32.0f * u * R2 * up;
+  const float lam_lo = (float)beta_d * __builtin_sqrtf(__uint_as_float(r2_bits)) * 0.999999f;  // divisor
+  const float lam_hi = beta * R * up;
+  const float eol = eps / lam_lo * up;  // eps / lam, rounded up
+  const float kappa = 3.04f * u + 2.03f * eol;
+  const float K2 = (10.1f * u * b2 + 4.04f * eol * b2) * up;
+  const float K0 = (4.0f * eps * eps + 4.0f * b2 * eps + 4.1f * u * b4 + 2.02f * eol * b4 +
+                    2.02f * eps * lam_hi + 1.3e-13f * beta * R2 * R + 8e-15f * b2 * R2) * up;
+  const bool ok = (R2 > 1e-30f) && (R2 < 1e30f) && (beta_d > 0) && (kappa <= 0.25f) && (b4 > 1e-35f) &&
+                  (kappa == kappa) && (K0 == K0) && (K0 < 1e30f);
+  const float sc = 1.001f / (1.0f - (ok ? kappa : 0.0f));
+  const float k2 = K2 * sc * up, k0 = K0 * sc * up;
+  const float m2b2 = (float)(-2.0 * beta_d * beta_d), fb4 = (float)(beta_d * beta_d * beta_d * beta_d);
+  c.m2b2 = (f32x2){m2b2, m2b2};
+  c.b4 = (f32x2){fb4, fb4};
+  c.K2 = (f32x2){k2, k2};
+  c.K0 = (f32x2){k0, k0};
+  c.tau = (b2 * (1 + 8 * u) + 2.1f * eps) * up;
+  c.use_mfma = ok ? 1 : 0;
+  return c;
+}
+
+// One 32 x 32 MFMA tile of pairs: rows rbase + r, columns of this lane's column point.
+// Accumulator map (v_mfma_f32_32x32x2_f32): lane l holds column l & 31, rows
+// (q & 3) + 8 (q >> 2) + 4 (l >> 5) for its 16 registers q.
+struct MfmaTile {
+  f32x16 A, B;
+  unsigned int colbits;  // bit q = predicate of accumulator register q (this lane's column)
+  f32x2 tmin;
+  MfmaConst kc;
+  uint64_t unc;  // OR of the uncertain-lane masks of the tile (wave-uniform)
+
+  template <int Q>
+  __device__ __forceinline__ void consume(float d, float band) {
+    // NaN-safe "inside the band"; any hit sends the whole tile to the FP64 redo after the loop
+    // (d = +-0 is always inside the band, so the sign bit alone decides d <= 0 outside it)
+    unc |= __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(d) > band));
+    // colbits = (colbits << 1) | sign(d): one v_alignbit_b32
+    colbits = __builtin_amdgcn_alignbit(colbits, __float_as_uint(d), 31);
+  }
+
+  template <int QP>
+  __device__ __forceinline__ void pair_step() {
+    const f32x2 a = {A[2 * QP], A[2 * QP + 1]}, b = {B[2 * QP], B[2 * QP + 1]};
+    const f32x2 D = a - b, t = a + b;
+    const f32x2 e = __builtin_elementwise_fma(t, kc.m2b2, kc.b4);
+    const f32x2 d = __builtin_elementwise_fma(D, D, e);
+    const f32x2 band = __builtin_elementwise_fma(t, kc.K2, kc.K0);
+    tmin = __builtin_elementwise_min(tmin, t);
+    consume<2 * QP + 1>(d.y, band.y);  // descending q: bit q of colbits = register q
+    consume<2 * QP>(d.x, band.x);
+  }
+  template <int... QPs>
+  __device__ __forceinline__ void run(std::integer_sequence<int, QPs...>) {
+    (pair_step<7 - QPs>(), ...);
+  }
+  template <int Q>
+  __device__ __forceinline__ void scalar_step() {
+    const float a = A[Q], b = B[Q];
+    const float D = a - b, t = a + b;
+    const float e = __builtin_fmaf(t, kc.m2b2.x, kc.b4.x);
+    const float d = __builtin_fmaf(D, D, e);
+    const float band = __builtin_fmaf(t, kc.K2.x, kc.K0.x);
+    tmin.x = __builtin_fminf(tmin.x, t);
+    consume<Q>(d, band);
+  }
+  template <int... Qs>
+  __device__ __forceinline__ void run_scalar(std::integer_sequence<int, Qs...>) {
+    (scalar_step<15 - Qs>(), ...);
+  }
+
+};
+
+// FP64 evaluation of one whole 32 x 32 tile with the reference expression (a pair inside the band,
+// or with t <= tau, is in it): returns this lane's 16 column bits (bit q = accumulator register q).
+__device__ __forceinline__ unsigned int tim_tile_exact(const double* __restrict__ ps,
+                                                       const double* __restrict__ pd, int n,
+                                                       int row0, int colpt, int h, double beta) {
+  const double cx = ps[3 * colpt], cy = ps[3 * colpt + 1], cz = ps[3 * colpt + 2];
+  const double ex = pd[3 * colpt], ey = pd[3 * colpt + 1], ez = pd[3 * colpt + 2];
+  unsigned int bits = 0;
+  for (int q = 15; q >= 0; --q) {
+    const int r = min(row0 + (q & 3) + 8 * (q >> 2) + 4 * h, n - 1);
+    const bool e = tim_edge_exact(cx - ps[3 * r], cy - ps[3 * r + 1], cz - ps[3 * r + 2],
+                                  ex - pd[3 * r], ey - pd[3 * r + 1], ez - pd[3 * r + 2], beta);
+    bits = (bits << 1) | (e ? 1u : 0u);
+  }
+  return bits;
+}
+
+// nibble q>>2 of the 16 column bits -> bits 8 (q>>2) + (q&3): the rows of half h = 0
+__device__ __forceinline__ unsigned int spread_nibbles(unsigned int v) {
+  v = (v | (v << 8)) & 0x00FF00FFu;
+  v = (v | (v << 4)) & 0x0F0F0F0Fu;
+  return v;
+}
+
+// VAR (timing experiments only, TEASER_K1_VARIANT): 0 product; 1 no epilogue; 2 no MFMA;
+// 3 scalar f32 epilogue instead of packed.  Variants 1-2 write an all-zero bitmap.
+template <int VAR>
+__global__ __launch_bounds__(256) void tim_graph_mfma_kernel(
+    const ProbDesc* __restrict__ descs, const double* __restrict__ src,
+    const double* __restrict__ dst, const float4* __restrict__ pk_src,
+    const float4* __restrict__ pk_dst, const TimPrep* __restrict__ prep,
+    uint64_t* __restrict__ bitmap, double beta, int gx, int gy) {
+  const ProbDesc d = descs[blockIdx.y];
+  const int n = d.n, W = d.W;
+  const int T = W;
+  int I, X;
+  tim_block_coords(gx, gy, &I, &X);
+  if (I >= T) return;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int Jbase = (X * kWavesPerBlock + wave) * kColTilesPerWave;
+  if (Jbase + kColTilesPerWave - 1 < I || Jbase >= T) return;
+
+  const double* __restrict__ ps = src + 3 * d.pt_off;
+  const double* __restrict__ pd = dst + 3 * d.pt_off;
+  uint64_t* __restrict__ bm = bitmap + d.bm_off;
+  __shared__ __attribute__((aligned(16))) double cbuf[kWavesPerBlock][64 * 6];
+  const MfmaConst mc = mfma_consts(beta, prep[blockIdx.y].r2_bits);
+  if (!__builtin_amdgcn_readfirstlane(mc.use_mfma)) {
+    EdgeConst kc;
+    kc.beta = beta;
+    kc.beta2 = beta * beta;
+    kc.m2beta2 = -2.0 * kc.beta2;
+    kc.beta4 = kc.beta2 * kc.beta2;
+    kc.s_hat = 1.0;
+    tim_wave_fp64<0>(ps, pd, bm, n, W, I, Jbase, kc, cbuf[wave]);
+    return;
+  }
+  const float4* __restrict__ qs = pk_src + d.pt_off;
+  const float4* __restrict__ qd = pk_dst + d.pt_off;
+  const int h = lane >> 5, c = lane & 31;
+
+  // row operands (A side): k-steps (x | y), (z | n), (1 | 0) for lanes (h = 0 | h = 1)
+  float as[2][3], ad[2][3];
+  for (int rt = 0; rt < 2; ++rt) {
+    const int r = min(I * 64 + 32 * rt + c, n - 1);
+    const float4 u = qs[r], v = qd[r];
+    as[rt][0] = h ? u.y : u.x; as[rt][1] = h ? u.w : u.z; as[rt][2] = h ? 0.f : 1.f;
+    ad[rt][0] = h ? v.y : v.x; ad[rt][1] = h ? v.w : v.z; ad[rt][2] = h ? 0.f : 1.f;
+  }
+  const uint64_t rowmask = (n - I * 64 >= 64) ? ~0ull : ((1ull << (n - I * 64)) - 1ull);
+  const int i = I * 64 + lane;
+
+  // per-lane keep masks of the 5 transpose stages: m_j for the lower lane of a pair, ~m_j for the upper
+  unsigned int tmask[5];
+  {
+    const unsigned int m[5] = {0x0000FFFFu, 0x00FF00FFu, 0x0F0F0F0Fu, 0x33333333u, 0x55555555u};
+    for (int st = 0; st < 5; ++st) tmask[st] = (lane & (16 >> st)) ? ~m[st] : m[st];
+  }
+  // column operands are prefetched one half-block (32 columns) ahead: the float4 loads of the next
+  // half are in flight while the current one is on the matrix / vector pipes
+  const int Jfirst = max(Jbase, I), Jend = min(Jbase + kColTilesPerWave, T);
+  float4 nu, nv;  // packed (x, y, z, n) of this lane's next column point, src / dst
+  {
+    const int cp = min(Jfirst * 64 + c, n - 1);
+    nu = qs[cp];
+    nv = qd[cp];
+  }
+  for (int J = Jfirst; J < Jend; ++J) {
+    const int j0 = J * 64;
+    unsigned int tr[2][2];  // [ct][rt]: this lane's 16 column bits
+    unsigned int redo = 0;  // wave-uniform: tiles (2 ct + rt) to re-evaluate in FP64
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      // column operands (B side): (-2x | -2y), (-2z | 1), (n | 0)
+      const float4 u = nu, v = nv;
+      {
+        const int nxt = (ct == 0) ? j0 + 32 + c : ((J + 1 < Jend) ? j0 + 64 + c : j0 + c);
+        const int np = min(nxt, n - 1);
+        nu = qs[np];
+        nv = qd[np];
+      }
+      const float bs0 = -2.f * (h ? u.y : u.x), bs1 = h ? 1.f : -2.f * u.z, bs2 = h ? 0.f : u.w;
+      const float bd0 = -2.f * (h ? v.y : v.x), bd1 = h ? 1.f : -2.f * v.z, bd2 = h ? 0.f : v.w;
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        MfmaTile mt;
+        f32x16 z;
+        for (int k = 0; k < 16; ++k) z[k] = 0.f;
+        if (VAR != 2) {
+          mt.A = __builtin_amdgcn_mfma_f32_32x32x2f32(as[rt][0], bs0, z, 0, 0, 0);
+          mt.A = __builtin_amdgcn_mfma_f32_32x32x2f32(as[rt][1], bs1, mt.A, 0, 0, 0);
+          mt.A = __builtin_amdgcn_mfma_f32_32x32x2f32(as[rt][2], bs2, mt.A, 0, 0, 0);
+          mt.B = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[rt][0], bd0, z, 0, 0, 0);
+          mt.B = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[rt][1], bd1, mt.B, 0, 0, 0);
+          mt.B = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[rt][2], bd2, mt.B, 0, 0, 0);
+        } else {
+          for (int k = 0; k < 16; ++k) {  // far outside the band: no edge, no redo
+            mt.A[k] = 1.0f;
+            mt.B[k] = 0.2f;
+            asm volatile("" : "+v"(mt.A[k]), "+v"(mt.B[k]));
+          }
+        }
+        mt.colbits = 0;
+        mt.unc = 0;
+        mt.tmin = (f32x2){INFINITY, INFINITY};
+        mt.kc = mc;
+        if (VAR == 1) {
+          for (int k = 0; k < 16; ++k) asm volatile("" ::"v"(mt.A[k]), "v"(mt.B[k]));
+        } else if (VAR == 3) {
+          mt.run_scalar(std::make_integer_sequence<int, 16>());
+        } else {
+          mt.run(std::make_integer_sequence<int, 8>());
+        }
+        const float tm = mt.tmin.x < mt.tmin.y ? mt.tmin.x : mt.tmin.y;
+        if ((mt.unc | __builtin_amdgcn_ballot_w64(!(tm > mc.tau))) != 0ull) redo |= 1u << (2 * ct + rt);
+        tr[ct][rt] = mt.colbits;
+      }
+    }
+    while (__builtin_expect(redo != 0u, 0)) {  // rare: ONE copy of the FP64 tile code per kernel
+      const int t = __builtin_ctz(redo);
+      redo &= redo - 1;
+      const int ct = t >> 1, rt = t & 1;
+      const unsigned int bits = tim_tile_exact(ps, pd, n, I * 64 + 32 * rt, min(j0 + 32 * ct + c, n - 1),
+                                               h, beta);
+      tr[0][0] = (t == 0) ? bits : tr[0][0];
+      tr[0][1] = (t == 1) ? bits : tr[0][1];
+      tr[1][0] = (t == 2) ? bits : tr[1][0];
+      tr[1][1] = (t == 3) ? bits : tr[1][1];
+    }
+    // transposed words: lane (c, h) holds rows 4h + (q&3) + 8(q>>2) of column (ct, c); after the
+    // half swap lanes 0-31 hold column (0, c) and lanes 32-63 column (1, c) = column `lane`
+    unsigned int tw[2], ow[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      unsigned int s0 = spread_nibbles(tr[0][rt]) << (4 * h);
+      unsigned int s1 = spread_nibbles(tr[1][rt]) << (4 * h);
+      const auto r = __builtin_amdgcn_permlane32_swap(s0, s1, false, false);
+      tw[rt] = r[0] | r[1];
+      // The row-major words are the 32 x 32 bit transpose of the column words inside each half
+      // (lane c: bits over rows -> lane r: bits over columns): 5 butterfly stages, each one
+      // ds_swizzle (lane ^ j), one v_alignbit (rotate towards the kept blocks) and one v_bfi.
+      unsigned int x = tw[rt];
+#pragma unroll
+      for (int st = 0; st < 5; ++st) {
+        const int j = 16 >> st;
+        unsigned int p;
+        switch (st) {  // BitMode swizzle: and_mask 0x1f, or_mask 0, xor_mask j
+          case 0: p = __builtin_amdgcn_ds_swizzle(x, (16 << 10) | 0x1f); break;
+          case 1: p = __builtin_amdgcn_ds_swizzle(x, (8 << 10) | 0x1f); break;
+          case 2: p = __builtin_amdgcn_ds_swizzle(x, (4 << 10) | 0x1f); break;
+          case 3: p = __builtin_amdgcn_ds_swizzle(x, (2 << 10) | 0x1f); break;
+          default: p = __builtin_amdgcn_ds_swizzle(x, (1 << 10) | 0x1f); break;
+        }
+        const bool up = (lane & j) != 0;
+        // lower lane keeps x & m and takes (p << j) & ~m; upper keeps x & ~m, takes (p >> j) & m
+        const unsigned int shifted = __builtin_amdgcn_alignbit(p, p, up ? j : 32 - j);
+        x = (x & tmask[st]) | (shifted & ~tmask[st]);
+      }
+      ow[rt] = x;  // lane (r, half ct): the 32 column bits (ct) of row 32 rt + r
+    }
+    // lanes L: rows L of the block; low word = ct 0, high word = ct 1
+    const auto ro = __builtin_amdgcn_permlane32_swap(ow[0], ow[1], false, false);
+    uint64_t ownw = ((uint64_t)ro[1] << 32) | ro[0];
+    const uint64_t trw = ((uint64_t)tw[1] << 32) | tw[0];
+    const uint64_t colmask = (n - j0 >= 64) ? ~0ull : ((1ull << (n - j0)) - 1ull);
+    ownw &= colmask;
+    if (J == I) ownw &= ~(1ull << lane);
+    if (VAR == 4) {  // full compute, (almost) no stores
+      if (ownw == 0x123456789ull && trw == 0x987654321ull) bm[0] = 1;
+      continue;
+    }
+    if (VAR == 1 || VAR == 2) {
+      if (i < n) bm[(int64_t)i * W + J] = 0;
+      if (J != I && j0 + lane < n) bm[(int64_t)(j0 + lane) * W + I] = (ownw ^ trw) == 0x123456789ull;
+      continue;
+    }
+    if (i < n) bm[(int64_t)i * W + J] = ownw;
+    if (J != I && j0 + lane < n) bm[(int64_t)(j0 + lane) * W + I] = trw & rowmask;
+  }
+}
+
 void launch_tim_graph(hipStream_t s, const ProbDesc* d_desc, int batch, int max_n,
                       const double* d_src, const double* d_dst, uint64_t* d_bitmap,
                       double noise_bound, double cbar2, int mode, const ProbState* d_state) {
@@ -299,6 +725,39 @@ void launch_tim_graph(hipStream_t s, const ProbDesc* d_desc, int batch, int max_
   else
     hipLaunchKernelGGL(tim_graph_kernel<1>, grid, dim3(256), 0, s, d_desc, d_src, d_dst, d_bitmap,
                        beta, gx, gy, d_state);
+}
+
+// MODE 0 on the matrix cores: pre-pass (centres, packed f32 points, R^2) + tim_graph_mfma_kernel.
+// d_pk: 2 * total_pts float4 (src then dst); d_prep: batch * sizeof(TimPrep) bytes.
+int64_t tim_prep_bytes(int batch) { return (int64_t)batch * (int64_t)sizeof(TimPrep); }
+
+void launch_tim_graph_mfma(hipStream_t s, const ProbDesc* d_desc, int batch, int max_n,
+                           int64_t total_pts, const double* d_src, const double* d_dst,
+                           void* d_pk, void* d_prep, uint64_t* d_bitmap, double noise_bound,
+                           double cbar2) {
+  if (batch <= 0 || max_n <= 0) return;
+  const int T = (max_n + 63) / 64;
+  const double beta = 2 * noise_bound * sqrt(cbar2);  // registration.cc:438
+  float4* pk_src = reinterpret_cast<float4*>(d_pk);
+  float4* pk_dst = pk_src + total_pts;
+  TimPrep* prep = reinterpret_cast<TimPrep*>(d_prep);
+  (void)hipMemsetAsync(prep, 0, sizeof(TimPrep) * (size_t)batch, s);
+  hipLaunchKernelGGL(tim_prep_bbox_kernel, dim3((max_n + 1023) / 1024, batch), dim3(256), 0, s, d_desc,
+                     d_src, d_dst, prep);
+  hipLaunchKernelGGL(tim_prep_pack_kernel, dim3((max_n + 255) / 256, batch), dim3(256), 0, s, d_desc,
+                     d_src, d_dst, prep, pk_src, pk_dst);
+  const int gx = (T + kColTilesPerBlock - 1) / kColTilesPerBlock, gy = T;
+  static const int var = getenv("TEASER_K1_VARIANT") ? atoi(getenv("TEASER_K1_VARIANT")) : 0;
+  const dim3 grid(gx * gy, batch);
+#define LAUNCH_MFMA(V)                                                                          \
+  hipLaunchKernelGGL(tim_graph_mfma_kernel<V>, grid, dim3(256), 0, s, d_desc, d_src, d_dst, pk_src, \
+                     pk_dst, prep, d_bitmap, beta, gx, gy)
+  if (var == 1) LAUNCH_MFMA(1);
+  else if (var == 2) LAUNCH_MFMA(2);
+  else if (var == 3) LAUNCH_MFMA(3);
+  else if (var == 4) LAUNCH_MFMA(4);
+  else LAUNCH_MFMA(0);
+#undef LAUNCH_MFMA
 }
 
 // ------------------------------------------------------------------------------------------

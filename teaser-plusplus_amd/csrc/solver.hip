@@ -97,7 +97,8 @@ struct teaser_hip_solver {
   bool have_graph = false;
 
   DevBuf d_desc, d_state, d_src, d_dst, d_bitmap, d_deg, d_clique, d_start_cliques, d_alive_a,
-      d_alive_b, d_next_count, d_weights, d_rot_inl, d_trans_inl, d_tls_scratch, d_tim_off;
+      d_alive_b, d_next_count, d_weights, d_rot_inl, d_trans_inl, d_tls_scratch, d_tim_off,
+      d_pk, d_prep;
   // colouring bound
   DevBuf c_sel, c_colour, c_tent, c_xlist;
   std::vector<int32_t> colour_x;  // |X| per problem of the last solve (-1: stage not run)
@@ -557,6 +558,10 @@ int32_t solve_packed(teaser_hip_solver* h, const double* d_src, const double* d_
     HIPCHK(h, h->d_alive_a.ensure(8 * (size_t)std::max<int64_t>(wo, 1)));
     HIPCHK(h, h->d_alive_b.ensure(8 * (size_t)std::max<int64_t>(wo, 1)));
     HIPCHK(h, h->d_next_count.ensure(4 * (size_t)batch));
+    if (!P.estimate_scaling) {  // K1 on the matrix cores: packed f32 points + per-problem pre-pass record
+      HIPCHK(h, h->d_pk.ensure(32 * (size_t)total_n));
+      HIPCHK(h, h->d_prep.ensure((size_t)tim_prep_bytes(batch)));
+    }
   }
   {
     StageScope sc(h, ST_H2D);
@@ -582,8 +587,12 @@ int32_t solve_packed(teaser_hip_solver* h, const double* d_src, const double* d_
   if (need_graph) {
     {
       StageScope sc(h, ST_TIM);
-      launch_tim_graph(s, dd, batch, max_n, d_src, d_dst, h->d_bitmap.as<uint64_t>(), P.noise_bound,
-                       P.cbar2, P.estimate_scaling ? 1 : 0, ds);
+      if (P.estimate_scaling)
+        launch_tim_graph(s, dd, batch, max_n, d_src, d_dst, h->d_bitmap.as<uint64_t>(), P.noise_bound,
+                         P.cbar2, 1, ds);
+      else
+        launch_tim_graph_mfma(s, dd, batch, max_n, total_n, d_src, d_dst, h->d_pk.p, h->d_prep.p,
+                              h->d_bitmap.as<uint64_t>(), P.noise_bound, P.cbar2);
     }
     for (int b = 0; b < batch; ++b) {
       const int64_t nn = h->descs[(size_t)b].n;
@@ -786,7 +795,7 @@ int32_t teaser_hip_solver_destroy(teaser_hip_solver* h) {
   DevBuf* bufs[] = {&h->d_desc, &h->d_state, &h->d_src, &h->d_dst, &h->d_bitmap, &h->d_deg,
                     &h->d_clique, &h->d_start_cliques, &h->d_alive_a, &h->d_alive_b,
                     &h->d_next_count, &h->d_weights, &h->d_rot_inl, &h->d_trans_inl,
-                    &h->d_tls_scratch, &h->d_tim_off, &h->x_order, &h->x_src, &h->x_dst,
+                    &h->d_tls_scratch, &h->d_tim_off, &h->d_pk, &h->d_prep, &h->x_order, &h->x_src, &h->x_dst,
                     &h->x_bitmap, &h->x_desc, &h->x_state, &h->x_ctrl, &h->x_clique, &h->x_arena,
                     &h->c_sel, &h->c_colour, &h->c_tent, &h->c_xlist,
                     &h->s_a, &h->s_b, &h->s_c, &h->s_d, &h->s_e};
