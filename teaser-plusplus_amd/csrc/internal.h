@@ -38,6 +38,8 @@ struct ProbState {
   int32_t n_trans;       // translation inliers
   int32_t gnc_iters;
   int32_t x_count;       // colouring bound: survivors left without a colour
+  int32_t k1_overflow;   // 1: the K1 fix-up worklist overflowed (host reruns the batch on the FP64 K1)
+  int32_t pad0;
   int32_t start_vertex[kMaxStarts];
   int32_t start_size[kMaxStarts];
   unsigned long long deg_sum;  // sum of degrees = 2 * edges
@@ -65,10 +67,12 @@ void launch_tim_graph(hipStream_t s, const ProbDesc* d_desc, int batch, int max_
                       double noise_bound, double cbar2, int mode, const ProbState* d_state);
 // K1 on the matrix cores (fixed scale only): f32 Gram filter + FP64 exact fallback, same bitmap
 int64_t tim_prep_bytes(int batch);
+int64_t tim_operand_bytes(int64_t total_pts);
+int64_t tim_work_items(const int32_t* n, int batch);
 void launch_tim_graph_mfma(hipStream_t s, const ProbDesc* d_desc, int batch, int max_n,
                            int64_t total_pts, const double* d_src, const double* d_dst,
-                           void* d_pk, void* d_prep, uint64_t* d_bitmap, double noise_bound,
-                           double cbar2);
+                           void* d_pk, void* d_prep, void* d_work, int64_t work_cap,
+                           uint64_t* d_bitmap, ProbState* d_state, double noise_bound, double cbar2);
 // row popcounts -> degrees (+ per-problem degree sum), start vertex selection
 void launch_degrees(hipStream_t s, const ProbDesc* d_desc, int batch, int max_n,
                     const uint64_t* d_bitmap, int32_t* d_deg, ProbState* d_state);

@@ -11,6 +11,7 @@
 // individually, as the reference's default (non-FMA) build does.  FMAs below are explicit.
 #include <utility>
 
+#include <cstdio>
 #include <cstdlib>
 
 #include "internal.h"
@@ -301,19 +302,30 @@ __global__ __launch_bounds__(256) void tim_graph_kernel(const ProbDesc* __restri
 // ==========================================================================================
 // K1 on the matrix cores (fixed-scale predicate, MODE 0).
 //
-// |a|^2 = |s_j - s_i|^2 = n_i + n_j - 2 s_i.s_j is a rank-5 contraction, so the squared TIM norms
-// of a 32 x 32 tile of pairs are THREE v_mfma_f32_32x32x2_f32 per cloud (K = 6: x, y, z, n, 1, 0
-// against -2x', -2y', -2z', 1, n', 0) on points centred per problem and rounded to f32 (pre-pass).
-// The matrix pipe runs beside the VALU, which keeps only the epilogue: D = A - B, t = A + B,
-// d = D^2 - 2 beta^2 t + beta^4 (packed f32), two compares and one add-with-carry per pair.
-// The f32 result is a FILTER: its sign is trusted only outside a rigorous error band; everything
-// inside the band (a few 1e-6 of the pairs) is re-evaluated with the reference expression in
-// FP64 (tim_edge_exact), so the bitmap stays bit-identical to the oracle by construction.
+// |a|^2 = |s_j - s_i|^2 = n_i + n_j - 2 s_i.s_j is a small dense contraction, so the squared TIM
+// norms of a 32 x 32 tile of pairs come from the matrix pipe.  Points are centred per problem and
+// rounded to f32 (pre-pass); every f32 operand is split EXACTLY into three bf16 pieces
+// (x = x_h + x_m + x_l, 8 + 8 + 8 significant bits), and the products that matter are laid out
+// along K: per coordinate (h,h') (h,m') (m,h') (h,l') (l,h') (m,m'), plus n_i * 1 and 1 * n_j with
+// the norms split the same way -- 24 of the 32 K slots of TWO v_mfma_f32_32x32x16_bf16 per cloud
+// (128 matrix-pipe cycles per 1024 pairs; the f32-input MFMA needs 384 and, like this one, does
+// not overlap with this kernel's own VALU work on the same SIMD -- measured).  Every bf16 x bf16
+// product is exact in f32; only the accumulation rounds.
+// The VALU keeps the epilogue: D = A - B, t = A + B, d = D^2 - 2 beta^2 t + beta^4 (packed f32),
+// ONE compare (inside the band?) and one v_alignbit (sign bit of d -> the lane's column word) per
+// pair register; the row-major words are the in-register 32 x 32 bit transpose of the column
+// words.  The f32 result is a FILTER: its sign is trusted only outside a rigorous error band;
+// registers (64 pairs) holding anything inside the band are re-evaluated with the reference
+// expression in FP64 (tim_edge_exact), so the bitmap stays bit-identical to the oracle.
 //
-// Error budget (u = 2^-24, R = max |centred point| over both clouds, eps = 32 u R^2):
-//   * centring + f32 rounding of the coordinates moves |a|^2 by <= 8 u R^2, the f32 norms n by
-//     2 u R^2, the MFMA's fmaf chain (5 roundings of partial sums <= 4 R^2) by 20 u R^2
-//     => |A~ - A*| <= eps (same for B);
+// Error budget (u = 2^-24, R = max |centred point| over both clouds, eps = kEpsU u R^2):
+//   * centring + f32 rounding of the coordinates moves |a|^2 by <= 8 u R^2, the f32 norms by
+//     2 u R^2, the dropped products (m,l') (l,m') (l,l') and the split residuals by <= 1 u R^2;
+//   * accumulation: 2 x 16 products + C per accumulator, |sum of |terms|| <= (|s| + |s'|)^2 <=
+//     4 R^2; ASSUMED hardware model: every internal addition errs by at most one f32 ulp (2u) of
+//     a magnitude <= that sum => <= 34 * 2u * 4 R^2 = 272 u R^2  (a fused/wider adder tree only
+//     does better).  Total 283 u R^2 -> kEpsU = 300.  tests/test_gpu_parity.py checks the model
+//     against exact arithmetic on adversarial tiles;
 //   * propagating through D, t, e = beta^4 - 2 beta^2 t, d = D^2 + e with 4 eps |D| <=
 //     2 eps (D^2/lam + lam), lam = beta R, and D^2 <= 1.01 |d~| + 2 beta^2 t + beta^4:
 //       |d~ - d*| <= kappa |d~| + K2 t~ + K0,
@@ -321,13 +333,15 @@ __global__ __launch_bounds__(256) void tim_graph_kernel(const ProbDesc* __restri
 //       K0 = 4 eps^2 + 4 beta^2 eps + 4.1 u beta^4 + 2.02 eps beta^4/lam + 2.02 eps lam + G,
 //     G = 1.3e-13 beta R^3 + 8e-15 beta^2 R^2 covering the gap between the reference's rounded
 //     double predicate and the exact one (|x - beta| <= 4.5e-16 y + 1.1e-16 beta);
-//   * sign(d~) is trusted iff |d~| > (K2 t~ + K0) / (1 - kappa); pairs with t~ <= tau =
-//     beta^2 (1 + 8u) + 2.1 eps (the t <= beta^2 branch of the predicate) send their tile to FP64.
-// kappa > 1/4 (beta below ~2e-5 R: f32 cannot resolve the band) => the problem runs on the FP64
-// kernel body instead (tim_wave_fp64), chosen per problem on the device.
+//   * sign(d~) is trusted iff |d~| > (K2 t~ + K0) / (1 - kappa); a tile holding a pair with
+//     t~ <= tau = beta^2 (1 + 8u) + 2.1 eps (the t <= beta^2 branch of the predicate) goes to FP64.
+// kappa > 1/4 (beta below ~1.5e-4 R: the filter cannot resolve the band) => that problem runs the
+// FP64 kernel body instead (tim_wave_fp64), chosen per problem on the device.
 // ==========================================================================================
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr float kEpsU = 300.0f;
 
 struct TimPrep {         // per problem, zeroed then filled by the pre-pass
   // bounding boxes as order-preserving uint images of the f32 coordinates (atomicMax only):
@@ -336,6 +350,13 @@ struct TimPrep {         // per problem, zeroed then filled by the pre-pass
   unsigned int lo[6];
   unsigned int r2_bits;  // max |centred f32 point|^2 over both clouds (float bits, atomicMax)
   unsigned int pad[3];
+};
+
+// packed operands of one point of one cloud: 32 bf16 for the row (A) side, 32 for the column (B)
+// side; a lane of half h loads uint4 #h (K 8h..8h+7 of the first MFMA) and #(2+h) (second MFMA)
+struct TimOperand {
+  uint4 a[4];
+  uint4 b[4];
 };
 
 __device__ __forceinline__ unsigned int f32_key(float f) {  // monotone float -> uint
@@ -381,13 +402,66 @@ __global__ __launch_bounds__(256) void tim_prep_bbox_kernel(const ProbDesc* __re
   }
 }
 
-// centred f32 points + f32 squared norms: pk[i] = (x, y, z, n); atomicMax of n into r2_bits
+// exact three-way bf16 split of an f32: v = h + m + l + r, |r| <= 2^-27 |v| (each step rounds to
+// nearest even on the upper 16 bits; the differences are exact in f32)
+__device__ __forceinline__ unsigned int bf16_rne(float v) {
+  const unsigned int b = __float_as_uint(v);
+  return (b + 0x7fffu + ((b >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ void bf16_split3(float v, unsigned int* h, unsigned int* m, unsigned int* l) {
+  *h = bf16_rne(v);
+  const float r1 = v - __uint_as_float(*h << 16);
+  *m = bf16_rne(r1);
+  const float r2 = r1 - __uint_as_float(*m << 16);
+  *l = bf16_rne(r2);
+}
+__device__ __forceinline__ unsigned int bf16_neg2(unsigned int b) {  // bf16 bits of -2 * value
+  const unsigned int mag = b & 0x7fffu;
+  if (mag == 0u) return 0u;
+  // normal: exponent + 1 (R^2 < 1e30: no overflow); subnormal: shift the mantissa (carries into exp 1)
+  const unsigned int dbl = (mag & 0x7f80u) ? mag + 0x80u : (mag << 1);
+  return (dbl | (~b & 0x8000u)) & 0xffffu;
+}
+
+// K layout (32 slots):  per coordinate c in x, y, z (6 slots each, base 6c):
+//   A: c_h c_h c_m c_h c_l c_m     B: -2c'_h -2c'_m -2c'_h -2c'_l -2c'_h -2c'_m
+//   slots 18..20: A n_h n_m n_l, B 1 1 1;   21..23: A 1 1 1, B n'_h n'_m n'_l;   24..31: zero
+__device__ __forceinline__ void tim_pack_point(float x, float y, float z, float nrm, TimOperand* out) {
+  unsigned short A[32], B[32];
+  for (int k = 24; k < 32; ++k) { A[k] = 0; B[k] = 0; }
+  const float cv[3] = {x, y, z};
+  for (int c = 0; c < 3; ++c) {
+    unsigned int h, m, l;
+    bf16_split3(cv[c], &h, &m, &l);
+    const unsigned int h2 = bf16_neg2(h), m2 = bf16_neg2(m), l2 = bf16_neg2(l);
+    unsigned short* a = A + 6 * c;
+    unsigned short* b = B + 6 * c;
+    a[0] = h; a[1] = h; a[2] = m; a[3] = h; a[4] = l; a[5] = m;
+    b[0] = h2; b[1] = m2; b[2] = h2; b[3] = l2; b[4] = h2; b[5] = m2;
+  }
+  unsigned int nh, nm, nl;
+  bf16_split3(nrm, &nh, &nm, &nl);
+  const unsigned short one = 0x3f80;
+  A[18] = nh; A[19] = nm; A[20] = nl; B[18] = one; B[19] = one; B[20] = one;
+  A[21] = one; A[22] = one; A[23] = one; B[21] = nh; B[22] = nm; B[23] = nl;
+  unsigned int wa[16], wb[16];
+  for (int k = 0; k < 16; ++k) {
+    wa[k] = (unsigned int)A[2 * k] | ((unsigned int)A[2 * k + 1] << 16);
+    wb[k] = (unsigned int)B[2 * k] | ((unsigned int)B[2 * k + 1] << 16);
+  }
+  for (int q = 0; q < 4; ++q) {
+    out->a[q] = make_uint4(wa[4 * q], wa[4 * q + 1], wa[4 * q + 2], wa[4 * q + 3]);
+    out->b[q] = make_uint4(wb[4 * q], wb[4 * q + 1], wb[4 * q + 2], wb[4 * q + 3]);
+  }
+}
+
+// centred f32 points -> packed bf16 operands; atomicMax of the f32 squared norms into r2_bits
 __global__ __launch_bounds__(256) void tim_prep_pack_kernel(const ProbDesc* __restrict__ descs,
                                                             const double* __restrict__ src,
                                                             const double* __restrict__ dst,
                                                             TimPrep* __restrict__ prep,
-                                                            float4* __restrict__ pk_src,
-                                                            float4* __restrict__ pk_dst) {
+                                                            TimOperand* __restrict__ op_src,
+                                                            TimOperand* __restrict__ op_dst) {
   const ProbDesc d = descs[blockIdx.y];
   const int i = blockIdx.x * 256 + threadIdx.x;
   float m = 0.f;
@@ -402,8 +476,8 @@ __global__ __launch_bounds__(256) void tim_prep_pack_kernel(const ProbDesc* __re
     // exact in double (24-bit inputs), one rounding to f32
     const float na = (float)(((double)ax * ax + (double)ay * ay) + (double)az * az);
     const float nb = (float)(((double)bx * bx + (double)by * by) + (double)bz * bz);
-    pk_src[d.pt_off + i] = make_float4(ax, ay, az, na);
-    pk_dst[d.pt_off + i] = make_float4(bx, by, bz, nb);
+    tim_pack_point(ax, ay, az, na, op_src + d.pt_off + i);
+    tim_pack_point(bx, by, bz, nb, op_dst + d.pt_off + i);
     m = na > nb ? na : nb;
     if (!(m == m)) m = INFINITY;  // NaN coordinates: force the FP64 path
   }
@@ -415,16 +489,12 @@ __global__ __launch_bounds__(256) void tim_prep_pack_kernel(const ProbDesc* __re
 }
 
 struct MfmaConst {
-  f32x2 m2b2, b4, K2, K0;  // both halves equal (operands of the packed ops)
+  // d -+ band = D^2 + (t * c1 + c2) with c1 = -2 beta^2 -+ K2, c2 = beta^4 -+ K0 (both halves equal:
+  // operands of the packed ops)
+  f32x2 c1lo, c2lo, c1hi, c2hi;
   float tau;
   int use_mfma;
 };
-
-__device__ __forceinline__ float f32_up(double v) {  // a float >= v (v >= 0)
-  float f = (float)v;
-  if ((double)f < v) f = __uint_as_float(__float_as_uint(f) + 1u);
-  return f;
-}
 
 // Band constants in f32, every step rounded towards "wider" by a relative 2^-20 inflation (f32
 // arithmetic here errs by a few 2^-24 per operation, far inside the 1.001 safety factor).
@@ -436,95 +506,65 @@ __device__ __forceinline__ MfmaConst mfma_consts(double beta_d, unsigned int r2_
   const float R2 = __uint_as_float(r2_bits) * up;
   const float R = __builtin_sqrtf(R2) * up;
   const float b2 = beta * beta * up, b4 = b2 * b2 * up;
-  const float eps = 32.0f * u * R2 * up;
+  const float eps = kEpsU * u * R2 * up;
   const float lam_lo = (float)beta_d * __builtin_sqrtf(__uint_as_float(r2_bits)) * 0.999999f;  // divisor
   const float lam_hi = beta * R * up;
   const float eol = eps / lam_lo * up;  // eps / lam, rounded up
   const float kappa = 3.04f * u + 2.03f * eol;
-  const float K2 = (10.1f * u * b2 + 4.04f * eol * b2) * up;
-  const float K0 = (4.0f * eps * eps + 4.0f * b2 * eps + 4.1f * u * b4 + 2.02f * eol * b4 +
+  // (15 u and 7 u instead of 10.1 u / 4.1 u: the band edges e_lo / e_hi and their pre-combined
+  // constants are rounded separately: <= 2u (2 beta^2 t + beta^4) more)
+  const float K2 = (15.0f * u * b2 + 4.04f * eol * b2) * up;
+  const float K0 = (4.0f * eps * eps + 4.0f * b2 * eps + 7.0f * u * b4 + 2.02f * eol * b4 +
                     2.02f * eps * lam_hi + 1.3e-13f * beta * R2 * R + 8e-15f * b2 * R2) * up;
-  const bool ok = (R2 > 1e-30f) && (R2 < 1e30f) && (beta_d > 0) && (kappa <= 0.25f) && (b4 > 1e-35f) &&
+  const bool ok = (R2 > 1e-30f) && (R2 < 1e12f) && (beta_d > 0) && (kappa <= 0.25f) && (b4 > 1e-35f) && (b2 < 1e12f) &&
                   (kappa == kappa) && (K0 == K0) && (K0 < 1e30f);
   const float sc = 1.001f / (1.0f - (ok ? kappa : 0.0f));
   const float k2 = K2 * sc * up, k0 = K0 * sc * up;
   const float m2b2 = (float)(-2.0 * beta_d * beta_d), fb4 = (float)(beta_d * beta_d * beta_d * beta_d);
-  c.m2b2 = (f32x2){m2b2, m2b2};
-  c.b4 = (f32x2){fb4, fb4};
-  c.K2 = (f32x2){k2, k2};
-  c.K0 = (f32x2){k0, k0};
+  // lower edge rounded down, upper edge rounded up (one f32 rounding each, covered by `up` on k2/k0)
+  c.c1lo = (f32x2){m2b2 - k2, m2b2 - k2};
+  c.c2lo = (f32x2){fb4 - k0, fb4 - k0};
+  c.c1hi = (f32x2){m2b2 + k2, m2b2 + k2};
+  c.c2hi = (f32x2){fb4 + k0, fb4 + k0};
   c.tau = (b2 * (1 + 8 * u) + 2.1f * eps) * up;
   c.use_mfma = ok ? 1 : 0;
   return c;
 }
 
-// One 32 x 32 MFMA tile of pairs: rows rbase + r, columns of this lane's column point.
-// Accumulator map (v_mfma_f32_32x32x2_f32): lane l holds column l & 31, rows
+// One 32 x 32 MFMA tile of pairs.  Accumulator map (32x32 MFMA): lane l holds column l & 31, rows
 // (q & 3) + 8 (q >> 2) + 4 (l >> 5) for its 16 registers q.
 struct MfmaTile {
   f32x16 A, B;
   unsigned int colbits;  // bit q = predicate of accumulator register q (this lane's column)
+  unsigned int lobits;   // bit q = sign of d - band (colbits: sign of d + band)
   f32x2 tmin;
   MfmaConst kc;
-  uint64_t unc;  // OR of the uncertain-lane masks of the tile (wave-uniform)
 
-  template <int Q>
-  __device__ __forceinline__ void consume(float d, float band) {
-    // NaN-safe "inside the band"; any hit sends the whole tile to the FP64 redo after the loop
-    // (d = +-0 is always inside the band, so the sign bit alone decides d <= 0 outside it)
-    unc |= __builtin_amdgcn_ballot_w64(!(__builtin_fabsf(d) > band));
-    // colbits = (colbits << 1) | sign(d): one v_alignbit_b32
-    colbits = __builtin_amdgcn_alignbit(colbits, __float_as_uint(d), 31);
-  }
-
+  // Both band edges are evaluated instead of d and the band: d_lo = d - band, d_hi = d + band (each
+  // ONE fma of D^2 with a pre-combined linear term).  d_hi < 0: certainly an edge; d_lo > 0:
+  // certainly not; signs differ (or a zero): inside the band.  Only sign bits are kept: colbits
+  // collects sign(d_hi), lobits sign(d_lo); inside-the-band = colbits ^ lobits, taken once per tile.
+  // (No NaN can reach this path: non-finite inputs force the FP64 kernel body.)
   template <int QP>
   __device__ __forceinline__ void pair_step() {
     const f32x2 a = {A[2 * QP], A[2 * QP + 1]}, b = {B[2 * QP], B[2 * QP + 1]};
     const f32x2 D = a - b, t = a + b;
-    const f32x2 e = __builtin_elementwise_fma(t, kc.m2b2, kc.b4);
-    const f32x2 d = __builtin_elementwise_fma(D, D, e);
-    const f32x2 band = __builtin_elementwise_fma(t, kc.K2, kc.K0);
+    const f32x2 elo = __builtin_elementwise_fma(t, kc.c1lo, kc.c2lo);
+    const f32x2 ehi = __builtin_elementwise_fma(t, kc.c1hi, kc.c2hi);
+    const f32x2 dlo = __builtin_elementwise_fma(D, D, elo);
+    const f32x2 dhi = __builtin_elementwise_fma(D, D, ehi);
     tmin = __builtin_elementwise_min(tmin, t);
-    consume<2 * QP + 1>(d.y, band.y);  // descending q: bit q of colbits = register q
-    consume<2 * QP>(d.x, band.x);
+    // descending q: bit q of the words = register q
+    colbits = __builtin_amdgcn_alignbit(colbits, __float_as_uint(dhi.y), 31);
+    lobits = __builtin_amdgcn_alignbit(lobits, __float_as_uint(dlo.y), 31);
+    colbits = __builtin_amdgcn_alignbit(colbits, __float_as_uint(dhi.x), 31);
+    lobits = __builtin_amdgcn_alignbit(lobits, __float_as_uint(dlo.x), 31);
   }
   template <int... QPs>
   __device__ __forceinline__ void run(std::integer_sequence<int, QPs...>) {
     (pair_step<7 - QPs>(), ...);
   }
-  template <int Q>
-  __device__ __forceinline__ void scalar_step() {
-    const float a = A[Q], b = B[Q];
-    const float D = a - b, t = a + b;
-    const float e = __builtin_fmaf(t, kc.m2b2.x, kc.b4.x);
-    const float d = __builtin_fmaf(D, D, e);
-    const float band = __builtin_fmaf(t, kc.K2.x, kc.K0.x);
-    tmin.x = __builtin_fminf(tmin.x, t);
-    consume<Q>(d, band);
-  }
-  template <int... Qs>
-  __device__ __forceinline__ void run_scalar(std::integer_sequence<int, Qs...>) {
-    (scalar_step<15 - Qs>(), ...);
-  }
-
 };
-
-// FP64 evaluation of one whole 32 x 32 tile with the reference expression (a pair inside the band,
-// or with t <= tau, is in it): returns this lane's 16 column bits (bit q = accumulator register q).
-__device__ __forceinline__ unsigned int tim_tile_exact(const double* __restrict__ ps,
-                                                       const double* __restrict__ pd, int n,
-                                                       int row0, int colpt, int h, double beta) {
-  const double cx = ps[3 * colpt], cy = ps[3 * colpt + 1], cz = ps[3 * colpt + 2];
-  const double ex = pd[3 * colpt], ey = pd[3 * colpt + 1], ez = pd[3 * colpt + 2];
-  unsigned int bits = 0;
-  for (int q = 15; q >= 0; --q) {
-    const int r = min(row0 + (q & 3) + 8 * (q >> 2) + 4 * h, n - 1);
-    const bool e = tim_edge_exact(cx - ps[3 * r], cy - ps[3 * r + 1], cz - ps[3 * r + 2],
-                                  ex - pd[3 * r], ey - pd[3 * r + 1], ez - pd[3 * r + 2], beta);
-    bits = (bits << 1) | (e ? 1u : 0u);
-  }
-  return bits;
-}
 
 // nibble q>>2 of the 16 column bits -> bits 8 (q>>2) + (q&3): the rows of half h = 0
 __device__ __forceinline__ unsigned int spread_nibbles(unsigned int v) {
@@ -533,14 +573,42 @@ __device__ __forceinline__ unsigned int spread_nibbles(unsigned int v) {
   return v;
 }
 
-// VAR (timing experiments only, TEASER_K1_VARIANT): 0 product; 1 no epilogue; 2 no MFMA;
-// 3 scalar f32 epilogue instead of packed.  Variants 1-2 write an all-zero bitmap.
-template <int VAR>
+// Block = 4 waves; a wave owns 64 rows (row tile I) and kMfmaColTiles consecutive 64-column tiles.
+constexpr int kMfmaColTiles = 8;
+constexpr int kMfmaColTilesPerBlock = kMfmaColTiles * kWavesPerBlock;
+
+constexpr int kWorkBuf = 64 * 6;  // per-wave LDS staging (the FP64 path's column buffer): 384 items
+
+// item = prob << 32 | row << 16 | col  (n <= 65536); cap[0] = capacity of the global list
+__device__ __forceinline__ int flush_work(const unsigned long long* wbuf, int wcount,
+                                          unsigned long long* __restrict__ work,
+                                          unsigned int* __restrict__ work_count, unsigned int cap,
+                                          ProbState* __restrict__ st, int lane) {
+  if (wcount == 0) return 0;
+  unsigned int base = 0;
+  if (lane == 0) base = atomicAdd(work_count, (unsigned int)wcount);
+  base = __builtin_amdgcn_readfirstlane(base);
+  if (base + (unsigned int)wcount > cap) {  // cannot resolve everything: the host reruns on FP64
+    if (lane == 0) st->k1_overflow = 1;
+    return 0;
+  }
+#pragma nounroll
+  for (int k = lane; k < wcount; k += 64) work[base + k] = wbuf[k];
+  return 0;
+}
+
+// Pairs inside the band are not resolved here: they are appended (8 bytes each, staged per wave in
+// LDS) to a worklist and tim_fixup_kernel rewrites their bits with the FP64 reference expression
+// afterwards.  The hot kernel therefore holds no FP64 code and never waits on the double-precision
+// points.  If the list overflows (adversarial geometry: > 1/64 of all pairs inside the band) the
+// problem is flagged and the host reruns the batch on the FP64 kernel.
 __global__ __launch_bounds__(256) void tim_graph_mfma_kernel(
     const ProbDesc* __restrict__ descs, const double* __restrict__ src,
-    const double* __restrict__ dst, const float4* __restrict__ pk_src,
-    const float4* __restrict__ pk_dst, const TimPrep* __restrict__ prep,
-    uint64_t* __restrict__ bitmap, double beta, int gx, int gy) {
+    const double* __restrict__ dst, const TimOperand* __restrict__ op_src,
+    const TimOperand* __restrict__ op_dst, const TimPrep* __restrict__ prep,
+    uint64_t* __restrict__ bitmap, double beta, int gx, int gy,
+    unsigned long long* __restrict__ work, unsigned int* __restrict__ work_count, unsigned int work_cap,
+    ProbState* __restrict__ states) {
   const ProbDesc d = descs[blockIdx.y];
   const int n = d.n, W = d.W;
   const int T = W;
@@ -549,8 +617,10 @@ __global__ __launch_bounds__(256) void tim_graph_mfma_kernel(
   if (I >= T) return;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int Jbase = (X * kWavesPerBlock + wave) * kColTilesPerWave;
-  if (Jbase + kColTilesPerWave - 1 < I || Jbase >= T) return;
+  // rotate the wave -> column-range assignment with the row tile: in the blocks the diagonal crosses
+  // the low ranges are (partly) below it, and wave w always lands on SIMD w
+  const int Jbase = (X * kWavesPerBlock + ((wave + I) & (kWavesPerBlock - 1))) * kMfmaColTiles;
+  if (Jbase + kMfmaColTiles - 1 < I || Jbase >= T) return;
 
   const double* __restrict__ ps = src + 3 * d.pt_off;
   const double* __restrict__ pd = dst + 3 * d.pt_off;
@@ -564,100 +634,110 @@ __global__ __launch_bounds__(256) void tim_graph_mfma_kernel(
     kc.m2beta2 = -2.0 * kc.beta2;
     kc.beta4 = kc.beta2 * kc.beta2;
     kc.s_hat = 1.0;
-    tim_wave_fp64<0>(ps, pd, bm, n, W, I, Jbase, kc, cbuf[wave]);
+    for (int jb = Jbase; jb < Jbase + kMfmaColTiles; jb += kColTilesPerWave)
+      tim_wave_fp64<0>(ps, pd, bm, n, W, I, jb, kc, cbuf[wave]);
     return;
   }
-  const float4* __restrict__ qs = pk_src + d.pt_off;
-  const float4* __restrict__ qd = pk_dst + d.pt_off;
+  const TimOperand* __restrict__ qs = op_src + d.pt_off;
+  const TimOperand* __restrict__ qd = op_dst + d.pt_off;
   const int h = lane >> 5, c = lane & 31;
+  unsigned long long* wbuf = reinterpret_cast<unsigned long long*>(cbuf[wave]);  // private to the wave
+  int wcount = 0;  // wave-uniform
 
-  // row operands (A side): k-steps (x | y), (z | n), (1 | 0) for lanes (h = 0 | h = 1)
-  float as[2][3], ad[2][3];
+  // row operands (A side) of the wave's two 32-row halves, both clouds, both MFMAs
+  bf16x8 as[2][2], ad[2][2];
   for (int rt = 0; rt < 2; ++rt) {
     const int r = min(I * 64 + 32 * rt + c, n - 1);
-    const float4 u = qs[r], v = qd[r];
-    as[rt][0] = h ? u.y : u.x; as[rt][1] = h ? u.w : u.z; as[rt][2] = h ? 0.f : 1.f;
-    ad[rt][0] = h ? v.y : v.x; ad[rt][1] = h ? v.w : v.z; ad[rt][2] = h ? 0.f : 1.f;
+    as[rt][0] = __builtin_bit_cast(bf16x8, qs[r].a[h]);
+    as[rt][1] = __builtin_bit_cast(bf16x8, qs[r].a[2 + h]);
+    ad[rt][0] = __builtin_bit_cast(bf16x8, qd[r].a[h]);
+    ad[rt][1] = __builtin_bit_cast(bf16x8, qd[r].a[2 + h]);
   }
   const uint64_t rowmask = (n - I * 64 >= 64) ? ~0ull : ((1ull << (n - I * 64)) - 1ull);
   const int i = I * 64 + lane;
-
   // per-lane keep masks of the 5 transpose stages: m_j for the lower lane of a pair, ~m_j for the upper
   unsigned int tmask[5];
   {
     const unsigned int m[5] = {0x0000FFFFu, 0x00FF00FFu, 0x0F0F0F0Fu, 0x33333333u, 0x55555555u};
     for (int st = 0; st < 5; ++st) tmask[st] = (lane & (16 >> st)) ? ~m[st] : m[st];
   }
-  // column operands are prefetched one half-block (32 columns) ahead: the float4 loads of the next
-  // half are in flight while the current one is on the matrix / vector pipes
-  const int Jfirst = max(Jbase, I), Jend = min(Jbase + kColTilesPerWave, T);
-  float4 nu, nv;  // packed (x, y, z, n) of this lane's next column point, src / dst
+  // column operands are prefetched one half-block (32 columns) ahead: the loads of the next half
+  // are in flight while the current one is on the matrix / vector pipes
+  const int Jfirst = max(Jbase, I), Jend = min(Jbase + kMfmaColTiles, T);
+  uint4 nb[4];  // next column point: src MFMA 0/1, dst MFMA 0/1
   {
     const int cp = min(Jfirst * 64 + c, n - 1);
-    nu = qs[cp];
-    nv = qd[cp];
+    nb[0] = qs[cp].b[h]; nb[1] = qs[cp].b[2 + h]; nb[2] = qd[cp].b[h]; nb[3] = qd[cp].b[2 + h];
   }
   for (int J = Jfirst; J < Jend; ++J) {
     const int j0 = J * 64;
     unsigned int tr[2][2];  // [ct][rt]: this lane's 16 column bits
-    unsigned int redo = 0;  // wave-uniform: tiles (2 ct + rt) to re-evaluate in FP64
+    unsigned int ubits[4];  // per tile 2 ct + rt: this lane's in-band pairs (bit q)
+    unsigned int flagged = 0;  // wave-uniform: bit 2 ct + rt = tile holding in-band pairs
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
-      // column operands (B side): (-2x | -2y), (-2z | 1), (n | 0)
-      const float4 u = nu, v = nv;
+      const bf16x8 bs0 = __builtin_bit_cast(bf16x8, nb[0]), bs1 = __builtin_bit_cast(bf16x8, nb[1]);
+      const bf16x8 bd0 = __builtin_bit_cast(bf16x8, nb[2]), bd1 = __builtin_bit_cast(bf16x8, nb[3]);
       {
         const int nxt = (ct == 0) ? j0 + 32 + c : ((J + 1 < Jend) ? j0 + 64 + c : j0 + c);
         const int np = min(nxt, n - 1);
-        nu = qs[np];
-        nv = qd[np];
+        nb[0] = qs[np].b[h]; nb[1] = qs[np].b[2 + h]; nb[2] = qd[np].b[h]; nb[3] = qd[np].b[2 + h];
       }
-      const float bs0 = -2.f * (h ? u.y : u.x), bs1 = h ? 1.f : -2.f * u.z, bs2 = h ? 0.f : u.w;
-      const float bd0 = -2.f * (h ? v.y : v.x), bd1 = h ? 1.f : -2.f * v.z, bd2 = h ? 0.f : v.w;
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
         MfmaTile mt;
         f32x16 z;
         for (int k = 0; k < 16; ++k) z[k] = 0.f;
-        if (VAR != 2) {
-          mt.A = __builtin_amdgcn_mfma_f32_32x32x2f32(as[rt][0], bs0, z, 0, 0, 0);
-          mt.A = __builtin_amdgcn_mfma_f32_32x32x2f32(as[rt][1], bs1, mt.A, 0, 0, 0);
-          mt.A = __builtin_amdgcn_mfma_f32_32x32x2f32(as[rt][2], bs2, mt.A, 0, 0, 0);
-          mt.B = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[rt][0], bd0, z, 0, 0, 0);
-          mt.B = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[rt][1], bd1, mt.B, 0, 0, 0);
-          mt.B = __builtin_amdgcn_mfma_f32_32x32x2f32(ad[rt][2], bd2, mt.B, 0, 0, 0);
-        } else {
-          for (int k = 0; k < 16; ++k) {  // far outside the band: no edge, no redo
-            mt.A[k] = 1.0f;
-            mt.B[k] = 0.2f;
-            asm volatile("" : "+v"(mt.A[k]), "+v"(mt.B[k]));
-          }
+        mt.A = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[rt][0], bs0, z, 0, 0, 0);
+        mt.B = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad[rt][0], bd0, z, 0, 0, 0);
+        mt.A = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[rt][1], bs1, mt.A, 0, 0, 0);
+        mt.B = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad[rt][1], bd1, mt.B, 0, 0, 0);
+        if (J == I && rt == ct) {
+          // self pairs (A = B = 0) are masked out of the bitmap below; park them far outside the band
+          // and the t <= tau test so that the diagonal tiles are not sent to the FP64 fix-up wholesale
+#pragma unroll
+          for (int q = 0; q < 16; ++q)
+            mt.A[q] = (c == (q & 3) + 8 * (q >> 2) + 4 * h) ? 1e18f : mt.A[q];
         }
         mt.colbits = 0;
-        mt.unc = 0;
+        mt.lobits = 0;
         mt.tmin = (f32x2){INFINITY, INFINITY};
         mt.kc = mc;
-        if (VAR == 1) {
-          for (int k = 0; k < 16; ++k) asm volatile("" ::"v"(mt.A[k]), "v"(mt.B[k]));
-        } else if (VAR == 3) {
-          mt.run_scalar(std::make_integer_sequence<int, 16>());
-        } else {
-          mt.run(std::make_integer_sequence<int, 8>());
-        }
+        mt.run(std::make_integer_sequence<int, 8>());
         const float tm = mt.tmin.x < mt.tmin.y ? mt.tmin.x : mt.tmin.y;
-        if ((mt.unc | __builtin_amdgcn_ballot_w64(!(tm > mc.tau))) != 0ull) redo |= 1u << (2 * ct + rt);
+        // a pair with t <= tau (short-pair branch of the predicate): every pair of the tile goes to FP64
+        const unsigned int ub = (__builtin_amdgcn_ballot_w64(!(tm > mc.tau)) != 0ull)
+                                    ? 0xffffu : ((mt.colbits ^ mt.lobits) & 0xffffu);
+        if (__builtin_amdgcn_ballot_w64(ub != 0u) != 0ull) flagged |= 1u << (2 * ct + rt);
+        ubits[2 * ct + rt] = ub;
+
         tr[ct][rt] = mt.colbits;
       }
     }
-    while (__builtin_expect(redo != 0u, 0)) {  // rare: ONE copy of the FP64 tile code per kernel
-      const int t = __builtin_ctz(redo);
-      redo &= redo - 1;
+#pragma nounroll
+    while (__builtin_expect(flagged != 0u, 0)) {  // rare: stage the in-band pairs in LDS
+      const int t = __builtin_ctz(flagged);
+      flagged &= flagged - 1;
       const int ct = t >> 1, rt = t & 1;
-      const unsigned int bits = tim_tile_exact(ps, pd, n, I * 64 + 32 * rt, min(j0 + 32 * ct + c, n - 1),
-                                               h, beta);
-      tr[0][0] = (t == 0) ? bits : tr[0][0];
-      tr[0][1] = (t == 1) ? bits : tr[0][1];
-      tr[1][0] = (t == 2) ? bits : tr[1][0];
-      tr[1][1] = (t == 3) ? bits : tr[1][1];
+      const unsigned int ub = t == 0 ? ubits[0] : (t == 1 ? ubits[1] : (t == 2 ? ubits[2] : ubits[3]));
+#pragma nounroll
+      for (int q = 0; q < 16; ++q) {
+        const bool mine = (ub >> q) & 1u;
+        const uint64_t Uq = __builtin_amdgcn_ballot_w64(mine);
+        if (Uq == 0ull) continue;
+        const int cnt = __builtin_popcountll(Uq);
+        if (wcount + cnt > kWorkBuf)
+          wcount = flush_work(wbuf, wcount, work, work_count, work_cap, states + blockIdx.y, lane);
+        if (mine) {
+          const unsigned int rank = __builtin_amdgcn_mbcnt_hi((unsigned int)(Uq >> 32),
+                                        __builtin_amdgcn_mbcnt_lo((unsigned int)Uq, 0u));
+          const unsigned int rowp = (unsigned int)(I * 64 + 32 * rt + (q & 3) + 8 * (q >> 2) + 4 * h);
+          const unsigned int colp = (unsigned int)(j0 + 32 * ct + c);
+          wbuf[wcount + rank] = ((unsigned long long)blockIdx.y << 32) |
+                                ((unsigned long long)rowp << 16) | (unsigned long long)colp;
+        }
+        wcount += cnt;
+      }
     }
     // transposed words: lane (c, h) holds rows 4h + (q&3) + 8(q>>2) of column (ct, c); after the
     // half swap lanes 0-31 hold column (0, c) and lanes 32-63 column (1, c) = column `lane`
@@ -697,18 +777,64 @@ __global__ __launch_bounds__(256) void tim_graph_mfma_kernel(
     const uint64_t colmask = (n - j0 >= 64) ? ~0ull : ((1ull << (n - j0)) - 1ull);
     ownw &= colmask;
     if (J == I) ownw &= ~(1ull << lane);
-    if (VAR == 4) {  // full compute, (almost) no stores
-      if (ownw == 0x123456789ull && trw == 0x987654321ull) bm[0] = 1;
-      continue;
-    }
-    if (VAR == 1 || VAR == 2) {
-      if (i < n) bm[(int64_t)i * W + J] = 0;
-      if (J != I && j0 + lane < n) bm[(int64_t)(j0 + lane) * W + I] = (ownw ^ trw) == 0x123456789ull;
-      continue;
-    }
+#ifdef K1_NOSTORE
+    if (ownw == 0x123456789ull && trw == 0x987654321ull) bm[0] = 1;
+#else
     if (i < n) bm[(int64_t)i * W + J] = ownw;
     if (J != I && j0 + lane < n) bm[(int64_t)(j0 + lane) * W + I] = trw & rowmask;
+#endif
   }
+  flush_work(wbuf, wcount, work, work_count, work_cap, states + blockIdx.y, lane);
+}
+
+// FP64 resolution of the worklist: one thread per pair, bits rewritten with atomics (a row word
+// can receive several patches).  Diagonal blocks evaluate (r, c) and (c, r) as separate pairs, each
+// patching only its own bit; elsewhere one pair patches both the row-major and the transposed bit.
+__global__ __launch_bounds__(256) void tim_fixup_kernel(const ProbDesc* __restrict__ descs,
+                                                        const double* __restrict__ src,
+                                                        const double* __restrict__ dst,
+                                                        uint64_t* __restrict__ bitmap, double beta,
+                                                        const unsigned long long* __restrict__ work,
+                                                        const unsigned int* __restrict__ work_count,
+                                                        unsigned int cap) {
+  unsigned int total = *work_count;
+  if (total > cap) total = cap;  // overflow: the host reruns the batch
+  for (unsigned int w = blockIdx.x * 256 + threadIdx.x; w < total; w += gridDim.x * 256) {
+    const unsigned long long it = work[w];
+    const int prob = (int)(it >> 32), r = (int)((it >> 16) & 0xffff), col = (int)(it & 0xffff);
+    const ProbDesc d = descs[prob];
+    const int n = d.n, W = d.W;
+    if (r >= n || col >= n || r == col) continue;  // masked bits: already zero
+    const double* ps = src + 3 * d.pt_off;
+    const double* pd = dst + 3 * d.pt_off;
+    unsigned int* bm32 = reinterpret_cast<unsigned int*>(bitmap + d.bm_off);
+    const bool e = tim_edge_exact(ps[3 * col] - ps[3 * r], ps[3 * col + 1] - ps[3 * r + 1],
+                                  ps[3 * col + 2] - ps[3 * r + 2], pd[3 * col] - pd[3 * r],
+                                  pd[3 * col + 1] - pd[3 * r + 1], pd[3 * col + 2] - pd[3 * r + 2], beta);
+    {  // row r, column col
+      unsigned int* wp = bm32 + 2 * ((int64_t)r * W + (col >> 6)) + ((col >> 5) & 1);
+      const unsigned int bit = 1u << (col & 31);
+      if (e) atomicOr(wp, bit); else atomicAnd(wp, ~bit);
+    }
+    if ((r >> 6) != (col >> 6)) {  // the transposed copy
+      unsigned int* wp = bm32 + 2 * ((int64_t)col * W + (r >> 6)) + ((r >> 5) & 1);
+      const unsigned int bit = 1u << (r & 31);
+      if (e) atomicOr(wp, bit); else atomicAnd(wp, ~bit);
+    }
+  }
+}
+
+// A problem whose fix-up list overflowed has unresolved (and, in diagonal blocks, possibly
+// asymmetric) bits: its bitmap is cleared so that the stages enqueued behind K1 see an empty graph
+// until the host reruns the batch on the FP64 kernel.
+__global__ __launch_bounds__(256) void tim_overflow_clear_kernel(const ProbDesc* __restrict__ descs,
+                                                                 const ProbState* __restrict__ states,
+                                                                 uint64_t* __restrict__ bitmap) {
+  if (!states[blockIdx.y].k1_overflow) return;
+  const ProbDesc d = descs[blockIdx.y];
+  const int64_t words = (int64_t)d.n * d.W;
+  for (int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x; w < words; w += (int64_t)gridDim.x * 256)
+    bitmap[d.bm_off + w] = 0;
 }
 
 void launch_tim_graph(hipStream_t s, const ProbDesc* d_desc, int batch, int max_n,
@@ -729,35 +855,51 @@ void launch_tim_graph(hipStream_t s, const ProbDesc* d_desc, int batch, int max_
 
 // MODE 0 on the matrix cores: pre-pass (centres, packed f32 points, R^2) + tim_graph_mfma_kernel.
 // d_pk: 2 * total_pts float4 (src then dst); d_prep: batch * sizeof(TimPrep) bytes.
-int64_t tim_prep_bytes(int batch) { return (int64_t)batch * (int64_t)sizeof(TimPrep); }
+int64_t tim_prep_bytes(int batch) { return (int64_t)batch * (int64_t)sizeof(TimPrep) + 64; }
+int64_t tim_operand_bytes(int64_t total_pts) { return 2 * total_pts * (int64_t)sizeof(TimOperand); }
+
+// worklist capacity: 1/64 of all pairs of the launch (>= 2^20); typical use is ~2e-4 of the pairs
+int64_t tim_work_items(const int32_t* n, int batch) {
+  int64_t pairs = 0;
+  for (int b = 0; b < batch; ++b) pairs += (int64_t)n[b] * (n[b] - 1) / 2;
+  int64_t items = pairs / 64;
+  if (items < (1 << 20)) items = 1 << 20;
+  if (items > 0x7fffffffll) items = 0x7fffffffll;
+  return items;
+}
 
 void launch_tim_graph_mfma(hipStream_t s, const ProbDesc* d_desc, int batch, int max_n,
                            int64_t total_pts, const double* d_src, const double* d_dst,
-                           void* d_pk, void* d_prep, uint64_t* d_bitmap, double noise_bound,
-                           double cbar2) {
+                           void* d_pk, void* d_prep, void* d_work, int64_t work_cap,
+                           uint64_t* d_bitmap, ProbState* d_state, double noise_bound, double cbar2) {
   if (batch <= 0 || max_n <= 0) return;
   const int T = (max_n + 63) / 64;
   const double beta = 2 * noise_bound * sqrt(cbar2);  // registration.cc:438
-  float4* pk_src = reinterpret_cast<float4*>(d_pk);
-  float4* pk_dst = pk_src + total_pts;
+  TimOperand* op_src = reinterpret_cast<TimOperand*>(d_pk);
+  TimOperand* op_dst = op_src + total_pts;
   TimPrep* prep = reinterpret_cast<TimPrep*>(d_prep);
-  (void)hipMemsetAsync(prep, 0, sizeof(TimPrep) * (size_t)batch, s);
+  (void)hipMemsetAsync(prep, 0, sizeof(TimPrep) * (size_t)batch + 64, s);  // + the worklist counter
   hipLaunchKernelGGL(tim_prep_bbox_kernel, dim3((max_n + 1023) / 1024, batch), dim3(256), 0, s, d_desc,
                      d_src, d_dst, prep);
   hipLaunchKernelGGL(tim_prep_pack_kernel, dim3((max_n + 255) / 256, batch), dim3(256), 0, s, d_desc,
-                     d_src, d_dst, prep, pk_src, pk_dst);
-  const int gx = (T + kColTilesPerBlock - 1) / kColTilesPerBlock, gy = T;
-  static const int var = getenv("TEASER_K1_VARIANT") ? atoi(getenv("TEASER_K1_VARIANT")) : 0;
-  const dim3 grid(gx * gy, batch);
-#define LAUNCH_MFMA(V)                                                                          \
-  hipLaunchKernelGGL(tim_graph_mfma_kernel<V>, grid, dim3(256), 0, s, d_desc, d_src, d_dst, pk_src, \
-                     pk_dst, prep, d_bitmap, beta, gx, gy)
-  if (var == 1) LAUNCH_MFMA(1);
-  else if (var == 2) LAUNCH_MFMA(2);
-  else if (var == 3) LAUNCH_MFMA(3);
-  else if (var == 4) LAUNCH_MFMA(4);
-  else LAUNCH_MFMA(0);
-#undef LAUNCH_MFMA
+                     d_src, d_dst, prep, op_src, op_dst);
+  const int gx = (T + kMfmaColTilesPerBlock - 1) / kMfmaColTilesPerBlock, gy = T;
+  unsigned long long* work = reinterpret_cast<unsigned long long*>(d_work);
+  unsigned int* work_count = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(d_prep) +
+                                                            sizeof(TimPrep) * (size_t)batch);
+  hipLaunchKernelGGL(tim_graph_mfma_kernel, dim3(gx * gy, batch), dim3(256), 0, s, d_desc, d_src, d_dst,
+                     op_src, op_dst, prep, d_bitmap, beta, gx, gy, work, work_count,
+                     (unsigned int)work_cap, d_state);
+  hipLaunchKernelGGL(tim_fixup_kernel, dim3(512), dim3(256), 0, s, d_desc, d_src, d_dst, d_bitmap, beta,
+                     work, work_count, (unsigned int)work_cap);
+  hipLaunchKernelGGL(tim_overflow_clear_kernel, dim3(64, batch), dim3(256), 0, s, d_desc, d_state, d_bitmap);
+  static const bool dbg = getenv("TEASER_K1_DEBUG") != nullptr;
+  if (dbg) {  // diagnostics only: registers sent to the FP64 fix-up
+    unsigned int cnt = 0;
+    (void)hipStreamSynchronize(s);
+    (void)hipMemcpy(&cnt, work_count, 4, hipMemcpyDeviceToHost);
+    fprintf(stderr, "[teaser_hip] K1 fix-up items: %u (batch %d, max_n %d)\n", cnt, batch, max_n);
+  }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -98,7 +98,7 @@ struct teaser_hip_solver {
 
   DevBuf d_desc, d_state, d_src, d_dst, d_bitmap, d_deg, d_clique, d_start_cliques, d_alive_a,
       d_alive_b, d_next_count, d_weights, d_rot_inl, d_trans_inl, d_tls_scratch, d_tim_off,
-      d_pk, d_prep;
+      d_pk, d_prep, d_work;
   // colouring bound
   DevBuf c_sel, c_colour, c_tent, c_xlist;
   std::vector<int32_t> colour_x;  // |X| per problem of the last solve (-1: stage not run)
@@ -483,8 +483,9 @@ int32_t close_clique_bounds(teaser_hip_solver* h, int batch, int64_t total_n, bo
 // --------------------------------------------------------------------------------------------
 // the batched pipeline; inputs are device-resident and packed
 // --------------------------------------------------------------------------------------------
-int32_t solve_packed(teaser_hip_solver* h, const double* d_src, const double* d_dst,
-                     const int64_t* pt_off, const int32_t* n, int batch, teaser_solution_c* out) {
+int32_t solve_packed_impl(teaser_hip_solver* h, const double* d_src, const double* d_dst,
+                          const int64_t* pt_off, const int32_t* n, int batch,
+                          teaser_solution_c* out, bool fp64_k1, bool* k1_overflow) {
   hipStream_t s = h->stream;
   const teaser_params_c& P = h->params;
   if (!params_supported(P)) {
@@ -551,6 +552,8 @@ int32_t solve_packed(teaser_hip_solver* h, const double* d_src, const double* d_
   const int64_t tls_stride = tls_scratch_bytes(std::max(max_n, 1));
   HIPCHK(h, h->d_tls_scratch.ensure((size_t)tls_stride * (size_t)batch));
   const bool need_graph = (mode != TEASER_INLIER_NONE) && max_n >= 1;
+  // K1 on the matrix cores (fixed scale; worklist items hold 16-bit point indices: n <= 65536)
+  const bool mfma_k1 = need_graph && !P.estimate_scaling && max_n <= 65536 && !fp64_k1;
   if (need_graph) {
     HIPCHK(h, h->d_bitmap.ensure(8 * (size_t)std::max<int64_t>(bm, 1)));
     HIPCHK(h, h->d_deg.ensure(4 * (size_t)total_n));
@@ -558,9 +561,11 @@ int32_t solve_packed(teaser_hip_solver* h, const double* d_src, const double* d_
     HIPCHK(h, h->d_alive_a.ensure(8 * (size_t)std::max<int64_t>(wo, 1)));
     HIPCHK(h, h->d_alive_b.ensure(8 * (size_t)std::max<int64_t>(wo, 1)));
     HIPCHK(h, h->d_next_count.ensure(4 * (size_t)batch));
-    if (!P.estimate_scaling) {  // K1 on the matrix cores: packed f32 points + per-problem pre-pass record
-      HIPCHK(h, h->d_pk.ensure(32 * (size_t)total_n));
+    // K1 on the matrix cores (worklist items index 64-row tiles with 10 bits: n <= 65536)
+    if (mfma_k1) {
+      HIPCHK(h, h->d_pk.ensure((size_t)tim_operand_bytes(total_n)));
       HIPCHK(h, h->d_prep.ensure((size_t)tim_prep_bytes(batch)));
+      HIPCHK(h, h->d_work.ensure(8 * (size_t)tim_work_items(n, batch) + 64));
     }
   }
   {
@@ -587,12 +592,13 @@ int32_t solve_packed(teaser_hip_solver* h, const double* d_src, const double* d_
   if (need_graph) {
     {
       StageScope sc(h, ST_TIM);
-      if (P.estimate_scaling)
+      if (!mfma_k1)
         launch_tim_graph(s, dd, batch, max_n, d_src, d_dst, h->d_bitmap.as<uint64_t>(), P.noise_bound,
-                         P.cbar2, 1, ds);
+                         P.cbar2, P.estimate_scaling ? 1 : 0, ds);
       else
         launch_tim_graph_mfma(s, dd, batch, max_n, total_n, d_src, d_dst, h->d_pk.p, h->d_prep.p,
-                              h->d_bitmap.as<uint64_t>(), P.noise_bound, P.cbar2);
+                              h->d_work.p, tim_work_items(n, batch), h->d_bitmap.as<uint64_t>(), ds,
+                              P.noise_bound, P.cbar2);
     }
     for (int b = 0; b < batch; ++b) {
       const int64_t nn = h->descs[(size_t)b].n;
@@ -650,6 +656,10 @@ int32_t solve_packed(teaser_hip_solver* h, const double* d_src, const double* d_
   int32_t rc = run_estimators();
   if (rc != TEASER_HIP_OK) return rc;
 
+  *k1_overflow = false;
+  for (int b = 0; b < batch; ++b)
+    if (h->states[(size_t)b].k1_overflow) *k1_overflow = true;
+  if (*k1_overflow) return TEASER_HIP_OK;  // the caller reruns the batch with the FP64 K1
   for (int b = 0; b < batch; ++b) h->heu_size[(size_t)b] = h->states[(size_t)b].lb;
   if (need_graph && mode == TEASER_INLIER_PMC_EXACT) {
     bool changed = false;
@@ -688,6 +698,17 @@ int32_t solve_packed(teaser_hip_solver* h, const double* d_src, const double* d_
     o.gnc_iterations = st.gnc_iters;
   }
   return TEASER_HIP_OK;
+}
+
+// K1 runs as the matrix-core filter; if its FP64 fix-up list overflowed (adversarial geometry) the
+// whole batch is solved again with the all-FP64 K1 -- same results, slower.
+int32_t solve_packed(teaser_hip_solver* h, const double* d_src, const double* d_dst,
+                     const int64_t* pt_off, const int32_t* n, int batch, teaser_solution_c* out) {
+  bool overflow = false;
+  int32_t rc = solve_packed_impl(h, d_src, d_dst, pt_off, n, batch, out, false, &overflow);
+  if (rc == TEASER_HIP_OK && overflow)
+    rc = solve_packed_impl(h, d_src, d_dst, pt_off, n, batch, out, true, &overflow);
+  return rc;
 }
 
 int32_t upload_and_solve(teaser_hip_solver* h, const double* const* src, const double* const* dst,
@@ -795,7 +816,7 @@ int32_t teaser_hip_solver_destroy(teaser_hip_solver* h) {
   DevBuf* bufs[] = {&h->d_desc, &h->d_state, &h->d_src, &h->d_dst, &h->d_bitmap, &h->d_deg,
                     &h->d_clique, &h->d_start_cliques, &h->d_alive_a, &h->d_alive_b,
                     &h->d_next_count, &h->d_weights, &h->d_rot_inl, &h->d_trans_inl,
-                    &h->d_tls_scratch, &h->d_tim_off, &h->d_pk, &h->d_prep, &h->x_order, &h->x_src, &h->x_dst,
+                    &h->d_tls_scratch, &h->d_tim_off, &h->d_pk, &h->d_prep, &h->d_work, &h->x_order, &h->x_src, &h->x_dst,
                     &h->x_bitmap, &h->x_desc, &h->x_state, &h->x_ctrl, &h->x_clique, &h->x_arena,
                     &h->c_sel, &h->c_colour, &h->c_tent, &h->c_xlist,
                     &h->s_a, &h->s_b, &h->s_c, &h->s_d, &h->s_e};

@@ -109,6 +109,74 @@ def test_k1_guard_band_exact_path():
     assert (s.getInlierGraphBitmap() == ref2).all()
 
 
+def k1_only_params(nb):
+    """Only the bitmap is under test: heuristic clique mode + a short time limit keep the stages
+    behind K1 bounded on these deliberately degenerate graphs."""
+    return bench_params(noise_bound=nb, inlier_selection_mode=tp.InlierSelectionMode.PMC_HEU,
+                        max_clique_time_limit=5.0)
+
+
+def test_k1_filter_fallbacks():
+    """The matrix-core K1 is a filter; these inputs exercise every way out of it, all of which must
+    still give the oracle's bitmap bit for bit:
+      * a fix-up worklist overflow (duplicated points: every pair is a short pair) -> the host
+        reruns the batch on the all-FP64 K1;
+      * beta far below the filter's resolution (kappa > 1/4) -> FP64 kernel body chosen on the device;
+      * huge coordinate offsets (centring must absorb them) and non-finite coordinates."""
+    rng = np.random.default_rng(14)
+    nb = 0.01
+    # overflow: 3000 points drawn from 6 distinct locations -> ~750k zero-length pairs + short pairs
+    base = rng.uniform(size=(3, 6))
+    idx = rng.integers(0, 6, size=3000)
+    src = base[:, idx] + rng.uniform(-1e-4, 1e-4, size=(3, 3000))
+    dst = src + rng.uniform(-2e-3, 2e-3, size=src.shape)
+    s = make_solver(**k1_only_params(nb))
+    s.solve(src, dst)
+    _, ref = oracle.inlier_bitmap(src, dst, nb, 1.0, False)
+    assert (s.getInlierGraphBitmap() == ref).all()
+    # beta tiny relative to the cloud: the f32 filter cannot resolve it
+    pr = tp.synth_problem(20250523 + 15, 700, 0.5, 1e-7)
+    s2 = make_solver(**k1_only_params(1e-7))
+    s2.solve(pr["src"], pr["dst"])
+    _, ref2 = oracle.inlier_bitmap(pr["src"], pr["dst"], 1e-7, 1.0, False)
+    assert (s2.getInlierGraphBitmap() == ref2).all()
+    # large offsets: src near (1e4, -2e4, 3e4), dst near (-5e3, 7e3, 1e3)
+    pr = tp.synth_problem(20250523 + 16, 1500, 0.8, nb)
+    src3 = pr["src"] + np.array([[1e4], [-2e4], [3e4]])
+    dst3 = pr["dst"] + np.array([[-5e3], [7e3], [1e3]])
+    s.solve(src3, dst3)
+    _, ref3 = oracle.inlier_bitmap(src3, dst3, nb, 1.0, False)
+    assert (s.getInlierGraphBitmap() == ref3).all()
+    # a non-finite coordinate: NaN/inf comparisons are false in the reference -> no edges there
+    src4, dst4 = pr["src"].copy(), pr["dst"].copy()
+    src4[0, 3] = np.inf
+    dst4[1, 7] = np.nan
+    s.solve(src4, dst4)
+    _, ref4 = oracle.inlier_bitmap(src4, dst4, nb, 1.0, False)
+    assert (s.getInlierGraphBitmap() == ref4).all()
+
+
+def test_k1_filter_adversarial_band():
+    """Pairs engineered to sit at every distance from the decision boundary (ulps to 1e-3 beta), at
+    several scales: whatever the filter cannot decide must be resolved by the FP64 fix-up."""
+    rng = np.random.default_rng(17)
+    for scale, nb in ((1.0, 0.01), (250.0, 0.05), (0.02, 1e-4)):
+        beta = 2 * nb
+        n = 2048
+        src = rng.uniform(-1, 1, size=(3, n)) * scale
+        # dst = src moved radially from a common origin so that many pair length differences land
+        # within a few 1e-k beta of +-beta
+        R0 = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+        dst = R0 @ src
+        off = rng.choice([0, 1, -1], size=n) * beta * (1 + rng.choice([0, 1e-15, 1e-12, 1e-9, 1e-7, 1e-5, 1e-3], size=n))
+        d = dst / np.linalg.norm(dst, axis=0)
+        dst = dst + d * off * rng.uniform(0.3, 1.0, size=n)
+        s = make_solver(**k1_only_params(nb))
+        s.solve(src, dst)
+        _, ref = oracle.inlier_bitmap(src, dst, nb, 1.0, False)
+        assert (s.getInlierGraphBitmap() == ref).all()
+
+
 # ---------------------------------------------------------------------------------------------
 # stage solvers: the reference's own known answers (through the HIP kernels)
 # ---------------------------------------------------------------------------------------------
