@@ -13,8 +13,11 @@ its own problems (weak scaling, no data-path collective); the fixed-size result 
 all-gathered over RCCL at the end, inside the timed region.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- K1 (tim_graph_kernel), from HIP events recorded on the solver's stream during
-                  the timed region: algorithmic bytes 48 n + 8 n ceil(n/64) per problem.
+  roofline     -- K1 (tim_graph_mfma_kernel, the dominant kernel), from HIP events recorded on the
+                  solver's stream around that kernel alone during the timed region.  The kernel is
+                  compute-side: executed bf16 MFMA flops against the dense bf16 MFMA peak at the top
+                  level; the HBM view (algorithmic bytes 48 n + 8 n ceil(n/64) per problem, PMC
+                  traffic) and the algorithmic FP64-equivalent rate are nested beside it.
   cpu_baseline -- the CPU oracle (a port of the reference path; the reference itself cannot be
                   built here: no Eigen3 / pmc) timed on a bounded sample of the same workload.
 """
@@ -32,22 +35,27 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+MFMA_BF16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (not the 2:1-sparsity figure)
 FP64_VEC_PEAK_TF = 78.6    # FP64 vector peak, FMA = 2 flops
-K1_FLOPS_PER_PAIR = 20.0
+K1_FLOPS_PER_PAIR = 20.0   # algorithmic FP64 flops of the reference predicate
+# executed by K1 per pair: 4 x v_mfma_f32_32x32x16_bf16 (2*32*32*16 flops each) per 1024 pairs
+K1_MFMA_FLOPS_PER_PAIR = 4 * 2 * 32 * 32 * 16 / 1024.0
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="independent problems per step and per GPU")
+    ap.add_argument("--batch", type=int, default=64, help="independent problems per step and per GPU")
     ap.add_argument("--n", type=int, default=10000)
     ap.add_argument("--outlier-ratio", type=float, default=0.95)
     ap.add_argument("--noise-bound", type=float, default=0.01)
     ap.add_argument("--pool", type=int, default=4, help="distinct batches cycled through the steps")
     ap.add_argument("--seed", type=int, default=20250523)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true",
+                    help="skip the single-problem latency probe (rocprofv3 runs: keeps every K1 launch the same size)")
     ap.add_argument("--cpu-solves", type=int, default=16)
     return ap.parse_args()
 
@@ -56,6 +64,23 @@ def solver_params(tp, nb):
     return tp.RobustRegistrationSolver.Params(
         noise_bound=nb, cbar2=1.0, estimate_scaling=False, rotation_gnc_factor=1.4,
         rotation_max_iterations=100, rotation_cost_threshold=0.005)
+
+
+def k1_traffic(batch, n):
+    """HBM bytes per K1 launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE are
+    collected in SEPARATE runs of this same command, profiles/<round>/pmc_traffic.json, with the
+    gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md); null when no pass matches this shape."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json"))):
+        try:
+            doc = json.load(open(path))
+        except Exception:
+            continue
+        for k in doc.get("kernels", []):
+            if "tim_graph_mfma_kernel" in k["kernel"] and k.get("batch") == batch and k.get("n") == n:
+                best = (k["hbm_bytes_per_launch"], os.path.relpath(path, ROOT))
+    return best if best else (None, None)
 
 
 def cpu_baseline(tp, args):
@@ -149,7 +174,7 @@ def main():
         assert np.linalg.norm(np.array(o.translation[:]) - t) < 0.05
 
     solver.set_profiling(True)  # HIP events around K1 on the solver's stream, inside the timed region
-    k1_ms, k1_launches, k1_bytes, k1_pairs = 0.0, 0, 0, 0
+    k1_ms, k1_launches, k1_bytes, k1_pairs, k1_aux_ms = 0.0, 0, 0, 0, 0.0
     sync_all()
     t0 = time.perf_counter()
     last = None
@@ -160,6 +185,7 @@ def main():
         k1_launches += pf["tim_graph_launches"]
         k1_bytes += pf["tim_graph_bytes"]
         k1_pairs += pf["tim_graph_pairs"]
+        k1_aux_ms += pf["tim_aux_ms"]
     # final gather of the fixed-size result records (256 B each; RCCL over xGMI when N > 1)
     rec = tp.batched.pack_records([last[b] for b in range(B)], first_index=rank * B)
     allrec = tp.batched.gather_records(rec, world * B, dist if world > 1 else None, device=dev)
@@ -176,12 +202,12 @@ def main():
     lat = []
     s_t, d_t = pool[0]
     one_off, one_n = np.zeros(1, dtype=np.int64), np.array([n], dtype=np.int32)
-    for _ in range(10):
+    for _ in range(0 if args.no_latency else 10):
         torch.cuda.synchronize()
         a = time.perf_counter()
         solver.solve_batch_device(s_t.data_ptr(), d_t.data_ptr(), one_off, one_n)
         lat.append(time.perf_counter() - a)
-    lat_ms = 1e3 * float(np.median(lat))
+    lat_ms = 1e3 * float(np.median(lat)) if lat else None
 
     if rank == 0:
         total_regs = world * B * args.steps
@@ -191,6 +217,9 @@ def main():
         flops_per_launch = K1_FLOPS_PER_PAIR * k1_pairs / max(k1_launches, 1)
         hbm_gbs = bytes_per_launch / k1_avg_s / 1e9 if k1_avg_s > 0 else 0.0
         fp64_tf = flops_per_launch / k1_avg_s / 1e12 if k1_avg_s > 0 else 0.0
+        pairs_per_launch = k1_pairs / max(k1_launches, 1)
+        mfma_tf = K1_MFMA_FLOPS_PER_PAIR * pairs_per_launch / k1_avg_s / 1e12 if k1_avg_s > 0 else 0.0
+        traffic, traffic_src = k1_traffic(B, n)
         line = {
             "metric": "registrations/sec at N=%d correspondences, %.0f%% outliers" % (n, 100 * args.outlier_ratio),
             "value": value, "unit": "registrations/s", "n_gpus": world, "steps": args.steps,
@@ -203,15 +232,27 @@ def main():
                        "problems_per_step_per_gpu": B, "ms_per_registration": 1e3 * elapsed / (args.steps * B),
                        "single_problem_latency_ms": lat_ms, "inputs": "resident in HBM",
                        "parallelism": "independent problems per GPU, RCCL all_gather of result records"},
-            "roofline": {"kernel": "tim_graph_kernel<0> (K1: TIM norms + prune + adjacency bitmap)",
-                         "bound": "hbm", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"kernel": "tim_graph_mfma_kernel (K1: squared TIM norms on the matrix cores + "
+                                   "prune + adjacency bitmap)",
+                         "bound": "mfma", "achieved": mfma_tf, "peak": MFMA_BF16_PEAK_TF,
+                         "unit": "TFLOP/s", "frac": mfma_tf / MFMA_BF16_PEAK_TF,
+                         "traffic": traffic,
                          "avg_launch_ms": 1e3 * k1_avg_s, "launches": k1_launches,
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "fp64_valu": {"achieved": fp64_tf, "peak": FP64_VEC_PEAK_TF, "unit": "TFLOP/s",
-                                       "frac": fp64_tf / FP64_VEC_PEAK_TF,
-                                       "note": "K1 is FP64-VALU bound (SURVEY.md F6): 20 flops/pair "
-                                               "algorithmic, n(n-1)/2 pairs"}},
+                         "mfma_flops_per_launch": K1_MFMA_FLOPS_PER_PAIR * pairs_per_launch,
+                         "pairs_per_launch": pairs_per_launch,
+                         "note": "executed bf16 MFMA flops (128/pair: 4 x 32x32x16 per 1024 pairs) / HIP-event "
+                                 "time of the kernel alone; the kernel is bound by its packed-f32 VALU epilogue "
+                                 "(sign-bit packing, bit transposes), which on gfx950 does not overlap with the "
+                                 "same SIMD's MFMA issue (DESIGN.md 3); pre-pass + FP64 fix-up: aux_ms_per_launch",
+                         "aux_ms_per_launch": k1_aux_ms / max(k1_launches, 1),
+                         "hbm": {"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": hbm_gbs / HBM_PEAK_GBS,
+                                 "algorithmic_bytes_per_launch": bytes_per_launch,
+                                 "traffic_bytes_per_launch": traffic, "traffic_source": traffic_src},
+                         "fp64_equivalent": {"achieved": fp64_tf, "peak": FP64_VEC_PEAK_TF, "unit": "TFLOP/s",
+                                             "frac": fp64_tf / FP64_VEC_PEAK_TF,
+                                             "note": "20 FP64 flops/pair of the reference predicate (SURVEY.md "
+                                                     "8(d)); frac > 1 is possible: the filter runs in bf16/f32"}},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(tp, args)

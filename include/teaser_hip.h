@@ -101,7 +101,7 @@ typedef struct teaser_solution_c {
  * teaser_hip_set_profiling(h, 1).  Milliseconds, summed over the launches of that stage. */
 typedef struct teaser_profile_c {
   float h2d_ms;
-  float tim_graph_ms;    /* K1: TIM norms + prune + adjacency bitmap */
+  float tim_graph_ms;    /* K1 main kernel only: TIM norms + prune + adjacency bitmap */
   int32_t tim_graph_launches;
   float degree_ms;
   float heuristic_ms;
@@ -114,7 +114,7 @@ typedef struct teaser_profile_c {
   int64_t tim_graph_pairs; /* unordered pairs evaluated by K1 in the last call */
   int64_t tim_graph_bytes; /* algorithmic bytes of K1: 48 n + 8 n ceil(n/64), summed over problems */
   float colour_ms;         /* global colouring bound (only for problems the peel did not close) */
-  int32_t reserved0;
+  float tim_aux_ms;        /* K1 pre-pass (bbox, operand packing) + FP64 fix-up + overflow clear */
 } teaser_profile_c;
 
 typedef struct teaser_hip_solver teaser_hip_solver;

@@ -4,7 +4,9 @@ prescribes) into per-kernel, per-launch HBM traffic.  Units: rocprofv3 reports K
 correction from MI355X_MICROARCH.md (HBM section): FETCH_SIZE counts 64 B per 128-B request for
 wide streaming reads, i.e. reports HALF the bytes -> doubled here; WRITE_SIZE is taken as is
 (uncalibrated per the guide).
-usage: summarize_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>"""
+usage: summarize_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [batch n]
+With batch and n, the K1 rows whose grid is that batched launch are tagged so that bench.py can
+report them as roofline.traffic."""
 import collections
 import csv
 import json
@@ -33,6 +35,13 @@ def main():
                      "launches_write_pass": len(wv), "FETCH_SIZE_KB_raw": fetch_kb,
                      "WRITE_SIZE_KB_raw": write_kb,
                      "hbm_bytes_per_launch": 2.0 * fetch_kb * 1024 + write_kb * 1024})
+    if len(sys.argv) >= 6:
+        batch, n = int(sys.argv[4]), int(sys.argv[5])
+        T = (n + 63) // 64
+        grid = ((T + 31) // 32) * T * 256 * batch  # tim_graph_mfma_kernel: 32 column tiles per block
+        for r in rows:
+            if "tim_graph_mfma_kernel" in r["kernel"] and r["grid_size"] == grid:
+                r["batch"], r["n"] = batch, n
     json.dump({"note": __doc__.strip().split("usage")[0].strip(), "kernels": rows},
               open(sys.argv[3], "w"), indent=1)
     for r in rows:

@@ -106,7 +106,7 @@ class ProfileC(C.Structure):
         ("tim_graph_pairs", C.c_int64),
         ("tim_graph_bytes", C.c_int64),
         ("colour_ms", C.c_float),
-        ("reserved0", C.c_int32),
+        ("tim_aux_ms", C.c_float),
     ]
 
 

@@ -69,7 +69,7 @@ void launch_tim_graph(hipStream_t s, const ProbDesc* d_desc, int batch, int max_
 int64_t tim_prep_bytes(int batch);
 int64_t tim_operand_bytes(int64_t total_pts);
 int64_t tim_work_items(const int32_t* n, int batch);
-void launch_tim_graph_mfma(hipStream_t s, const ProbDesc* d_desc, int batch, int max_n,
+void launch_tim_graph_mfma(hipStream_t s, int phase, const ProbDesc* d_desc, int batch, int max_n,
                            int64_t total_pts, const double* d_src, const double* d_dst,
                            void* d_pk, void* d_prep, void* d_work, int64_t work_cap,
                            uint64_t* d_bitmap, ProbState* d_state, double noise_bound, double cbar2);

@@ -868,7 +868,9 @@ int64_t tim_work_items(const int32_t* n, int batch) {
   return items;
 }
 
-void launch_tim_graph_mfma(hipStream_t s, const ProbDesc* d_desc, int batch, int max_n,
+// phase 0 pre-pass (bbox, centred bf16 operands, R^2), 1 the matrix-core kernel, 2 FP64 fix-up of the
+// worklist + overflow clear.  Three calls so that the profiling span of phase 1 is that kernel alone.
+void launch_tim_graph_mfma(hipStream_t s, int phase, const ProbDesc* d_desc, int batch, int max_n,
                            int64_t total_pts, const double* d_src, const double* d_dst,
                            void* d_pk, void* d_prep, void* d_work, int64_t work_cap,
                            uint64_t* d_bitmap, ProbState* d_state, double noise_bound, double cbar2) {
@@ -878,27 +880,32 @@ void launch_tim_graph_mfma(hipStream_t s, const ProbDesc* d_desc, int batch, int
   TimOperand* op_src = reinterpret_cast<TimOperand*>(d_pk);
   TimOperand* op_dst = op_src + total_pts;
   TimPrep* prep = reinterpret_cast<TimPrep*>(d_prep);
-  (void)hipMemsetAsync(prep, 0, sizeof(TimPrep) * (size_t)batch + 64, s);  // + the worklist counter
-  hipLaunchKernelGGL(tim_prep_bbox_kernel, dim3((max_n + 1023) / 1024, batch), dim3(256), 0, s, d_desc,
-                     d_src, d_dst, prep);
-  hipLaunchKernelGGL(tim_prep_pack_kernel, dim3((max_n + 255) / 256, batch), dim3(256), 0, s, d_desc,
-                     d_src, d_dst, prep, op_src, op_dst);
-  const int gx = (T + kMfmaColTilesPerBlock - 1) / kMfmaColTilesPerBlock, gy = T;
   unsigned long long* work = reinterpret_cast<unsigned long long*>(d_work);
   unsigned int* work_count = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(d_prep) +
                                                             sizeof(TimPrep) * (size_t)batch);
-  hipLaunchKernelGGL(tim_graph_mfma_kernel, dim3(gx * gy, batch), dim3(256), 0, s, d_desc, d_src, d_dst,
-                     op_src, op_dst, prep, d_bitmap, beta, gx, gy, work, work_count,
-                     (unsigned int)work_cap, d_state);
-  hipLaunchKernelGGL(tim_fixup_kernel, dim3(512), dim3(256), 0, s, d_desc, d_src, d_dst, d_bitmap, beta,
-                     work, work_count, (unsigned int)work_cap);
-  hipLaunchKernelGGL(tim_overflow_clear_kernel, dim3(64, batch), dim3(256), 0, s, d_desc, d_state, d_bitmap);
-  static const bool dbg = getenv("TEASER_K1_DEBUG") != nullptr;
-  if (dbg) {  // diagnostics only: registers sent to the FP64 fix-up
-    unsigned int cnt = 0;
-    (void)hipStreamSynchronize(s);
-    (void)hipMemcpy(&cnt, work_count, 4, hipMemcpyDeviceToHost);
-    fprintf(stderr, "[teaser_hip] K1 fix-up items: %u (batch %d, max_n %d)\n", cnt, batch, max_n);
+  if (phase == 0) {
+    (void)hipMemsetAsync(prep, 0, sizeof(TimPrep) * (size_t)batch + 64, s);  // + the worklist counter
+    hipLaunchKernelGGL(tim_prep_bbox_kernel, dim3((max_n + 1023) / 1024, batch), dim3(256), 0, s, d_desc,
+                       d_src, d_dst, prep);
+    hipLaunchKernelGGL(tim_prep_pack_kernel, dim3((max_n + 255) / 256, batch), dim3(256), 0, s, d_desc,
+                       d_src, d_dst, prep, op_src, op_dst);
+  } else if (phase == 1) {
+    const int gx = (T + kMfmaColTilesPerBlock - 1) / kMfmaColTilesPerBlock, gy = T;
+    hipLaunchKernelGGL(tim_graph_mfma_kernel, dim3(gx * gy, batch), dim3(256), 0, s, d_desc, d_src, d_dst,
+                       op_src, op_dst, prep, d_bitmap, beta, gx, gy, work, work_count,
+                       (unsigned int)work_cap, d_state);
+  } else {
+    hipLaunchKernelGGL(tim_fixup_kernel, dim3(512), dim3(256), 0, s, d_desc, d_src, d_dst, d_bitmap, beta,
+                       work, work_count, (unsigned int)work_cap);
+    hipLaunchKernelGGL(tim_overflow_clear_kernel, dim3(64, batch), dim3(256), 0, s, d_desc, d_state,
+                       d_bitmap);
+    static const bool dbg = getenv("TEASER_K1_DEBUG") != nullptr;
+    if (dbg) {  // diagnostics only: pairs sent to the FP64 fix-up
+      unsigned int cnt = 0;
+      (void)hipStreamSynchronize(s);
+      (void)hipMemcpy(&cnt, work_count, 4, hipMemcpyDeviceToHost);
+      fprintf(stderr, "[teaser_hip] K1 fix-up items: %u (batch %d, max_n %d)\n", cnt, batch, max_n);
+    }
   }
 }
 

@@ -66,7 +66,7 @@ struct DevBuf {
   }
 };
 
-enum Stage { ST_H2D = 0, ST_TIM, ST_DEG, ST_HEU, ST_PEEL, ST_EXACT, ST_ROT, ST_TRANS, ST_D2H, ST_COLOUR, ST_COUNT };
+enum Stage { ST_H2D = 0, ST_TIM, ST_DEG, ST_HEU, ST_PEEL, ST_EXACT, ST_ROT, ST_TRANS, ST_D2H, ST_COLOUR, ST_TIMAUX, ST_COUNT };
 
 }  // namespace
 
@@ -159,7 +159,7 @@ void profile_end(teaser_hip_solver* h) {
   float* slot[ST_COUNT] = {&h->prof.h2d_ms,  &h->prof.tim_graph_ms, &h->prof.degree_ms,
                            &h->prof.heuristic_ms, &h->prof.peel_ms, &h->prof.exact_ms,
                            &h->prof.rotation_ms, &h->prof.translation_ms, &h->prof.d2h_ms,
-                           &h->prof.colour_ms};
+                           &h->prof.colour_ms, &h->prof.tim_aux_ms};
   for (auto& s : h->spans) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
@@ -590,15 +590,17 @@ int32_t solve_packed_impl(teaser_hip_solver* h, const double* d_src, const doubl
     }
   }
   if (need_graph) {
-    {
+    if (!mfma_k1) {
       StageScope sc(h, ST_TIM);
-      if (!mfma_k1)
-        launch_tim_graph(s, dd, batch, max_n, d_src, d_dst, h->d_bitmap.as<uint64_t>(), P.noise_bound,
-                         P.cbar2, P.estimate_scaling ? 1 : 0, ds);
-      else
-        launch_tim_graph_mfma(s, dd, batch, max_n, total_n, d_src, d_dst, h->d_pk.p, h->d_prep.p,
-                              h->d_work.p, tim_work_items(n, batch), h->d_bitmap.as<uint64_t>(), ds,
-                              P.noise_bound, P.cbar2);
+      launch_tim_graph(s, dd, batch, max_n, d_src, d_dst, h->d_bitmap.as<uint64_t>(), P.noise_bound,
+                       P.cbar2, P.estimate_scaling ? 1 : 0, ds);
+    } else {
+      const int64_t cap = tim_work_items(n, batch);
+      for (int phase = 0; phase < 3; ++phase) {
+        StageScope sc(h, phase == 1 ? ST_TIM : ST_TIMAUX);
+        launch_tim_graph_mfma(s, phase, dd, batch, max_n, total_n, d_src, d_dst, h->d_pk.p, h->d_prep.p,
+                              h->d_work.p, cap, h->d_bitmap.as<uint64_t>(), ds, P.noise_bound, P.cbar2);
+      }
     }
     for (int b = 0; b < batch; ++b) {
       const int64_t nn = h->descs[(size_t)b].n;
