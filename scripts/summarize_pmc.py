@@ -38,7 +38,7 @@ def main():
     if len(sys.argv) >= 6:
         batch, n = int(sys.argv[4]), int(sys.argv[5])
         T = (n + 63) // 64
-        grid = ((T + 31) // 32) * T * 256 * batch  # tim_graph_mfma_kernel: 32 column tiles per block
+        grid = ((T + 7) // 8) * ((T + 3) // 4) * 256 * batch  # tim_graph_mfma_kernel: 4 row x 8 column tiles / block
         for r in rows:
             if "tim_graph_mfma_kernel" in r["kernel"] and r["grid_size"] == grid:
                 r["batch"], r["n"] = batch, n

@@ -573,9 +573,9 @@ __device__ __forceinline__ unsigned int spread_nibbles(unsigned int v) {
   return v;
 }
 
-// Block = 4 waves; a wave owns 64 rows (row tile I) and kMfmaColTiles consecutive 64-column tiles.
+// Block = 4 waves = 4 consecutive row tiles (64 rows each) x kMfmaColTiles 64-column tiles.
+constexpr int kMfmaRowTiles = 4;
 constexpr int kMfmaColTiles = 8;
-constexpr int kMfmaColTilesPerBlock = kMfmaColTiles * kWavesPerBlock;
 
 constexpr int kWorkBuf = 64 * 6;  // per-wave LDS staging (the FP64 path's column buffer): 384 items
 
@@ -606,36 +606,41 @@ __global__ __launch_bounds__(256) void tim_graph_mfma_kernel(
     const ProbDesc* __restrict__ descs, const double* __restrict__ src,
     const double* __restrict__ dst, const TimOperand* __restrict__ op_src,
     const TimOperand* __restrict__ op_dst, const TimPrep* __restrict__ prep,
-    uint64_t* __restrict__ bitmap, double beta, int gx, int gy,
+    uint64_t* __restrict__ bitmap, double beta, int gyr,
     unsigned long long* __restrict__ work, unsigned int* __restrict__ work_count, unsigned int work_cap,
     ProbState* __restrict__ states) {
   const ProbDesc d = descs[blockIdx.y];
   const int n = d.n, W = d.W;
   const int T = W;
-  int I, X;
-  tim_block_coords(gx, gy, &I, &X);
-  if (I >= T) return;
+  // block = kMfmaRowTiles consecutive row tiles (one per wave) x kMfmaColTiles column tiles; row group
+  // fastest, so the blocks in flight share a column group
+  const int Ig = blockIdx.x % gyr, X = blockIdx.x / gyr;
+  const int I0 = Ig * kMfmaRowTiles, Jbase = X * kMfmaColTiles;
+  if (I0 >= T || Jbase >= T || Jbase + kMfmaColTiles - 1 < I0) return;  // outside / below the diagonal
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  // rotate the wave -> column-range assignment with the row tile: in the blocks the diagonal crosses
-  // the low ranges are (partly) below it, and wave w always lands on SIMD w
-  const int Jbase = (X * kWavesPerBlock + ((wave + I) & (kWavesPerBlock - 1))) * kMfmaColTiles;
-  if (Jbase + kMfmaColTiles - 1 < I || Jbase >= T) return;
+  const int I = I0 + wave;
 
   const double* __restrict__ ps = src + 3 * d.pt_off;
   const double* __restrict__ pd = dst + 3 * d.pt_off;
   uint64_t* __restrict__ bm = bitmap + d.bm_off;
-  __shared__ __attribute__((aligned(16))) double cbuf[kWavesPerBlock][64 * 6];
+  __shared__ __attribute__((aligned(16))) double cbuf[kMfmaRowTiles][64 * 6];
+  // write staging: transposed words of the 4 row tiles (double-buffered over J), and the wave's own
+  // words of all its column tiles -- so that every global store covers whole 32 / 64-byte runs
+  __shared__ uint64_t lds_tr[2][kMfmaRowTiles][64];
+  __shared__ uint64_t lds_own[kMfmaRowTiles][64][kMfmaColTiles + 1];  // +1: conflict-free column reads
   const MfmaConst mc = mfma_consts(beta, prep[blockIdx.y].r2_bits);
-  if (!__builtin_amdgcn_readfirstlane(mc.use_mfma)) {
+  if (!__builtin_amdgcn_readfirstlane(mc.use_mfma)) {  // per problem: uniform over the block
     EdgeConst kc;
     kc.beta = beta;
     kc.beta2 = beta * beta;
     kc.m2beta2 = -2.0 * kc.beta2;
     kc.beta4 = kc.beta2 * kc.beta2;
     kc.s_hat = 1.0;
-    for (int jb = Jbase; jb < Jbase + kMfmaColTiles; jb += kColTilesPerWave)
-      tim_wave_fp64<0>(ps, pd, bm, n, W, I, jb, kc, cbuf[wave]);
+    if (I < T)
+      for (int jb = Jbase; jb < Jbase + kMfmaColTiles; jb += kColTilesPerWave)
+        if (!(jb + kColTilesPerWave - 1 < I || jb >= T))
+          tim_wave_fp64<0>(ps, pd, bm, n, W, I, jb, kc, cbuf[wave]);
     return;
   }
   const TimOperand* __restrict__ qs = op_src + d.pt_off;
@@ -653,8 +658,8 @@ __global__ __launch_bounds__(256) void tim_graph_mfma_kernel(
     ad[rt][0] = __builtin_bit_cast(bf16x8, qd[r].a[h]);
     ad[rt][1] = __builtin_bit_cast(bf16x8, qd[r].a[2 + h]);
   }
-  const uint64_t rowmask = (n - I * 64 >= 64) ? ~0ull : ((1ull << (n - I * 64)) - 1ull);
-  const int i = I * 64 + lane;
+  const bool rowvalid = I < T;  // (T need not be a multiple of the block's row tiles)
+  const uint64_t rowmask = !rowvalid ? 0ull : (n - I * 64 >= 64) ? ~0ull : ((1ull << (n - I * 64)) - 1ull);
   // per-lane keep masks of the 5 transpose stages: m_j for the lower lane of a pair, ~m_j for the upper
   unsigned int tmask[5];
   {
@@ -663,14 +668,18 @@ __global__ __launch_bounds__(256) void tim_graph_mfma_kernel(
   }
   // column operands are prefetched one half-block (32 columns) ahead: the loads of the next half
   // are in flight while the current one is on the matrix / vector pipes
+  // a wave is active for J >= I (a suffix of the block's column range); every wave walks the whole
+  // range because the staged stores are block-wide
   const int Jfirst = max(Jbase, I), Jend = min(Jbase + kMfmaColTiles, T);
   uint4 nb[4];  // next column point: src MFMA 0/1, dst MFMA 0/1
   {
     const int cp = min(Jfirst * 64 + c, n - 1);
     nb[0] = qs[cp].b[h]; nb[1] = qs[cp].b[2 + h]; nb[2] = qd[cp].b[h]; nb[3] = qd[cp].b[2 + h];
   }
-  for (int J = Jfirst; J < Jend; ++J) {
+  for (int J = Jbase; J < Jend; ++J) {
     const int j0 = J * 64;
+    uint64_t trw_out = 0;
+    if (rowvalid && J >= I) {
     unsigned int tr[2][2];  // [ct][rt]: this lane's 16 column bits
     unsigned int ubits[4];  // per tile 2 ct + rt: this lane's in-band pairs (bit q)
     unsigned int flagged = 0;  // wave-uniform: bit 2 ct + rt = tile holding in-band pairs
@@ -777,12 +786,25 @@ __global__ __launch_bounds__(256) void tim_graph_mfma_kernel(
     const uint64_t colmask = (n - j0 >= 64) ? ~0ull : ((1ull << (n - j0)) - 1ull);
     ownw &= colmask;
     if (J == I) ownw &= ~(1ull << lane);
-#ifdef K1_NOSTORE
-    if (ownw == 0x123456789ull && trw == 0x987654321ull) bm[0] = 1;
-#else
-    if (i < n) bm[(int64_t)i * W + J] = ownw;
-    if (J != I && j0 + lane < n) bm[(int64_t)(j0 + lane) * W + I] = trw & rowmask;
-#endif
+    lds_own[wave][lane][J - Jbase] = ownw;
+    trw_out = (J != I) ? (trw & rowmask) : 0ull;
+    }  // active
+    // transposed words: the 4 waves' words I0..I0+3 of row j are 32 contiguous bytes -> one lane group
+    const int buf = (J - Jbase) & 1;
+    lds_tr[buf][wave][lane] = trw_out;
+    __syncthreads();  // (one barrier per J: the other buffer is rewritten only after the next one)
+    {
+      const int r = 16 * wave + (lane >> 2), k = lane & 3, Ik = I0 + k;
+      if (Ik < J && Ik < T && j0 + r < n) bm[(int64_t)(j0 + r) * W + Ik] = lds_tr[buf][k][r];
+    }
+  }
+  // own words: lanes 8r..8r+7 store the (up to) 8 consecutive words of one row
+  if (rowvalid) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int r = it * 8 + (lane >> 3), k = lane & 7, J = Jbase + k;
+      if (J >= I && J < Jend && I * 64 + r < n) bm[(int64_t)(I * 64 + r) * W + J] = lds_own[wave][r][k];
+    }
   }
   flush_work(wbuf, wcount, work, work_count, work_cap, states + blockIdx.y, lane);
 }
@@ -797,8 +819,10 @@ __global__ __launch_bounds__(256) void tim_fixup_kernel(const ProbDesc* __restri
                                                         const unsigned long long* __restrict__ work,
                                                         const unsigned int* __restrict__ work_count,
                                                         unsigned int cap) {
-  unsigned int total = *work_count;
-  if (total > cap) total = cap;  // overflow: the host reruns the batch
+  const unsigned int total = *work_count;
+  // overflow: the wave whose reservation crossed the capacity wrote NOTHING, so slots below `cap` may
+  // hold stale items -- resolve nothing; the flagged problems are cleared and rerun by the host
+  if (total > cap) return;
   for (unsigned int w = blockIdx.x * 256 + threadIdx.x; w < total; w += gridDim.x * 256) {
     const unsigned long long it = work[w];
     const int prob = (int)(it >> 32), r = (int)((it >> 16) & 0xffff), col = (int)(it & 0xffff);
@@ -824,13 +848,17 @@ __global__ __launch_bounds__(256) void tim_fixup_kernel(const ProbDesc* __restri
   }
 }
 
-// A problem whose fix-up list overflowed has unresolved (and, in diagonal blocks, possibly
-// asymmetric) bits: its bitmap is cleared so that the stages enqueued behind K1 see an empty graph
-// until the host reruns the batch on the FP64 kernel.
+// The worklist is shared by the batch: if it overflowed, NO problem of the launch was resolved (the
+// fix-up kernel skips everything).  Every bitmap is cleared (so that the stages enqueued behind K1 see
+// empty graphs instead of unresolved, possibly asymmetric bits) and every problem is flagged; the
+// host then reruns the whole batch on the FP64 kernel.
 __global__ __launch_bounds__(256) void tim_overflow_clear_kernel(const ProbDesc* __restrict__ descs,
-                                                                 const ProbState* __restrict__ states,
-                                                                 uint64_t* __restrict__ bitmap) {
-  if (!states[blockIdx.y].k1_overflow) return;
+                                                                 ProbState* __restrict__ states,
+                                                                 uint64_t* __restrict__ bitmap,
+                                                                 const unsigned int* __restrict__ work_count,
+                                                                 unsigned int cap) {
+  if (*work_count <= cap) return;
+  if (blockIdx.x == 0 && threadIdx.x == 0) states[blockIdx.y].k1_overflow = 1;
   const ProbDesc d = descs[blockIdx.y];
   const int64_t words = (int64_t)d.n * d.W;
   for (int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x; w < words; w += (int64_t)gridDim.x * 256)
@@ -890,15 +918,15 @@ void launch_tim_graph_mfma(hipStream_t s, int phase, const ProbDesc* d_desc, int
     hipLaunchKernelGGL(tim_prep_pack_kernel, dim3((max_n + 255) / 256, batch), dim3(256), 0, s, d_desc,
                        d_src, d_dst, prep, op_src, op_dst);
   } else if (phase == 1) {
-    const int gx = (T + kMfmaColTilesPerBlock - 1) / kMfmaColTilesPerBlock, gy = T;
-    hipLaunchKernelGGL(tim_graph_mfma_kernel, dim3(gx * gy, batch), dim3(256), 0, s, d_desc, d_src, d_dst,
-                       op_src, op_dst, prep, d_bitmap, beta, gx, gy, work, work_count,
+    const int gxc = (T + kMfmaColTiles - 1) / kMfmaColTiles, gyr = (T + kMfmaRowTiles - 1) / kMfmaRowTiles;
+    hipLaunchKernelGGL(tim_graph_mfma_kernel, dim3(gxc * gyr, batch), dim3(256), 0, s, d_desc, d_src, d_dst,
+                       op_src, op_dst, prep, d_bitmap, beta, gyr, work, work_count,
                        (unsigned int)work_cap, d_state);
   } else {
     hipLaunchKernelGGL(tim_fixup_kernel, dim3(512), dim3(256), 0, s, d_desc, d_src, d_dst, d_bitmap, beta,
                        work, work_count, (unsigned int)work_cap);
     hipLaunchKernelGGL(tim_overflow_clear_kernel, dim3(64, batch), dim3(256), 0, s, d_desc, d_state,
-                       d_bitmap);
+                       d_bitmap, work_count, (unsigned int)work_cap);
     static const bool dbg = getenv("TEASER_K1_DEBUG") != nullptr;
     if (dbg) {  // diagnostics only: pairs sent to the FP64 fix-up
       unsigned int cnt = 0;

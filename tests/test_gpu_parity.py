@@ -134,6 +134,12 @@ def test_k1_filter_fallbacks():
     s.solve(src, dst)
     _, ref = oracle.inlier_bitmap(src, dst, nb, 1.0, False)
     assert (s.getInlierGraphBitmap() == ref).all()
+    # the worklist is shared by a batch: an overflowing problem must not leave its neighbour unresolved
+    prn = tp.synth_problem(20250523 + 18, 2000, 0.9, nb)
+    s.solve_batch([src, prn["src"]], [dst, prn["dst"]])
+    assert (s.getInlierGraphBitmap(0) == ref).all()
+    _, refn = oracle.inlier_bitmap(prn["src"], prn["dst"], nb, 1.0, False)
+    assert (s.getInlierGraphBitmap(1) == refn).all()
     # beta tiny relative to the cloud: the f32 filter cannot resolve it
     pr = tp.synth_problem(20250523 + 15, 700, 0.5, 1e-7)
     s2 = make_solver(**k1_only_params(1e-7))
