@@ -231,6 +231,9 @@ def main():
                                    "PMC_EXACT, CHAIN" % (n, 100 * args.outlier_ratio, args.noise_bound),
                        "problems_per_step_per_gpu": B, "ms_per_registration": 1e3 * elapsed / (args.steps * B),
                        "single_problem_latency_ms": lat_ms, "inputs": "resident in HBM",
+                       "arithmetic": "FP64 estimators and FP64 reference expression for every pruning decision the "
+                                     "K1 filter (exact bf16 split on MFMA + f32 epilogue with a rigorous error band) "
+                                     "cannot make; bitmap bit-identical to the FP64 oracle",
                        "parallelism": "independent problems per GPU, RCCL all_gather of result records"},
             "roofline": {"kernel": "tim_graph_mfma_kernel (K1: squared TIM norms on the matrix cores + "
                                    "prune + adjacency bitmap)",

@@ -9,7 +9,7 @@ import csv,collections
 rows=list(csv.DictReader(open("$OUT/pmc_k1_$tag/k1_counter_collection.csv")))
 agg=collections.defaultdict(list)
 for r in rows:
-    if "mfma_kernel" in r["Kernel_Name"] and r["Grid_Size"]=="6430720":
+    if "mfma_kernel" in r["Kernel_Name"] and r["Grid_Size"]=="3276800":
         agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k,v in agg.items(): print(k, len(v), sum(v)/len(v))
 EOF

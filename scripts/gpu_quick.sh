@@ -6,9 +6,9 @@ cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 if [ -n "$2" ]; then
-timeout 1200 python -m pytest tests -m gpu -q --timeout=600 -x -k "$2" > $OUT/tests_$TAG.log 2>&1; echo "tests rc=$?"
+timeout 300 python -m pytest tests -m gpu -q -x -k "$2" > $OUT/tests_$TAG.log 2>&1; echo "tests rc=$?"
 else
-timeout 1200 python -m pytest tests -m gpu -q --timeout=600 -x > $OUT/tests_$TAG.log 2>&1; echo "tests rc=$?"
+timeout 300 python -m pytest tests -m gpu -q -x > $OUT/tests_$TAG.log 2>&1; echo "tests rc=$?"
 fi
 tail -15 $OUT/tests_$TAG.log
 timeout 600 python scripts/profile_stages.py > $OUT/stages_$TAG.log 2>&1; cat $OUT/stages_$TAG.log

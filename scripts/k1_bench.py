@@ -21,8 +21,7 @@ def run(n, rho, batch, reps=5):
     pairs = batch * n * (n - 1) / 2
     ms = float(np.median(t))
     print(json.dumps(dict(n=n, batch=batch, k1_ms=round(ms, 4), gpairs_s=round(pairs / ms / 1e6, 1),
-                          tflops20=round(20 * pairs / ms / 1e9, 2),
-                          remap=os.environ.get("TEASER_K1_REMAP", "default"))), flush=True)
+                          tflops20=round(20 * pairs / ms / 1e9, 2))), flush=True)
 
 if __name__ == "__main__":
     for n, b in [(10000, 1), (10000, 16), (20000, 4), (50000, 1)]:

@@ -436,6 +436,77 @@ def test_solve_parity_config2_10k():
     assert s.raw_solution().num_edges == o["num_edges"]
 
 
+def numpy_rows_predicate(src, dst, rows, beta):
+    """Rows of the adjacency matrix with the reference expression (registration.cc:434-442) in numpy:
+    individually rounded IEEE double products / sums / sqrt, sum order (x^2 + y^2) + z^2."""
+    out = np.zeros((len(rows), src.shape[1]), dtype=bool)
+    for k, i in enumerate(rows):
+        a = src - src[:, [i]]
+        b = dst - dst[:, [i]]
+        v1 = np.sqrt((a[0] * a[0] + a[1] * a[1]) + a[2] * a[2])
+        v2 = np.sqrt((b[0] * b[0] + b[1] * b[1]) + b[2] * b[2])
+        out[k] = np.abs(v1 - v2) <= beta
+        out[k, i] = False
+    return out
+
+
+def test_solve_config3_50k_properties():
+    """BASELINE config 3: N = 50 000, 99 % outliers (1.25e9 pairs, 313 MB bitmap).  The oracle needs
+    minutes here, so size-independent properties: sampled bitmap rows bit-exact against the reference
+    expression evaluated in numpy, symmetry, degree sum = 2 edges, the clique is a clique containing
+    the planted inliers, ground-truth pose."""
+    n, nb = 50000, 0.01
+    pr = tp.synth_problem(20250523 + 3, n, 0.99, nb)
+    s = make_solver(**bench_params())
+    sol = s.solve(pr["src"], pr["dst"])
+    assert sol.valid
+    bm = s.getInlierGraphBitmap()
+    bits = lambda rows: np.unpackbits(bm[rows].view(np.uint8), axis=1, bitorder="little")[:, :n].astype(bool)
+    rng = np.random.default_rng(3)
+    rows = np.sort(rng.choice(n, size=48, replace=False))
+    ref = numpy_rows_predicate(pr["src"], pr["dst"], rows, 2 * nb)
+    got = bits(rows)
+    assert (got == ref).all()
+    # symmetry on the sampled rows: bit (i, j) == bit (j, i)
+    for k, i in enumerate(rows[:8]):
+        js = np.flatnonzero(got[k])
+        col = (bm[js, i >> 6] >> np.uint64(i & 63)) & np.uint64(1)
+        assert col.all()
+    deg = s.getDegrees()
+    assert int(deg.sum()) == 2 * int(s.raw_solution().num_edges)
+    assert (deg[rows] == got.sum(1)).all()
+    clique = np.array(s.getInlierMaxClique())
+    inl = np.flatnonzero(pr["inliers"])
+    assert set(inl.tolist()) <= set(clique.tolist()) and len(clique) <= len(inl) + 3
+    sub = numpy_rows_predicate(pr["src"][:, clique], pr["dst"][:, clique], range(len(clique)), 2 * nb)
+    assert (sub | np.eye(len(clique), dtype=bool)).all()
+    assert angular_error(pr["R"], sol.rotation) < 0.01
+    assert np.linalg.norm(sol.translation - pr["t"]) < 0.01
+
+
+def test_solve_config4_batch_5k_properties():
+    """BASELINE config 4 (one GPU's share): 128 independent N = 5 000 problems, 90 % outliers, in one
+    batched call; every problem recovers its planted clique and pose, and batched results are
+    identical to solving the same problem alone."""
+    B, n, nb = 128, 5000, 0.01
+    probs = [tp.synth_problem(20250523 + 4000 + b, n, 0.9, nb) for b in range(B)]
+    s = make_solver(**bench_params())
+    sols = s.solve_batch([p["src"] for p in probs], [p["dst"] for p in probs])
+    cliques = [s.getInlierMaxClique(b) for b in range(B)]
+    for b, (p, sol) in enumerate(zip(probs, sols)):
+        assert sol.valid
+        inl = set(np.flatnonzero(p["inliers"]).tolist())
+        assert inl <= set(cliques[b]) and len(cliques[b]) <= len(inl) + 3
+        assert angular_error(p["R"], sol.rotation) < 0.02
+        assert np.linalg.norm(sol.translation - p["t"]) < 0.02
+    s1 = make_solver(**bench_params())
+    for b in (0, 57, 127):
+        one = s1.solve(probs[b]["src"], probs[b]["dst"])
+        assert s1.getInlierMaxClique() == cliques[b]
+        assert np.array_equal(one.rotation, sols[b].rotation)
+        assert np.array_equal(one.translation, sols[b].translation)
+
+
 def test_solve_object_scene_fixed_scale():
     """Hard clique fixture (max_core+1 > omega): registration-test.cc:313-391 bounds."""
     obj, scn = G["object_in"], G["scene_in"]
