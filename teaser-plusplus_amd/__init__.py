@@ -181,6 +181,10 @@ def lib():
     return L
 
 
+# teaserpp_python.OMP_MAX_THREADS (python/teaserpp_python/teaserpp_python.cc:45): host threads
+OMP_MAX_THREADS = os.cpu_count() or 1
+
+
 def device_count():
     return int(lib().teaser_hip_device_count())
 
@@ -312,6 +316,7 @@ class RobustRegistrationSolver:
         self._check(self._lib.teaser_hip_solve(self._h, _ptr(s), _ptr(d), s.shape[0], C.byref(out)))
         self._sols = [out]
         self._sol = RegistrationSolution(out)
+        self._inputs = [(s, d)]
         return self._sol
 
     def solve_correspondences(self, src_cloud, dst_cloud, correspondences):  # registration.h:567-569
@@ -341,6 +346,7 @@ class RobustRegistrationSolver:
         self._check(self._lib.teaser_hip_solve_batch(self._h, sp, dp, _ptr(n, _ip), B, out))
         self._sols = list(out)
         self._sol = RegistrationSolution(out[0]) if B else None
+        self._inputs = list(zip(ss, ds))
         return [RegistrationSolution(o) for o in out]
 
     def solve_batch_device(self, d_src_ptr, d_dst_ptr, point_offsets, n):
@@ -468,6 +474,64 @@ class RobustRegistrationSolver:
         mp = self.getScaleInliersMap(problem)
         mk = self.getScaleInliersMask(problem)
         return [(int(a), int(b)) for a, b in zip(mp[0][mk], mp[1][mk])]
+
+    # TIM products (registration.h:778-824).  The device never materialises them; they are rebuilt
+    # here on the host, on request, from the last inputs of solve()/solve_batch().
+    def _last_points(self, problem):
+        inputs = getattr(self, "_inputs", None)
+        if not inputs or problem >= len(inputs):
+            raise RuntimeError("TIM getters need the host inputs of the last solve()/solve_batch() call")
+        return inputs[problem]
+
+    @staticmethod
+    def _compute_tims(v):
+        """computeTIMs (registration.cc:512-551): 3 x M, column k(i,j) = v_j - v_i, row-major pair order."""
+        n = v.shape[0]
+        iu = np.triu_indices(n, 1)
+        return (v[iu[1]] - v[iu[0]]).T.copy()
+
+    def getSrcTIMs(self, problem=0):  # registration.h:778
+        return self._compute_tims(self._last_points(problem)[0])
+
+    def getDstTIMs(self, problem=0):  # registration.h:784
+        return self._compute_tims(self._last_points(problem)[1])
+
+    src_tims = property(getSrcTIMs)
+    dst_tims = property(getDstTIMs)
+
+    def _clique_tims(self, which, problem):
+        pts = self._last_points(problem)[which]
+        c = np.array(self.getInlierMaxClique(problem), dtype=np.int64)
+        if int(self._params.rotation_tim_graph) == 0:  # CHAIN, registration.cc:657-680
+            leaf = np.roll(c, -1)
+            t = (pts[leaf] - pts[c]).T.copy()
+        else:                                          # COMPLETE, registration.cc:681-694
+            t = self._compute_tims(pts[c])
+        if which == 1:  # registration.cc:697: pruned_dst_tims_ *= 1 / scale
+            t *= 1.0 / float(self._sols[problem].scale)
+        return t
+
+    def getMaxCliqueSrcTIMs(self, problem=0):  # registration.h:790
+        return self._clique_tims(0, problem)
+
+    def getMaxCliqueDstTIMs(self, problem=0):  # registration.h:796 (after the de-scaling of :697)
+        return self._clique_tims(1, problem)
+
+    max_clique_src_tims = property(getMaxCliqueSrcTIMs)
+    max_clique_dst_tims = property(getMaxCliqueDstTIMs)
+
+    def getSrcTIMsMapForRotation(self, problem=0):  # registration.h:814
+        c = np.array(self.getInlierMaxClique(problem), dtype=np.int32)
+        if int(self._params.rotation_tim_graph) == 0:  # (leaf, root) in input indices, registration.cc:674-678
+            return np.vstack([np.roll(c, -1), c]).astype(np.int32)
+        iu = np.triu_indices(len(c), 1)  # computeTIMs map: positions within the clique
+        return np.vstack([iu[0], iu[1]]).astype(np.int32)
+
+    getDstTIMsMapForRotation = getSrcTIMsMapForRotation  # registration.h:822 (same maps)
+    src_tims_map_for_rotation = property(getSrcTIMsMapForRotation)
+    dst_tims_map_for_rotation = property(getSrcTIMsMapForRotation)
+    src_tims_map = property(lambda self: self.getScaleInliersMap())
+    dst_tims_map = property(lambda self: self.getScaleInliersMap())
 
     # --- stage entry points (registration.h:584-601) ---------------------------------------
     def solveForRotation(self, v1, v2, noise_bound=None):

@@ -1,0 +1,18 @@
+"""Drop-in module name for users of the reference's Python binding: `import teaserpp_python`
+resolves to the MI355X implementation (teaser-plusplus_amd), which mirrors the names registered in
+python/teaserpp_python/teaserpp_python.cc:27-177 (RobustRegistrationSolver, its Params, the three
+enums, RegistrationSolution, OMP_MAX_THREADS).  The certifier classes of the reference module
+(DRSCertifier, CertificationResult, EigSolverType) are outside this repo's scope."""
+import importlib as _importlib
+
+_impl = _importlib.import_module("teaser-plusplus_amd")
+
+RobustRegistrationSolver = _impl.RobustRegistrationSolver
+RegistrationSolution = _impl.RegistrationSolution
+RotationEstimationAlgorithm = _impl.RotationEstimationAlgorithm
+InlierGraphFormulation = _impl.InlierGraphFormulation
+InlierSelectionMode = _impl.InlierSelectionMode
+OMP_MAX_THREADS = _impl.OMP_MAX_THREADS
+
+__all__ = ["RobustRegistrationSolver", "RegistrationSolution", "RotationEstimationAlgorithm",
+           "InlierGraphFormulation", "InlierSelectionMode", "OMP_MAX_THREADS"]

@@ -749,6 +749,26 @@ def test_complete_tim_graph():
     check_solution_parity(s, sol, o)
 
 
+def test_tim_product_getters():
+    """getSrcTIMs / getMaxClique*TIMs / get*TIMsMapForRotation (registration.h:778-824): rebuilt on
+    the host from the last inputs, in the reference's pair order and chain convention."""
+    pr = tp.synth_problem(20250523 + 61, 150, 0.6, 0.01)
+    s = make_solver(**bench_params())
+    sol = s.solve(pr["src"], pr["dst"])
+    t_src, _ = oracle.compute_tims(pr["src"])
+    assert np.array_equal(s.getSrcTIMs(), t_src.T if t_src.shape[0] != 3 else t_src)
+    c = np.array(s.getInlierMaxClique())
+    K = len(c)
+    m = s.getSrcTIMsMapForRotation()
+    assert m.shape == (2, K) and (m[1] == c).all() and (m[0] == np.roll(c, -1)).all()  # (leaf, root)
+    ts, td = s.getMaxCliqueSrcTIMs(), s.getMaxCliqueDstTIMs()
+    assert ts.shape == (3, K) and np.allclose(ts[:, 0], pr["src"][:, c[1]] - pr["src"][:, c[0]])
+    # rotated src TIMs match the (de-scaled) dst TIMs on the rotation inliers
+    inl = s.getRotationInliers()
+    res = td[:, inl] - sol.rotation @ ts[:, inl]
+    assert np.abs(res).max() < 4 * 0.01
+
+
 def test_correspondence_overload():
     """solve(PointCloud, PointCloud, correspondences), registration.cc:553-566."""
     pr = tp.synth_problem(33, 500, 0.6, 0.01)

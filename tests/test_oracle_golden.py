@@ -286,3 +286,22 @@ def test_thousand_point_smoke():
     dst = G["scene1000"].astype(np.float64).T
     o = oracle.solve(src, dst, noise_bound=0.0067364, estimate_scaling=0, rotation_cost_threshold=0.005)
     assert o["valid"] and len(o["max_clique"]) > 2
+
+
+def test_python_mirror_names_and_tim_helper():
+    """Host-side pieces of the Python mirror that need no GPU: the drop-in module name, the enum
+    and Params surface of python/teaserpp_python/teaserpp_python.cc:27-110, and the lazily rebuilt
+    TIM product (pair order of registration.cc:531) against the oracle's computeTIMs."""
+    import teaserpp_python as t
+    p = t.RobustRegistrationSolver.Params()
+    assert (p.noise_bound, p.cbar2, p.estimate_scaling, p.rotation_gnc_factor, p.rotation_max_iterations,
+            p.rotation_cost_threshold, p.kcore_heuristic_threshold, p.max_clique_time_limit) == \
+        (0.01, 1, True, 1.4, 100, 1e-6, 0.5, 3600)
+    assert int(t.RotationEstimationAlgorithm.QUATRO) == 2 and int(t.InlierSelectionMode.NONE) == 3
+    assert int(t.InlierGraphFormulation.COMPLETE) == 1 and t.OMP_MAX_THREADS >= 1
+    assert t.RobustRegistrationSolver.ROTATION_ESTIMATION_ALGORITHM is t.RotationEstimationAlgorithm
+    rng = np.random.default_rng(5)
+    v = rng.normal(size=(3, 37))
+    tims, mp = oracle.compute_tims(v)
+    mine = t.RobustRegistrationSolver._compute_tims(np.ascontiguousarray(v.T))
+    assert np.array_equal(mine, tims.T if tims.shape[0] != 3 else tims)
