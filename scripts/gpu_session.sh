@@ -20,3 +20,5 @@ cd $GRAFT_REPO_ROOT
 find gpurun_out/prof_$TAG gpurun_out/pmc_fetch_$TAG gpurun_out/pmc_write_$TAG -type f | head -40
 find gpurun_out/prof_$TAG -name "*kernel_stats*" | head -1 | xargs -I{} head -30 {}
 timeout 120 python bench.py --batch 16 --steps 30 --no-cpu-baseline > $OUT/bench16_$TAG.log 2>&1; tail -1 $OUT/bench16_$TAG.log | cut -c1-400
+timeout 120 python bench.py --streams 3 --steps 30 --no-cpu-baseline --no-latency > $OUT/bench_streams3_$TAG.log 2>&1; tail -1 $OUT/bench_streams3_$TAG.log | cut -c1-300
+timeout 60 python scripts/profile_stages.py big > $OUT/stages_big_$TAG.log 2>&1; grep '^{' $OUT/stages_big_$TAG.log | cut -c1-300

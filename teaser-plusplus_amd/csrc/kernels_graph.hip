@@ -311,12 +311,12 @@ __global__ __launch_bounds__(256) void tim_graph_kernel(const ProbDesc* __restri
 // (128 matrix-pipe cycles per 1024 pairs; the f32-input MFMA needs 384 and, like this one, does
 // not overlap with this kernel's own VALU work on the same SIMD -- measured).  Every bf16 x bf16
 // product is exact in f32; only the accumulation rounds.
-// The VALU keeps the epilogue: D = A - B, t = A + B, d = D^2 - 2 beta^2 t + beta^4 (packed f32),
-// ONE compare (inside the band?) and one v_alignbit (sign bit of d -> the lane's column word) per
-// pair register; the row-major words are the in-register 32 x 32 bit transpose of the column
-// words.  The f32 result is a FILTER: its sign is trusted only outside a rigorous error band;
-// registers (64 pairs) holding anything inside the band are re-evaluated with the reference
-// expression in FP64 (tim_edge_exact), so the bitmap stays bit-identical to the oracle.
+// The VALU keeps the epilogue (packed f32): D = A - B, t = A + B, then BOTH band edges
+// d -+ band = D^2 + (t c1 + c2) with pre-combined constants, and two v_alignbit per pair register
+// collecting their sign bits (no compares, no branches); the row-major words are the in-register
+// 32 x 32 bit transpose of the column words.  The f32 result is a FILTER: its sign is trusted only
+// outside a rigorous error band; pairs inside the band go to a worklist and are re-evaluated with
+// the reference expression in FP64 (tim_fixup_kernel), so the bitmap stays bit-identical to the oracle.
 //
 // Error budget (u = 2^-24, R = max |centred point| over both clouds, eps = kEpsU u R^2):
 //   * centring + f32 rounding of the coordinates moves |a|^2 by <= 8 u R^2, the f32 norms by
@@ -324,19 +324,22 @@ __global__ __launch_bounds__(256) void tim_graph_kernel(const ProbDesc* __restri
 //   * accumulation: 2 x 16 products + C per accumulator, |sum of |terms|| <= (|s| + |s'|)^2 <=
 //     4 R^2; ASSUMED hardware model: every internal addition errs by at most one f32 ulp (2u) of
 //     a magnitude <= that sum => <= 34 * 2u * 4 R^2 = 272 u R^2  (a fused/wider adder tree only
-//     does better).  Total 283 u R^2 -> kEpsU = 300.  tests/test_gpu_parity.py checks the model
-//     against exact arithmetic on adversarial tiles;
+//     does better; scripts/probe/mfma_bf16_error.hip measures <= 4.9 u * sum|terms| per instruction
+//     on this hardware).  Total 283 u R^2 -> kEpsU = 300;
 //   * propagating through D, t, e = beta^4 - 2 beta^2 t, d = D^2 + e with 4 eps |D| <=
 //     2 eps (D^2/lam + lam), lam = beta R, and D^2 <= 1.01 |d~| + 2 beta^2 t + beta^4:
 //       |d~ - d*| <= kappa |d~| + K2 t~ + K0,
-//       kappa = 3.04 u + 2.03 eps/lam,  K2 = 10.1 u beta^2 + 4.04 eps beta^2/lam,
-//       K0 = 4 eps^2 + 4 beta^2 eps + 4.1 u beta^4 + 2.02 eps beta^4/lam + 2.02 eps lam + G,
+//       kappa = 3.04 u + 2.03 eps/lam,  K2 = 15 u beta^2 + 4.04 eps beta^2/lam,
+//       K0 = 4 eps^2 + 4 beta^2 eps + 7 u beta^4 + 2.02 eps beta^4/lam + 2.02 eps lam + G,
+//     (15 u / 7 u: the two band edges and their pre-combined constants are rounded separately)
 //     G = 1.3e-13 beta R^3 + 8e-15 beta^2 R^2 covering the gap between the reference's rounded
 //     double predicate and the exact one (|x - beta| <= 4.5e-16 y + 1.1e-16 beta);
 //   * sign(d~) is trusted iff |d~| > (K2 t~ + K0) / (1 - kappa); a tile holding a pair with
-//     t~ <= tau = beta^2 (1 + 8u) + 2.1 eps (the t <= beta^2 branch of the predicate) goes to FP64.
-// kappa > 1/4 (beta below ~1.5e-4 R: the filter cannot resolve the band) => that problem runs the
-// FP64 kernel body instead (tim_wave_fp64), chosen per problem on the device.
+//     t~ <= tau = beta^2 (1 + 8u) + 2.1 eps (the t <= beta^2 branch of the predicate) goes to the
+//     FP64 fix-up as a whole (self pairs of diagonal tiles are parked outside first).
+// kappa > 1/4 (beta below ~1.5e-4 R: the filter cannot resolve the band), non-finite input, R^2 or
+// beta^2 beyond 1e12 => that problem runs the FP64 kernel body instead (tim_wave_fp64), chosen per
+// problem on the device; n > 65536 (16-bit worklist indices) => the host launches tim_graph_kernel<0>.
 // ==========================================================================================
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
