@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -66,6 +67,28 @@ struct DevBuf {
   }
 };
 
+// page-locked host memory: an async D2H into pageable memory blocks the host until the stream has
+// drained, which would serialise the lanes of a pipelined batch
+struct PinnedBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+    const size_t want = bytes + bytes / 2 + 256;
+    hipError_t e = hipHostMalloc(&p, want, hipHostMallocDefault);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
 enum Stage { ST_H2D = 0, ST_TIM, ST_DEG, ST_HEU, ST_PEEL, ST_EXACT, ST_ROT, ST_TRANS, ST_D2H, ST_COLOUR, ST_TIMAUX, ST_COUNT };
 
 }  // namespace
@@ -106,6 +129,25 @@ struct teaser_hip_solver {
   DevBuf x_order, x_src, x_dst, x_bitmap, x_desc, x_state, x_ctrl, x_clique, x_arena;
   // stand-alone stages
   DevBuf s_a, s_b, s_c, s_d, s_e;
+
+  PinnedBuf pin_states;  // D2H landing zone of the problem states
+  PinnedBuf pin_in;      // H2D staging of the problem descriptors / initial states
+
+  // ---- state carried from the enqueue half of a solve to its finish half -----------------
+  struct Pending {
+    const double* d_src = nullptr;
+    const double* d_dst = nullptr;
+    int batch = 0, mode = 0;
+    bool need_graph = false;
+    int64_t total_n = 0, tls_stride = 0;
+  } pend;
+  // ---- pipelined batches: lanes = child handles, one HIP stream each (see solve_pipelined) ----
+  std::vector<teaser_hip_solver*> lanes;
+  std::vector<std::pair<int, int>> route;  // problem -> (lane, index inside the lane); empty: not piped
+  hipEvent_t k1_done = nullptr;            // recorded after this handle's K1 kernel
+  hipEvent_t wait_before_k1 = nullptr;     // the previous lane's k1_done (staggers the K1 kernels)
+  int pipeline_chunks = 1;                 // lanes of a pipelined batch (TEASER_HIP_PIPELINE); 1 = off
+  bool is_lane = false;
 };
 
 namespace {
@@ -155,6 +197,7 @@ void profile_begin(teaser_hip_solver* h) {
 
 void profile_end(teaser_hip_solver* h) {
   if (!h->profiling) return;
+  if (!h->route.empty()) return;  // pipelined batch: h->prof already holds the sum over the lanes
   (void)hipStreamSynchronize(h->stream);  // the last span may still be in flight
   float* slot[ST_COUNT] = {&h->prof.h2d_ms,  &h->prof.tim_graph_ms, &h->prof.degree_ms,
                            &h->prof.heuristic_ms, &h->prof.peel_ms, &h->prof.exact_ms,
@@ -483,9 +526,37 @@ int32_t close_clique_bounds(teaser_hip_solver* h, int batch, int64_t total_n, bo
 // --------------------------------------------------------------------------------------------
 // the batched pipeline; inputs are device-resident and packed
 // --------------------------------------------------------------------------------------------
-int32_t solve_packed_impl(teaser_hip_solver* h, const double* d_src, const double* d_dst,
-                          const int64_t* pt_off, const int32_t* n, int batch,
-                          teaser_solution_c* out, bool fp64_k1, bool* k1_overflow) {
+// rotation + translation estimators on the current cliques, then the async copy-back of the
+// problem states (no host sync here)
+int32_t enqueue_estimators(teaser_hip_solver* h) {
+  hipStream_t s = h->stream;
+  const int batch = h->pend.batch;
+  const ProbDesc* dd = h->d_desc.as<ProbDesc>();
+  ProbState* ds = h->d_state.as<ProbState>();
+  const EstParams ep = est_params(h->params);
+  {
+    StageScope sc(h, ST_ROT);
+    launch_gnc_tls(s, dd, batch, h->pend.d_src, h->pend.d_dst, h->d_clique.as<int32_t>(), ds, ep,
+                   h->d_weights.as<double>(), h->d_rot_inl.as<int32_t>(), h->d_tim_off.as<int64_t>());
+  }
+  {
+    StageScope sc(h, ST_TRANS);
+    launch_tls_translation(s, dd, batch, h->pend.d_src, h->pend.d_dst, h->d_clique.as<int32_t>(), ds, ep,
+                           h->d_tls_scratch.as<char>(), h->pend.tls_stride, h->d_trans_inl.as<int32_t>());
+  }
+  HIPCHK(h, hipGetLastError());
+  {
+    StageScope sc(h, ST_D2H);
+    HIPCHK(h, h->pin_states.ensure(sizeof(ProbState) * (size_t)batch));
+    HIPCHK(h, hipMemcpyAsync(h->pin_states.p, h->d_state.p, sizeof(ProbState) * (size_t)batch,
+                             hipMemcpyDeviceToHost, s));
+  }
+  return TEASER_HIP_OK;
+}
+
+// First half of a solve: everything that can be enqueued without a host sync.
+int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const double* d_dst,
+                             const int64_t* pt_off, const int32_t* n, int batch, bool fp64_k1) {
   hipStream_t s = h->stream;
   const teaser_params_c& P = h->params;
   if (!params_supported(P)) {
@@ -570,17 +641,22 @@ int32_t solve_packed_impl(teaser_hip_solver* h, const double* d_src, const doubl
   }
   {
     StageScope sc(h, ST_H2D);
-    HIPCHK(h, hipMemcpyAsync(h->d_desc.p, h->descs.data(), sizeof(ProbDesc) * (size_t)batch,
-                             hipMemcpyHostToDevice, s));
-    HIPCHK(h, hipMemcpyAsync(h->d_state.p, h->states.data(), sizeof(ProbState) * (size_t)batch,
-                             hipMemcpyHostToDevice, s));
-    HIPCHK(h, hipMemcpyAsync(h->d_tim_off.p, h->tim_off.data(), 8 * (size_t)batch,
-                             hipMemcpyHostToDevice, s));
+    // staged through page-locked memory: an async H2D from pageable memory blocks the host until the
+    // copy has completed (tens of microseconds each while the GPU is busy with the other lanes)
+    const size_t b_desc = sizeof(ProbDesc) * (size_t)batch, b_state = sizeof(ProbState) * (size_t)batch,
+                 b_off = 8 * (size_t)batch;
+    HIPCHK(h, h->pin_in.ensure(b_desc + b_state + b_off));
+    char* stage = reinterpret_cast<char*>(h->pin_in.p);
+    memcpy(stage, h->descs.data(), b_desc);
+    memcpy(stage + b_desc, h->states.data(), b_state);
+    memcpy(stage + b_desc + b_state, h->tim_off.data(), b_off);
+    HIPCHK(h, hipMemcpyAsync(h->d_desc.p, stage, b_desc, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(h->d_state.p, stage + b_desc, b_state, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(h->d_tim_off.p, stage + b_desc + b_state, b_off, hipMemcpyHostToDevice, s));
     if (need_graph) HIPCHK(h, hipMemsetAsync(h->d_next_count.p, 0, 4 * (size_t)batch, s));
   }
   const ProbDesc* dd = h->d_desc.as<ProbDesc>();
   ProbState* ds = h->d_state.as<ProbState>();
-  const EstParams ep = est_params(P);
 
   if (P.estimate_scaling) {
     StageScope sc(h, ST_TIM);
@@ -597,9 +673,16 @@ int32_t solve_packed_impl(teaser_hip_solver* h, const double* d_src, const doubl
     } else {
       const int64_t cap = tim_work_items(n, batch);
       for (int phase = 0; phase < 3; ++phase) {
-        StageScope sc(h, phase == 1 ? ST_TIM : ST_TIMAUX);
-        launch_tim_graph_mfma(s, phase, dd, batch, max_n, total_n, d_src, d_dst, h->d_pk.p, h->d_prep.p,
-                              h->d_work.p, cap, h->d_bitmap.as<uint64_t>(), ds, P.noise_bound, P.cbar2);
+        // lanes of a pipelined batch run their K1 kernels one after the other (this lane's starts when
+        // the previous lane's has finished), so that a K1 shares the GPU only with the latency-bound
+        // tail stages of the lanes before it
+        if (phase == 1 && h->wait_before_k1) HIPCHK(h, hipStreamWaitEvent(s, h->wait_before_k1, 0));
+        {
+          StageScope sc(h, phase == 1 ? ST_TIM : ST_TIMAUX);
+          launch_tim_graph_mfma(s, phase, dd, batch, max_n, total_n, d_src, d_dst, h->d_pk.p, h->d_prep.p,
+                                h->d_work.p, cap, h->d_bitmap.as<uint64_t>(), ds, P.noise_bound, P.cbar2);
+        }
+        if (phase == 1 && h->k1_done) HIPCHK(h, hipEventRecord(h->k1_done, s));
       }
     }
     for (int b = 0; b < batch; ++b) {
@@ -632,44 +715,37 @@ int32_t solve_packed_impl(teaser_hip_solver* h, const double* d_src, const doubl
   }
   HIPCHK(h, hipGetLastError());
 
-  auto run_estimators = [&]() -> int32_t {
-    {
-      StageScope sc(h, ST_ROT);
-      launch_gnc_tls(s, dd, batch, d_src, d_dst, h->d_clique.as<int32_t>(), ds, ep,
-                     h->d_weights.as<double>(), h->d_rot_inl.as<int32_t>(),
-                     h->d_tim_off.as<int64_t>());
-    }
-    {
-      StageScope sc(h, ST_TRANS);
-      launch_tls_translation(s, dd, batch, d_src, d_dst, h->d_clique.as<int32_t>(), ds, ep,
-                             h->d_tls_scratch.as<char>(), tls_stride, h->d_trans_inl.as<int32_t>());
-    }
-    HIPCHK(h, hipGetLastError());
-    {
-      StageScope sc(h, ST_D2H);
-      HIPCHK(h, hipMemcpyAsync(h->states.data(), h->d_state.p, sizeof(ProbState) * (size_t)batch,
-                               hipMemcpyDeviceToHost, s));
-    }
-    HIPCHK(h, hipStreamSynchronize(s));
-    return TEASER_HIP_OK;
-  };
+  h->pend.d_src = d_src;
+  h->pend.d_dst = d_dst;
+  h->pend.batch = batch;
+  h->pend.mode = mode;
+  h->pend.need_graph = need_graph;
+  h->pend.total_n = total_n;
+  h->pend.tls_stride = tls_stride;
   // speculative: the greedy clique is almost always the maximum one, so the estimators are
   // enqueued before the host learns whether the peel closed the bound (one sync per solve)
-  int32_t rc = run_estimators();
-  if (rc != TEASER_HIP_OK) return rc;
+  return enqueue_estimators(h);
+}
 
+// Second half of a solve: the ONE host sync, then the (rare) bound-closing work and the outputs.
+int32_t solve_packed_finish(teaser_hip_solver* h, teaser_solution_c* out, bool* k1_overflow) {
+  const int batch = h->pend.batch;
+  HIPCHK(h, hipStreamSynchronize(h->stream));
+  memcpy(h->states.data(), h->pin_states.p, sizeof(ProbState) * (size_t)batch);
   *k1_overflow = false;
   for (int b = 0; b < batch; ++b)
     if (h->states[(size_t)b].k1_overflow) *k1_overflow = true;
   if (*k1_overflow) return TEASER_HIP_OK;  // the caller reruns the batch with the FP64 K1
   for (int b = 0; b < batch; ++b) h->heu_size[(size_t)b] = h->states[(size_t)b].lb;
-  if (need_graph && mode == TEASER_INLIER_PMC_EXACT) {
+  if (h->pend.need_graph && h->pend.mode == TEASER_INLIER_PMC_EXACT) {
     bool changed = false;
-    rc = close_clique_bounds(h, batch, total_n, /*from_points=*/true, &changed);
+    int32_t rc = close_clique_bounds(h, batch, h->pend.total_n, /*from_points=*/true, &changed);
     if (rc != TEASER_HIP_OK) return rc;
     if (changed) {
-      rc = run_estimators();
+      rc = enqueue_estimators(h);
       if (rc != TEASER_HIP_OK) return rc;
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      memcpy(h->states.data(), h->pin_states.p, sizeof(ProbState) * (size_t)batch);
     }
   }
 
@@ -702,10 +778,100 @@ int32_t solve_packed_impl(teaser_hip_solver* h, const double* d_src, const doubl
   return TEASER_HIP_OK;
 }
 
+int32_t solve_packed_impl(teaser_hip_solver* h, const double* d_src, const double* d_dst,
+                          const int64_t* pt_off, const int32_t* n, int batch,
+                          teaser_solution_c* out, bool fp64_k1, bool* k1_overflow) {
+  const int32_t rc = solve_packed_enqueue(h, d_src, d_dst, pt_off, n, batch, fp64_k1);
+  if (rc != TEASER_HIP_OK) return rc;
+  return solve_packed_finish(h, out, k1_overflow);
+}
+
+int32_t make_lane(teaser_hip_solver* h, teaser_hip_solver** out);
+
+// EXPERIMENTAL, off by default (TEASER_HIP_PIPELINE=<lanes> enables it).  Measured on one MI355X at
+// 64 x N=10k: 2 lanes 2.68 ms/step (= unpipelined), 4 lanes 3.2 ms: one host thread needs ~0.3 ms to
+// enqueue a lane (~45 API calls), the K1 kernels slow down by ~15 % when they share the GPU with the
+// tails, and the runtime maps the lanes' streams onto two hardware queues (lanes sharing a queue
+// serialise).  Feeding independent handles from several host threads (bench.py --streams) does pay
+// (+26 % at 3); the enqueue/finish split below is the base for doing that inside the library.
+//
+// Pipelined batch: the problems are cut into contiguous chunks, each solved by a LANE (a child
+// handle with its own HIP stream and arenas).  All lanes are enqueued before the first host sync;
+// a lane's K1 kernel waits for the previous lane's (hipStreamWaitEvent), so the GPU runs
+//   K1(0) | K1(1) + tail(0) | K1(2) + tail(1) | ... | tail(last)
+// where tail = fix-up, degrees, greedy clique, peel, GNC, TLS: one workgroup per problem, far from
+// filling 256 CUs on their own.  Results and getters are identical to the unpipelined path (every
+// problem is solved by exactly the same kernels; only the co-scheduling differs).
+int32_t solve_pipelined(teaser_hip_solver* h, const double* d_src, const double* d_dst,
+                        const int64_t* pt_off, const int32_t* n, int batch, int chunks,
+                        teaser_solution_c* out) {
+  while ((int)h->lanes.size() < chunks) {
+    teaser_hip_solver* lane = nullptr;
+    const int32_t rc = make_lane(h, &lane);
+    if (rc != TEASER_HIP_OK) return rc;
+    h->lanes.push_back(lane);
+  }
+  h->route.assign((size_t)batch, std::make_pair(0, 0));
+  std::vector<int> lo((size_t)chunks + 1, 0);
+  for (int c = 0; c < chunks; ++c) lo[(size_t)c + 1] = (int)((int64_t)batch * (c + 1) / chunks);
+  int32_t rc = TEASER_HIP_OK;
+  int enq = 0;
+  for (int c = 0; c < chunks && rc == TEASER_HIP_OK; ++c) {
+    teaser_hip_solver* lane = h->lanes[(size_t)c];
+    lane->params = h->params;
+    lane->profiling = h->profiling;
+    lane->wait_before_k1 = c > 0 ? h->lanes[(size_t)c - 1]->k1_done : nullptr;
+    profile_begin(lane);
+    const int b0 = lo[(size_t)c], nb = lo[(size_t)c + 1] - b0;
+    for (int b = 0; b < nb; ++b) h->route[(size_t)(b0 + b)] = std::make_pair(c, b);
+    rc = solve_packed_enqueue(lane, d_src, d_dst, pt_off + b0, n + b0, nb, false);
+    if (rc != TEASER_HIP_OK) h->err = lane->err;
+    ++enq;
+  }
+  for (int c = 0; c < enq; ++c) {  // every enqueued lane is drained, also after an error
+    teaser_hip_solver* lane = h->lanes[(size_t)c];
+    const int b0 = lo[(size_t)c], nb = lo[(size_t)c + 1] - b0;
+    bool overflow = false;
+    int32_t r2 = (rc == TEASER_HIP_OK) ? solve_packed_finish(lane, out + b0, &overflow)
+                                       : (int32_t)(hipStreamSynchronize(lane->stream) == hipSuccess
+                                                       ? TEASER_HIP_OK : TEASER_HIP_ERR_HIP);
+    if (r2 == TEASER_HIP_OK && rc == TEASER_HIP_OK && overflow) {
+      lane->wait_before_k1 = nullptr;  // K1 fix-up list overflowed: this chunk again, all-FP64 K1
+      r2 = solve_packed_impl(lane, d_src, d_dst, pt_off + b0, n + b0, nb, out + b0, true, &overflow);
+    }
+    if (r2 != TEASER_HIP_OK && rc == TEASER_HIP_OK) {
+      rc = r2;
+      h->err = lane->err;
+    }
+    profile_end(lane);
+  }
+  // the parent's profile is the sum over the lanes (K1 launches = chunks)
+  memset(&h->prof, 0, sizeof(h->prof));
+  for (int c = 0; c < enq; ++c) {
+    const teaser_profile_c& q = h->lanes[(size_t)c]->prof;
+    h->prof.h2d_ms += q.h2d_ms; h->prof.tim_graph_ms += q.tim_graph_ms;
+    h->prof.tim_graph_launches += q.tim_graph_launches; h->prof.degree_ms += q.degree_ms;
+    h->prof.heuristic_ms += q.heuristic_ms; h->prof.peel_ms += q.peel_ms; h->prof.exact_ms += q.exact_ms;
+    h->prof.rotation_ms += q.rotation_ms; h->prof.translation_ms += q.translation_ms;
+    h->prof.d2h_ms += q.d2h_ms; h->prof.total_ms += q.total_ms;
+    h->prof.tim_graph_pairs += q.tim_graph_pairs; h->prof.tim_graph_bytes += q.tim_graph_bytes;
+    h->prof.colour_ms += q.colour_ms; h->prof.tim_aux_ms += q.tim_aux_ms;
+  }
+  h->batch = batch;
+  h->have_graph = true;
+  return rc;
+}
+
 // K1 runs as the matrix-core filter; if its FP64 fix-up list overflowed (adversarial geometry) the
 // whole batch is solved again with the all-FP64 K1 -- same results, slower.
 int32_t solve_packed(teaser_hip_solver* h, const double* d_src, const double* d_dst,
                      const int64_t* pt_off, const int32_t* n, int batch, teaser_solution_c* out) {
+  h->route.clear();
+  // batches of >= 16 problems are pipelined over up to pipeline_chunks lanes (>= 8 problems each)
+  const int chunks = std::min(h->pipeline_chunks, batch / 8);
+  if (!h->is_lane && chunks >= 2 && effective_mode(h->params) != TEASER_INLIER_NONE &&
+      !h->params.estimate_scaling && params_supported(h->params))
+    return solve_pipelined(h, d_src, d_dst, pt_off, n, batch, chunks, out);
   bool overflow = false;
   int32_t rc = solve_packed_impl(h, d_src, d_dst, pt_off, n, batch, out, false, &overflow);
   if (rc == TEASER_HIP_OK && overflow)
@@ -735,6 +901,7 @@ int32_t upload_and_solve(teaser_hip_solver* h, const double* const* src, const d
                                hipMemcpyHostToDevice, h->stream));
     }
   }
+  if (batch >= 16) HIPCHK(h, hipStreamSynchronize(h->stream));  // lanes read the inputs on other streams
   int32_t rc = solve_packed(h, h->d_src.as<double>(), h->d_dst.as<double>(), off.data(), n, batch, out);
   profile_end(h);
   return rc;
@@ -751,7 +918,54 @@ int32_t copy_out(teaser_hip_solver* h, const T* d_ptr, int64_t count, T* buf, in
   return TEASER_HIP_OK;
 }
 
+int32_t make_lane(teaser_hip_solver* h, teaser_hip_solver** out) {
+  teaser_hip_solver* lane = new teaser_hip_solver();
+  lane->device = h->device;
+  lane->params = h->params;
+  lane->is_lane = true;
+  lane->pipeline_chunks = 1;
+  memset(&lane->prof, 0, sizeof(lane->prof));
+  if (hipStreamCreateWithFlags(&lane->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&lane->k1_done, hipEventDisableTiming) != hipSuccess) {
+    if (lane->stream) (void)hipStreamDestroy(lane->stream);
+    delete lane;
+    h->err = "could not create a pipeline lane (stream / event)";
+    return TEASER_HIP_ERR_HIP;
+  }
+  *out = lane;
+  return TEASER_HIP_OK;
+}
+
+void release_handle_resources(teaser_hip_solver* h) {
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  DevBuf* bufs[] = {&h->d_desc, &h->d_state, &h->d_src, &h->d_dst, &h->d_bitmap, &h->d_deg,
+                    &h->d_clique, &h->d_start_cliques, &h->d_alive_a, &h->d_alive_b,
+                    &h->d_next_count, &h->d_weights, &h->d_rot_inl, &h->d_trans_inl,
+                    &h->d_tls_scratch, &h->d_tim_off, &h->d_pk, &h->d_prep, &h->d_work, &h->x_order,
+                    &h->x_src, &h->x_dst, &h->x_bitmap, &h->x_desc, &h->x_state, &h->x_ctrl,
+                    &h->x_clique, &h->x_arena, &h->c_sel, &h->c_colour, &h->c_tent, &h->c_xlist,
+                    &h->s_a, &h->s_b, &h->s_c, &h->s_d, &h->s_e};
+  for (DevBuf* b : bufs) b->release();
+  h->pin_states.release();
+  h->pin_in.release();
+  for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+  h->ev_pool.clear();
+  if (h->k1_done) (void)hipEventDestroy(h->k1_done);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  h->k1_done = nullptr;
+  h->stream = nullptr;
+}
+
+// problem index of the caller -> the handle that solved it (a lane of a pipelined batch, or h itself)
+teaser_hip_solver* route_problem(teaser_hip_solver* h, int32_t* problem) {
+  if (h->route.empty() || *problem < 0 || *problem >= (int32_t)h->route.size()) return h;
+  const std::pair<int, int> r = h->route[(size_t)*problem];
+  *problem = r.second;
+  return h->lanes[(size_t)r.first];
+}
+
 }  // namespace
+
 
 // ================================================================================================
 // C ABI
@@ -807,6 +1021,10 @@ int32_t teaser_hip_solver_create(const teaser_params_c* params, int32_t device,
     delete h;
     return TEASER_HIP_ERR_HIP;
   }
+  if (const char* e = getenv("TEASER_HIP_PIPELINE")) {  // lanes of a pipelined batch; 1 = off
+    const int v = atoi(e);
+    if (v >= 1 && v <= 16) h->pipeline_chunks = v;
+  }
   *out = h;
   return TEASER_HIP_OK;
 }
@@ -814,17 +1032,12 @@ int32_t teaser_hip_solver_create(const teaser_params_c* params, int32_t device,
 int32_t teaser_hip_solver_destroy(teaser_hip_solver* h) {
   if (!h) return TEASER_HIP_OK;
   (void)hipSetDevice(h->device);
-  if (h->stream) (void)hipStreamSynchronize(h->stream);
-  DevBuf* bufs[] = {&h->d_desc, &h->d_state, &h->d_src, &h->d_dst, &h->d_bitmap, &h->d_deg,
-                    &h->d_clique, &h->d_start_cliques, &h->d_alive_a, &h->d_alive_b,
-                    &h->d_next_count, &h->d_weights, &h->d_rot_inl, &h->d_trans_inl,
-                    &h->d_tls_scratch, &h->d_tim_off, &h->d_pk, &h->d_prep, &h->d_work, &h->x_order, &h->x_src, &h->x_dst,
-                    &h->x_bitmap, &h->x_desc, &h->x_state, &h->x_ctrl, &h->x_clique, &h->x_arena,
-                    &h->c_sel, &h->c_colour, &h->c_tent, &h->c_xlist,
-                    &h->s_a, &h->s_b, &h->s_c, &h->s_d, &h->s_e};
-  for (DevBuf* b : bufs) b->release();
-  for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
-  if (h->stream) (void)hipStreamDestroy(h->stream);
+  for (teaser_hip_solver* lane : h->lanes) {
+    release_handle_resources(lane);
+    delete lane;
+  }
+  h->lanes.clear();
+  release_handle_resources(h);
   delete h;
   return TEASER_HIP_OK;
 }
@@ -834,6 +1047,7 @@ int32_t teaser_hip_solver_reset(teaser_hip_solver* h, const teaser_params_c* par
   h->params = *params;
   h->batch = 0;  // reset() clears max_clique_/inliers/graph, registration.h:881-885
   h->have_graph = false;
+  h->route.clear();
   return TEASER_HIP_OK;
 }
 
@@ -904,9 +1118,11 @@ int32_t teaser_hip_solve_batch_device(teaser_hip_solver* h, const double* d_src,
   return rc;
 }
 
-#define CHECK_PROBLEM(h, problem)                                            \
+// validates the index, then redirects (h, problem) to the lane that solved it (pipelined batches)
+#define CHECK_PROBLEM(h, problem)                                                      \
   if (!(h) || (problem) < 0 || (problem) >= (h)->batch) return TEASER_HIP_ERR_BAD_ARG; \
-  (void)hipSetDevice((h)->device)
+  (void)hipSetDevice((h)->device);                                                     \
+  (h) = route_problem((h), &(problem))
 
 int32_t teaser_hip_get_max_clique(teaser_hip_solver* h, int32_t problem, int32_t* buf, int64_t* len) {
   CHECK_PROBLEM(h, problem);
