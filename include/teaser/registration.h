@@ -177,6 +177,31 @@ class RobustRegistrationSolver {
     return adopt(o);
   }
 
+  // Stage entry points (registration.h:593-601): 3 x K TIMs / points -> the stage's estimate; the
+  // result is also stored in the solution, like the reference does.
+  Matrix3 solveForRotation(const Matrix3X& v1, const Matrix3X& v2) {
+    if (v1.cols() != v2.cols()) throw std::invalid_argument("solveForRotation: sizes differ");
+    double R[9], cost = 0;
+    int32_t iters = 0;
+    stage_mask_.assign((size_t)v1.cols(), 0);
+    check(teaser_hip_solve_for_rotation(h_, v1.data(), v2.data(), (int32_t)v1.cols(), params_.noise_bound, R,
+                                        stage_mask_.data(), &cost, &iters));
+    raw_.gnc_cost = cost;
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) solution_.rotation(r, c) = R[3 * r + c];
+    return solution_.rotation;
+  }
+  Vector3 solveForTranslation(const Matrix3X& v1, const Matrix3X& v2) {
+    if (v1.cols() != v2.cols()) throw std::invalid_argument("solveForTranslation: sizes differ");
+    double t[3];
+    stage_mask_.assign((size_t)v1.cols(), 0);
+    check(teaser_hip_solve_for_translation(h_, v1.data(), v2.data(), (int32_t)v1.cols(), t, stage_mask_.data()));
+    for (int r = 0; r < 3; ++r) solution_.translation(r) = t[r];
+    return solution_.translation;
+  }
+  // inlier mask of the last stage call above (one entry per column)
+  std::vector<bool> getStageInliersMask() const { return std::vector<bool>(stage_mask_.begin(), stage_mask_.end()); }
+
   RegistrationSolution getSolution() { return solution_; }                              // :617
   double getGNCRotationCostAtTermination() { return raw_.gnc_cost; }                    // :609-611
   std::vector<int> getInlierMaxClique() { return list(teaser_hip_get_max_clique); }     // :770
@@ -290,6 +315,7 @@ class RobustRegistrationSolver {
   RegistrationSolution solution_;
   teaser_solution_c raw_{};
   bool have_solution_ = false;
+  std::vector<uint8_t> stage_mask_;
 };
 
 }  // namespace teaser

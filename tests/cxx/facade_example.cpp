@@ -46,6 +46,20 @@ int main() {
     for (int v : clique) hit += inl[(size_t)v];
     std::printf("valid %d  |R-R*|_F %.3e  |t-t*| %.3e  clique %zu (planted %zu, hit %zu)  trans inliers %zu\n",
                 (int)solution.valid, std::sqrt(dR), std::sqrt(dt), clique.size(), planted, hit, tin.size());
+    // stage entry point (registration.h:593): rotation-only problem, dst = R* src exactly
+    teaser::Matrix3X V1(3, 200), V2(3, 200);
+    for (int i = 0; i < 200; ++i)
+      for (int r = 0; r < 3; ++r) V1(r, i) = S(r, i) - S(r, 0);
+    for (int i = 0; i < 200; ++i)
+      for (int r = 0; r < 3; ++r)
+        V2(r, i) = Rt[(size_t)(3 * r)] * V1(0, i) + Rt[(size_t)(3 * r + 1)] * V1(1, i) +
+                   Rt[(size_t)(3 * r + 2)] * V1(2, i);
+    const auto Rs = solver.solveForRotation(V1, V2);
+    double dRs = 0;
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) dRs += std::pow(Rs(r, c) - Rt[(size_t)(3 * r + c)], 2);
+    std::printf("solveForRotation |R-R*|_F %.3e\n", std::sqrt(dRs));
+    if (std::sqrt(dRs) > 1e-6) return 1;
     // second solve on the same object (the reference object is single-use; this one is not)
     solver.solve(S, D);
     const bool ok = solution.valid && std::sqrt(dR) < 0.02 && std::sqrt(dt) < 0.02 && hit >= planted &&
