@@ -867,6 +867,10 @@ int32_t solve_pipelined(teaser_hip_solver* h, const double* d_src, const double*
 int32_t solve_packed(teaser_hip_solver* h, const double* d_src, const double* d_dst,
                      const int64_t* pt_off, const int32_t* n, int batch, teaser_solution_c* out) {
   h->route.clear();
+  if (batch > 65535) {  // problems are indexed by blockIdx.y
+    h->err = "a batch holds at most 65535 problems; split larger batches across calls";
+    return TEASER_HIP_ERR_UNSUPPORTED;
+  }
   // batches of >= 16 problems are pipelined over up to pipeline_chunks lanes (>= 8 problems each)
   const int chunks = std::min(h->pipeline_chunks, batch / 8);
   if (!h->is_lane && chunks >= 2 && effective_mode(h->params) != TEASER_INLIER_NONE &&
