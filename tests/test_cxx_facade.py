@@ -37,3 +37,47 @@ def test_facade_solves_on_gpu():
     exe = build_example()
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+# --- examples/teaser_hip_ply.cpp: the reference's teaser_cpp_ply workflow through the facade ---------
+EX_SRC = os.path.join(ROOT, "examples", "teaser_hip_ply.cpp")
+EX_EXE = os.path.join(ROOT, "tests", "cxx", "teaser_hip_ply")
+
+
+def build_ply_example():
+    if not os.path.exists(os.path.join(LIBDIR, "libteaser_hip.so")):
+        pytest.skip("libteaser_hip.so not built (run __graft_entry__.build())")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           EX_SRC, "-o", EX_EXE, "-L" + LIBDIR, "-lteaser_hip", "-Wl,-rpath," + LIBDIR,
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    return EX_EXE
+
+
+def bunny_ply(path):
+    """The reference's example cloud (golden `bunny` = examples/example_data/bun_zipper_res3.ply)."""
+    import numpy as np
+    from util import golden
+    pts = golden()["bunny"].astype(np.float32)
+    with open(path, "w") as f:
+        f.write("ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
+                "end_header\n" % len(pts))
+        for p in pts:
+            f.write(" ".join(repr(float(v)) for v in p) + "\n")
+    return path
+
+
+def test_ply_example_builds_and_fails_loudly_without_gpu(tmp_path):
+    exe = build_ply_example()
+    rc = subprocess.call([exe, bunny_ply(str(tmp_path / "bunny.ply"))], stdout=subprocess.DEVNULL)
+    import importlib
+    tp = importlib.import_module("teaser-plusplus_amd")
+    assert rc == (0 if tp.device_count() > 0 else 77)
+    assert subprocess.call([exe, str(tmp_path / "missing.ply")], stdout=subprocess.DEVNULL) == 2
+
+
+@pytest.mark.gpu
+def test_ply_example_registers_the_bunny(tmp_path):
+    """BASELINE config 1 through the C++ facade: Bunny, 1889 correspondences, 1700 outlier draws."""
+    exe = build_ply_example()
+    out = subprocess.run([exe, bunny_ply(str(tmp_path / "bunny.ply"))], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
