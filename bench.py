@@ -60,7 +60,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=1,
                     help="solver handles (one HIP stream each) fed from as many host threads: consecutive "
                          "steps overlap, so one batch's latency-bound stages (clique, GNC, TLS: one "
-                         "workgroup per problem) run beside the next batch's K1 (+18 % at 2, +26 % at 3 on "
+                         "workgroup per problem) run beside the next batch's K1 (+18 %% at 2, +26 %% at 3 on "
                          "one MI355X).  Default 1: per-kernel HIP-event / rocprofv3 durations -- the roofline "
                          "object -- are only meaningful when kernels of different steps do not share the GPU")
     return ap.parse_args()

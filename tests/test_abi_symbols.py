@@ -52,3 +52,15 @@ def test_product_does_not_import_the_oracle():
                                  r"libteaser_oracle|dlopen[^\n]*oracle", txt, flags=re.M):
                         bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_bench_cli_parses_without_gpu():
+    """bench.py --help must work (argparse help strings) and, without a GPU, the run must stop with the
+    explicit no-device message rather than a traceback from deep inside."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True)
+    assert r.returncode == 0 and "--streams" in r.stdout and "--batch" in r.stdout
+    if tp.device_count() == 0:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")], capture_output=True, text=True)
+        assert r.returncode != 0 and "needs an MI355X" in (r.stderr + r.stdout)
