@@ -64,3 +64,22 @@ def test_bench_cli_parses_without_gpu():
     if tp.device_count() == 0:
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")], capture_output=True, text=True)
         assert r.returncode != 0 and "needs an MI355X" in (r.stderr + r.stdout)
+
+
+def test_bench_roofline_object():
+    """The roofline arithmetic of bench.py on the r1g numbers (64 x N=10k per launch, 1.414 ms)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    pairs = 64 * 10000 * 9999 // 2
+    byts = 64 * (48 * 10000 + 8 * 10000 * 157)
+    r = bench.roofline_object(k1_ms=20 * 1.414, k1_launches=20, k1_bytes=20 * byts, k1_pairs=20 * pairs,
+                              k1_aux_ms=20 * 0.15, traffic=2.5e9, traffic_src="profiles/x")
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 78.6
+    assert abs(r["avg_launch_ms"] - 1.414) < 1e-9 and r["launches"] == 20
+    assert abs(r["achieved"] - 20 * pairs / 1.414e-3 / 1e12) < 1e-6 and abs(r["frac"] - r["achieved"] / 78.6) < 1e-12
+    assert abs(r["executed_mfma"]["achieved"] - 128 * pairs / 1.414e-3 / 1e12) < 1e-6
+    assert abs(r["hbm"]["achieved"] - byts / 1.414e-3 / 1e9) < 1e-6 and r["traffic"] == 2.5e9
+    z = bench.roofline_object(0.0, 0, 0, 0, 0.0, None, None)  # no launches: no division by zero
+    assert z["achieved"] == 0.0 and z["traffic"] is None
