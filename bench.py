@@ -1,30 +1,42 @@
 #!/usr/bin/env python3
 """bench.py -- registrations/sec of the MI355X-native TEASER++ solve() hot path.
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: the script re-launches ITSELF as N ranks (one process per GPU) under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`; when it is
+already running under torch.distributed.run (RANK / WORLD_SIZE set) it uses those ranks.
 
 Workload (BASELINE.json configs[1], the configuration the metric is quoted on): synthetic
 N = 10 000 correspondences, 95 % outliers, noise_bound 0.01, estimate_scaling = false, GNC-TLS
 (SURVEY.md 8(d)).  One STEP = one batched pass of the whole hot path (TIM build + pruning ->
 adjacency bitmap -> max clique -> GNC-TLS rotation -> TLS translation) over `--batch` independent
-problems whose point arrays are already resident in HBM; every step sees different problems
-(a pool of seeded problems is cycled).  Multi-GPU: problems are independent, so each rank owns
-its own problems (weak scaling, no data-path collective); the fixed-size result records are
-all-gathered over RCCL at the end, inside the timed region.
+problems; EVERY step sees problems it has not seen before (steps + warmup distinct seeded batches).
+`value` is measured with the point arrays already resident in HBM when the timed region starts (the
+bench contract); the same loop fed from page-locked HOST memory, H2D inside the timer (SURVEY.md
+8(d)'s timer scope), is reported next to it as config.host_resident.  Steps are submitted through
+the library's asynchronous batch API (teaser_hip_submit_batch / teaser_hip_wait, `--depth` batches in
+flight from ONE host thread), which is how a throughput caller drives it: the host enqueues batch
+k+1 while the GPU runs batch k.  Multi-GPU: problems are independent, so each rank owns its own
+problems (weak scaling, no data-path collective); the fixed-size result records are all-gathered over
+RCCL at the end, inside the timed region.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- K1 (tim_graph_mfma_kernel, the dominant kernel), from HIP events recorded on the
-                  solver's stream around that kernel alone during the timed region: algorithmic
+  roofline     -- K1 (tim_graph_mfma_kernel, the dominant kernel), from HIP events recorded around
+                  that kernel alone on the stream it runs on, during the timed region: algorithmic
                   flops (20 FP64 flop per pair) against the dense FP64 peak at the top
                   level; the issued bf16 MFMA work and the HBM view (algorithmic bytes 48 n +
                   8 n ceil(n/64) per problem, PMC traffic) are nested beside it.
   cpu_baseline -- the CPU oracle (a port of the reference path; the reference itself cannot be
-                  built here: no Eigen3 / pmc) timed on a bounded sample of the same workload.
+                  built here: no Eigen3 / pmc) timed on a bounded sample of the same workload, in its
+                  streaming form and in the reference-faithful materialising form.
 """
 import argparse
+import collections
 import importlib
 import json
 import os
+import socket
 import sys
 import time
 
@@ -42,7 +54,7 @@ K1_FLOPS_PER_PAIR = 20.0   # algorithmic FP64 flops of the refer
 K1_MFMA_FLOPS_PER_PAIR = 4 * 2 * 32 * 32 * 16 / 1024.0
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -51,19 +63,24 @@ def parse():
     ap.add_argument("--n", type=int, default=10000)
     ap.add_argument("--outlier-ratio", type=float, default=0.95)
     ap.add_argument("--noise-bound", type=float, default=0.01)
-    ap.add_argument("--pool", type=int, default=4, help="distinct batches cycled through the steps")
+    ap.add_argument("--pool", type=int, default=0,
+                    help="distinct batches (0: steps + warmup, capped at 48: every step sees new problems)")
     ap.add_argument("--seed", type=int, default=20250523)
+    ap.add_argument("--depth", type=int, default=3,
+                    help="batches in flight (teaser_hip_submit_batch / teaser_hip_wait lanes, one HIP stream "
+                         "each, fed from ONE host thread): the host enqueues batch k+1 while the GPU runs batch "
+                         "k, and the latency-bound tail of batch k (clique, GNC, TLS: one workgroup per problem) "
+                         "shares the GPU with batch k+1's K1.  1 = strictly one batch at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-resident", action="store_true",
+                    help="skip the second timed loop fed from page-locked host memory")
     ap.add_argument("--no-latency", action="store_true",
                     help="skip the single-problem latency probe (rocprofv3 runs: keeps every K1 launch the same size)")
     ap.add_argument("--cpu-solves", type=int, default=16)
-    ap.add_argument("--streams", type=int, default=1,
-                    help="solver handles (one HIP stream each) fed from as many host threads: consecutive "
-                         "steps overlap, so one batch's latency-bound stages (clique, GNC, TLS: one "
-                         "workgroup per problem) run beside the next batch's K1 (+18 %% at 2, +26 %% at 3 on "
-                         "one MI355X).  Default 1: per-kernel HIP-event / rocprofv3 durations -- the roofline "
-                         "object -- are only meaningful when kernels of different steps do not share the GPU")
-    return ap.parse_args()
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="testing on a 1-GPU box: ranks beyond the visible devices share them (record gather "
+                         "over gloo, since RCCL refuses two ranks on one device)")
+    return ap.parse_args(argv)
 
 
 def solver_params(tp, nb):
@@ -101,8 +118,8 @@ def roofline_object(k1_ms, k1_launches, k1_bytes, k1_pairs, k1_aux_ms, traffic, 
                 "the kernel alone; peak = dense FP64 peak (matrix = vector = 78.6 TFLOP/s).  The kernel computes "
                 "the same decisions with an exact bf16-split MFMA + f32 filter and an FP64 fix-up, so this is "
                 "speed relative to the algorithm as specified, not issued FP64 work (see executed_mfma); it is "
-                "bound by its packed-f32 VALU epilogue, which on gfx950 does not overlap with the same SIMD's "
-                "MFMA issue (DESIGN.md 3).  aux_ms_per_launch = pre-pass + FP64 fix-up kernels",
+                "bound by its packed-f32 VALU epilogue (DESIGN.md 3).  With --depth > 1 the kernel shares the GPU "
+                "with the latency-bound tail kernels of the previous batch, which is included in its time",
         "executed_mfma": {"achieved": mfma_tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                           "frac": mfma_tf / MFMA_BF16_PEAK_TF,
                           "flops_per_launch": K1_MFMA_FLOPS_PER_PAIR * pairs_per_launch,
@@ -131,36 +148,103 @@ def k1_traffic(batch, n):
 
 
 def cpu_baseline(tp, args):
-    """Oracle (kind = port) on a bounded sample of the same workload, all host cores."""
+    """Oracle (kind = port: the reference needs Eigen3 + pmc, absent here) on a bounded sample of the
+    same workload, all host cores, built gcc -O3 -fopenmp without -march=native (the reference's
+    default flags, CMakeLists.txt:27).  Two forms, SURVEY.md 8(d): (i) STREAMING -- no TIM storage,
+    adjacency bitmap: the faster one, reported as `value`; (ii) REFERENCE-FAITHFUL -- materialises both
+    3 x M TIM matrices, index maps, norm vectors and the bool mask and builds the vector-of-vectors graph
+    with the duplicate-edge scan, as registration.cc:512-551, 427-443, 614-619 do."""
     from oracle import oracle
 
     cores = os.cpu_count() or 1
-    times = []
-    t_all = time.perf_counter()
-    for i in range(args.cpu_solves):
-        pr = tp.synth_problem(args.seed + 100000 + i, args.n, args.outlier_ratio, args.noise_bound)
-        t0 = time.perf_counter()
-        o = oracle.solve(pr["src"], pr["dst"], noise_bound=args.noise_bound, cbar2=1.0,
-                         estimate_scaling=0, rotation_gnc_factor=1.4, rotation_max_iterations=100,
-                         rotation_cost_threshold=0.005, max_clique_num_threads=cores)
-        times.append(time.perf_counter() - t0)
-        assert o["valid"]
-        if time.perf_counter() - t_all > 25.0:
-            break
-    med = float(np.median(times))
-    return {"value": 1.0 / med, "unit": "registrations/s", "cores": cores, "kind": "port",
-            "sample": "%d solves of the bench workload (N=%d, %.0f%% outliers), median %.1f ms each, "
-                      "oracle built gcc -O2 -fopenmp without -march=native, OMP threads = %d"
-                      % (len(times), args.n, 100 * args.outlier_ratio, 1e3 * med, cores)}
+    kw = dict(noise_bound=args.noise_bound, cbar2=1.0, estimate_scaling=0, rotation_gnc_factor=1.4,
+              rotation_max_iterations=100, rotation_cost_threshold=0.005, max_clique_num_threads=cores)
+
+    def run(materialise, max_solves, budget_s):
+        times = []
+        t_all = time.perf_counter()
+        for i in range(max_solves):
+            pr = tp.synth_problem(args.seed + 100000 + i, args.n, args.outlier_ratio, args.noise_bound)
+            t0 = time.perf_counter()
+            o = oracle.solve(pr["src"], pr["dst"], materialise=materialise, **kw)
+            times.append(time.perf_counter() - t0)
+            assert o["valid"]
+            if time.perf_counter() - t_all > budget_s:
+                break
+        return times
+
+    run(False, 1, 0.0)  # warm-up (OpenMP pool, page faults)
+    ts = run(False, args.cpu_solves, 10.0)
+    med = float(np.median(ts))
+    out = {"value": 1.0 / med, "unit": "registrations/s", "cores": cores, "kind": "port",
+           "sample": "%d solves of the bench workload (N=%d, %.0f%% outliers), median %.1f ms each, streaming "
+                     "oracle (no TIM storage), gcc -O3 -fopenmp without -march=native, OMP threads = %d"
+                     % (len(ts), args.n, 100 * args.outlier_ratio, 1e3 * med, cores)}
+    pairs = args.n * (args.n - 1) // 2
+    if pairs * 81 < 24e9:  # the materialised form needs ~81 B per pair of host memory
+        tm = run(True, 2, 8.0)
+        mm = float(np.median(tm))
+        out["reference_faithful"] = {
+            "value": 1.0 / mm, "unit": "registrations/s",
+            "sample": "%d solves, median %.1f ms each, TIMs materialised (~%.1f GB), serial mask and "
+                      "vector-of-vectors graph build as the reference" % (len(tm), 1e3 * mm, pairs * 81 / 1e9)}
+    else:
+        out["reference_faithful"] = {"value": None, "sample": "infeasible: ~%.0f GB of TIM storage" % (pairs * 81 / 1e9)}
+    return out
+
+
+def relaunch_as_ranks(args):
+    """`python bench.py --gpus N` with N > 1 outside torch.distributed.run: start the N ranks ourselves."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    os.execvpe(cmd[0], cmd, env)
+
+
+def make_pool(tp, args, rank, n_batches):
+    """n_batches distinct seeded batches as packed host arrays [B*n, 3] (+ ground truth)."""
+    B, n = args.batch, args.n
+    pool, truth = [], []
+    for k in range(n_batches):
+        src = np.empty((B * n, 3))
+        dst = np.empty((B * n, 3))
+        tr = []
+        for b in range(B):
+            seed = args.seed + ((rank * 4096 + k) * B + b)
+            pr = tp.synth_problem(seed, n, args.outlier_ratio, args.noise_bound)
+            src[b * n:(b + 1) * n] = pr["src"].T
+            dst[b * n:(b + 1) * n] = pr["dst"].T
+            tr.append((pr["R"], pr["t"], int(pr["inliers"].sum())))
+        pool.append((src, dst))
+        truth.append(tr)
+    return pool, truth
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        relaunch_as_ranks(args)  # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch as `python bench.py --gpus N`, or "
+                         "torch.distributed.run --nproc-per-node N bench.py --gpus N)" % (args.gpus, world))
     import torch
 
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no HIP device visible); the product has no CPU path")
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev and not args.share_gpu:
+        raise SystemExit("bench.py: rank %d has no device of its own (%d visible); --share-gpu is for testing "
+                         "the multi-rank path on fewer GPUs" % (local_rank, ndev))
+    dev_index = local_rank % ndev
+    shared = world > ndev
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
@@ -168,42 +252,24 @@ def main():
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no HIP device visible); the product has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if dist is not None:
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if shared:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)
+    gather_dev = torch.device("cpu") if shared else dev
 
     tp = importlib.import_module("teaser-plusplus_amd")
     B, n = args.batch, args.n
-    S = max(1, args.streams)
-    solvers = [tp.RobustRegistrationSolver(solver_params(tp, args.noise_bound), device=local_rank)
-               for _ in range(S)]
-    solver = solvers[0]
+    D = max(1, args.depth)
+    solver = tp.RobustRegistrationSolver(solver_params(tp, args.noise_bound), device=dev_index)
+    solver.set_pipeline_depth(D)
 
-    # problem pool, resident in HBM before the timed region (packed [B*n, 3] doubles per batch)
-    pool = []
-    truth = []
-    for k in range(args.pool):
-        src = np.empty((B * n, 3))
-        dst = np.empty((B * n, 3))
-        tr = []
-        for b in range(B):
-            seed = args.seed + ((rank * args.pool + k) * B + b)
-            pr = tp.synth_problem(seed, n, args.outlier_ratio, args.noise_bound)
-            src[b * n:(b + 1) * n] = pr["src"].T
-            dst[b * n:(b + 1) * n] = pr["dst"].T
-            tr.append((pr["R"], pr["t"], int(pr["inliers"].sum())))
-        pool.append((torch.from_numpy(src).to(dev), torch.from_numpy(dst).to(dev)))
-        truth.append(tr)
+    n_batches = args.pool if args.pool > 0 else min(args.steps + args.warmup + 1, 48)
+    host_pool, truth = make_pool(tp, args, rank, n_batches)
+    # HBM-resident copies (the headline loop) and page-locked host copies (the host-resident loop)
+    pool = [(torch.from_numpy(s).to(dev), torch.from_numpy(d).to(dev)) for s, d in host_pool]
     offsets = np.arange(B, dtype=np.int64) * n
     sizes = np.full(B, n, dtype=np.int32)
-
-    def step(k, sv=None):
-        s_t, d_t = pool[k % args.pool]
-        out = (sv or solver).solve_batch_device(s_t.data_ptr(), d_t.data_ptr(), offsets, sizes)
-        return out
 
     def sync_all():
         torch.cuda.synchronize()
@@ -211,68 +277,82 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for k in range(args.warmup):
-        step(k, solvers[k % S])
-    for sv in solvers[1:]:  # every handle has its arenas sized before the timed region
-        step(0, sv)
-    # correctness guard on the last warm-up batch: the work is not skipped and is right
-    out = step(args.warmup)
+    def run_steps(first, count, buffers, host, acc=None):
+        """`count` steps through the asynchronous batch API, at most D in flight; returns the last outputs."""
+        tickets = collections.deque()
+        last = None
+
+        def retire():
+            nonlocal last
+            last = solver.wait(tickets.popleft())
+            if acc is not None:
+                pf = solver.get_profile()
+                acc["ms"] += pf["tim_graph_ms"]
+                acc["launches"] += pf["tim_graph_launches"]
+                acc["bytes"] += pf["tim_graph_bytes"]
+                acc["pairs"] += pf["tim_graph_pairs"]
+                acc["aux"] += pf["tim_aux_ms"]
+
+        for k in range(first, first + count):
+            if len(tickets) == D:
+                retire()
+            s_t, d_t = buffers[k % len(buffers)]
+            tickets.append(solver.submit_batch(s_t.data_ptr(), d_t.data_ptr(), offsets, sizes, host=host))
+        while tickets:
+            retire()
+        return last
+
+    # warm-up (arenas of every lane sized, kernels loaded), then a correctness guard on a batch the timed
+    # region will not see again: the work is not skipped and is right
+    run_steps(0, max(args.warmup, D), pool, False)
+    k_chk = args.warmup % n_batches
+    out = run_steps(k_chk, 1, pool, False)
     for b in range(B):
-        R, t, n_in = truth[args.warmup % args.pool][b]
+        R, t, n_in = truth[k_chk][b]
         o = out[b]
         # an outlier consistent with every inlier legitimately enlarges the maximum clique
         assert o.valid == 1 and n_in <= o.clique_size <= n_in + 3, (o.valid, o.clique_size, n_in)
         assert np.linalg.norm(np.array(o.rotation[:]).reshape(3, 3) - R) < 0.05
         assert np.linalg.norm(np.array(o.translation[:]) - t) < 0.05
 
-    for sv in solvers:
-        sv.set_profiling(True)  # HIP events around K1 on each solver's stream, inside the timed region
-    import threading
-
-    acc = [dict(ms=0.0, launches=0, bytes=0, pairs=0, aux=0.0, last=None, err=None) for _ in range(S)]
-
-    def worker(t):
-        a = acc[t]
-        try:
-            for k in range(t, args.steps, S):  # steps k = t (mod S) on handle t; ctypes drops the GIL
-                a["last"] = (k, step(k, solvers[t]))
-                pf = solvers[t].get_profile()
-                a["ms"] += pf["tim_graph_ms"]
-                a["launches"] += pf["tim_graph_launches"]
-                a["bytes"] += pf["tim_graph_bytes"]
-                a["pairs"] += pf["tim_graph_pairs"]
-                a["aux"] += pf["tim_aux_ms"]
-        except Exception as e:  # surfaced after the join
-            a["err"] = e
-
+    # ---- timed region: EXACTLY args.steps steps, inputs resident in HBM -------------------------
+    solver.set_profiling(2)  # HIP events around the K1 kernel only (two per step), inside the timed region
+    acc = dict(ms=0.0, launches=0, bytes=0, pairs=0, aux=0.0)
     sync_all()
     t0 = time.perf_counter()
-    threads = [threading.Thread(target=worker, args=(t,)) for t in range(S)]
-    for th in threads:
-        th.start()
-    for th in threads:
-        th.join()
-    for a in acc:
-        if a["err"] is not None:
-            raise a["err"]
-    k1_ms = sum(a["ms"] for a in acc)
-    k1_launches = sum(a["launches"] for a in acc)
-    k1_bytes = sum(a["bytes"] for a in acc)
-    k1_pairs = sum(a["pairs"] for a in acc)
-    k1_aux_ms = sum(a["aux"] for a in acc)
-    last = max((a["last"] for a in acc if a["last"] is not None), key=lambda kv: kv[0])[1]
+    last = run_steps(args.warmup + 1, args.steps, pool, False, acc)
     # final gather of the fixed-size result records (256 B each; RCCL over xGMI when N > 1)
     rec = tp.batched.pack_records([last[b] for b in range(B)], first_index=rank * B)
-    allrec = tp.batched.gather_records(rec, world * B, dist if world > 1 else None, device=dev)
+    allrec = tp.batched.gather_records(rec, world * B, dist if world > 1 else None, device=gather_dev)
     assert allrec.shape[0] == world * B
     sync_all()
     elapsed = time.perf_counter() - t0
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device=gather_dev)
     if dist is not None:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
     elapsed = float(t_max.item())
-    for sv in solvers:
-        sv.set_profiling(False)
+    solver.set_profiling(0)
+
+    # ---- the same loop fed from page-locked HOST memory: H2D inside the timer (SURVEY.md 8(d)) ----
+    host_line = None
+    if not args.no_host_resident:
+        pinned = [(torch.from_numpy(s).pin_memory(), torch.from_numpy(d).pin_memory()) for s, d in host_pool]
+        run_steps(0, D, pinned, True)
+        sync_all()
+        th0 = time.perf_counter()
+        run_steps(args.warmup + 1, args.steps, pinned, True)
+        sync_all()
+        th = time.perf_counter() - th0
+        tt = torch.tensor([th], dtype=torch.float64, device=gather_dev)
+        if dist is not None:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        th = float(tt.item())
+        host_line = {"value": world * B * args.steps / th, "unit": "registrations/s",
+                     "ms_per_step": 1e3 * th / args.steps,
+                     "h2d_bytes_per_step_per_gpu": 48 * B * n,
+                     "note": "same steps, inputs in page-locked host memory, one H2D copy per cloud and step "
+                             "inside the timed region (PCIe-inclusive rate; never `value`)"}
+        del pinned
 
     # single-problem latency (not the headline value; reported for the ms/solve half of the metric)
     lat = []
@@ -298,13 +378,18 @@ def main():
             "config": {"workload": "synthetic N=%d correspondences, %.0f%% outliers, single-MI355X config "
                                    "(BASELINE configs[1]); noise_bound=%g, estimate_scaling=false, GNC-TLS, "
                                    "PMC_EXACT, CHAIN" % (n, 100 * args.outlier_ratio, args.noise_bound),
-                       "problems_per_step_per_gpu": B, "streams": S, "ms_per_registration": 1e3 * elapsed / (args.steps * B),
+                       "problems_per_step_per_gpu": B, "batches_in_flight": D,
+                       "distinct_batches": n_batches,
+                       "ms_per_registration": 1e3 * elapsed / (args.steps * B),
                        "single_problem_latency_ms": lat_ms, "inputs": "resident in HBM",
+                       "host_resident": host_line,
                        "arithmetic": "FP64 estimators and FP64 reference expression for every pruning decision the "
                                      "K1 filter (exact bf16 split on MFMA + f32 epilogue with a rigorous error band) "
                                      "cannot make; bitmap bit-identical to the FP64 oracle",
-                       "parallelism": "independent problems per GPU, RCCL all_gather of result records"},
-            "roofline": roofline_object(k1_ms, k1_launches, k1_bytes, k1_pairs, k1_aux_ms, traffic, traffic_src),
+                       "parallelism": "independent problems per GPU, %s all_gather of result records"
+                                      % ("gloo (ranks share a GPU: test mode)" if shared else "RCCL")},
+            "roofline": roofline_object(acc["ms"], acc["launches"], acc["bytes"], acc["pairs"], acc["aux"],
+                                        traffic, traffic_src),
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(tp, args)

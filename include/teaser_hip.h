@@ -48,7 +48,8 @@ typedef enum teaser_hip_status {
   TEASER_HIP_ERR_UNSUPPORTED = 4,  /* parameter value outside the reference's own domain */
   TEASER_HIP_ERR_TIME_LIMIT = 5,   /* max_clique_time_limit hit; incumbent returned (graph.cc:44) */
   TEASER_HIP_ERR_SCRATCH = 6,      /* exact clique search ran out of device scratch */
-  TEASER_HIP_ERR_OOM = 7
+  TEASER_HIP_ERR_OOM = 7,
+  TEASER_HIP_ERR_BUSY = 8          /* every lane holds a submitted batch: teaser_hip_wait first */
 } teaser_hip_status;
 
 /* enums: registration.h:382-412 (same numeric values) */
@@ -97,8 +98,11 @@ typedef struct teaser_solution_c {
   int64_t num_edges;             /* edges of the inlier graph */
 } teaser_solution_c;
 
-/* Per-stage device time of the last solve call (HIP events on the handle's stream), enabled by
- * teaser_hip_set_profiling(h, 1).  Milliseconds, summed over the launches of that stage. */
+/* Per-stage device time of the last solve call (HIP events on the stream the kernels run on),
+ * enabled by teaser_hip_set_profiling(h, level): 1 = every stage, 2 = K1 only (the kernel itself,
+ * and its pre-pass / fix-up: three event pairs per solve, what bench.py keeps on inside its timed
+ * region).  Milliseconds, summed over the
+ * launches of that stage. */
 typedef struct teaser_profile_c {
   float h2d_ms;
   float tim_graph_ms;    /* K1 main kernel only: TIM norms + prune + adjacency bitmap */
@@ -162,6 +166,45 @@ TEASER_HIP_API int32_t teaser_hip_solve_batch_device(teaser_hip_solver* h, const
                                       const double* d_dst, const int64_t* point_offset,
                                       const int32_t* n, int32_t batch, teaser_solution_c* out);
 
+/* Asynchronous batches (no reference equivalent).  submit enqueues everything of a batched solve
+ * that needs no host sync on one of the handle's LANES (child contexts with their own HIP stream
+ * and arenas, used round-robin; teaser_hip_set_pipeline_depth, default 3) and returns a ticket;
+ * wait blocks on that lane's one host sync, finishes the rare bound-closing work and writes the
+ * solutions.  With 2-3 batches in flight the host enqueues batch k+1 while the GPU runs batch k,
+ * and the latency-bound tail of batch k (clique, GNC, TLS: one workgroup per problem) shares the GPU
+ * with batch k+1's K1.  Results are identical to teaser_hip_solve_batch_device (same kernels).
+ *   flags = TEASER_HIP_INPUT_DEVICE: src/dst are packed DEVICE arrays (as solve_batch_device), which
+ *           must stay valid and unmodified until the matching wait;
+ *   flags = TEASER_HIP_INPUT_HOST:   src/dst are packed HOST arrays of the same layout (problem b =
+ *           points [offset[b], offset[b]+n[b])); page-locked memory (hipHostMalloc /
+ *           hipHostRegister) is copied asynchronously at PCIe speed, and must stay valid until wait.
+ * point_offset / n are host arrays, copied at submit.  Tickets must be waited for in any order,
+ * each exactly once; after wait the getters address that batch until the next wait / solve.
+ * TEASER_HIP_ERR_BUSY: all lanes are in flight. */
+enum { TEASER_HIP_INPUT_DEVICE = 0, TEASER_HIP_INPUT_HOST = 1 };
+TEASER_HIP_API int32_t teaser_hip_submit_batch(teaser_hip_solver* h, const double* src, const double* dst,
+                                const int64_t* point_offset, const int32_t* n, int32_t batch,
+                                int32_t flags, int32_t* ticket);
+TEASER_HIP_API int32_t teaser_hip_wait(teaser_hip_solver* h, int32_t ticket, teaser_solution_c* out /* [batch] */);
+TEASER_HIP_API int32_t teaser_hip_set_pipeline_depth(teaser_hip_solver* h, int32_t depth /* 1..16 */);
+
+/* One process, several devices ("a batch call may fan out across all visible
+ * devices"): a multi-solver owns one handle per listed device (a device may be listed twice) and one
+ * host thread per handle; solve_batch cuts the batch into contiguous blocks, one per handle, and
+ * runs them concurrently (host pointers per problem, as teaser_hip_solve_batch).  No collective:
+ * the problems are independent and the solutions land in the caller's array.  The getters of
+ * problem p are reached through teaser_hip_multi_route(mh, p, &h, &local) -> h's getters with `local`. */
+typedef struct teaser_hip_multi teaser_hip_multi;
+TEASER_HIP_API int32_t teaser_hip_multi_create(const teaser_params_c* params, const int32_t* devices,
+                                int32_t n_devices /* 0: every visible device */, teaser_hip_multi** out);
+TEASER_HIP_API int32_t teaser_hip_multi_destroy(teaser_hip_multi* mh);
+TEASER_HIP_API int32_t teaser_hip_multi_solve_batch(teaser_hip_multi* mh, const double* const* src,
+                                     const double* const* dst, const int32_t* n, int32_t batch,
+                                     teaser_solution_c* out /* [batch] */);
+TEASER_HIP_API int32_t teaser_hip_multi_route(teaser_hip_multi* mh, int32_t problem, teaser_hip_solver** h,
+                               int32_t* local_problem);
+TEASER_HIP_API int32_t teaser_hip_multi_device_count(const teaser_hip_multi* mh);
+
 /* Getters on the last solve call; `problem` indexes the batch (0 for single solves).  Each copies
  * into buf when buf != NULL and *len (capacity in elements on entry) suffices, and always writes
  * the required length to *len.
@@ -203,7 +246,7 @@ TEASER_HIP_API int32_t teaser_hip_max_clique(teaser_hip_solver* h, const uint64_
                               int32_t* clique, int32_t* clique_size, int32_t* exact_run);
 
 /* Profiling / diagnostics. */
-TEASER_HIP_API int32_t teaser_hip_set_profiling(teaser_hip_solver* h, int32_t enable);
+TEASER_HIP_API int32_t teaser_hip_set_profiling(teaser_hip_solver* h, int32_t level /* 0, 1, 2 */);
 TEASER_HIP_API int32_t teaser_hip_get_profile(const teaser_hip_solver* h, teaser_profile_c* out);
 /* The HIP stream (hipStream_t) all kernels of this handle are launched on. */
 TEASER_HIP_API void* teaser_hip_get_stream(teaser_hip_solver* h);

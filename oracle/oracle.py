@@ -225,9 +225,12 @@ def tls_translation(src, dst, noise_bound, cbar2=1.0):
     return t, mask.astype(bool)
 
 
-def solve(src, dst, params=None, **kw):
-    """Full oracle solve; returns a dict mirroring what the product's getters expose."""
+def solve(src, dst, params=None, materialise=False, **kw):
+    """Full oracle solve; returns a dict mirroring what the product's getters expose.
+    materialise=True: the reference-faithful front half (TIMs, maps, mask and adjacency lists
+    materialised, registration.cc:512-551, 427-443, 614-619) instead of the streaming one."""
     p = params if params is not None else default_params(**kw)
+    lib().oracle_set_materialise(1 if materialise else 0)
     s, d = _cm(src), _cm(dst)
     n = s.shape[0]
     sol = OracleSolution()

@@ -120,7 +120,9 @@ EXPORTED_SYMBOLS = [
     "teaser_hip_solve_for_translation", "teaser_hip_scalar_tls", "teaser_hip_max_clique",
     "teaser_hip_set_profiling", "teaser_hip_get_profile", "teaser_hip_get_stream",
     "teaser_hip_last_error", "teaser_hip_abi_version", "teaser_hip_device_count",
-    "teaser_hip_synth_problem",
+    "teaser_hip_synth_problem", "teaser_hip_submit_batch", "teaser_hip_wait",
+    "teaser_hip_set_pipeline_depth", "teaser_hip_multi_create", "teaser_hip_multi_destroy",
+    "teaser_hip_multi_solve_batch", "teaser_hip_multi_route", "teaser_hip_multi_device_count",
 ]
 
 
@@ -169,6 +171,15 @@ def lib():
     L.teaser_hip_solve_for_translation.argtypes = [_vp, _dp, _dp, C.c_int32, _dp, _u8p]
     L.teaser_hip_scalar_tls.argtypes = [_vp, _dp, _dp, C.c_int32, _dp, _u8p]
     L.teaser_hip_max_clique.argtypes = [_vp, _u64p, C.c_int32, _ip, _ip, _ip]
+    L.teaser_hip_submit_batch.argtypes = [_vp, _vp, _vp, _i64p, _ip, C.c_int32, C.c_int32, _ip]
+    L.teaser_hip_wait.argtypes = [_vp, C.c_int32, C.POINTER(SolutionC)]
+    L.teaser_hip_set_pipeline_depth.argtypes = [_vp, C.c_int32]
+    L.teaser_hip_multi_create.argtypes = [C.POINTER(ParamsC), _ip, C.c_int32, C.POINTER(_vp)]
+    L.teaser_hip_multi_destroy.argtypes = [_vp]
+    L.teaser_hip_multi_solve_batch.argtypes = [_vp, C.POINTER(_dp), C.POINTER(_dp), _ip, C.c_int32,
+                                               C.POINTER(SolutionC)]
+    L.teaser_hip_multi_route.argtypes = [_vp, C.c_int32, C.POINTER(_vp), _ip]
+    L.teaser_hip_multi_device_count.argtypes = [_vp]
     L.teaser_hip_set_profiling.argtypes = [_vp, C.c_int32]
     L.teaser_hip_get_profile.argtypes = [_vp, C.POINTER(ProfileC)]
     L.teaser_hip_get_stream.argtypes = [_vp]
@@ -357,6 +368,36 @@ class RobustRegistrationSolver:
         out = (SolutionC * B)()
         self._check(self._lib.teaser_hip_solve_batch_device(self._h, _vp(d_src_ptr), _vp(d_dst_ptr),
                                                             _ptr(off, _i64p), _ptr(nn, _ip), B, out))
+        self._sols = list(out)
+        self._sol = RegistrationSolution(out[0]) if B else None
+        return out
+
+    # --- asynchronous batches (teaser_hip_submit_batch / teaser_hip_wait) -----------------
+    INPUT_DEVICE, INPUT_HOST = 0, 1
+
+    def set_pipeline_depth(self, depth):
+        self._check(self._lib.teaser_hip_set_pipeline_depth(self._h, int(depth)))
+
+    def submit_batch(self, src_ptr, dst_ptr, point_offsets, n, host=False):
+        """Enqueue a batch without waiting (raw pointers to packed [sum n, 3] float64 arrays: device
+        memory, or -- host=True -- host memory, ideally page-locked).  Returns a ticket for wait();
+        the arrays must stay valid until then."""
+        off = np.ascontiguousarray(point_offsets, dtype=np.int64)
+        nn = np.ascontiguousarray(n, dtype=np.int32)
+        t = C.c_int32(-1)
+        self._check(self._lib.teaser_hip_submit_batch(
+            self._h, _vp(src_ptr), _vp(dst_ptr), _ptr(off, _i64p), _ptr(nn, _ip), nn.size,
+            self.INPUT_HOST if host else self.INPUT_DEVICE, C.byref(t)))
+        self._pending = getattr(self, "_pending", {})
+        self._pending[t.value] = nn.size
+        return t.value
+
+    def wait(self, ticket):
+        """Block until the batch behind `ticket` is solved; returns its SolutionC array.  The getters
+        (getInlierMaxClique(problem) ...) address this batch afterwards."""
+        B = self._pending.pop(ticket)
+        out = (SolutionC * B)()
+        self._check(self._lib.teaser_hip_wait(self._h, int(ticket), out))
         self._sols = list(out)
         self._sol = RegistrationSolution(out[0]) if B else None
         return out
@@ -577,7 +618,8 @@ class RobustRegistrationSolver:
 
     # --- diagnostics ---------------------------------------------------------------------
     def set_profiling(self, on=True):
-        self._check(self._lib.teaser_hip_set_profiling(self._h, 1 if on else 0))
+        """True / 1: HIP events around every stage; 2: around the K1 kernel only; False / 0: off."""
+        self._check(self._lib.teaser_hip_set_profiling(self._h, int(on)))
 
     def get_profile(self):
         p = ProfileC()
@@ -589,8 +631,66 @@ class RobustRegistrationSolver:
         return self._lib.teaser_hip_get_stream(self._h)
 
 
+class MultiDeviceSolver:
+    """teaser_hip_multi_*: one process, one handle + host thread per listed device; a batch is cut
+    into contiguous blocks that run concurrently.  devices=None: every visible device."""
+
+    def __init__(self, params=None, devices=None, **kw):
+        if params is None:
+            params = RobustRegistrationSolver.Params(**kw)
+        self._lib = lib()
+        self._h = _vp()
+        c = params.to_c()
+        devs = np.ascontiguousarray([] if devices is None else devices, dtype=np.int32)
+        rc = self._lib.teaser_hip_multi_create(C.byref(c), _ptr(devs, _ip) if devs.size else None,
+                                               int(devs.size), C.byref(self._h))
+        if rc != 0:
+            self._h = _vp()
+            raise TeaserHipError(rc, "(no MI355X visible: the product has no CPU path)" if rc == 3 else "")
+
+    def device_count(self):
+        return int(self._lib.teaser_hip_multi_device_count(self._h))
+
+    def solve_batch(self, srcs, dsts):
+        ss = [_colmajor(s, "src") for s in srcs]
+        ds = [_colmajor(d, "dst") for d in dsts]
+        B = len(ss)
+        sp = (_dp * B)(*[_ptr(a) for a in ss])
+        dp = (_dp * B)(*[_ptr(a) for a in ds])
+        n = np.array([a.shape[0] for a in ss], dtype=np.int32)
+        out = (SolutionC * B)()
+        rc = self._lib.teaser_hip_multi_solve_batch(self._h, sp, dp, _ptr(n, _ip), B, out)
+        if rc not in (0, 5):
+            raise TeaserHipError(rc)
+        return out
+
+    def max_clique(self, problem):
+        """getInlierMaxClique() of problem `problem` of the last batch (routed to its handle)."""
+        h, loc = _vp(), C.c_int32()
+        rc = self._lib.teaser_hip_multi_route(self._h, int(problem), C.byref(h), C.byref(loc))
+        if rc != 0:
+            raise TeaserHipError(rc)
+        ln = C.c_int64(0)
+        self._lib.teaser_hip_get_max_clique(h, loc.value, None, C.byref(ln))
+        buf = np.zeros(max(ln.value, 1), dtype=np.int32)
+        cap = C.c_int64(buf.size)
+        self._lib.teaser_hip_get_max_clique(h, loc.value, _ptr(buf, _ip), C.byref(cap))
+        return buf[:ln.value].tolist()
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.teaser_hip_multi_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 from . import batched  # noqa: E402,F401  (sharding + record gather for the multi-GPU batched mode)
 
-__all__ = ["batched", "RobustRegistrationSolver", "RegistrationSolution", "RotationEstimationAlgorithm",
+__all__ = ["batched", "MultiDeviceSolver", "RobustRegistrationSolver", "RegistrationSolution", "RotationEstimationAlgorithm",
            "InlierSelectionMode", "InlierGraphFormulation", "TeaserHipError", "synth_problem",
            "device_count", "build", "lib", "LIB_PATH", "EXPORTED_SYMBOLS"]

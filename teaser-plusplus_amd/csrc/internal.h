@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "teaser_hip.h"
 
 namespace thip {
@@ -60,6 +62,29 @@ struct EstParams {
   int32_t algorithm;  // TEASER_ROT_GNC_TLS / _FGR / _QUATRO
 };
 
+// Opt-in for more than 64 KB of dynamic LDS.  hipFuncSetAttribute applies to the CURRENT device, and
+// handles of several devices (and several host threads) share this process, so the largest size
+// granted so far is tracked per device, lock-free (a racing duplicate call is harmless).
+struct DynLdsOptIn {
+  static constexpr int kMaxDevices = 64;
+  std::atomic<int> granted[kMaxDevices];
+  DynLdsOptIn() {
+    for (auto& g : granted) g.store(0);
+  }
+  void ensure(const void* func, int bytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const bool tracked = dev >= 0 && dev < kMaxDevices;
+    if (tracked && granted[dev].load(std::memory_order_acquire) >= bytes) return;
+    (void)hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (tracked) {
+      int cur = granted[dev].load();
+      while (cur < bytes && !granted[dev].compare_exchange_weak(cur, bytes)) {
+      }
+    }
+  }
+};
+
 // ---- kernel launchers (implemented in the .hip files) -------------------------------------
 // K1: fused TIM norms + scale pruning + symmetric adjacency bitmap (kernels_graph.hip)
 void launch_tim_graph(hipStream_t s, const ProbDesc* d_desc, int batch, int max_n,
@@ -73,12 +98,11 @@ void launch_tim_graph_mfma(hipStream_t s, int phase, const ProbDesc* d_desc, int
                            int64_t total_pts, const double* d_src, const double* d_dst,
                            void* d_pk, void* d_prep, void* d_work, int64_t work_cap,
                            uint64_t* d_bitmap, ProbState* d_state, double noise_bound, double cbar2);
-// row popcounts -> degrees (+ per-problem degree sum), start vertex selection
+// row popcounts -> degrees
 void launch_degrees(hipStream_t s, const ProbDesc* d_desc, int batch, int max_n,
                     const uint64_t* d_bitmap, int32_t* d_deg, ProbState* d_state);
-void launch_pick_starts(hipStream_t s, const ProbDesc* d_desc, int batch, const int32_t* d_deg,
-                        ProbState* d_state);
-// greedy multi-start clique heuristic; writes per-start cliques, then the per-problem best
+// greedy multi-start clique heuristic (each workgroup picks its own start vertex; the problem states
+// must arrive zeroed); writes per-start cliques, then the per-problem best
 void launch_heuristic(hipStream_t s, const ProbDesc* d_desc, int batch, int max_W,
                       const uint64_t* d_bitmap, const int32_t* d_deg, ProbState* d_state,
                       int32_t* d_start_cliques /* [kMaxStarts][sum n] */, int64_t total_n,

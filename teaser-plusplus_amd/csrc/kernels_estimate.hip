@@ -845,12 +845,8 @@ void launch_tls_translation(hipStream_t s, const ProbDesc* d_desc, int batch, co
                             EstParams ep, char* d_scratch, int64_t scratch_stride,
                             int32_t* d_trans_inliers) {
   if (batch <= 0) return;
-  static bool attr_set = false;
-  if (!attr_set) {  // 3 groups x 42 KB of dynamic LDS exceed the 64 KB default
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(tls_translation_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 3 * kTlsGroupLds);
-    attr_set = true;
-  }
+  static DynLdsOptIn optin;  // 3 groups x 42 KB of dynamic LDS exceed the 64 KB default
+  optin.ensure(reinterpret_cast<const void*>(tls_translation_kernel), 3 * kTlsGroupLds);
   hipLaunchKernelGGL(tls_translation_kernel, dim3(batch), dim3(768), 3 * kTlsGroupLds, s, d_desc,
                      d_src, d_dst, d_clique, d_state, ep, d_scratch, scratch_stride,
                      d_trans_inliers);

@@ -344,6 +344,7 @@ __global__ __launch_bounds__(256) void tim_graph_kernel(const ProbDesc* __restri
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 constexpr float kEpsU = 300.0f;
 
 struct TimPrep {         // per problem, zeroed then filled by the pre-pass
@@ -605,7 +606,13 @@ __device__ __forceinline__ int flush_work(const unsigned long long* wbuf, int wc
 // afterwards.  The hot kernel therefore holds no FP64 code and never waits on the double-precision
 // points.  If the list overflows (adversarial geometry: > 1/64 of all pairs inside the band) the
 // problem is flagged and the host reruns the batch on the FP64 kernel.
-__global__ __launch_bounds__(256) void tim_graph_mfma_kernel(
+// V (scheduling variant, same results): 0 = the transposed words of column tile J are stored right
+// after J's barrier; 1 = that store is issued in the middle of iteration J+1, AFTER the wave has
+// waited for its prefetched column operands.  On gfx9-family hardware loads and stores share the
+// in-order vmcnt counter, so with V = 0 every `s_waitcnt vmcnt` for the prefetch also waits for the
+// previous iteration's global store to be acknowledged by L2 (hundreds of cycles, every J).
+template <int V>
+__global__ __launch_bounds__(256, 3) void tim_graph_mfma_kernel(
     const ProbDesc* __restrict__ descs, const double* __restrict__ src,
     const double* __restrict__ dst, const TimOperand* __restrict__ op_src,
     const TimOperand* __restrict__ op_dst, const TimPrep* __restrict__ prep,
@@ -679,10 +686,31 @@ __global__ __launch_bounds__(256) void tim_graph_mfma_kernel(
     const int cp = min(Jfirst * 64 + c, n - 1);
     nb[0] = qs[cp].b[h]; nb[1] = qs[cp].b[2 + h]; nb[2] = qd[cp].b[h]; nb[3] = qd[cp].b[2 + h];
   }
+  // transposed words of column tile Jp, staged in lds_tr by all 4 waves: the 4 waves' words I0..I0+3
+  // of row j are 32 contiguous bytes -> one lane group
+  // V = 1 stores through a buffer descriptor with NO branch: lanes (and whole iterations) that have
+  // nothing to store use an out-of-range offset, which the hardware drops -- so the compiler can count
+  // the store in its vmcnt bookkeeping exactly instead of assuming the worst at every wait.
+  const __amdgpu_buffer_rsrc_t bm_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)bm, 0, (int)((unsigned int)n * (unsigned int)W * 8u), 0x00020000);
+  auto store_tr = [&](int Jp) {
+    const int r = 16 * wave + (lane >> 2), k = lane & 3, Ik = I0 + k, jp0 = Jp * 64;
+    const bool ok = Jp >= Jbase && Ik < Jp && Ik < T && jp0 + r < n;
+    if (V == 1) {
+      const uint64_t w = lds_tr[(Jp - Jbase) & 1][k][r];
+      const u32x2 dw = {(unsigned int)w, (unsigned int)(w >> 32)};
+      const unsigned int off = ok ? ((unsigned int)(jp0 + r) * (unsigned int)W + (unsigned int)Ik) * 8u : 0xffffffffu;
+      __builtin_amdgcn_raw_buffer_store_b64(dw, bm_rsrc, off, 0, 0);
+    } else if (ok) {
+      bm[(int64_t)(jp0 + r) * W + Ik] = lds_tr[(Jp - Jbase) & 1][k][r];
+    }
+  };
   for (int J = Jbase; J < Jend; ++J) {
     const int j0 = J * 64;
     uint64_t trw_out = 0;
-    if (rowvalid && J >= I) {
+    if (!(rowvalid && J >= I)) {
+      if (V == 1) store_tr(J - 1);
+    } else {
     unsigned int tr[2][2];  // [ct][rt]: this lane's 16 column bits
     unsigned int ubits[4];  // per tile 2 ct + rt: this lane's in-band pairs (bit q)
     unsigned int flagged = 0;  // wave-uniform: bit 2 ct + rt = tile holding in-band pairs
@@ -724,6 +752,13 @@ __global__ __launch_bounds__(256) void tim_graph_mfma_kernel(
         ubits[2 * ct + rt] = ub;
 
         tr[ct][rt] = mt.colbits;
+      }
+      if (V == 1 && ct == 0) {
+        // the previous tile's transposed words: issued behind this iteration's operand wait and its
+        // first MFMAs, half an iteration before the next wait needs the counter to drain
+        __builtin_amdgcn_sched_barrier(0);
+        store_tr(J - 1);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
 #pragma nounroll
@@ -792,15 +827,12 @@ __global__ __launch_bounds__(256) void tim_graph_mfma_kernel(
     lds_own[wave][lane][J - Jbase] = ownw;
     trw_out = (J != I) ? (trw & rowmask) : 0ull;
     }  // active
-    // transposed words: the 4 waves' words I0..I0+3 of row j are 32 contiguous bytes -> one lane group
     const int buf = (J - Jbase) & 1;
     lds_tr[buf][wave][lane] = trw_out;
     __syncthreads();  // (one barrier per J: the other buffer is rewritten only after the next one)
-    {
-      const int r = 16 * wave + (lane >> 2), k = lane & 3, Ik = I0 + k;
-      if (Ik < J && Ik < T && j0 + r < n) bm[(int64_t)(j0 + r) * W + Ik] = lds_tr[buf][k][r];
-    }
+    if (V == 0) store_tr(J);
   }
+  if (V == 1 && Jend > Jbase) store_tr(Jend - 1);
   // own words: lanes 8r..8r+7 store the (up to) 8 consecutive words of one row
   if (rowvalid) {
 #pragma unroll
@@ -815,17 +847,27 @@ __global__ __launch_bounds__(256) void tim_graph_mfma_kernel(
 // FP64 resolution of the worklist: one thread per pair, bits rewritten with atomics (a row word
 // can receive several patches).  Diagonal blocks evaluate (r, c) and (c, r) as separate pairs, each
 // patching only its own bit; elsewhere one pair patches both the row-major and the transposed bit.
-__global__ __launch_bounds__(256) void tim_fixup_kernel(const ProbDesc* __restrict__ descs,
+// The worklist is shared by the batch: if it overflowed, NO problem of the launch can be resolved
+// (the wave whose reservation crossed the capacity wrote nothing, so slots below `cap` may hold stale
+// items).  Then every bitmap is cleared instead (the stages enqueued behind K1 see empty graphs, not
+// unresolved, possibly asymmetric bits), every problem is flagged, and the host reruns the whole batch
+// on the FP64 kernel.
+__global__ __launch_bounds__(256) void tim_fixup_kernel(const ProbDesc* __restrict__ descs, int batch,
                                                         const double* __restrict__ src,
                                                         const double* __restrict__ dst,
                                                         uint64_t* __restrict__ bitmap, double beta,
                                                         const unsigned long long* __restrict__ work,
                                                         const unsigned int* __restrict__ work_count,
-                                                        unsigned int cap) {
+                                                        unsigned int cap, ProbState* __restrict__ states) {
   const unsigned int total = *work_count;
-  // overflow: the wave whose reservation crossed the capacity wrote NOTHING, so slots below `cap` may
-  // hold stale items -- resolve nothing; the flagged problems are cleared and rerun by the host
-  if (total > cap) return;
+  if (total > cap) {
+    const ProbDesc last = descs[batch - 1];
+    const int64_t words = last.bm_off + (int64_t)last.n * last.W;
+    for (int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x; w < words; w += (int64_t)gridDim.x * 256)
+      bitmap[w] = 0;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < batch; p += gridDim.x * 256) states[p].k1_overflow = 1;
+    return;
+  }
   for (unsigned int w = blockIdx.x * 256 + threadIdx.x; w < total; w += gridDim.x * 256) {
     const unsigned long long it = work[w];
     const int prob = (int)(it >> 32), r = (int)((it >> 16) & 0xffff), col = (int)(it & 0xffff);
@@ -849,23 +891,6 @@ __global__ __launch_bounds__(256) void tim_fixup_kernel(const ProbDesc* __restri
       if (e) atomicOr(wp, bit); else atomicAnd(wp, ~bit);
     }
   }
-}
-
-// The worklist is shared by the batch: if it overflowed, NO problem of the launch was resolved (the
-// fix-up kernel skips everything).  Every bitmap is cleared (so that the stages enqueued behind K1 see
-// empty graphs instead of unresolved, possibly asymmetric bits) and every problem is flagged; the
-// host then reruns the whole batch on the FP64 kernel.
-__global__ __launch_bounds__(256) void tim_overflow_clear_kernel(const ProbDesc* __restrict__ descs,
-                                                                 ProbState* __restrict__ states,
-                                                                 uint64_t* __restrict__ bitmap,
-                                                                 const unsigned int* __restrict__ work_count,
-                                                                 unsigned int cap) {
-  if (*work_count <= cap) return;
-  if (blockIdx.x == 0 && threadIdx.x == 0) states[blockIdx.y].k1_overflow = 1;
-  const ProbDesc d = descs[blockIdx.y];
-  const int64_t words = (int64_t)d.n * d.W;
-  for (int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x; w < words; w += (int64_t)gridDim.x * 256)
-    bitmap[d.bm_off + w] = 0;
 }
 
 void launch_tim_graph(hipStream_t s, const ProbDesc* d_desc, int batch, int max_n,
@@ -915,21 +940,27 @@ void launch_tim_graph_mfma(hipStream_t s, int phase, const ProbDesc* d_desc, int
   unsigned int* work_count = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(d_prep) +
                                                             sizeof(TimPrep) * (size_t)batch);
   if (phase == 0) {
-    (void)hipMemsetAsync(prep, 0, sizeof(TimPrep) * (size_t)batch + 64, s);  // + the worklist counter
+    // prep (and the worklist counter behind it) arrive zeroed: part of the solve's header upload
     hipLaunchKernelGGL(tim_prep_bbox_kernel, dim3((max_n + 1023) / 1024, batch), dim3(256), 0, s, d_desc,
                        d_src, d_dst, prep);
     hipLaunchKernelGGL(tim_prep_pack_kernel, dim3((max_n + 255) / 256, batch), dim3(256), 0, s, d_desc,
                        d_src, d_dst, prep, op_src, op_dst);
   } else if (phase == 1) {
     const int gxc = (T + kMfmaColTiles - 1) / kMfmaColTiles, gyr = (T + kMfmaRowTiles - 1) / kMfmaRowTiles;
-    hipLaunchKernelGGL(tim_graph_mfma_kernel, dim3(gxc * gyr, batch), dim3(256), 0, s, d_desc, d_src, d_dst,
-                       op_src, op_dst, prep, d_bitmap, beta, gyr, work, work_count,
-                       (unsigned int)work_cap, d_state);
+    // scheduling variant of the same kernel (diagnostics; read per launch so that a probe can switch)
+    const char* ev = getenv("TEASER_K1_VARIANT");
+    const int variant = ev ? atoi(ev) : 1;
+    if (variant == 0)
+      hipLaunchKernelGGL(tim_graph_mfma_kernel<0>, dim3(gxc * gyr, batch), dim3(256), 0, s, d_desc, d_src,
+                         d_dst, op_src, op_dst, prep, d_bitmap, beta, gyr, work, work_count,
+                         (unsigned int)work_cap, d_state);
+    else
+      hipLaunchKernelGGL(tim_graph_mfma_kernel<1>, dim3(gxc * gyr, batch), dim3(256), 0, s, d_desc, d_src,
+                         d_dst, op_src, op_dst, prep, d_bitmap, beta, gyr, work, work_count,
+                         (unsigned int)work_cap, d_state);
   } else {
-    hipLaunchKernelGGL(tim_fixup_kernel, dim3(512), dim3(256), 0, s, d_desc, d_src, d_dst, d_bitmap, beta,
-                       work, work_count, (unsigned int)work_cap);
-    hipLaunchKernelGGL(tim_overflow_clear_kernel, dim3(64, batch), dim3(256), 0, s, d_desc, d_state,
-                       d_bitmap, work_count, (unsigned int)work_cap);
+    hipLaunchKernelGGL(tim_fixup_kernel, dim3(512), dim3(256), 0, s, d_desc, batch, d_src, d_dst, d_bitmap,
+                       beta, work, work_count, (unsigned int)work_cap, d_state);
     static const bool dbg = getenv("TEASER_K1_DEBUG") != nullptr;
     if (dbg) {  // diagnostics only: pairs sent to the FP64 fix-up
       unsigned int cnt = 0;
@@ -962,54 +993,6 @@ void launch_degrees(hipStream_t s, const ProbDesc* d_desc, int batch, int max_n,
   if (batch <= 0 || max_n <= 0) return;
   dim3 grid((max_n + 3) / 4, batch);
   hipLaunchKernelGGL(degree_kernel, grid, dim3(256), 0, s, d_desc, d_bitmap, d_deg);
-}
-
-// ------------------------------------------------------------------------------------------
-// start vertices: the max-(degree, lowest index) vertex of each residue class mod kMaxStarts;
-// also the degree sum (edge count) of the problem.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void pick_starts_kernel(const ProbDesc* __restrict__ descs,
-                                                          const int32_t* __restrict__ deg,
-                                                          ProbState* __restrict__ states) {
-  __shared__ unsigned long long keys[256];
-  __shared__ unsigned long long sums[4];
-  const ProbDesc d = descs[blockIdx.x];
-  const int32_t* dg = deg + d.pt_off;
-  unsigned long long best = 0, sum = 0;
-  // 256 % kMaxStarts == 0, so thread t only ever sees class t % kMaxStarts
-  for (int v = threadIdx.x; v < d.n; v += 256) {
-    const unsigned long long dv = (unsigned int)dg[v];
-    sum += dv;
-    const unsigned long long key = ((dv + 1) << 32) | (0xffffffffu - (unsigned int)v);
-    best = key > best ? key : best;
-  }
-  keys[threadIdx.x] = best;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-  if ((threadIdx.x & 63) == 0) sums[threadIdx.x >> 6] = sum;
-  __syncthreads();
-  ProbState* st = states + blockIdx.x;
-  if (threadIdx.x < kMaxStarts) {
-    unsigned long long b = 0;
-    for (int t = threadIdx.x; t < 256; t += kMaxStarts) b = keys[t] > b ? keys[t] : b;
-    st->start_vertex[threadIdx.x] = b ? (int)(0xffffffffu - (unsigned int)(b & 0xffffffffu)) : -1;
-    st->start_size[threadIdx.x] = 0;
-  }
-  if (threadIdx.x == 0) {
-    st->deg_sum = sums[0] + sums[1] + sums[2] + sums[3];
-    st->lb = 0;
-    st->best_start = -1;
-    st->alive_count = 0;
-    st->peel_done = 0;
-    st->proven = 0;
-    st->clique_size = 0;
-  }
-}
-
-void launch_pick_starts(hipStream_t s, const ProbDesc* d_desc, int batch, const int32_t* d_deg,
-                        ProbState* d_state) {
-  if (batch <= 0) return;
-  hipLaunchKernelGGL(pick_starts_kernel, dim3(batch), dim3(256), 0, s, d_desc, d_deg, d_state);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1074,15 +1057,43 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
 
   ProbState* st = states + blockIdx.y;
   const int sidx = blockIdx.x;
-  const int v0 = st->start_vertex[sidx];
-  if (v0 < 0 || n <= 0) {
-    if (threadIdx.x == 0) st->start_size[sidx] = 0;
-    return;
-  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint64_t* bm = bitmap + d.bm_off;
   const int32_t* dg = deg + d.pt_off;
   int32_t* C = start_cliques + (int64_t)sidx * total_n + d.pt_off;
+  // start vertex of this workgroup: the max-(degree, lowest index) vertex of residue class
+  // sidx mod kMaxStarts (pmc_heu grows a clique from every vertex in core order; 16 well spread,
+  // high-degree starts stand in for that).  Workgroup 0 also leaves the degree sum (2 x edges).
+  int v0 = -1;
+  {
+    unsigned long long best = 0, sum = 0;
+    for (int v = sidx + kMaxStarts * tid; v < n; v += kMaxStarts * kGreedyThreads) {
+      const unsigned long long dv = (unsigned int)dg[v];
+      const unsigned long long key = ((dv + 1) << 32) | (0xffffffffu - (unsigned int)v);
+      best = key > best ? key : best;
+    }
+    best = blockN_max_u64(best, red64);
+    if (best) v0 = (int)(0xffffffffu - (unsigned int)(best & 0xffffffffu));
+    if (sidx == 0) {
+      for (int v = tid; v < n; v += kGreedyThreads) sum += (unsigned int)dg[v];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+      __syncthreads();
+      if (lane == 0) red64[wave] = sum;
+      __syncthreads();
+      if (tid == 0) {
+        unsigned long long tot = 0;
+        for (int k = 0; k < kGreedyWaves; ++k) tot += red64[k];
+        st->deg_sum = tot;
+      }
+      __syncthreads();
+    }
+    if (tid == 0) st->start_vertex[sidx] = v0;
+  }
+  if (v0 < 0 || n <= 0) {
+    if (threadIdx.x == 0) st->start_size[sidx] = 0;
+    return;
+  }
 
   int csize = 1;
   if (tid == 0) C[0] = v0;
@@ -1450,12 +1461,8 @@ void launch_heuristic(hipStream_t s, const ProbDesc* d_desc, int batch, int max_
                       int32_t* d_clique) {
   if (batch <= 0) return;
   const size_t lds = greedy_lds_bytes(max_W);
-  static size_t lds_cap = 0;
-  if (lds > lds_cap) {  // beyond the 64 KB default dynamic-LDS limit
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(greedy_clique_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    lds_cap = lds;
-  }
+  static DynLdsOptIn optin;  // beyond the 64 KB default dynamic-LDS limit once W >= ~300
+  if (lds > 48 * 1024) optin.ensure(reinterpret_cast<const void*>(greedy_clique_kernel), (int)lds);
   hipLaunchKernelGGL(greedy_clique_kernel, dim3(kMaxStarts, batch), dim3(kGreedyThreads), lds, s,
                      d_desc, d_bitmap, d_deg, d_state, d_start_cliques, total_n);
 }

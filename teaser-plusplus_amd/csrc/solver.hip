@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "internal.h"
@@ -42,8 +43,20 @@ namespace {
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
+  bool view = false;  // p points into another DevBuf (the per-solve header block): never freed here
+  void set_view(void* q, size_t bytes) {
+    if (p && !view) (void)hipFree(p);
+    p = q;
+    cap = bytes;
+    view = true;
+  }
   hipError_t ensure(size_t bytes) {
-    if (bytes <= cap) return hipSuccess;
+    if (bytes <= cap && !view) return hipSuccess;
+    if (view) {
+      p = nullptr;
+      cap = 0;
+      view = false;
+    }
     if (p) (void)hipFree(p);
     p = nullptr;
     cap = 0;
@@ -57,9 +70,10 @@ struct DevBuf {
     return e;
   }
   void release() {
-    if (p) (void)hipFree(p);
+    if (p && !view) (void)hipFree(p);
     p = nullptr;
     cap = 0;
+    view = false;
   }
   template <typename T>
   T* as() const {
@@ -98,7 +112,7 @@ struct teaser_hip_solver {
   int device = 0;
   hipStream_t stream = nullptr;
   std::string err;
-  bool profiling = false;
+  int profiling = 0;  // 0 off, 1 every stage, 2 K1 only (the kernel, and its pre-pass / fix-up)
   teaser_profile_c prof;
   std::vector<hipEvent_t> ev_pool;
   struct Span { int stage; hipEvent_t a, b; };
@@ -141,13 +155,32 @@ struct teaser_hip_solver {
     bool need_graph = false;
     int64_t total_n = 0, tls_stride = 0;
   } pend;
-  // ---- pipelined batches: lanes = child handles, one HIP stream each (see solve_pipelined) ----
+  // ---- asynchronous batches (teaser_hip_submit_batch / teaser_hip_wait): lanes = child handles
+  // with their own HIP stream and arenas, used round-robin, so that the latency-bound tail of one
+  // batch (clique, GNC, TLS: one workgroup per problem) runs beside the next batch's K1 ----------
   std::vector<teaser_hip_solver*> lanes;
-  std::vector<std::pair<int, int>> route;  // problem -> (lane, index inside the lane); empty: not piped
+  std::vector<std::pair<int, int>> route;  // problem -> (lane, index inside the lane); empty: h itself
   hipEvent_t k1_done = nullptr;            // recorded after this handle's K1 kernel
-  hipEvent_t wait_before_k1 = nullptr;     // the previous lane's k1_done (staggers the K1 kernels)
-  int pipeline_chunks = 1;                 // lanes of a pipelined batch (TEASER_HIP_PIPELINE); 1 = off
+  hipEvent_t wait_before_k1 = nullptr;     // the previously submitted lane's k1_done (staggers the K1s)
+  bool k1_recorded = false;
+  int depth = 3;                           // lanes (TEASER_HIP_DEPTH / teaser_hip_set_pipeline_depth)
+  int next_lane = 0, last_lane = -1;
+  bool stagger_k1 = true;                  // TEASER_HIP_STAGGER=0 lets the K1 kernels of the lanes co-run
   bool is_lane = false;
+  struct Job {                             // a submitted, not yet waited-for batch (lanes only)
+    bool busy = false;
+    std::vector<int64_t> off;
+    std::vector<int32_t> n;
+    const double* d_src = nullptr;
+    const double* d_dst = nullptr;
+  } job;
+  DevBuf hdr;                              // descs | states | tim offsets | peel counters | K1 prep
+};
+
+// several devices, one process: one handle (and one host thread per solve call) per device
+struct teaser_hip_multi {
+  std::vector<teaser_hip_solver*> handles;
+  std::vector<int32_t> first;  // handle g solved problems [first[g], first[g+1]) of the last call
 };
 
 namespace {
@@ -166,7 +199,9 @@ struct StageScope {
   bool on;
   hipEvent_t a = nullptr, b = nullptr;
   int stage;
-  StageScope(teaser_hip_solver* hh, int st) : h(hh), on(hh->profiling), stage(st) {
+  StageScope(teaser_hip_solver* hh, int st)
+      : h(hh), on(hh->profiling == 1 || (hh->profiling == 2 && (st == ST_TIM || st == ST_TIMAUX))),
+        stage(st) {
     if (!on) return;
     if (h->ev_used + 2 > h->ev_pool.size()) {
       for (int i = 0; i < 16; ++i) {
@@ -197,7 +232,6 @@ void profile_begin(teaser_hip_solver* h) {
 
 void profile_end(teaser_hip_solver* h) {
   if (!h->profiling) return;
-  if (!h->route.empty()) return;  // pipelined batch: h->prof already holds the sum over the lanes
   (void)hipStreamSynchronize(h->stream);  // the last span may still be in flight
   float* slot[ST_COUNT] = {&h->prof.h2d_ms,  &h->prof.tim_graph_ms, &h->prof.degree_ms,
                            &h->prof.heuristic_ms, &h->prof.peel_ms, &h->prof.exact_ms,
@@ -613,9 +647,23 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
   const int max_W = h->max_W;
   const int64_t total_n = std::max<int64_t>(maxpt, 1);
 
-  HIPCHK(h, h->d_desc.ensure(sizeof(ProbDesc) * (size_t)batch));
-  HIPCHK(h, h->d_state.ensure(sizeof(ProbState) * (size_t)batch));
-  HIPCHK(h, h->d_tim_off.ensure(8 * (size_t)batch));
+  // descs | initial states | tim offsets | peel counters (zero) | K1 prep + worklist counter (zero):
+  // ONE device block, filled by ONE H2D copy per solve (no memsets, no per-array copies)
+  const size_t b_desc = sizeof(ProbDesc) * (size_t)batch, b_state = sizeof(ProbState) * (size_t)batch,
+               b_off = 8 * (size_t)batch, b_next = 4 * (size_t)batch, b_prep = (size_t)tim_prep_bytes(batch);
+  auto al256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  const size_t o_desc = 0, o_state = al256(o_desc + b_desc), o_off = al256(o_state + b_state),
+               o_next = al256(o_off + b_off), o_prep = al256(o_next + b_next),
+               hdr_bytes = al256(o_prep + b_prep);
+  HIPCHK(h, h->hdr.ensure(hdr_bytes));
+  {
+    char* base = h->hdr.as<char>();
+    h->d_desc.set_view(base + o_desc, b_desc);
+    h->d_state.set_view(base + o_state, b_state);
+    h->d_tim_off.set_view(base + o_off, b_off);
+    h->d_next_count.set_view(base + o_next, b_next);
+    h->d_prep.set_view(base + o_prep, b_prep);
+  }
   HIPCHK(h, h->d_clique.ensure(4 * (size_t)total_n));
   HIPCHK(h, h->d_weights.ensure(8 * (size_t)std::max<int64_t>(tims, 1)));
   HIPCHK(h, h->d_rot_inl.ensure(4 * (size_t)std::max<int64_t>(tims, 1)));
@@ -624,18 +672,19 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
   HIPCHK(h, h->d_tls_scratch.ensure((size_t)tls_stride * (size_t)batch));
   const bool need_graph = (mode != TEASER_INLIER_NONE) && max_n >= 1;
   // K1 on the matrix cores (fixed scale; worklist items hold 16-bit point indices: n <= 65536)
-  const bool mfma_k1 = need_graph && !P.estimate_scaling && max_n <= 65536 && !fp64_k1;
+  // (TEASER_K1_VARIANT=-1: diagnostics, forces the all-FP64 kernel)
+  const char* k1_env = getenv("TEASER_K1_VARIANT");
+  const bool mfma_k1 = need_graph && !P.estimate_scaling && max_n <= 65536 && !fp64_k1 &&
+                       !(k1_env && atoi(k1_env) < 0);
   if (need_graph) {
     HIPCHK(h, h->d_bitmap.ensure(8 * (size_t)std::max<int64_t>(bm, 1)));
     HIPCHK(h, h->d_deg.ensure(4 * (size_t)total_n));
     HIPCHK(h, h->d_start_cliques.ensure(4 * (size_t)total_n * kMaxStarts));
     HIPCHK(h, h->d_alive_a.ensure(8 * (size_t)std::max<int64_t>(wo, 1)));
     HIPCHK(h, h->d_alive_b.ensure(8 * (size_t)std::max<int64_t>(wo, 1)));
-    HIPCHK(h, h->d_next_count.ensure(4 * (size_t)batch));
     // K1 on the matrix cores (worklist items index 64-row tiles with 10 bits: n <= 65536)
     if (mfma_k1) {
       HIPCHK(h, h->d_pk.ensure((size_t)tim_operand_bytes(total_n)));
-      HIPCHK(h, h->d_prep.ensure((size_t)tim_prep_bytes(batch)));
       HIPCHK(h, h->d_work.ensure(8 * (size_t)tim_work_items(n, batch) + 64));
     }
   }
@@ -643,17 +692,13 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
     StageScope sc(h, ST_H2D);
     // staged through page-locked memory: an async H2D from pageable memory blocks the host until the
     // copy has completed (tens of microseconds each while the GPU is busy with the other lanes)
-    const size_t b_desc = sizeof(ProbDesc) * (size_t)batch, b_state = sizeof(ProbState) * (size_t)batch,
-                 b_off = 8 * (size_t)batch;
-    HIPCHK(h, h->pin_in.ensure(b_desc + b_state + b_off));
+    HIPCHK(h, h->pin_in.ensure(hdr_bytes));
     char* stage = reinterpret_cast<char*>(h->pin_in.p);
-    memcpy(stage, h->descs.data(), b_desc);
-    memcpy(stage + b_desc, h->states.data(), b_state);
-    memcpy(stage + b_desc + b_state, h->tim_off.data(), b_off);
-    HIPCHK(h, hipMemcpyAsync(h->d_desc.p, stage, b_desc, hipMemcpyHostToDevice, s));
-    HIPCHK(h, hipMemcpyAsync(h->d_state.p, stage + b_desc, b_state, hipMemcpyHostToDevice, s));
-    HIPCHK(h, hipMemcpyAsync(h->d_tim_off.p, stage + b_desc + b_state, b_off, hipMemcpyHostToDevice, s));
-    if (need_graph) HIPCHK(h, hipMemsetAsync(h->d_next_count.p, 0, 4 * (size_t)batch, s));
+    memset(stage, 0, hdr_bytes);
+    memcpy(stage + o_desc, h->descs.data(), b_desc);
+    memcpy(stage + o_state, h->states.data(), b_state);
+    memcpy(stage + o_off, h->tim_off.data(), b_off);
+    HIPCHK(h, hipMemcpyAsync(h->hdr.p, stage, hdr_bytes, hipMemcpyHostToDevice, s));
   }
   const ProbDesc* dd = h->d_desc.as<ProbDesc>();
   ProbState* ds = h->d_state.as<ProbState>();
@@ -673,16 +718,22 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
     } else {
       const int64_t cap = tim_work_items(n, batch);
       for (int phase = 0; phase < 3; ++phase) {
-        // lanes of a pipelined batch run their K1 kernels one after the other (this lane's starts when
-        // the previous lane's has finished), so that a K1 shares the GPU only with the latency-bound
-        // tail stages of the lanes before it
-        if (phase == 1 && h->wait_before_k1) HIPCHK(h, hipStreamWaitEvent(s, h->wait_before_k1, 0));
+        // lanes (asynchronous batches in flight) run their K1 kernels one after the other: this
+        // lane's starts when the previously submitted lane's has finished, so that a K1 shares the
+        // GPU only with the latency-bound tail stages of the batches before it
+        if (phase == 1 && h->wait_before_k1) {
+          HIPCHK(h, hipStreamWaitEvent(s, h->wait_before_k1, 0));
+          h->wait_before_k1 = nullptr;
+        }
         {
           StageScope sc(h, phase == 1 ? ST_TIM : ST_TIMAUX);
           launch_tim_graph_mfma(s, phase, dd, batch, max_n, total_n, d_src, d_dst, h->d_pk.p, h->d_prep.p,
                                 h->d_work.p, cap, h->d_bitmap.as<uint64_t>(), ds, P.noise_bound, P.cbar2);
         }
-        if (phase == 1 && h->k1_done) HIPCHK(h, hipEventRecord(h->k1_done, s));
+        if (phase == 1 && h->k1_done) {
+          HIPCHK(h, hipEventRecord(h->k1_done, s));
+          h->k1_recorded = true;
+        }
       }
     }
     for (int b = 0; b < batch; ++b) {
@@ -693,7 +744,6 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
     {
       StageScope sc(h, ST_DEG);
       launch_degrees(s, dd, batch, max_n, h->d_bitmap.as<uint64_t>(), h->d_deg.as<int32_t>(), ds);
-      launch_pick_starts(s, dd, batch, h->d_deg.as<int32_t>(), ds);
     }
     {
       StageScope sc(h, ST_HEU);
@@ -788,80 +838,6 @@ int32_t solve_packed_impl(teaser_hip_solver* h, const double* d_src, const doubl
 
 int32_t make_lane(teaser_hip_solver* h, teaser_hip_solver** out);
 
-// EXPERIMENTAL, off by default (TEASER_HIP_PIPELINE=<lanes> enables it).  Measured on one MI355X at
-// 64 x N=10k: 2 lanes 2.68 ms/step (= unpipelined), 4 lanes 3.2 ms: one host thread needs ~0.3 ms to
-// enqueue a lane (~45 API calls), the K1 kernels slow down by ~15 % when they share the GPU with the
-// tails, and the runtime maps the lanes' streams onto two hardware queues (lanes sharing a queue
-// serialise).  Feeding independent handles from several host threads (bench.py --streams) does pay
-// (+26 % at 3); the enqueue/finish split below is the base for doing that inside the library.
-//
-// Pipelined batch: the problems are cut into contiguous chunks, each solved by a LANE (a child
-// handle with its own HIP stream and arenas).  All lanes are enqueued before the first host sync;
-// a lane's K1 kernel waits for the previous lane's (hipStreamWaitEvent), so the GPU runs
-//   K1(0) | K1(1) + tail(0) | K1(2) + tail(1) | ... | tail(last)
-// where tail = fix-up, degrees, greedy clique, peel, GNC, TLS: one workgroup per problem, far from
-// filling 256 CUs on their own.  Results and getters are identical to the unpipelined path (every
-// problem is solved by exactly the same kernels; only the co-scheduling differs).
-int32_t solve_pipelined(teaser_hip_solver* h, const double* d_src, const double* d_dst,
-                        const int64_t* pt_off, const int32_t* n, int batch, int chunks,
-                        teaser_solution_c* out) {
-  while ((int)h->lanes.size() < chunks) {
-    teaser_hip_solver* lane = nullptr;
-    const int32_t rc = make_lane(h, &lane);
-    if (rc != TEASER_HIP_OK) return rc;
-    h->lanes.push_back(lane);
-  }
-  h->route.assign((size_t)batch, std::make_pair(0, 0));
-  std::vector<int> lo((size_t)chunks + 1, 0);
-  for (int c = 0; c < chunks; ++c) lo[(size_t)c + 1] = (int)((int64_t)batch * (c + 1) / chunks);
-  int32_t rc = TEASER_HIP_OK;
-  int enq = 0;
-  for (int c = 0; c < chunks && rc == TEASER_HIP_OK; ++c) {
-    teaser_hip_solver* lane = h->lanes[(size_t)c];
-    lane->params = h->params;
-    lane->profiling = h->profiling;
-    lane->wait_before_k1 = c > 0 ? h->lanes[(size_t)c - 1]->k1_done : nullptr;
-    profile_begin(lane);
-    const int b0 = lo[(size_t)c], nb = lo[(size_t)c + 1] - b0;
-    for (int b = 0; b < nb; ++b) h->route[(size_t)(b0 + b)] = std::make_pair(c, b);
-    rc = solve_packed_enqueue(lane, d_src, d_dst, pt_off + b0, n + b0, nb, false);
-    if (rc != TEASER_HIP_OK) h->err = lane->err;
-    ++enq;
-  }
-  for (int c = 0; c < enq; ++c) {  // every enqueued lane is drained, also after an error
-    teaser_hip_solver* lane = h->lanes[(size_t)c];
-    const int b0 = lo[(size_t)c], nb = lo[(size_t)c + 1] - b0;
-    bool overflow = false;
-    int32_t r2 = (rc == TEASER_HIP_OK) ? solve_packed_finish(lane, out + b0, &overflow)
-                                       : (int32_t)(hipStreamSynchronize(lane->stream) == hipSuccess
-                                                       ? TEASER_HIP_OK : TEASER_HIP_ERR_HIP);
-    if (r2 == TEASER_HIP_OK && rc == TEASER_HIP_OK && overflow) {
-      lane->wait_before_k1 = nullptr;  // K1 fix-up list overflowed: this chunk again, all-FP64 K1
-      r2 = solve_packed_impl(lane, d_src, d_dst, pt_off + b0, n + b0, nb, out + b0, true, &overflow);
-    }
-    if (r2 != TEASER_HIP_OK && rc == TEASER_HIP_OK) {
-      rc = r2;
-      h->err = lane->err;
-    }
-    profile_end(lane);
-  }
-  // the parent's profile is the sum over the lanes (K1 launches = chunks)
-  memset(&h->prof, 0, sizeof(h->prof));
-  for (int c = 0; c < enq; ++c) {
-    const teaser_profile_c& q = h->lanes[(size_t)c]->prof;
-    h->prof.h2d_ms += q.h2d_ms; h->prof.tim_graph_ms += q.tim_graph_ms;
-    h->prof.tim_graph_launches += q.tim_graph_launches; h->prof.degree_ms += q.degree_ms;
-    h->prof.heuristic_ms += q.heuristic_ms; h->prof.peel_ms += q.peel_ms; h->prof.exact_ms += q.exact_ms;
-    h->prof.rotation_ms += q.rotation_ms; h->prof.translation_ms += q.translation_ms;
-    h->prof.d2h_ms += q.d2h_ms; h->prof.total_ms += q.total_ms;
-    h->prof.tim_graph_pairs += q.tim_graph_pairs; h->prof.tim_graph_bytes += q.tim_graph_bytes;
-    h->prof.colour_ms += q.colour_ms; h->prof.tim_aux_ms += q.tim_aux_ms;
-  }
-  h->batch = batch;
-  h->have_graph = true;
-  return rc;
-}
-
 // K1 runs as the matrix-core filter; if its FP64 fix-up list overflowed (adversarial geometry) the
 // whole batch is solved again with the all-FP64 K1 -- same results, slower.
 int32_t solve_packed(teaser_hip_solver* h, const double* d_src, const double* d_dst,
@@ -871,11 +847,6 @@ int32_t solve_packed(teaser_hip_solver* h, const double* d_src, const double* d_
     h->err = "a batch holds at most 65535 problems; split larger batches across calls";
     return TEASER_HIP_ERR_UNSUPPORTED;
   }
-  // batches of >= 16 problems are pipelined over up to pipeline_chunks lanes (>= 8 problems each)
-  const int chunks = std::min(h->pipeline_chunks, batch / 8);
-  if (!h->is_lane && chunks >= 2 && effective_mode(h->params) != TEASER_INLIER_NONE &&
-      !h->params.estimate_scaling && params_supported(h->params))
-    return solve_pipelined(h, d_src, d_dst, pt_off, n, batch, chunks, out);
   bool overflow = false;
   int32_t rc = solve_packed_impl(h, d_src, d_dst, pt_off, n, batch, out, false, &overflow);
   if (rc == TEASER_HIP_OK && overflow)
@@ -905,7 +876,6 @@ int32_t upload_and_solve(teaser_hip_solver* h, const double* const* src, const d
                                hipMemcpyHostToDevice, h->stream));
     }
   }
-  if (batch >= 16) HIPCHK(h, hipStreamSynchronize(h->stream));  // lanes read the inputs on other streams
   int32_t rc = solve_packed(h, h->d_src.as<double>(), h->d_dst.as<double>(), off.data(), n, batch, out);
   profile_end(h);
   return rc;
@@ -927,7 +897,6 @@ int32_t make_lane(teaser_hip_solver* h, teaser_hip_solver** out) {
   lane->device = h->device;
   lane->params = h->params;
   lane->is_lane = true;
-  lane->pipeline_chunks = 1;
   memset(&lane->prof, 0, sizeof(lane->prof));
   if (hipStreamCreateWithFlags(&lane->stream, hipStreamNonBlocking) != hipSuccess ||
       hipEventCreateWithFlags(&lane->k1_done, hipEventDisableTiming) != hipSuccess) {
@@ -945,7 +914,7 @@ void release_handle_resources(teaser_hip_solver* h) {
   DevBuf* bufs[] = {&h->d_desc, &h->d_state, &h->d_src, &h->d_dst, &h->d_bitmap, &h->d_deg,
                     &h->d_clique, &h->d_start_cliques, &h->d_alive_a, &h->d_alive_b,
                     &h->d_next_count, &h->d_weights, &h->d_rot_inl, &h->d_trans_inl,
-                    &h->d_tls_scratch, &h->d_tim_off, &h->d_pk, &h->d_prep, &h->d_work, &h->x_order,
+                    &h->d_tls_scratch, &h->d_tim_off, &h->d_pk, &h->d_prep, &h->d_work, &h->hdr, &h->x_order,
                     &h->x_src, &h->x_dst, &h->x_bitmap, &h->x_desc, &h->x_state, &h->x_ctrl,
                     &h->x_clique, &h->x_arena, &h->c_sel, &h->c_colour, &h->c_tent, &h->c_xlist,
                     &h->s_a, &h->s_b, &h->s_c, &h->s_d, &h->s_e};
@@ -958,6 +927,104 @@ void release_handle_resources(teaser_hip_solver* h) {
   if (h->stream) (void)hipStreamDestroy(h->stream);
   h->k1_done = nullptr;
   h->stream = nullptr;
+}
+
+// ---- asynchronous batches ------------------------------------------------------------------
+// submit: everything of a solve that needs no host sync is enqueued on a free lane's stream
+// (H2D of host inputs, K1, clique stages, estimators, D2H of the states); wait: that lane's ONE
+// host sync, the rare bound-closing work, the outputs.  With two or three batches in flight the
+// host enqueues batch k+1 while the GPU runs batch k, and the one-workgroup-per-problem tail of
+// batch k shares the GPU with batch k+1's K1.
+int32_t ensure_lanes(teaser_hip_solver* h) {
+  while ((int)h->lanes.size() < h->depth) {
+    teaser_hip_solver* lane = nullptr;
+    const int32_t rc = make_lane(h, &lane);
+    if (rc != TEASER_HIP_OK) return rc;
+    h->lanes.push_back(lane);
+  }
+  return TEASER_HIP_OK;
+}
+
+int32_t submit_impl(teaser_hip_solver* h, const double* src, const double* dst,
+                    const int64_t* pt_off, const int32_t* n, int batch, int flags, int32_t* ticket) {
+  int32_t rc = ensure_lanes(h);
+  if (rc != TEASER_HIP_OK) return rc;
+  const int idx = h->next_lane;
+  teaser_hip_solver* lane = h->lanes[(size_t)idx];
+  if (lane->job.busy) {
+    h->err = "every lane holds a submitted batch: call teaser_hip_wait first (or raise the depth)";
+    return TEASER_HIP_ERR_BUSY;
+  }
+  lane->params = h->params;
+  lane->profiling = h->profiling;
+  lane->job.off.assign(pt_off, pt_off + batch);
+  lane->job.n.assign(n, n + batch);
+  profile_begin(lane);
+  const double* d_src = src;
+  const double* d_dst = dst;
+  if (flags & TEASER_HIP_INPUT_HOST) {
+    // packed host arrays: ONE copy per cloud (page-locked caller memory moves at PCIe speed and the
+    // copy overlaps the previous batch's kernels; pageable memory is staged by the runtime)
+    int64_t tot = 0;
+    for (int b = 0; b < batch; ++b) {
+      if (n[b] < 0 || pt_off[b] < 0) return TEASER_HIP_ERR_BAD_ARG;
+      tot = std::max<int64_t>(tot, pt_off[b] + n[b]);
+    }
+    HIPCHK(h, lane->d_src.ensure((size_t)std::max<int64_t>(tot, 1) * 24));
+    HIPCHK(h, lane->d_dst.ensure((size_t)std::max<int64_t>(tot, 1) * 24));
+    if (tot > 0) {
+      StageScope sc(lane, ST_H2D);
+      HIPCHK(h, hipMemcpyAsync(lane->d_src.p, src, (size_t)tot * 24, hipMemcpyHostToDevice, lane->stream));
+      HIPCHK(h, hipMemcpyAsync(lane->d_dst.p, dst, (size_t)tot * 24, hipMemcpyHostToDevice, lane->stream));
+    }
+    d_src = lane->d_src.as<double>();
+    d_dst = lane->d_dst.as<double>();
+  }
+  lane->job.d_src = d_src;
+  lane->job.d_dst = d_dst;
+  lane->wait_before_k1 = nullptr;
+  if (h->stagger_k1 && h->last_lane >= 0 && h->last_lane != idx) {
+    teaser_hip_solver* prev = h->lanes[(size_t)h->last_lane];
+    if (prev->k1_recorded) lane->wait_before_k1 = prev->k1_done;
+  }
+  rc = solve_packed_enqueue(lane, d_src, d_dst, lane->job.off.data(), lane->job.n.data(), batch, false);
+  if (rc != TEASER_HIP_OK) {
+    h->err = lane->err;
+    (void)hipStreamSynchronize(lane->stream);
+    return rc;
+  }
+  lane->job.busy = true;
+  h->last_lane = idx;
+  h->next_lane = (idx + 1) % h->depth;
+  *ticket = idx;
+  return TEASER_HIP_OK;
+}
+
+int32_t wait_impl(teaser_hip_solver* h, int32_t ticket, teaser_solution_c* out) {
+  if (ticket < 0 || ticket >= (int32_t)h->lanes.size() || !h->lanes[(size_t)ticket]->job.busy) {
+    h->err = "teaser_hip_wait: no submitted batch behind this ticket";
+    return TEASER_HIP_ERR_BAD_ARG;
+  }
+  teaser_hip_solver* lane = h->lanes[(size_t)ticket];
+  const int batch = (int)lane->job.n.size();
+  bool overflow = false;
+  int32_t rc = solve_packed_finish(lane, out, &overflow);
+  if (rc == TEASER_HIP_OK && overflow)  // K1 fix-up list overflowed: this batch again, all-FP64 K1
+    rc = solve_packed_impl(lane, lane->job.d_src, lane->job.d_dst, lane->job.off.data(),
+                           lane->job.n.data(), batch, out, true, &overflow);
+  if (rc != TEASER_HIP_OK) {
+    h->err = lane->err;
+    (void)hipStreamSynchronize(lane->stream);
+  }
+  profile_end(lane);
+  h->prof = lane->prof;
+  lane->job.busy = false;
+  // getters now address this batch
+  h->route.assign((size_t)batch, std::make_pair(0, 0));
+  for (int b = 0; b < batch; ++b) h->route[(size_t)b] = std::make_pair((int)ticket, b);
+  h->batch = batch;
+  h->have_graph = lane->have_graph;
+  return rc;
 }
 
 // problem index of the caller -> the handle that solved it (a lane of a pipelined batch, or h itself)
@@ -1025,10 +1092,11 @@ int32_t teaser_hip_solver_create(const teaser_params_c* params, int32_t device,
     delete h;
     return TEASER_HIP_ERR_HIP;
   }
-  if (const char* e = getenv("TEASER_HIP_PIPELINE")) {  // lanes of a pipelined batch; 1 = off
+  if (const char* e = getenv("TEASER_HIP_DEPTH")) {  // lanes for asynchronous batches
     const int v = atoi(e);
-    if (v >= 1 && v <= 16) h->pipeline_chunks = v;
+    if (v >= 1 && v <= 16) h->depth = v;
   }
+  if (const char* e = getenv("TEASER_HIP_STAGGER")) h->stagger_k1 = atoi(e) != 0;
   *out = h;
   return TEASER_HIP_OK;
 }
@@ -1342,7 +1410,6 @@ int32_t teaser_hip_max_clique(teaser_hip_solver* h, const uint64_t* bitmap, int3
   ProbState* ds = h->d_state.as<ProbState>();
   const bool exact = (mode == TEASER_INLIER_PMC_EXACT);
   launch_degrees(s, dd, 1, n, h->d_bitmap.as<uint64_t>(), h->d_deg.as<int32_t>(), ds);
-  launch_pick_starts(s, dd, 1, h->d_deg.as<int32_t>(), ds);
   launch_heuristic(s, dd, 1, W, h->d_bitmap.as<uint64_t>(), h->d_deg.as<int32_t>(), ds,
                    h->d_start_cliques.as<int32_t>(), n, nullptr, h->d_clique.as<int32_t>());
   launch_select_best(s, dd, 1, W, h->d_deg.as<int32_t>(), ds, h->d_start_cliques.as<int32_t>(), n,
@@ -1365,9 +1432,132 @@ int32_t teaser_hip_max_clique(teaser_hip_solver* h, const uint64_t* bitmap, int3
   return h->prob_status[0];
 }
 
-int32_t teaser_hip_set_profiling(teaser_hip_solver* h, int32_t enable) {
-  if (!h) return TEASER_HIP_ERR_BAD_ARG;
-  h->profiling = enable != 0;
+int32_t teaser_hip_submit_batch(teaser_hip_solver* h, const double* src, const double* dst,
+                                const int64_t* point_offset, const int32_t* n, int32_t batch,
+                                int32_t flags, int32_t* ticket) {
+  if (!h || !ticket || batch <= 0 || !src || !dst || !point_offset || !n) return TEASER_HIP_ERR_BAD_ARG;
+  if (batch > 65535) {
+    h->err = "a batch holds at most 65535 problems; split larger batches across calls";
+    return TEASER_HIP_ERR_UNSUPPORTED;
+  }
+  (void)hipSetDevice(h->device);
+  return submit_impl(h, src, dst, point_offset, n, batch, flags, ticket);
+}
+
+int32_t teaser_hip_wait(teaser_hip_solver* h, int32_t ticket, teaser_solution_c* out) {
+  if (!h || !out) return TEASER_HIP_ERR_BAD_ARG;
+  (void)hipSetDevice(h->device);
+  return wait_impl(h, ticket, out);
+}
+
+int32_t teaser_hip_set_pipeline_depth(teaser_hip_solver* h, int32_t depth) {
+  if (!h || depth < 1 || depth > 16) return TEASER_HIP_ERR_BAD_ARG;
+  for (teaser_hip_solver* lane : h->lanes)
+    if (lane->job.busy) return TEASER_HIP_ERR_BUSY;
+  if (depth < (int32_t)h->lanes.size()) {
+    (void)hipSetDevice(h->device);
+    for (size_t k = (size_t)depth; k < h->lanes.size(); ++k) {
+      release_handle_resources(h->lanes[k]);
+      delete h->lanes[k];
+    }
+    h->lanes.resize((size_t)depth);
+    h->route.clear();
+    h->batch = 0;
+  }
+  h->depth = depth;
+  h->next_lane = 0;
+  h->last_lane = -1;
+  return TEASER_HIP_OK;
+}
+
+// ---- one process, several devices -------------------------------------------------------------
+int32_t teaser_hip_multi_create(const teaser_params_c* params, const int32_t* devices,
+                                int32_t n_devices, teaser_hip_multi** out) {
+  if (!out || n_devices < 0 || (n_devices > 0 && !devices)) return TEASER_HIP_ERR_BAD_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return TEASER_HIP_ERR_NO_DEVICE;
+  std::vector<int32_t> devs;
+  if (n_devices == 0)
+    for (int d = 0; d < count; ++d) devs.push_back(d);
+  else
+    devs.assign(devices, devices + n_devices);
+  teaser_hip_multi* mh = new teaser_hip_multi();
+  for (int32_t d : devs) {
+    teaser_hip_solver* h = nullptr;
+    const int32_t rc = (d < 0 || d >= count) ? (int32_t)TEASER_HIP_ERR_BAD_ARG
+                                             : teaser_hip_solver_create(params, d, &h);
+    if (rc != TEASER_HIP_OK) {
+      teaser_hip_multi_destroy(mh);
+      return rc;
+    }
+    mh->handles.push_back(h);
+  }
+  *out = mh;
+  return TEASER_HIP_OK;
+}
+
+int32_t teaser_hip_multi_destroy(teaser_hip_multi* mh) {
+  if (!mh) return TEASER_HIP_OK;
+  for (teaser_hip_solver* h : mh->handles) teaser_hip_solver_destroy(h);
+  delete mh;
+  return TEASER_HIP_OK;
+}
+
+int32_t teaser_hip_multi_device_count(const teaser_hip_multi* mh) {
+  return mh ? (int32_t)mh->handles.size() : 0;
+}
+
+int32_t teaser_hip_multi_solve_batch(teaser_hip_multi* mh, const double* const* src,
+                                     const double* const* dst, const int32_t* n, int32_t batch,
+                                     teaser_solution_c* out) {
+  if (!mh || mh->handles.empty() || batch < 0 || (batch > 0 && (!src || !dst || !n || !out)))
+    return TEASER_HIP_ERR_BAD_ARG;
+  // contiguous blocks, balanced by the O(n^2) pair count of the problems
+  const int G = (int)mh->handles.size();
+  std::vector<double> cost((size_t)batch + 1, 0.0);
+  for (int b = 0; b < batch; ++b) cost[(size_t)b + 1] = cost[(size_t)b] + (double)n[b] * (double)n[b] + 1.0;
+  mh->first.assign((size_t)G + 1, batch);
+  mh->first[0] = 0;
+  for (int g = 1, b = 0; g < G; ++g) {
+    const double target = cost[(size_t)batch] * g / G;
+    while (b < batch && cost[(size_t)b] < target) ++b;
+    mh->first[(size_t)g] = b;
+  }
+  std::vector<int32_t> rcs((size_t)G, TEASER_HIP_OK);
+  std::vector<std::thread> th;
+  for (int g = 0; g < G; ++g) {
+    const int b0 = mh->first[(size_t)g], nb = mh->first[(size_t)g + 1] - b0;
+    if (nb <= 0) {
+      mh->handles[(size_t)g]->batch = 0;
+      continue;
+    }
+    th.emplace_back([=, &rcs]() {  // one host thread per handle: HIP calls of different devices overlap
+      rcs[(size_t)g] = teaser_hip_solve_batch(mh->handles[(size_t)g], src + b0, dst + b0, n + b0, nb, out + b0);
+    });
+  }
+  for (std::thread& t : th) t.join();
+  for (int g = 0; g < G; ++g)
+    if (rcs[(size_t)g] != TEASER_HIP_OK) return rcs[(size_t)g];
+  return TEASER_HIP_OK;
+}
+
+int32_t teaser_hip_multi_route(teaser_hip_multi* mh, int32_t problem, teaser_hip_solver** h,
+                               int32_t* local_problem) {
+  if (!mh || !h || !local_problem || mh->first.empty() || problem < 0 || problem >= mh->first.back())
+    return TEASER_HIP_ERR_BAD_ARG;
+  for (size_t g = 0; g + 1 < mh->first.size(); ++g)
+    if (problem < mh->first[g + 1]) {
+      *h = mh->handles[g];
+      *local_problem = problem - mh->first[g];
+      return TEASER_HIP_OK;
+    }
+  return TEASER_HIP_ERR_BAD_ARG;
+}
+
+int32_t teaser_hip_set_profiling(teaser_hip_solver* h, int32_t level) {
+  if (!h || level < 0 || level > 2) return TEASER_HIP_ERR_BAD_ARG;
+  h->profiling = level;
   return TEASER_HIP_OK;
 }
 

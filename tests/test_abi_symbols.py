@@ -60,7 +60,7 @@ def test_bench_cli_parses_without_gpu():
     import subprocess
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True)
-    assert r.returncode == 0 and "--streams" in r.stdout and "--batch" in r.stdout
+    assert r.returncode == 0 and "--depth" in r.stdout and "--batch" in r.stdout and "--gpus" in r.stdout
     if tp.device_count() == 0:
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")], capture_output=True, text=True)
         assert r.returncode != 0 and "needs an MI355X" in (r.stderr + r.stdout)

@@ -484,6 +484,67 @@ def test_solve_config3_50k_properties():
     assert np.linalg.norm(sol.translation - pr["t"]) < 0.01
 
 
+def config_golden():
+    import json
+    import os
+    from util import ROOT
+    return json.load(open(os.path.join(ROOT, "tests", "golden", "config_golden.json")))
+
+
+def check_against_fixture(s, sol, fx, problem=0):
+    """Identity with the committed ORACLE result (tests/golden/make_config_golden.py): clique, rotation /
+    translation inlier lists, edge count, R and t to the north_star tolerances."""
+    assert bool(sol.valid) == fx["valid"]
+    assert s.raw_solution(problem).num_edges == fx["num_edges"]
+    clique = s.getInlierMaxClique(problem)
+    assert len(clique) == len(fx["max_clique"])
+    if fx["clique_unique"]:
+        assert clique == fx["max_clique"]
+        assert s.getRotationInliers(problem) == fx["rotation_inliers"]
+        assert s.getTranslationInliers(problem) == fx["translation_inliers"]
+        assert np.linalg.norm(np.asarray(sol.rotation).reshape(3, 3) - np.array(fx["rotation"]).reshape(3, 3)) <= R_TOL
+        assert np.linalg.norm(np.asarray(sol.translation) - np.array(fx["translation"])) <= T_TOL
+
+
+def test_solve_config3_50k_vs_oracle_fixture():
+    """BASELINE config 3 against the ORACLE (committed fixture: the oracle needs minutes at this size):
+    identical clique / inlier index sets, R and t within 1e-4, identical edge count, and the WHOLE 313 MB
+    adjacency bitmap bit for bit through its SHA-256."""
+    import hashlib
+    fx = config_golden()["config3"]
+    pr = tp.synth_problem(fx["seed"], fx["n"], fx["outlier_ratio"], fx["noise_bound"])
+    s = make_solver(**bench_params())
+    sol = s.solve(pr["src"], pr["dst"])
+    check_against_fixture(s, sol, fx)
+    assert fx["clique_unique"] and len(fx["max_clique"]) >= 500
+    bm = np.ascontiguousarray(s.getInlierGraphBitmap())
+    assert hashlib.sha256(bm.tobytes()).hexdigest() == fx["bitmap_sha256"]
+    deg = s.getDegrees().astype(np.int64)
+    assert int(deg.sum()) == fx["degree_sum"] and int(deg.max()) == fx["degree_max"]
+    assert int((deg * (np.arange(fx["n"], dtype=np.int64) % 1009 + 1)).sum()) == fx["degree_weighted_checksum"]
+
+
+def test_solve_config2_and_config4_elements_vs_oracle_fixture():
+    """Config 2 and three elements of the config-4 batch (solved inside the full 128-problem batch)
+    against the committed oracle fixture, bitmaps through their SHA-256."""
+    import hashlib
+    G4 = config_golden()
+    fx2 = G4["config2"]
+    pr = tp.synth_problem(fx2["seed"], fx2["n"], fx2["outlier_ratio"], fx2["noise_bound"])
+    s = make_solver(**bench_params())
+    check_against_fixture(s, s.solve(pr["src"], pr["dst"]), fx2)
+    assert hashlib.sha256(np.ascontiguousarray(s.getInlierGraphBitmap()).tobytes()).hexdigest() == fx2["bitmap_sha256"]
+    B, n = 128, 5000
+    probs = [tp.synth_problem(20250523 + 4000 + b, n, 0.9, 0.01) for b in range(B)]
+    sols = s.solve_batch([p["src"] for p in probs], [p["dst"] for p in probs])
+    for b in (0, 57, 127):
+        fx = G4["config4_b%d" % b]
+        assert fx["seed"] == 20250523 + 4000 + b
+        check_against_fixture(s, sols[b], fx, problem=b)
+        bm = np.ascontiguousarray(s.getInlierGraphBitmap(b))
+        assert hashlib.sha256(bm.tobytes()).hexdigest() == fx["bitmap_sha256"]
+
+
 def test_solve_config4_batch_5k_properties():
     """BASELINE config 4 (one GPU's share): 128 independent N = 5 000 problems, 90 % outliers, in one
     batched call; every problem recovers its planted clique and pose, and batched results are
@@ -779,10 +840,20 @@ def test_correspondence_overload():
     dst_shuffled = dst_cloud[perm]
     inv = np.argsort(perm)
     corr = np.stack([np.arange(500), inv], axis=1)
-    s = make_solver(**bench_params())
+    p = bench_params()
+    s = make_solver(**p)
     sol = s.solve_correspondences(src_cloud, dst_shuffled, corr)
-    s2 = make_solver(**bench_params())
-    sol2 = s2.solve(src_cloud.astype(np.float64).T, dst_cloud.astype(np.float64).T)
+    # the ORACLE on the gathered, float -> double widened arrays (registration.cc:557-565): pins the
+    # gather + widening semantics independently of the HIP path
+    gs = src_cloud[corr[:, 0]].astype(np.float64).T
+    gd = dst_shuffled[corr[:, 1]].astype(np.float64).T
+    o = oracle.solve(gs, gd, **oracle_params(p))
+    check_solution_parity(s, sol, o)
+    assert o["valid"] and o["clique_unique"]
+    assert s.getInlierMaxClique() == o["max_clique"].tolist()
+    # and the matrix overload of the HIP path agrees bit for bit with the correspondence overload
+    s2 = make_solver(**p)
+    sol2 = s2.solve(gs, gd)
     assert (sol.rotation == sol2.rotation).all() and (sol.translation == sol2.translation).all()
     assert s.getInlierMaxClique() == s2.getInlierMaxClique()
 
@@ -816,3 +887,99 @@ def test_determinism():
         assert (sol.rotation == first.rotation).all() and (sol.translation == first.translation).all()
         assert s.getInlierMaxClique() == c0
         assert (s.getInlierGraphBitmap() == b0).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# asynchronous batches (teaser_hip_submit_batch / teaser_hip_wait), host inputs, several handles
+# ---------------------------------------------------------------------------------------------
+def _packed(probs):
+    src = np.ascontiguousarray(np.concatenate([p["src"].T for p in probs], axis=0))
+    dst = np.ascontiguousarray(np.concatenate([p["dst"].T for p in probs], axis=0))
+    n = np.array([p["src"].shape[1] for p in probs], dtype=np.int32)
+    off = np.concatenate([[0], np.cumsum(n)[:-1]]).astype(np.int64)
+    return src, dst, off, n
+
+
+def test_async_batches_match_sync():
+    """Four ragged batches in flight over three lanes (device inputs, then host inputs): every problem
+    is identical -- clique, inliers, R, t bit for bit -- to the synchronous batched solve."""
+    import torch
+    sizes = [[300, 1000, 64, 777], [2000, 500], [1500, 1, 129, 640, 900], [1024, 2048]]
+    batches = [[tp.synth_problem(900 + 10 * k + i, n, 0.85, 0.01) for i, n in enumerate(sz)]
+               for k, sz in enumerate(sizes)]
+    ref = make_solver(**bench_params())
+    want = []
+    for probs in batches:
+        sols = ref.solve_batch([p["src"] for p in probs], [p["dst"] for p in probs])
+        want.append([(bool(o.valid), o.rotation.copy(), o.translation.copy(), ref.getInlierMaxClique(b),
+                      ref.getRotationInliers(b), ref.getTranslationInliers(b)) for b, o in enumerate(sols)])
+    s = make_solver(**bench_params())
+    s.set_pipeline_depth(3)
+    for host in (False, True):
+        keep, tickets = [], []
+        for probs in batches[:3]:
+            src, dst, off, n = _packed(probs)
+            if host:
+                a, b = torch.from_numpy(src).pin_memory(), torch.from_numpy(dst).pin_memory()
+            else:
+                a, b = torch.from_numpy(src).cuda(), torch.from_numpy(dst).cuda()
+            keep.append((a, b))
+            tickets.append(s.submit_batch(a.data_ptr(), b.data_ptr(), off, n, host=host))
+        # all three lanes are in flight: a fourth submit must be refused, loudly
+        src, dst, off, n = _packed(batches[3])
+        a = torch.from_numpy(src).pin_memory() if host else torch.from_numpy(src).cuda()
+        b = torch.from_numpy(dst).pin_memory() if host else torch.from_numpy(dst).cuda()
+        with pytest.raises(tp.TeaserHipError):
+            s.submit_batch(a.data_ptr(), b.data_ptr(), off, n, host=host)
+        order = [1, 0, 2]  # tickets may be waited for in any order
+        for k in order:
+            out = s.wait(tickets[k])
+            for bi, w in enumerate(want[k]):
+                o = out[bi]
+                assert bool(o.valid) == w[0]
+                assert s.getInlierMaxClique(bi) == w[3]
+                if w[0]:
+                    assert (np.array(o.rotation[:]).reshape(3, 3) == w[1]).all()
+                    assert (np.array(o.translation[:]) == w[2]).all()
+                    assert s.getRotationInliers(bi) == w[4] and s.getTranslationInliers(bi) == w[5]
+        t3 = s.submit_batch(a.data_ptr(), b.data_ptr(), off, n, host=host)
+        out = s.wait(t3)
+        for bi, w in enumerate(want[3]):
+            assert s.getInlierMaxClique(bi) == w[3]
+            assert (np.array(out[bi].rotation[:]).reshape(3, 3) == w[1]).all()
+        with pytest.raises(tp.TeaserHipError):
+            s.wait(t3)  # a ticket is waited for exactly once
+
+
+def test_multi_device_fan_out():
+    """teaser_hip_multi_*: two handles (the same GPU listed twice on a 1-GPU box), one host thread each;
+    a ragged batch cut into contiguous blocks gives the same results as one handle."""
+    sizes = [1200, 300, 64, 2000, 777, 1, 500, 1500, 900]
+    probs = [tp.synth_problem(700 + i, n, 0.8, 0.01) for i, n in enumerate(sizes)]
+    ref = make_solver(**bench_params())
+    want = ref.solve_batch([p["src"] for p in probs], [p["dst"] for p in probs])
+    cl = [ref.getInlierMaxClique(b) for b in range(len(probs))]
+    ndev = tp.device_count()
+    m = tp.MultiDeviceSolver(tp.RobustRegistrationSolver.Params(**bench_params()),
+                             devices=[0, 0] if ndev == 1 else None)
+    assert m.device_count() == (2 if ndev == 1 else ndev)
+    out = m.solve_batch([p["src"] for p in probs], [p["dst"] for p in probs])
+    for b in range(len(probs)):
+        assert bool(out[b].valid) == want[b].valid
+        assert m.max_clique(b) == cl[b]
+        if want[b].valid:
+            assert (np.array(out[b].rotation[:]).reshape(3, 3) == want[b].rotation).all()
+            assert (np.array(out[b].translation[:]) == want[b].translation).all()
+    m.close()
+
+
+def test_k1_scheduling_variants_bit_identical(monkeypatch):
+    """TEASER_K1_VARIANT: 0 / 1 are two instruction schedules of the matrix-core K1, -1 forces the
+    all-FP64 kernel; the three bitmaps are identical (and equal the oracle's)."""
+    pr = tp.synth_problem(61, 4500, 0.9, 0.01)
+    _, ref = oracle.inlier_bitmap(pr["src"], pr["dst"], 0.01, 1.0, False)
+    for v in ("-1", "0", "1"):
+        monkeypatch.setenv("TEASER_K1_VARIANT", v)
+        s = make_solver(**bench_params())
+        s.solve(pr["src"], pr["dst"])
+        assert (s.getInlierGraphBitmap() == ref).all(), v

@@ -305,3 +305,32 @@ def test_python_mirror_names_and_tim_helper():
     tims, mp = oracle.compute_tims(v)
     mine = t.RobustRegistrationSolver._compute_tims(np.ascontiguousarray(v.T))
     assert np.array_equal(mine, tims.T if tims.shape[0] != 3 else tims)
+
+
+def test_config_fixture_is_what_the_oracle_returns():
+    """tests/golden/config_golden.json (tests/golden/make_config_golden.py) holds oracle results for
+    the full-size BASELINE configs; the small entries are re-solved here so that a drift of the oracle
+    (flags, rebuild) against the committed fixture is caught on the CPU, and the materialising
+    (reference-faithful) front half must give the same graph as the streaming one."""
+    import hashlib
+    import importlib
+    import json
+    import os
+    from util import ROOT
+    tp = importlib.import_module("teaser-plusplus_amd")
+    fx_all = json.load(open(os.path.join(ROOT, "tests", "golden", "config_golden.json")))
+    kw = dict(noise_bound=0.01, cbar2=1.0, estimate_scaling=0, rotation_gnc_factor=1.4,
+              rotation_max_iterations=100, rotation_cost_threshold=0.005)
+    for name in ("config4_b0", "config4_b127"):
+        fx = fx_all[name]
+        pr = tp.synth_problem(fx["seed"], fx["n"], fx["outlier_ratio"], fx["noise_bound"])
+        for materialise in (False, True):
+            o = oracle.solve(pr["src"], pr["dst"], materialise=materialise, **kw)
+            assert o["max_clique"].tolist() == fx["max_clique"] and o["num_edges"] == fx["num_edges"]
+            assert o["rotation_inliers"].tolist() == fx["rotation_inliers"]
+            assert o["translation_inliers"].tolist() == fx["translation_inliers"]
+            assert np.abs(o["rotation"].reshape(-1) - np.array(fx["rotation"])).max() < 1e-12
+            assert np.abs(o["translation"] - np.array(fx["translation"])).max() < 1e-12
+        _, bm = oracle.inlier_bitmap(pr["src"], pr["dst"], 0.01, 1.0, False)
+        assert hashlib.sha256(np.ascontiguousarray(bm).tobytes()).hexdigest() == fx["bitmap_sha256"]
+    assert fx_all["config3"]["n"] == 50000 and fx_all["config3"]["clique_unique"]
