@@ -174,6 +174,17 @@ def max_clique(bitmap, n, mode=0, num_threads=0):
                 exact_run=bool(er.value))
 
 
+def kcore_heuristic(bitmap, n, threshold=0.5):
+    """KCORE_HEU shortcut of graph.cc:66-81: (taken, vertices with core >= max_core, max_core)."""
+    bm = np.ascontiguousarray(bitmap, dtype=np.uint64)
+    out = np.zeros(max(n, 1), dtype=np.int32)
+    size, mc = C.c_int32(), C.c_int32()
+    taken = lib().oracle_kcore_heuristic(bm.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_int32(n),
+                                         C.c_double(threshold), out.ctypes.data_as(C.POINTER(C.c_int32)),
+                                         C.byref(size), C.byref(mc))
+    return bool(taken), out[:size.value].copy(), mc.value
+
+
 def svd_rot(X, Y, W=None):
     x, y = _cm(X), _cm(Y)
     k = x.shape[0]

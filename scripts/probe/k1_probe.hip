@@ -90,7 +90,7 @@ int main(int argc, char** argv) {
   std::vector<uint64_t> bm((size_t)n * W);
 
   if (mode == "k1" || mode == "one") {
-    const char* variants_all[] = {"-1", "0", "1"};
+    const char* variants_all[] = {"-1", "0", "1", "2", "3"};
     std::vector<std::string> vs;
     if (mode == "one")
       vs.push_back(getenv("TEASER_K1_VARIANT") ? getenv("TEASER_K1_VARIANT") : "1");
@@ -133,44 +133,33 @@ int main(int argc, char** argv) {
     }
   }
   if (mode == "pipe") {
-    for (int stagger = 1; stagger >= 0; --stagger)
-      for (int depth = 1; depth <= 4; ++depth) {
-        if (depth == 1 && stagger == 0) continue;
-        setenv("TEASER_HIP_STAGGER", stagger ? "1" : "0", 1);
-        teaser_hip_solver* h = nullptr;
-        CK(teaser_hip_solver_create(&prm, 0, &h));
-        CK(teaser_hip_set_pipeline_depth(h, depth));
-        CK(teaser_hip_set_profiling(h, 2));
-        double k1 = 0;
-        int launches = 0;
-        double t0 = 0;
-        std::deque<int32_t> tk;
-        const int warm = 2 * depth + 2;
-        for (int it = 0; it < iters + warm; ++it) {
-          if (it == warm) {
-            while (!tk.empty()) {
-              CK(teaser_hip_wait(h, tk.front(), out.data()));
-              tk.pop_front();
-            }
-            CK(hipDeviceSynchronize());
-            k1 = 0;
-            launches = 0;
-            t0 = now_ms();
-          }
-          if ((int)tk.size() == depth) {
+    struct Cfg { int k1stream, depth, greedy; };
+    const Cfg cfgs[] = {{1, 1, 256}, {1, 2, 256}, {1, 3, 256}, {1, 4, 256}, {1, 3, 512}, {0, 3, 256}, {0, 4, 256}};
+    for (const Cfg& cf : cfgs) {
+      const int depth = cf.depth;
+      setenv("TEASER_HIP_K1_STREAM", cf.k1stream ? "1" : "0", 1);
+      setenv("TEASER_GREEDY_THREADS", cf.greedy == 512 ? "512" : "256", 1);
+      teaser_hip_solver* h = nullptr;
+      CK(teaser_hip_solver_create(&prm, 0, &h));
+      CK(teaser_hip_set_pipeline_depth(h, depth));
+      CK(teaser_hip_set_profiling(h, 2));
+      double k1 = 0;
+      int launches = 0;
+      double t0 = 0;
+      std::deque<int32_t> tk;
+      const int warm = 2 * depth + 2;
+      for (int it = 0; it < iters + warm; ++it) {
+        if (it == warm) {
+          while (!tk.empty()) {
             CK(teaser_hip_wait(h, tk.front(), out.data()));
             tk.pop_front();
-            teaser_profile_c pf;
-            teaser_hip_get_profile(h, &pf);
-            k1 += pf.tim_graph_ms;
-            launches += pf.tim_graph_launches;
           }
-          int32_t t = -1;
-          CK(teaser_hip_submit_batch(h, P.d_src[it % 4], P.d_dst[it % 4], P.off.data(), P.n.data(), B,
-                                     TEASER_HIP_INPUT_DEVICE, &t));
-          tk.push_back(t);
+          CK(hipDeviceSynchronize());
+          k1 = 0;
+          launches = 0;
+          t0 = now_ms();
         }
-        while (!tk.empty()) {
+        if ((int)tk.size() == depth) {
           CK(teaser_hip_wait(h, tk.front(), out.data()));
           tk.pop_front();
           teaser_profile_c pf;
@@ -178,15 +167,28 @@ int main(int argc, char** argv) {
           k1 += pf.tim_graph_ms;
           launches += pf.tim_graph_launches;
         }
-        CK(hipDeviceSynchronize());
-        const double t1 = now_ms();
-        printf("{\"probe\":\"pipe\",\"depth\":%d,\"stagger\":%d,\"batch\":%d,\"n\":%d,\"step_ms\":%.4f,\"reg_per_s\":%.0f,"
-               "\"k1_ms\":%.4f,\"clique0\":%d}\n",
-               depth, stagger, B, n, (t1 - t0) / iters, 1e3 * B * iters / (t1 - t0), launches ? k1 / launches : 0.0,
-               out[0].clique_size);
-        fflush(stdout);
-        teaser_hip_solver_destroy(h);
+        int32_t t = -1;
+        CK(teaser_hip_submit_batch(h, P.d_src[it % 4], P.d_dst[it % 4], P.off.data(), P.n.data(), B,
+                                   TEASER_HIP_INPUT_DEVICE, &t));
+        tk.push_back(t);
       }
+      while (!tk.empty()) {
+        CK(teaser_hip_wait(h, tk.front(), out.data()));
+        tk.pop_front();
+        teaser_profile_c pf;
+        teaser_hip_get_profile(h, &pf);
+        k1 += pf.tim_graph_ms;
+        launches += pf.tim_graph_launches;
+      }
+      CK(hipDeviceSynchronize());
+      const double t1 = now_ms();
+      printf("{\"probe\":\"pipe\",\"k1_stream\":%d,\"depth\":%d,\"greedy_threads\":%d,\"batch\":%d,\"n\":%d,"
+             "\"step_ms\":%.4f,\"reg_per_s\":%.0f,\"k1_ms\":%.4f,\"clique0\":%d}\n",
+             cf.k1stream, depth, cf.greedy, B, n, (t1 - t0) / iters, 1e3 * B * iters / (t1 - t0),
+             launches ? k1 / launches : 0.0, out[0].clique_size);
+      fflush(stdout);
+      teaser_hip_solver_destroy(h);
+    }
   }
   return 0;
 }

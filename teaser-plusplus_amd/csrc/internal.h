@@ -41,7 +41,9 @@ struct ProbState {
   int32_t gnc_iters;
   int32_t x_count;       // colouring bound: survivors left without a colour
   int32_t k1_overflow;   // 1: the K1 fix-up worklist overflowed (host reruns the batch on the FP64 K1)
-  int32_t pad0;
+  int32_t max_core;      // KCORE_HEU only: maximum core number of the inlier graph
+  int32_t tls_arrive;    // translation stage: axis workgroups of this problem that have finished
+  int32_t pad1;
   int32_t start_vertex[kMaxStarts];
   int32_t start_size[kMaxStarts];
   unsigned long long deg_sum;  // sum of degrees = 2 * edges
@@ -138,6 +140,12 @@ void launch_colour_bound(hipStream_t s, const ProbDesc* d_desc, const int32_t* d
                          int max_n, const uint64_t* d_bitmap, const uint64_t* d_alive,
                          const int32_t* d_clique, ProbState* d_state, int32_t* d_colour,
                          int32_t* d_tent, int32_t* d_xlist, int rounds);
+
+// KCORE_HEU (graph.cc:58-81): exact core numbers; when max_core > (int)(threshold * n) and
+// threshold != 1 the clique is replaced by every vertex of the maximum core (n <= 65536)
+void launch_kcore_heuristic(hipStream_t s, const ProbDesc* d_desc, int batch, const uint64_t* d_bitmap,
+                            const int32_t* d_deg, ProbState* d_state, int32_t* d_rem_deg, int32_t* d_core,
+                            int32_t* d_clique, double threshold);
 
 // K5/K6 (kernels_estimate.hip)
 void launch_gnc_tls(hipStream_t s, const ProbDesc* d_desc, int batch, const double* d_src,

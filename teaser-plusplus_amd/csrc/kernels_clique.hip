@@ -549,4 +549,149 @@ void launch_colour_bound(hipStream_t s, const ProbDesc* d_desc, const int32_t* d
                      (size_t)max_W * 8, s, d_desc, d_sel, d_bitmap, d_alive, d_state, d_xlist, d_tent);
 }
 
+// ------------------------------------------------------------------------------------------
+// KCORE_HEU (reference graph.cc:58-81): exact core numbers by parallel peeling, then the shortcut
+// "max_core > threshold * N  =>  the inlier set is every vertex of the maximum core".
+// One 1024-thread workgroup per problem.  Level-synchronous Batagelj-Zaversnik: at level k every alive
+// vertex whose remaining degree is <= k leaves with core number k (all at once -- core numbers do not
+// depend on the removal order), its alive neighbours lose one degree each; when nobody can leave, k
+// jumps to the smallest remaining degree.  alive / frontier are LDS bitsets (n <= 65536), the
+// remaining degrees live in global memory and are read/updated with agent-scope atomics only (plain
+// loads could hit this CU's L1, which atomics bypass).
+// ------------------------------------------------------------------------------------------
+constexpr int kCoreThreads = 1024;
+constexpr int kCoreWaves = kCoreThreads / 64;
+constexpr int kCoreMaxW = 1024;  // n <= 65536
+
+__global__ __launch_bounds__(kCoreThreads) void kcore_kernel(const ProbDesc* __restrict__ descs,
+                                                             const uint64_t* __restrict__ bitmap,
+                                                             const int32_t* __restrict__ deg,
+                                                             ProbState* __restrict__ states,
+                                                             int32_t* __restrict__ rem_deg,
+                                                             int32_t* __restrict__ core,
+                                                             int32_t* __restrict__ clique,
+                                                             double threshold) {
+  __shared__ uint64_t alive[kCoreMaxW];
+  __shared__ uint64_t front[kCoreMaxW];
+  __shared__ int red[kCoreWaves];
+  __shared__ int wcnt[kCoreMaxW];
+  const ProbDesc d = descs[blockIdx.x];
+  const int n = d.n, W = d.W;
+  if (n <= 0 || W > kCoreMaxW) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint64_t* bm = bitmap + d.bm_off;
+  int32_t* rd = rem_deg + d.pt_off;
+  int32_t* cr = core + d.pt_off;
+  for (int v = tid; v < n; v += kCoreThreads) __hip_atomic_store(&rd[v], deg[d.pt_off + v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int w = tid; w < W; w += kCoreThreads)
+    alive[w] = (n - w * 64 >= 64) ? ~0ull : ((1ull << (n - w * 64)) - 1ull);
+  __syncthreads();
+  int remaining = n, k = 0, max_core = 0;
+  while (remaining > 0) {
+    // frontier: wave `wave` builds words wave, wave + 16, ... with one ballot each
+    int cnt = 0, mind = 0x7fffffff;
+    for (int w = wave; w < W; w += kCoreWaves) {
+      const int v = w * 64 + lane;
+      const bool al = (alive[w] >> lane) & 1ull;
+      const int dv = al ? __hip_atomic_load(&rd[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
+      const uint64_t f = __ballot(al && dv <= k);
+      if (lane == 0) front[w] = f;
+      cnt += (lane == 0) ? __builtin_popcountll(f) : 0;
+      mind = min(mind, dv);
+    }
+    cnt = wsum(cnt);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mind = min(mind, __shfl_xor(mind, o, 64));
+    __syncthreads();
+    if (lane == 0) red[wave] = cnt;
+    __syncthreads();
+    int total = 0;
+    for (int q = 0; q < kCoreWaves; ++q) total += red[q];
+    __syncthreads();
+    if (total == 0) {  // nobody leaves at this level: jump to the smallest remaining degree
+      if (lane == 0) red[wave] = mind;
+      __syncthreads();
+      int m = 0x7fffffff;
+      for (int q = 0; q < kCoreWaves; ++q) m = min(m, red[q]);
+      __syncthreads();
+      k = m;
+      continue;
+    }
+    max_core = k;
+    remaining -= total;
+    for (int w = tid; w < W; w += kCoreThreads) {
+      uint64_t f = front[w];
+      alive[w] &= ~f;
+      while (f) {
+        cr[w * 64 + __builtin_ctzll(f)] = k;
+        f &= f - 1;
+      }
+    }
+    __syncthreads();
+    // every leaving vertex takes one degree from each of its alive neighbours: a wave per frontier
+    // vertex (frontier vertices are dealt round-robin over the 16 waves), lanes over the row words
+    int ord = 0;
+    for (int w = 0; w < W; ++w) {
+      uint64_t f = front[w];
+      while (f) {
+        const int b = __builtin_ctzll(f);
+        f &= f - 1;
+        if ((ord++ & (kCoreWaves - 1)) != wave) continue;
+        const uint64_t* row = bm + (int64_t)(w * 64 + b) * W;
+        for (int x = lane; x < W; x += 64) {
+          uint64_t m = row[x] & alive[x];
+          while (m) {
+            __hip_atomic_fetch_add(&rd[x * 64 + __builtin_ctzll(m)], -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            m &= m - 1;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  ProbState* st = states + blockIdx.x;
+  if (tid == 0) st->max_core = max_core;
+  // graph.cc:66-81: the shortcut applies iff threshold != 1 and max_core > (int)(threshold * N)
+  if (!(threshold != 1.0 && max_core > (int)(threshold * (double)n))) return;
+  // ascending list of the vertices with core number >= max_core (exclusive scan over word counts)
+  for (int w = wave; w < W; w += kCoreWaves) {
+    const int v = w * 64 + lane;
+    const uint64_t f = __ballot(v < n && cr[v] >= max_core);
+    if (lane == 0) {
+      front[w] = f;
+      wcnt[w] = __builtin_popcountll(f);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0;
+    for (int w = 0; w < W; ++w) {
+      const int c = wcnt[w];
+      wcnt[w] = acc;
+      acc += c;
+    }
+    st->clique_size = acc;
+    st->lb = acc;
+    st->proven = 1;
+    st->peel_done = 1;
+  }
+  __syncthreads();
+  for (int w = tid; w < W; w += kCoreThreads) {
+    uint64_t f = front[w];
+    int pos = wcnt[w];
+    while (f) {
+      clique[d.pt_off + pos++] = w * 64 + __builtin_ctzll(f);
+      f &= f - 1;
+    }
+  }
+}
+
+void launch_kcore_heuristic(hipStream_t s, const ProbDesc* d_desc, int batch, const uint64_t* d_bitmap,
+                            const int32_t* d_deg, ProbState* d_state, int32_t* d_rem_deg, int32_t* d_core,
+                            int32_t* d_clique, double threshold) {
+  if (batch <= 0) return;
+  hipLaunchKernelGGL(kcore_kernel, dim3(batch), dim3(kCoreThreads), 0, s, d_desc, d_bitmap, d_deg, d_state,
+                     d_rem_deg, d_core, d_clique, threshold);
+}
+
 }  // namespace thip

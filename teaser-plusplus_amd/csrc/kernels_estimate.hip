@@ -787,24 +787,29 @@ __device__ __forceinline__ TlsScratch tls_scratch(char* lds_group, char* glob_gr
   return sc;
 }
 
-// K6: translation.  Block = 3 groups of 256 threads, group a estimates axis a.
+// K6: translation.  One 256-thread workgroup per (axis, problem): blockIdx.x = axis a estimates
+// t_a = TLS((dst - s R src)_a) (registration.cc:455-461).  Small workgroups (4 waves, 42 KB of LDS) so
+// that they fit beside the K1 workgroups of the next batch; the AND of the three axis masks and
+// findNonzero (registration.cc:463-470, :731) is done by whichever of the problem's three workgroups
+// arrives last (agent-scope fence + counter).
 // Global scratch per problem: X[3][K] doubles, mask[3][K] bytes, then 3 endpoint areas.
-__global__ __launch_bounds__(768) void tls_translation_kernel(
+__global__ __launch_bounds__(256) void tls_translation_kernel(
     const ProbDesc* __restrict__ descs, const double* __restrict__ src,
     const double* __restrict__ dst, const int32_t* __restrict__ clique,
     ProbState* __restrict__ states, EstParams ep, char* __restrict__ scratch,
     int64_t scratch_stride, int32_t* __restrict__ trans_inliers) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int scan[257];
-  const ProbDesc d = descs[blockIdx.x];
-  ProbState* st = states + blockIdx.x;
+  __shared__ int s_last;
+  const ProbDesc d = descs[blockIdx.y];
+  ProbState* st = states + blockIdx.y;
   const int K = st->clique_size;
+  const int g = blockIdx.x, gt = threadIdx.x;
   if (K <= 1) {
-    if (threadIdx.x == 0) st->n_trans = 0;
+    if (g == 0 && threadIdx.x == 0) st->n_trans = 0;
     return;
   }
-  const int g = threadIdx.x >> 8, gt = threadIdx.x & 255;
-  char* ps = scratch + (int64_t)blockIdx.x * scratch_stride;
+  char* ps = scratch + (int64_t)blockIdx.y * scratch_stride;
   const int64_t Kp = (K + 1) & ~1;
   double* X = reinterpret_cast<double*>(ps) + g * Kp;
   uint8_t* mask = reinterpret_cast<uint8_t*>(ps + 3 * Kp * 8) + (int64_t)g * Kp;
@@ -826,18 +831,28 @@ __global__ __launch_bounds__(768) void tls_translation_kernel(
   }
   __syncthreads();
   const double beta = ep.noise_bound * sqrt(ep.cbar2);  // registration.cc:459 (not doubled)
-  TlsScratch sc = tls_scratch(smem + g * kTlsGroupLds, glob_ep, K);
+  TlsScratch sc = tls_scratch(smem, glob_ep, K);
   const double est = scalar_tls_group(X, nullptr, beta, K, sc, gt);
   for (int j = gt; j < K; j += 256) mask[j] = fabs(X[j] - est) <= beta ? 1 : 0;  // :86
   if (gt == 0) st->t[g] = est;
+  // publish this axis, find out whether the other two are done
+  __threadfence();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the write-back must have landed before the counter moves
   __syncthreads();
+  if (threadIdx.x == 0) s_last = (atomicAdd(&st->tls_arrive, 1) == 2) ? 1 : 0;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();  // acquire: the other workgroups' masks (this CU's L1 is invalidated)
   // AND of the three axis masks (registration.cc:463-470), then findNonzero (:731)
   const uint8_t* m0 = reinterpret_cast<uint8_t*>(ps + 3 * Kp * 8);
   const uint8_t* m1 = m0 + Kp;
   const uint8_t* m2 = m1 + Kp;
   const int cnt = block_compact(K, [&](int64_t j) { return (m0[j] & m1[j] & m2[j]) != 0; },
                                 trans_inliers + d.pt_off, scan);
-  if (threadIdx.x == 0) st->n_trans = cnt;
+  if (threadIdx.x == 0) {
+    st->n_trans = cnt;
+    st->tls_arrive = 0;  // the estimators may be enqueued again on the same states (clique grew)
+  }
 }
 
 void launch_tls_translation(hipStream_t s, const ProbDesc* d_desc, int batch, const double* d_src,
@@ -845,9 +860,7 @@ void launch_tls_translation(hipStream_t s, const ProbDesc* d_desc, int batch, co
                             EstParams ep, char* d_scratch, int64_t scratch_stride,
                             int32_t* d_trans_inliers) {
   if (batch <= 0) return;
-  static DynLdsOptIn optin;  // 3 groups x 42 KB of dynamic LDS exceed the 64 KB default
-  optin.ensure(reinterpret_cast<const void*>(tls_translation_kernel), 3 * kTlsGroupLds);
-  hipLaunchKernelGGL(tls_translation_kernel, dim3(batch), dim3(768), 3 * kTlsGroupLds, s, d_desc,
+  hipLaunchKernelGGL(tls_translation_kernel, dim3(3, batch), dim3(256), kTlsGroupLds, s, d_desc,
                      d_src, d_dst, d_clique, d_state, ep, d_scratch, scratch_stride,
                      d_trans_inliers);
 }

@@ -611,8 +611,11 @@ __device__ __forceinline__ int flush_work(const unsigned long long* wbuf, int wc
 // waited for its prefetched column operands.  On gfx9-family hardware loads and stores share the
 // in-order vmcnt counter, so with V = 0 every `s_waitcnt vmcnt` for the prefetch also waits for the
 // previous iteration's global store to be acknowledged by L2 (hundreds of cycles, every J).
-template <int V>
-__global__ __launch_bounds__(256, 3) void tim_graph_mfma_kernel(
+// V = 2: no LDS staging of the transposed words and NO block barrier in the loop: every wave stores
+// its own 8-byte transposed words straight away (branch-free buffer store); the 4 waves of a block
+// then only share the operand loads (through L1), and never wait for each other.
+template <int V, int OCC>
+__global__ __launch_bounds__(256, OCC) void tim_graph_mfma_kernel(
     const ProbDesc* __restrict__ descs, const double* __restrict__ src,
     const double* __restrict__ dst, const TimOperand* __restrict__ op_src,
     const TimOperand* __restrict__ op_dst, const TimPrep* __restrict__ prep,
@@ -710,6 +713,7 @@ __global__ __launch_bounds__(256, 3) void tim_graph_mfma_kernel(
     uint64_t trw_out = 0;
     if (!(rowvalid && J >= I)) {
       if (V == 1) store_tr(J - 1);
+      if (V == 2) continue;
     } else {
     unsigned int tr[2][2];  // [ct][rt]: this lane's 16 column bits
     unsigned int ubits[4];  // per tile 2 ct + rt: this lane's in-band pairs (bit q)
@@ -827,6 +831,15 @@ __global__ __launch_bounds__(256, 3) void tim_graph_mfma_kernel(
     lds_own[wave][lane][J - Jbase] = ownw;
     trw_out = (J != I) ? (trw & rowmask) : 0ull;
     }  // active
+    if (V == 2) {
+      // lane = row j0 + lane of the transposed block, word I: 8 bytes at a stride of W words
+      const u32x2 dw = {(unsigned int)trw_out, (unsigned int)(trw_out >> 32)};
+      const unsigned int off = (J != I && j0 + lane < n)
+                                   ? ((unsigned int)(j0 + lane) * (unsigned int)W + (unsigned int)I) * 8u
+                                   : 0xffffffffu;
+      __builtin_amdgcn_raw_buffer_store_b64(dw, bm_rsrc, off, 0, 0);
+      continue;
+    }
     const int buf = (J - Jbase) & 1;
     lds_tr[buf][wave][lane] = trw_out;
     __syncthreads();  // (one barrier per J: the other buffer is rewritten only after the next one)
@@ -950,14 +963,17 @@ void launch_tim_graph_mfma(hipStream_t s, int phase, const ProbDesc* d_desc, int
     // scheduling variant of the same kernel (diagnostics; read per launch so that a probe can switch)
     const char* ev = getenv("TEASER_K1_VARIANT");
     const int variant = ev ? atoi(ev) : 1;
-    if (variant == 0)
-      hipLaunchKernelGGL(tim_graph_mfma_kernel<0>, dim3(gxc * gyr, batch), dim3(256), 0, s, d_desc, d_src,
-                         d_dst, op_src, op_dst, prep, d_bitmap, beta, gyr, work, work_count,
-                         (unsigned int)work_cap, d_state);
-    else
-      hipLaunchKernelGGL(tim_graph_mfma_kernel<1>, dim3(gxc * gyr, batch), dim3(256), 0, s, d_desc, d_src,
-                         d_dst, op_src, op_dst, prep, d_bitmap, beta, gyr, work, work_count,
-                         (unsigned int)work_cap, d_state);
+#define TIM_K1_LAUNCH(V, OCC)                                                                            \
+  hipLaunchKernelGGL((tim_graph_mfma_kernel<V, OCC>), dim3(gxc * gyr, batch), dim3(256), 0, s, d_desc, d_src, \
+                     d_dst, op_src, op_dst, prep, d_bitmap, beta, gyr, work, work_count,                 \
+                     (unsigned int)work_cap, d_state)
+    switch (variant) {
+      case 0: TIM_K1_LAUNCH(0, 3); break;
+      case 2: TIM_K1_LAUNCH(2, 3); break;
+      case 3: TIM_K1_LAUNCH(2, 4); break;
+      default: TIM_K1_LAUNCH(1, 3); break;
+    }
+#undef TIM_K1_LAUNCH
   } else {
     hipLaunchKernelGGL(tim_fixup_kernel, dim3(512), dim3(256), 0, s, d_desc, batch, d_src, d_dst, d_bitmap,
                        beta, work, work_count, (unsigned int)work_cap, d_state);
@@ -1009,12 +1025,12 @@ void launch_degrees(hipStream_t s, const ProbDesc* d_desc, int batch, int max_n,
 //                 largest d joins and P shrinks to its neighbours.
 // Deterministic: every tie is broken towards the smallest vertex index.
 // ------------------------------------------------------------------------------------------
-constexpr int kGreedyThreads = 512;
-constexpr int kGreedyWaves = kGreedyThreads / 64;
+constexpr int kGreedyMaxThreads = 512;  // LDS layout is sized for this; the kernel runs with T <= it
 constexpr int kCap = 640;            // compact-mode candidate cap
 constexpr int kCapW = kCap / 64;     // words per compact row
 constexpr int kCapStride = kCapW + 1;  // odd row stride (in 8-byte words): conflict-free ds_read_b64
 
+template <int kGreedyWaves>
 __device__ __forceinline__ int blockN_sum_i(int v, int* red /* kGreedyWaves */) {
   v = wave_sum_i(v);
   __syncthreads();
@@ -1025,6 +1041,7 @@ __device__ __forceinline__ int blockN_sum_i(int v, int* red /* kGreedyWaves */) 
   for (int k = 0; k < kGreedyWaves; ++k) s += red[k];
   return s;
 }
+template <int kGreedyWaves>
 __device__ __forceinline__ unsigned long long blockN_max_u64(unsigned long long v,
                                                              unsigned long long* red) {
   v = wave_max_u64(v);
@@ -1037,10 +1054,15 @@ __device__ __forceinline__ unsigned long long blockN_max_u64(unsigned long long 
   return m;
 }
 
+// T threads per workgroup: 512 (lowest latency when the GPU is otherwise idle) or 256 (4 waves: a
+// workgroup then fits into the slot ONE retiring K1 workgroup frees, which is what lets the tail of a
+// batch run beside the next batch's K1).
+template <int kGreedyThreads>
 __global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
     const ProbDesc* __restrict__ descs, const uint64_t* __restrict__ bitmap,
     const int32_t* __restrict__ deg, ProbState* __restrict__ states,
     int32_t* __restrict__ start_cliques, int64_t total_n) {
+  constexpr int kGreedyWaves = kGreedyThreads / 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const ProbDesc d = descs[blockIdx.y];
   const int n = d.n, W = d.W;
@@ -1049,11 +1071,11 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
   uint64_t* U = P + Wpad;                                               // Wpad (streaming rounds)
   uint64_t* A = U + Wpad;                                               // kCap * kCapStride
   uint64_t* Pc = A + kCap * kCapStride;                                 // 16
-  unsigned long long* red64 = reinterpret_cast<unsigned long long*>(Pc + 16);  // kGreedyWaves
-  int* cand = reinterpret_cast<int*>(red64 + kGreedyWaves);             // kCap
-  int* wcnt = cand + kCap;                                              // kGreedyThreads
-  int* red = wcnt + kGreedyThreads;                                     // kGreedyWaves
-  int* misc = red + kGreedyWaves;                                       // 8
+  unsigned long long* red64 = reinterpret_cast<unsigned long long*>(Pc + 16);  // kGreedyMaxThreads / 64
+  int* cand = reinterpret_cast<int*>(red64 + kGreedyMaxThreads / 64);   // kCap
+  int* wcnt = cand + kCap;                                              // kGreedyMaxThreads
+  int* red = wcnt + kGreedyMaxThreads;                                  // kGreedyMaxThreads / 64
+  int* misc = red + kGreedyMaxThreads / 64;                             // 8
 
   ProbState* st = states + blockIdx.y;
   const int sidx = blockIdx.x;
@@ -1072,7 +1094,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
       const unsigned long long key = ((dv + 1) << 32) | (0xffffffffu - (unsigned int)v);
       best = key > best ? key : best;
     }
-    best = blockN_max_u64(best, red64);
+    best = blockN_max_u64<kGreedyWaves>(best, red64);
     if (best) v0 = (int)(0xffffffffu - (unsigned int)(best & 0xffffffffu));
     if (sidx == 0) {
       for (int v = tid; v < n; v += kGreedyThreads) sum += (unsigned int)dg[v];
@@ -1103,7 +1125,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
     P[w] = x;
     pc += __popcll(x);
   }
-  pc = blockN_sum_i(pc, red);
+  pc = blockN_sum_i<kGreedyWaves>(pc, red);
 
   // ---- phase 1: shrink P to at most kCap candidates --------------------------------------
   bool prefer_vote = false;
@@ -1121,7 +1143,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
           key = k > key ? k : key;
         }
       }
-      key = blockN_max_u64(key, red64);
+      key = blockN_max_u64<kGreedyWaves>(key, red64);
       const int u = (int)(0xffffffffu - (unsigned int)(key & 0xffffffffu));
       if (tid == 0) C[csize] = u;
       ++csize;
@@ -1132,7 +1154,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
         P[w] = x;
         c += __popcll(x);
       }
-      c = blockN_sum_i(c, red);
+      c = blockN_sum_i<kGreedyWaves>(c, red);
       prefer_vote = (long long)c * 10 > (long long)pc * 9;
       pc = c;
       continue;
@@ -1161,7 +1183,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
       }
       if (lane == 0) U[w] = uni;
     }
-    bestk = blockN_max_u64(bestk, red64);  // (barriers inside: U and misc[0] are visible after)
+    bestk = blockN_max_u64<kGreedyWaves>(bestk, red64);  // (barriers inside: U and misc[0] are visible after)
     // append the universal candidates (any order: the final clique is re-sorted) and drop them
     int nU = 0;
     for (int w = tid; w < W; w += kGreedyThreads) {
@@ -1177,7 +1199,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
         }
       }
     }
-    nU = blockN_sum_i(nU, red);
+    nU = blockN_sum_i<kGreedyWaves>(nU, red);
     csize += nU;
     const int left = pc - nU;
     if (left > 0 && bestk) {
@@ -1190,7 +1212,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
         P[w] = x;
         c += __popcll(x);
       }
-      c = blockN_sum_i(c, red);
+      c = blockN_sum_i<kGreedyWaves>(c, red);
       prefer_vote = (long long)c * 10 > (long long)left * 9;
       pc = c;
     } else {
@@ -1207,11 +1229,12 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
     for (int w = w0; w < w1; ++w) mycnt += __popcll(P[w]);
     wcnt[tid] = mycnt;
     __syncthreads();
-    if (wave == 0) {  // exclusive scan over 512 entries (8 per lane)
-      int a[8], tot = 0;
+    if (wave == 0) {  // exclusive scan over kGreedyThreads entries (kGreedyWaves per lane)
+      constexpr int kPer = kGreedyWaves;
+      int a[kPer], tot = 0;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        a[k] = wcnt[8 * lane + k];
+      for (int k = 0; k < kPer; ++k) {
+        a[k] = wcnt[kPer * lane + k];
         tot += a[k];
       }
       int incl = tot;
@@ -1222,8 +1245,8 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
       }
       int ex = incl - tot;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        wcnt[8 * lane + k] = ex;
+      for (int k = 0; k < kPer; ++k) {
+        wcnt[kPer * lane + k] = ex;
         ex += a[k];
       }
     }
@@ -1290,10 +1313,11 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
     // ---- phase 4: vote rounds on the compact matrix (all in LDS) ---------------------------
     int pcnt = pc;
     while (pcnt > 0) {
-      int dv[2];
-      bool in[2];
+      constexpr int kVote = (kCap + kGreedyThreads - 1) / kGreedyThreads;
+      int dv[kVote];
+      bool in[kVote];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < kVote; ++j) {
         const int c = tid + kGreedyThreads * j;
         in[j] = c < pc && ((Pc[c >> 6] >> (c & 63)) & 1ull);
         int dd = 0;
@@ -1305,7 +1329,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
       __syncthreads();  // all votes read Pc before it is modified
       unsigned long long bestk = 0;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < kVote; ++j) {
         const int c = tid + kGreedyThreads * j;
         const bool isU = in[j] && dv[j] == pcnt - 1;
         const uint64_t m = __ballot(isU);
@@ -1324,7 +1348,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
           bestk = kk > bestk ? kk : bestk;
         }
       }
-      bestk = blockN_max_u64(bestk, red64);
+      bestk = blockN_max_u64<kGreedyWaves>(bestk, red64);
       csize = misc[0];
       int left = 0;
       for (int w = 0; w < Wc; ++w) left += __popcll(Pc[w]);
@@ -1451,8 +1475,8 @@ __global__ __launch_bounds__(256) void select_best_kernel(
 
 size_t greedy_lds_bytes(int max_W) {
   const size_t Wpad = (size_t)((max_W + 1) & ~1);
-  return Wpad * 8 * 2 + (size_t)kCap * kCapStride * 8 + 16 * 8 + kGreedyWaves * 8 + (size_t)kCap * 4 +
-         kGreedyThreads * 4 + kGreedyWaves * 4 + 8 * 4;
+  return Wpad * 8 * 2 + (size_t)kCap * kCapStride * 8 + 16 * 8 + (kGreedyMaxThreads / 64) * 8 + (size_t)kCap * 4 +
+         kGreedyMaxThreads * 4 + (kGreedyMaxThreads / 64) * 4 + 8 * 4;
 }
 
 void launch_heuristic(hipStream_t s, const ProbDesc* d_desc, int batch, int max_W,
@@ -1461,10 +1485,19 @@ void launch_heuristic(hipStream_t s, const ProbDesc* d_desc, int batch, int max_
                       int32_t* d_clique) {
   if (batch <= 0) return;
   const size_t lds = greedy_lds_bytes(max_W);
-  static DynLdsOptIn optin;  // beyond the 64 KB default dynamic-LDS limit once W >= ~300
-  if (lds > 48 * 1024) optin.ensure(reinterpret_cast<const void*>(greedy_clique_kernel), (int)lds);
-  hipLaunchKernelGGL(greedy_clique_kernel, dim3(kMaxStarts, batch), dim3(kGreedyThreads), lds, s,
-                     d_desc, d_bitmap, d_deg, d_state, d_start_cliques, total_n);
+  // 256 threads by default (co-scheduling with K1, see the kernel); TEASER_GREEDY_THREADS=512: diagnostics
+  const char* ev = getenv("TEASER_GREEDY_THREADS");
+  const bool wide = ev && atoi(ev) == 512;
+  static DynLdsOptIn optin256, optin512;  // beyond the 64 KB default dynamic-LDS limit once W >= ~300
+  if (wide) {
+    if (lds > 48 * 1024) optin512.ensure(reinterpret_cast<const void*>(greedy_clique_kernel<512>), (int)lds);
+    hipLaunchKernelGGL(greedy_clique_kernel<512>, dim3(kMaxStarts, batch), dim3(512), lds, s, d_desc, d_bitmap,
+                       d_deg, d_state, d_start_cliques, total_n);
+  } else {
+    if (lds > 48 * 1024) optin256.ensure(reinterpret_cast<const void*>(greedy_clique_kernel<256>), (int)lds);
+    hipLaunchKernelGGL(greedy_clique_kernel<256>, dim3(kMaxStarts, batch), dim3(256), lds, s, d_desc, d_bitmap,
+                       d_deg, d_state, d_start_cliques, total_n);
+  }
 }
 
 // ------------------------------------------------------------------------------------------

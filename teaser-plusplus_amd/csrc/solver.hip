@@ -166,6 +166,16 @@ struct teaser_hip_solver {
   int depth = 3;                           // lanes (TEASER_HIP_DEPTH / teaser_hip_set_pipeline_depth)
   int next_lane = 0, last_lane = -1;
   bool stagger_k1 = true;                  // TEASER_HIP_STAGGER=0 lets the K1 kernels of the lanes co-run
+  // The K1 phase (header upload, pre-pass, K1, fix-up) of EVERY lane runs on ONE low-priority stream
+  // owned by the parent (in order: the K1 kernels follow each other back to back and keep the CUs
+  // full), the latency-bound tail of each lane on the lane's own HIGH-priority stream: whenever a K1
+  // workgroup retires, the dispatcher serves the waiting tail workgroups first.  TEASER_HIP_K1_STREAM=0
+  // falls back to one stream per lane for everything (+ the event stagger above).
+  hipStream_t k1_stream = nullptr;         // parent: owner; lane: borrowed from the parent
+  bool shared_k1_stream = true;
+  hipEvent_t k1_phase_done = nullptr;      // recorded on k1_stream after the fix-up
+  hipEvent_t inputs_ready = nullptr;       // host inputs copied (lane stream) -> K1 phase may start
+  bool inputs_pending = false;
   bool is_lane = false;
   struct Job {                             // a submitted, not yet waited-for batch (lanes only)
     bool busy = false;
@@ -199,9 +209,10 @@ struct StageScope {
   bool on;
   hipEvent_t a = nullptr, b = nullptr;
   int stage;
-  StageScope(teaser_hip_solver* hh, int st)
+  hipStream_t stream;
+  StageScope(teaser_hip_solver* hh, int st, hipStream_t on_stream = nullptr)
       : h(hh), on(hh->profiling == 1 || (hh->profiling == 2 && (st == ST_TIM || st == ST_TIMAUX))),
-        stage(st) {
+        stage(st), stream(on_stream ? on_stream : hh->stream) {
     if (!on) return;
     if (h->ev_used + 2 > h->ev_pool.size()) {
       for (int i = 0; i < 16; ++i) {
@@ -215,11 +226,11 @@ struct StageScope {
     }
     a = h->ev_pool[h->ev_used++];
     b = h->ev_pool[h->ev_used++];
-    (void)hipEventRecord(a, h->stream);
+    (void)hipEventRecord(a, stream);
   }
   ~StageScope() {
     if (!on) return;
-    (void)hipEventRecord(b, h->stream);
+    (void)hipEventRecord(b, stream);
     h->spans.push_back({stage, a, b});
   }
 };
@@ -592,6 +603,7 @@ int32_t enqueue_estimators(teaser_hip_solver* h) {
 int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const double* d_dst,
                              const int64_t* pt_off, const int32_t* n, int batch, bool fp64_k1) {
   hipStream_t s = h->stream;
+  hipStream_t s1 = s;  // stream of the K1 phase (set below once the K1 flavour is known)
   const teaser_params_c& P = h->params;
   if (!params_supported(P)) {
     h->err = "rotation_estimation_algorithm must be GNC_TLS, FGR or QUATRO";
@@ -688,8 +700,16 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
       HIPCHK(h, h->d_work.ensure(8 * (size_t)tim_work_items(n, batch) + 64));
     }
   }
+  if (mfma_k1 && h->is_lane && h->k1_stream) {
+    s1 = h->k1_stream;
+    if (h->inputs_pending) {  // host inputs are being copied on the lane's stream
+      HIPCHK(h, hipEventRecord(h->inputs_ready, s));
+      HIPCHK(h, hipStreamWaitEvent(s1, h->inputs_ready, 0));
+    }
+  }
+  h->inputs_pending = false;
   {
-    StageScope sc(h, ST_H2D);
+    StageScope sc(h, ST_H2D, s1);
     // staged through page-locked memory: an async H2D from pageable memory blocks the host until the
     // copy has completed (tens of microseconds each while the GPU is busy with the other lanes)
     HIPCHK(h, h->pin_in.ensure(hdr_bytes));
@@ -698,7 +718,7 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
     memcpy(stage + o_desc, h->descs.data(), b_desc);
     memcpy(stage + o_state, h->states.data(), b_state);
     memcpy(stage + o_off, h->tim_off.data(), b_off);
-    HIPCHK(h, hipMemcpyAsync(h->hdr.p, stage, hdr_bytes, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(h->hdr.p, stage, hdr_bytes, hipMemcpyHostToDevice, s1));
   }
   const ProbDesc* dd = h->d_desc.as<ProbDesc>();
   ProbState* ds = h->d_state.as<ProbState>();
@@ -721,19 +741,23 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
         // lanes (asynchronous batches in flight) run their K1 kernels one after the other: this
         // lane's starts when the previously submitted lane's has finished, so that a K1 shares the
         // GPU only with the latency-bound tail stages of the batches before it
-        if (phase == 1 && h->wait_before_k1) {
+        if (phase == 1 && h->wait_before_k1 && s1 == s) {
           HIPCHK(h, hipStreamWaitEvent(s, h->wait_before_k1, 0));
           h->wait_before_k1 = nullptr;
         }
         {
-          StageScope sc(h, phase == 1 ? ST_TIM : ST_TIMAUX);
-          launch_tim_graph_mfma(s, phase, dd, batch, max_n, total_n, d_src, d_dst, h->d_pk.p, h->d_prep.p,
+          StageScope sc(h, phase == 1 ? ST_TIM : ST_TIMAUX, s1);
+          launch_tim_graph_mfma(s1, phase, dd, batch, max_n, total_n, d_src, d_dst, h->d_pk.p, h->d_prep.p,
                                 h->d_work.p, cap, h->d_bitmap.as<uint64_t>(), ds, P.noise_bound, P.cbar2);
         }
-        if (phase == 1 && h->k1_done) {
+        if (phase == 1 && h->k1_done && s1 == s) {
           HIPCHK(h, hipEventRecord(h->k1_done, s));
           h->k1_recorded = true;
         }
+      }
+      if (s1 != s) {  // the tail (this handle's own stream) starts when the K1 phase has finished
+        HIPCHK(h, hipEventRecord(h->k1_phase_done, s1));
+        HIPCHK(h, hipStreamWaitEvent(s, h->k1_phase_done, 0));
       }
     }
     for (int b = 0; b < batch; ++b) {
@@ -752,6 +776,18 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
       launch_select_best(s, dd, batch, max_W, h->d_deg.as<int32_t>(), ds,
                          h->d_start_cliques.as<int32_t>(), total_n, h->d_clique.as<int32_t>(),
                          h->d_alive_a.as<uint64_t>(), mode == TEASER_INLIER_PMC_EXACT ? 1 : 0);
+    }
+    if (mode == TEASER_INLIER_KCORE_HEU) {  // graph.cc:58-81
+      if (max_n > 65536) {
+        h->err = "inlier_selection_mode = KCORE_HEU supports at most 65536 correspondences per problem";
+        return TEASER_HIP_ERR_UNSUPPORTED;
+      }
+      StageScope sc(h, ST_PEEL);
+      HIPCHK(h, h->c_colour.ensure(4 * (size_t)total_n));
+      HIPCHK(h, h->c_tent.ensure(4 * (size_t)total_n));
+      launch_kcore_heuristic(s, dd, batch, h->d_bitmap.as<uint64_t>(), h->d_deg.as<int32_t>(), ds,
+                             h->c_colour.as<int32_t>(), h->c_tent.as<int32_t>(), h->d_clique.as<int32_t>(),
+                             P.kcore_heuristic_threshold);
     }
     if (mode == TEASER_INLIER_PMC_EXACT) {
       StageScope sc(h, ST_PEEL);
@@ -898,13 +934,26 @@ int32_t make_lane(teaser_hip_solver* h, teaser_hip_solver** out) {
   lane->params = h->params;
   lane->is_lane = true;
   memset(&lane->prof, 0, sizeof(lane->prof));
-  if (hipStreamCreateWithFlags(&lane->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipEventCreateWithFlags(&lane->k1_done, hipEventDisableTiming) != hipSuccess) {
+  int prio_least = 0, prio_greatest = 0;
+  (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+  if (h->shared_k1_stream && !h->k1_stream &&
+      hipStreamCreateWithPriority(&h->k1_stream, hipStreamNonBlocking, prio_least) != hipSuccess)
+    h->k1_stream = nullptr;  // no shared K1 stream: every lane keeps all of its work on its own stream
+  const hipError_t es = h->k1_stream
+                            ? hipStreamCreateWithPriority(&lane->stream, hipStreamNonBlocking, prio_greatest)
+                            : hipStreamCreateWithFlags(&lane->stream, hipStreamNonBlocking);
+  if (es != hipSuccess || hipEventCreateWithFlags(&lane->k1_done, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&lane->k1_phase_done, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&lane->inputs_ready, hipEventDisableTiming) != hipSuccess) {
     if (lane->stream) (void)hipStreamDestroy(lane->stream);
+    if (lane->k1_done) (void)hipEventDestroy(lane->k1_done);
+    if (lane->k1_phase_done) (void)hipEventDestroy(lane->k1_phase_done);
+    if (lane->inputs_ready) (void)hipEventDestroy(lane->inputs_ready);
     delete lane;
-    h->err = "could not create a pipeline lane (stream / event)";
+    h->err = "could not create a lane (stream / events)";
     return TEASER_HIP_ERR_HIP;
   }
+  lane->k1_stream = h->k1_stream;  // borrowed
   *out = lane;
   return TEASER_HIP_OK;
 }
@@ -924,8 +973,15 @@ void release_handle_resources(teaser_hip_solver* h) {
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   h->ev_pool.clear();
   if (h->k1_done) (void)hipEventDestroy(h->k1_done);
+  if (h->k1_phase_done) (void)hipEventDestroy(h->k1_phase_done);
+  if (h->inputs_ready) (void)hipEventDestroy(h->inputs_ready);
+  if (h->k1_stream && !h->is_lane) {  // the parent owns the shared K1 stream (lanes borrow it)
+    (void)hipStreamSynchronize(h->k1_stream);
+    (void)hipStreamDestroy(h->k1_stream);
+  }
   if (h->stream) (void)hipStreamDestroy(h->stream);
-  h->k1_done = nullptr;
+  h->k1_done = h->k1_phase_done = h->inputs_ready = nullptr;
+  h->k1_stream = nullptr;
   h->stream = nullptr;
 }
 
@@ -976,6 +1032,7 @@ int32_t submit_impl(teaser_hip_solver* h, const double* src, const double* dst,
       StageScope sc(lane, ST_H2D);
       HIPCHK(h, hipMemcpyAsync(lane->d_src.p, src, (size_t)tot * 24, hipMemcpyHostToDevice, lane->stream));
       HIPCHK(h, hipMemcpyAsync(lane->d_dst.p, dst, (size_t)tot * 24, hipMemcpyHostToDevice, lane->stream));
+      lane->inputs_pending = true;
     }
     d_src = lane->d_src.as<double>();
     d_dst = lane->d_dst.as<double>();
@@ -990,6 +1047,7 @@ int32_t submit_impl(teaser_hip_solver* h, const double* src, const double* dst,
   rc = solve_packed_enqueue(lane, d_src, d_dst, lane->job.off.data(), lane->job.n.data(), batch, false);
   if (rc != TEASER_HIP_OK) {
     h->err = lane->err;
+    if (lane->k1_stream) (void)hipStreamSynchronize(lane->k1_stream);
     (void)hipStreamSynchronize(lane->stream);
     return rc;
   }
@@ -1097,6 +1155,7 @@ int32_t teaser_hip_solver_create(const teaser_params_c* params, int32_t device,
     if (v >= 1 && v <= 16) h->depth = v;
   }
   if (const char* e = getenv("TEASER_HIP_STAGGER")) h->stagger_k1 = atoi(e) != 0;
+  if (const char* e = getenv("TEASER_HIP_K1_STREAM")) h->shared_k1_stream = atoi(e) != 0;
   *out = h;
   return TEASER_HIP_OK;
 }

@@ -690,6 +690,43 @@ def test_edge_cases():
     assert len(s.getInlierMaxClique()) == 700
 
 
+def test_kcore_heuristic_mode_vs_oracle():
+    """inlier_selection_mode = KCORE_HEU (graph.cc:58-81 as documented): exact core numbers on the GPU;
+    when max_core > (int)(threshold * N) the inlier set is every vertex of the maximum core, otherwise
+    the heuristic clique.  Both branches, against the oracle's Batagelj-Zaversnik restatement."""
+    # (a) 70 % inliers: the inlier clique (size 280 of 400) makes max_core = 279 > 0.5 * 400 -> shortcut;
+    #     the maximum core is larger than the clique here (outliers attached to it), which is the
+    #     documented difference between KCORE_HEU and the clique modes
+    for seed, n, rho, thr in ((71, 400, 0.3, 0.5), (72, 600, 0.25, 0.4), (73, 1000, 0.45, 0.5)):
+        pr = tp.synth_problem(seed, n, rho, 0.01)
+        p = bench_params(inlier_selection_mode=tp.InlierSelectionMode.KCORE_HEU, kcore_heuristic_threshold=thr)
+        s = make_solver(**p)
+        sol = s.solve(pr["src"], pr["dst"])
+        _, bm = oracle.inlier_bitmap(pr["src"], pr["dst"], 0.01, 1.0, False)
+        taken, core_set, max_core = oracle.kcore_heuristic(bm, n, thr)
+        assert taken and max_core > int(thr * n)
+        assert s.getInlierMaxClique() == core_set.tolist()
+        o = oracle.solve(pr["src"], pr["dst"], **oracle_params(p))
+        assert o["max_clique"].tolist() == core_set.tolist()
+        check_solution_parity(s, sol, o)
+    # (b) 90 % outliers: max_core (~ inliers - 1) <= 0.5 * N -> no shortcut, the heuristic clique
+    pr = tp.synth_problem(74, 1000, 0.9, 0.01)
+    p = bench_params(inlier_selection_mode=tp.InlierSelectionMode.KCORE_HEU)
+    s = make_solver(**p)
+    sol = s.solve(pr["src"], pr["dst"])
+    _, bm = oracle.inlier_bitmap(pr["src"], pr["dst"], 0.01, 1.0, False)
+    taken, _, max_core = oracle.kcore_heuristic(bm, 1000, 0.5)
+    assert not taken
+    o = oracle.solve(pr["src"], pr["dst"], **oracle_params(p))
+    check_solution_parity(s, sol, o)
+    # threshold == 1 short-circuits the comparison (graph.cc:67): never the shortcut
+    pr = tp.synth_problem(71, 400, 0.3, 0.01)
+    p = bench_params(inlier_selection_mode=tp.InlierSelectionMode.KCORE_HEU, kcore_heuristic_threshold=1.0)
+    s = make_solver(**p)
+    s.solve(pr["src"], pr["dst"])
+    assert s.getInlierMaxClique() == np.flatnonzero(pr["inliers"]).tolist()
+
+
 def test_inlier_selection_modes():
     pr = tp.synth_problem(31, 400, 0.8, 0.01)
     truth = np.flatnonzero(pr["inliers"]).tolist()
@@ -903,7 +940,7 @@ def _packed(probs):
 def test_async_batches_match_sync():
     """Four ragged batches in flight over three lanes (device inputs, then host inputs): every problem
     is identical -- clique, inliers, R, t bit for bit -- to the synchronous batched solve."""
-    import torch
+    from util import HipBuffers
     sizes = [[300, 1000, 64, 777], [2000, 500], [1500, 1, 129, 640, 900], [1024, 2048]]
     batches = [[tp.synth_problem(900 + 10 * k + i, n, 0.85, 0.01) for i, n in enumerate(sz)]
                for k, sz in enumerate(sizes)]
@@ -913,26 +950,21 @@ def test_async_batches_match_sync():
         sols = ref.solve_batch([p["src"] for p in probs], [p["dst"] for p in probs])
         want.append([(bool(o.valid), o.rotation.copy(), o.translation.copy(), ref.getInlierMaxClique(b),
                       ref.getRotationInliers(b), ref.getTranslationInliers(b)) for b, o in enumerate(sols)])
+    mem = HipBuffers()
     s = make_solver(**bench_params())
     s.set_pipeline_depth(3)
     for host in (False, True):
-        keep, tickets = [], []
+        put = mem.pinned if host else mem.device
+        tickets = []
         for probs in batches[:3]:
             src, dst, off, n = _packed(probs)
-            if host:
-                a, b = torch.from_numpy(src).pin_memory(), torch.from_numpy(dst).pin_memory()
-            else:
-                a, b = torch.from_numpy(src).cuda(), torch.from_numpy(dst).cuda()
-            keep.append((a, b))
-            tickets.append(s.submit_batch(a.data_ptr(), b.data_ptr(), off, n, host=host))
+            tickets.append(s.submit_batch(put(src), put(dst), off, n, host=host))
         # all three lanes are in flight: a fourth submit must be refused, loudly
         src, dst, off, n = _packed(batches[3])
-        a = torch.from_numpy(src).pin_memory() if host else torch.from_numpy(src).cuda()
-        b = torch.from_numpy(dst).pin_memory() if host else torch.from_numpy(dst).cuda()
+        a, b = put(src), put(dst)
         with pytest.raises(tp.TeaserHipError):
-            s.submit_batch(a.data_ptr(), b.data_ptr(), off, n, host=host)
-        order = [1, 0, 2]  # tickets may be waited for in any order
-        for k in order:
+            s.submit_batch(a, b, off, n, host=host)
+        for k in (1, 0, 2):  # tickets may be waited for in any order
             out = s.wait(tickets[k])
             for bi, w in enumerate(want[k]):
                 o = out[bi]
@@ -942,13 +974,18 @@ def test_async_batches_match_sync():
                     assert (np.array(o.rotation[:]).reshape(3, 3) == w[1]).all()
                     assert (np.array(o.translation[:]) == w[2]).all()
                     assert s.getRotationInliers(bi) == w[4] and s.getTranslationInliers(bi) == w[5]
-        t3 = s.submit_batch(a.data_ptr(), b.data_ptr(), off, n, host=host)
+        t3 = s.submit_batch(a, b, off, n, host=host)
         out = s.wait(t3)
         for bi, w in enumerate(want[3]):
             assert s.getInlierMaxClique(bi) == w[3]
             assert (np.array(out[bi].rotation[:]).reshape(3, 3) == w[1]).all()
-        with pytest.raises(tp.TeaserHipError):
+        with pytest.raises((tp.TeaserHipError, KeyError)):
             s.wait(t3)  # a ticket is waited for exactly once
+    # the synchronous API on the same handle still works between asynchronous batches
+    one = s.solve(batches[0][1]["src"], batches[0][1]["dst"])
+    assert (one.rotation == want[0][1][1]).all() and s.getInlierMaxClique() == want[0][1][3]
+    del s
+    mem.free()
 
 
 def test_multi_device_fan_out():
@@ -974,11 +1011,11 @@ def test_multi_device_fan_out():
 
 
 def test_k1_scheduling_variants_bit_identical(monkeypatch):
-    """TEASER_K1_VARIANT: 0 / 1 are two instruction schedules of the matrix-core K1, -1 forces the
-    all-FP64 kernel; the three bitmaps are identical (and equal the oracle's)."""
+    """TEASER_K1_VARIANT: 0..3 are instruction schedules of the matrix-core K1, -1 forces the all-FP64
+    kernel; all bitmaps are identical (and equal the oracle's)."""
     pr = tp.synth_problem(61, 4500, 0.9, 0.01)
     _, ref = oracle.inlier_bitmap(pr["src"], pr["dst"], 0.01, 1.0, False)
-    for v in ("-1", "0", "1"):
+    for v in ("-1", "0", "1", "2", "3"):
         monkeypatch.setenv("TEASER_K1_VARIANT", v)
         s = make_solver(**bench_params())
         s.solve(pr["src"], pr["dst"])
