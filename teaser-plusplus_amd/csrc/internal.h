@@ -94,12 +94,14 @@ void launch_tim_graph(hipStream_t s, const ProbDesc* d_desc, int batch, int max_
                       double noise_bound, double cbar2, int mode, const ProbState* d_state);
 // K1 on the matrix cores (fixed scale only): f32 Gram filter + FP64 exact fallback, same bitmap
 int64_t tim_prep_bytes(int batch);
-int64_t tim_operand_bytes(int64_t total_pts);
+int64_t tim_operand_bytes(int64_t total_tiles);  // total_tiles = sum of the problems' W
 int64_t tim_work_items(const int32_t* n, int batch);
+// phase 1 also leaves the vertex degrees in d_deg (row popcounts accumulated by the kernel)
 void launch_tim_graph_mfma(hipStream_t s, int phase, const ProbDesc* d_desc, int batch, int max_n,
-                           int64_t total_pts, const double* d_src, const double* d_dst,
+                           int64_t total_tiles, const double* d_src, const double* d_dst,
                            void* d_pk, void* d_prep, void* d_work, int64_t work_cap,
-                           uint64_t* d_bitmap, ProbState* d_state, double noise_bound, double cbar2);
+                           uint64_t* d_bitmap, ProbState* d_state, int32_t* d_deg, double noise_bound,
+                           double cbar2);
 // row popcounts -> degrees
 void launch_degrees(hipStream_t s, const ProbDesc* d_desc, int batch, int max_n,
                     const uint64_t* d_bitmap, int32_t* d_deg, ProbState* d_state);

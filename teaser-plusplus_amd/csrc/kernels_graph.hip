@@ -356,11 +356,16 @@ struct TimPrep {         // per problem, zeroed then filled by the pre-pass
   unsigned int pad[3];
 };
 
-// packed operands of one point of one cloud: 32 bf16 for the row (A) side, 32 for the column (B)
-// side; a lane of half h loads uint4 #h (K 8h..8h+7 of the first MFMA) and #(2+h) (second MFMA)
-struct TimOperand {
-  uint4 a[4];
-  uint4 b[4];
+// Packed operands of one 64-point tile of one cloud (tile t of a problem = points 64 t .. 64 t + 63,
+// padded with copies of the problem's last point; tiles are indexed like the bitmap's row words,
+// ProbDesc.w_off + t).  Per point 32 bf16 for the row (A) side and 32 for the column (B) side, as two
+// uint4 per MFMA (lane half h holds K slots 8h..8h+7).  Laid out so that the 64 lanes of a wave --
+// lane = (h, c), c = point within a 32-point group -- load 1 KB of CONSECUTIVE memory per MFMA operand:
+// [32-point group][MFMA][h][c].  (The first layout, 128 B per point, made every such load touch 32
+// separate 128-B lines: the vector L1 was the kernel's hidden bottleneck.)
+struct TimOperandTile {
+  uint4 a[2][2][2][32];
+  uint4 b[2][2][2][32];
 };
 
 __device__ __forceinline__ unsigned int f32_key(float f) {  // monotone float -> uint
@@ -430,7 +435,8 @@ __device__ __forceinline__ unsigned int bf16_neg2(unsigned int b) {  // bf16 bit
 // K layout (32 slots):  per coordinate c in x, y, z (6 slots each, base 6c):
 //   A: c_h c_h c_m c_h c_l c_m     B: -2c'_h -2c'_m -2c'_h -2c'_l -2c'_h -2c'_m
 //   slots 18..20: A n_h n_m n_l, B 1 1 1;   21..23: A 1 1 1, B n'_h n'_m n'_l;   24..31: zero
-__device__ __forceinline__ void tim_pack_point(float x, float y, float z, float nrm, TimOperand* out) {
+__device__ __forceinline__ void tim_pack_point(float x, float y, float z, float nrm, TimOperandTile* tile,
+                                               int g, int c) {
   unsigned short A[32], B[32];
   for (int k = 24; k < 32; ++k) { A[k] = 0; B[k] = 0; }
   const float cv[3] = {x, y, z};
@@ -453,23 +459,27 @@ __device__ __forceinline__ void tim_pack_point(float x, float y, float z, float 
     wa[k] = (unsigned int)A[2 * k] | ((unsigned int)A[2 * k + 1] << 16);
     wb[k] = (unsigned int)B[2 * k] | ((unsigned int)B[2 * k + 1] << 16);
   }
-  for (int q = 0; q < 4; ++q) {
-    out->a[q] = make_uint4(wa[4 * q], wa[4 * q + 1], wa[4 * q + 2], wa[4 * q + 3]);
-    out->b[q] = make_uint4(wb[4 * q], wb[4 * q + 1], wb[4 * q + 2], wb[4 * q + 3]);
+  for (int q = 0; q < 4; ++q) {  // q = 2 * MFMA + h
+    tile->a[g][q >> 1][q & 1][c] = make_uint4(wa[4 * q], wa[4 * q + 1], wa[4 * q + 2], wa[4 * q + 3]);
+    tile->b[g][q >> 1][q & 1][c] = make_uint4(wb[4 * q], wb[4 * q + 1], wb[4 * q + 2], wb[4 * q + 3]);
   }
 }
 
-// centred f32 points -> packed bf16 operands; atomicMax of the f32 squared norms into r2_bits
+// centred f32 points -> packed bf16 operands (one thread per point of the padded tiles; the padding
+// repeats the problem's last point); atomicMax of the f32 squared norms into r2_bits; the vertex
+// degrees, which K1 accumulates with atomics, are zeroed here.
 __global__ __launch_bounds__(256) void tim_prep_pack_kernel(const ProbDesc* __restrict__ descs,
                                                             const double* __restrict__ src,
                                                             const double* __restrict__ dst,
                                                             TimPrep* __restrict__ prep,
-                                                            TimOperand* __restrict__ op_src,
-                                                            TimOperand* __restrict__ op_dst) {
+                                                            TimOperandTile* __restrict__ op_src,
+                                                            TimOperandTile* __restrict__ op_dst,
+                                                            int32_t* __restrict__ deg) {
   const ProbDesc d = descs[blockIdx.y];
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int ip = blockIdx.x * 256 + threadIdx.x;  // padded point index
   float m = 0.f;
-  if (i < d.n) {
+  if (ip < d.W * 64 && d.n > 0) {
+    const int i = min(ip, d.n - 1);
     const TimPrep* pr = prep + blockIdx.y;
     const double* a = src + 3 * (d.pt_off + i);
     const double* b = dst + 3 * (d.pt_off + i);
@@ -480,10 +490,12 @@ __global__ __launch_bounds__(256) void tim_prep_pack_kernel(const ProbDesc* __re
     // exact in double (24-bit inputs), one rounding to f32
     const float na = (float)(((double)ax * ax + (double)ay * ay) + (double)az * az);
     const float nb = (float)(((double)bx * bx + (double)by * by) + (double)bz * bz);
-    tim_pack_point(ax, ay, az, na, op_src + d.pt_off + i);
-    tim_pack_point(bx, by, bz, nb, op_dst + d.pt_off + i);
+    const int64_t tile = d.w_off + (ip >> 6);
+    tim_pack_point(ax, ay, az, na, op_src + tile, (ip >> 5) & 1, ip & 31);
+    tim_pack_point(bx, by, bz, nb, op_dst + tile, (ip >> 5) & 1, ip & 31);
     m = na > nb ? na : nb;
     if (!(m == m)) m = INFINITY;  // NaN coordinates: force the FP64 path
+    if (ip < d.n) deg[d.pt_off + ip] = 0;
   }
   for (int o = 32; o > 0; o >>= 1) {
     const float t = __shfl_xor(m, o, 64);
@@ -617,11 +629,11 @@ __device__ __forceinline__ int flush_work(const unsigned long long* wbuf, int wc
 template <int V, int OCC>
 __global__ __launch_bounds__(256, OCC) void tim_graph_mfma_kernel(
     const ProbDesc* __restrict__ descs, const double* __restrict__ src,
-    const double* __restrict__ dst, const TimOperand* __restrict__ op_src,
-    const TimOperand* __restrict__ op_dst, const TimPrep* __restrict__ prep,
+    const double* __restrict__ dst, const TimOperandTile* __restrict__ op_src,
+    const TimOperandTile* __restrict__ op_dst, const TimPrep* __restrict__ prep,
     uint64_t* __restrict__ bitmap, double beta, int gyr,
     unsigned long long* __restrict__ work, unsigned int* __restrict__ work_count, unsigned int work_cap,
-    ProbState* __restrict__ states) {
+    ProbState* __restrict__ states, int32_t* __restrict__ deg) {
   const ProbDesc d = descs[blockIdx.y];
   const int n = d.n, W = d.W;
   const int T = W;
@@ -656,20 +668,23 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma_kernel(
           tim_wave_fp64<0>(ps, pd, bm, n, W, I, jb, kc, cbuf[wave]);
     return;
   }
-  const TimOperand* __restrict__ qs = op_src + d.pt_off;
-  const TimOperand* __restrict__ qd = op_dst + d.pt_off;
+  const TimOperandTile* __restrict__ qs = op_src + d.w_off;  // tile t of this problem: qs[t]
+  const TimOperandTile* __restrict__ qd = op_dst + d.w_off;
   const int h = lane >> 5, c = lane & 31;
   unsigned long long* wbuf = reinterpret_cast<unsigned long long*>(cbuf[wave]);  // private to the wave
   int wcount = 0;  // wave-uniform
 
-  // row operands (A side) of the wave's two 32-row halves, both clouds, both MFMAs
+  // row operands (A side) of the wave's two 32-row halves, both clouds, both MFMAs: every load is
+  // 1 KB of consecutive memory per wave (lane = (h, c))
   bf16x8 as[2][2], ad[2][2];
-  for (int rt = 0; rt < 2; ++rt) {
-    const int r = min(I * 64 + 32 * rt + c, n - 1);
-    as[rt][0] = __builtin_bit_cast(bf16x8, qs[r].a[h]);
-    as[rt][1] = __builtin_bit_cast(bf16x8, qs[r].a[2 + h]);
-    ad[rt][0] = __builtin_bit_cast(bf16x8, qd[r].a[h]);
-    ad[rt][1] = __builtin_bit_cast(bf16x8, qd[r].a[2 + h]);
+  {
+    const int It = min(I, T - 1);
+    for (int rt = 0; rt < 2; ++rt) {
+      as[rt][0] = __builtin_bit_cast(bf16x8, qs[It].a[rt][0][h][c]);
+      as[rt][1] = __builtin_bit_cast(bf16x8, qs[It].a[rt][1][h][c]);
+      ad[rt][0] = __builtin_bit_cast(bf16x8, qd[It].a[rt][0][h][c]);
+      ad[rt][1] = __builtin_bit_cast(bf16x8, qd[It].a[rt][1][h][c]);
+    }
   }
   const bool rowvalid = I < T;  // (T need not be a multiple of the block's row tiles)
   const uint64_t rowmask = !rowvalid ? 0ull : (n - I * 64 >= 64) ? ~0ull : ((1ull << (n - I * 64)) - 1ull);
@@ -686,9 +701,15 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma_kernel(
   const int Jfirst = max(Jbase, I), Jend = min(Jbase + kMfmaColTiles, T);
   uint4 nb[4];  // next column point: src MFMA 0/1, dst MFMA 0/1
   {
-    const int cp = min(Jfirst * 64 + c, n - 1);
-    nb[0] = qs[cp].b[h]; nb[1] = qs[cp].b[2 + h]; nb[2] = qd[cp].b[h]; nb[3] = qd[cp].b[2 + h];
+    const int Jf = min(Jfirst, T - 1);
+    nb[0] = qs[Jf].b[0][0][h][c]; nb[1] = qs[Jf].b[0][1][h][c];
+    nb[2] = qd[Jf].b[0][0][h][c]; nb[3] = qd[Jf].b[0][1][h][c];
   }
+  // vertex degrees (row popcounts) are accumulated here instead of by a separate pass over the bitmap:
+  // own words per row in a register, transposed words with one fire-and-forget atomic per J
+  const __amdgpu_buffer_rsrc_t deg_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(deg + d.pt_off), 0, (int)((unsigned int)n * 4u), 0x00020000);
+  int degacc = 0;
   // transposed words of column tile Jp, staged in lds_tr by all 4 waves: the 4 waves' words I0..I0+3
   // of row j are 32 contiguous bytes -> one lane group
   // V = 1 stores through a buffer descriptor with NO branch: lanes (and whole iterations) that have
@@ -722,10 +743,10 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma_kernel(
     for (int ct = 0; ct < 2; ++ct) {
       const bf16x8 bs0 = __builtin_bit_cast(bf16x8, nb[0]), bs1 = __builtin_bit_cast(bf16x8, nb[1]);
       const bf16x8 bd0 = __builtin_bit_cast(bf16x8, nb[2]), bd1 = __builtin_bit_cast(bf16x8, nb[3]);
-      {
-        const int nxt = (ct == 0) ? j0 + 32 + c : ((J + 1 < Jend) ? j0 + 64 + c : j0 + c);
-        const int np = min(nxt, n - 1);
-        nb[0] = qs[np].b[h]; nb[1] = qs[np].b[2 + h]; nb[2] = qd[np].b[h]; nb[3] = qd[np].b[2 + h];
+      {  // prefetch: the other half of this tile, then the first half of the next one
+        const int Jn = (ct == 0 || J + 1 >= Jend) ? J : J + 1, gn = ct ^ 1;
+        nb[0] = qs[Jn].b[gn][0][h][c]; nb[1] = qs[Jn].b[gn][1][h][c];
+        nb[2] = qd[Jn].b[gn][0][h][c]; nb[3] = qd[Jn].b[gn][1][h][c];
       }
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
@@ -829,7 +850,12 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma_kernel(
     ownw &= colmask;
     if (J == I) ownw &= ~(1ull << lane);
     lds_own[wave][lane][J - Jbase] = ownw;
+    degacc += __builtin_popcountll(ownw);
     trw_out = (J != I) ? (trw & rowmask) : 0ull;
+    // degree of row j0 + lane gains the bits of its transposed word (rows beyond n hold no bits: the
+    // offset is out of range there and the hardware drops the atomic)
+    __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(__builtin_popcountll(trw_out), deg_rsrc,
+                                                   (unsigned int)(j0 + lane) * 4u, 0, 0);
     }  // active
     if (V == 2) {
       // lane = row j0 + lane of the transposed block, word I: 8 bytes at a stride of W words
@@ -854,6 +880,8 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma_kernel(
       if (J >= I && J < Jend && I * 64 + r < n) bm[(int64_t)(I * 64 + r) * W + J] = lds_own[wave][r][k];
     }
   }
+  if (rowvalid)
+    __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(degacc, deg_rsrc, (unsigned int)(I * 64 + lane) * 4u, 0, 0);
   flush_work(wbuf, wcount, work, work_count, work_cap, states + blockIdx.y, lane);
 }
 
@@ -871,7 +899,8 @@ __global__ __launch_bounds__(256) void tim_fixup_kernel(const ProbDesc* __restri
                                                         uint64_t* __restrict__ bitmap, double beta,
                                                         const unsigned long long* __restrict__ work,
                                                         const unsigned int* __restrict__ work_count,
-                                                        unsigned int cap, ProbState* __restrict__ states) {
+                                                        unsigned int cap, ProbState* __restrict__ states,
+                                                        int32_t* __restrict__ deg) {
   const unsigned int total = *work_count;
   if (total > cap) {
     const ProbDesc last = descs[batch - 1];
@@ -893,15 +922,18 @@ __global__ __launch_bounds__(256) void tim_fixup_kernel(const ProbDesc* __restri
     const bool e = tim_edge_exact(ps[3 * col] - ps[3 * r], ps[3 * col + 1] - ps[3 * r + 1],
                                   ps[3 * col + 2] - ps[3 * r + 2], pd[3 * col] - pd[3 * r],
                                   pd[3 * col + 1] - pd[3 * r + 1], pd[3 * col + 2] - pd[3 * r + 2], beta);
+    // (the degrees K1 accumulated counted the filter's provisional bit: follow every flip)
     {  // row r, column col
       unsigned int* wp = bm32 + 2 * ((int64_t)r * W + (col >> 6)) + ((col >> 5) & 1);
       const unsigned int bit = 1u << (col & 31);
-      if (e) atomicOr(wp, bit); else atomicAnd(wp, ~bit);
+      const unsigned int old = e ? atomicOr(wp, bit) : atomicAnd(wp, ~bit);
+      if (((old & bit) != 0u) != e) atomicAdd(deg + d.pt_off + r, e ? 1 : -1);
     }
     if ((r >> 6) != (col >> 6)) {  // the transposed copy
       unsigned int* wp = bm32 + 2 * ((int64_t)col * W + (r >> 6)) + ((r >> 5) & 1);
       const unsigned int bit = 1u << (r & 31);
-      if (e) atomicOr(wp, bit); else atomicAnd(wp, ~bit);
+      const unsigned int old = e ? atomicOr(wp, bit) : atomicAnd(wp, ~bit);
+      if (((old & bit) != 0u) != e) atomicAdd(deg + d.pt_off + col, e ? 1 : -1);
     }
   }
 }
@@ -925,7 +957,10 @@ void launch_tim_graph(hipStream_t s, const ProbDesc* d_desc, int batch, int max_
 // MODE 0 on the matrix cores: pre-pass (centres, packed f32 points, R^2) + tim_graph_mfma_kernel.
 // d_pk: 2 * total_pts float4 (src then dst); d_prep: batch * sizeof(TimPrep) bytes.
 int64_t tim_prep_bytes(int batch) { return (int64_t)batch * (int64_t)sizeof(TimPrep) + 64; }
-int64_t tim_operand_bytes(int64_t total_pts) { return 2 * total_pts * (int64_t)sizeof(TimOperand); }
+__global__ void degree_kernel(const ProbDesc* __restrict__ descs, const uint64_t* __restrict__ bitmap,
+                              int32_t* __restrict__ deg, const TimPrep* __restrict__ prep, double beta);
+
+int64_t tim_operand_bytes(int64_t total_tiles) { return 2 * total_tiles * (int64_t)sizeof(TimOperandTile); }
 
 // worklist capacity: 1/64 of all pairs of the launch (>= 2^20); typical use is ~2e-4 of the pairs
 int64_t tim_work_items(const int32_t* n, int batch) {
@@ -937,17 +972,20 @@ int64_t tim_work_items(const int32_t* n, int batch) {
   return items;
 }
 
-// phase 0 pre-pass (bbox, centred bf16 operands, R^2), 1 the matrix-core kernel, 2 FP64 fix-up of the
-// worklist + overflow clear.  Three calls so that the profiling span of phase 1 is that kernel alone.
+// phase 0 pre-pass (bbox, centred bf16 operands, R^2, degrees zeroed), 1 the matrix-core kernel (bitmap
+// + degrees), 2 FP64 fix-up of the worklist (+ overflow clear).  Three calls so that the profiling span
+// of phase 1 is that kernel alone.  d_pk: 2 * total_tiles TimOperandTile (src then dst), total_tiles =
+// sum of the problems' W; d_prep: tim_prep_bytes(batch), zeroed by the caller (header upload).
 void launch_tim_graph_mfma(hipStream_t s, int phase, const ProbDesc* d_desc, int batch, int max_n,
-                           int64_t total_pts, const double* d_src, const double* d_dst,
+                           int64_t total_tiles, const double* d_src, const double* d_dst,
                            void* d_pk, void* d_prep, void* d_work, int64_t work_cap,
-                           uint64_t* d_bitmap, ProbState* d_state, double noise_bound, double cbar2) {
+                           uint64_t* d_bitmap, ProbState* d_state, int32_t* d_deg, double noise_bound,
+                           double cbar2) {
   if (batch <= 0 || max_n <= 0) return;
   const int T = (max_n + 63) / 64;
   const double beta = 2 * noise_bound * sqrt(cbar2);  // registration.cc:438
-  TimOperand* op_src = reinterpret_cast<TimOperand*>(d_pk);
-  TimOperand* op_dst = op_src + total_pts;
+  TimOperandTile* op_src = reinterpret_cast<TimOperandTile*>(d_pk);
+  TimOperandTile* op_dst = op_src + total_tiles;
   TimPrep* prep = reinterpret_cast<TimPrep*>(d_prep);
   unsigned long long* work = reinterpret_cast<unsigned long long*>(d_work);
   unsigned int* work_count = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(d_prep) +
@@ -956,8 +994,8 @@ void launch_tim_graph_mfma(hipStream_t s, int phase, const ProbDesc* d_desc, int
     // prep (and the worklist counter behind it) arrive zeroed: part of the solve's header upload
     hipLaunchKernelGGL(tim_prep_bbox_kernel, dim3((max_n + 1023) / 1024, batch), dim3(256), 0, s, d_desc,
                        d_src, d_dst, prep);
-    hipLaunchKernelGGL(tim_prep_pack_kernel, dim3((max_n + 255) / 256, batch), dim3(256), 0, s, d_desc,
-                       d_src, d_dst, prep, op_src, op_dst);
+    hipLaunchKernelGGL(tim_prep_pack_kernel, dim3((T * 64 + 255) / 256, batch), dim3(256), 0, s, d_desc,
+                       d_src, d_dst, prep, op_src, op_dst, d_deg);
   } else if (phase == 1) {
     const int gxc = (T + kMfmaColTiles - 1) / kMfmaColTiles, gyr = (T + kMfmaRowTiles - 1) / kMfmaRowTiles;
     // scheduling variant of the same kernel (diagnostics; read per launch so that a probe can switch)
@@ -966,17 +1004,20 @@ void launch_tim_graph_mfma(hipStream_t s, int phase, const ProbDesc* d_desc, int
 #define TIM_K1_LAUNCH(V, OCC)                                                                            \
   hipLaunchKernelGGL((tim_graph_mfma_kernel<V, OCC>), dim3(gxc * gyr, batch), dim3(256), 0, s, d_desc, d_src, \
                      d_dst, op_src, op_dst, prep, d_bitmap, beta, gyr, work, work_count,                 \
-                     (unsigned int)work_cap, d_state)
+                     (unsigned int)work_cap, d_state, d_deg)
     switch (variant) {
       case 0: TIM_K1_LAUNCH(0, 3); break;
       case 2: TIM_K1_LAUNCH(2, 3); break;
-      case 3: TIM_K1_LAUNCH(2, 4); break;
       default: TIM_K1_LAUNCH(1, 3); break;
     }
 #undef TIM_K1_LAUNCH
   } else {
+    // problems whose geometry the filter cannot handle ran the FP64 body inside K1 (no degree atomics
+    // there): their degrees come from the row-popcount pass, which skips every other problem
+    hipLaunchKernelGGL(degree_kernel, dim3((max_n + 3) / 4, batch), dim3(256), 0, s, d_desc, d_bitmap, d_deg,
+                       prep, beta);
     hipLaunchKernelGGL(tim_fixup_kernel, dim3(512), dim3(256), 0, s, d_desc, batch, d_src, d_dst, d_bitmap,
-                       beta, work, work_count, (unsigned int)work_cap, d_state);
+                       beta, work, work_count, (unsigned int)work_cap, d_state, d_deg);
     static const bool dbg = getenv("TEASER_K1_DEBUG") != nullptr;
     if (dbg) {  // diagnostics only: pairs sent to the FP64 fix-up
       unsigned int cnt = 0;
@@ -992,7 +1033,11 @@ void launch_tim_graph_mfma(hipStream_t s, int phase, const ProbDesc* d_desc, int
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void degree_kernel(const ProbDesc* __restrict__ descs,
                                                      const uint64_t* __restrict__ bitmap,
-                                                     int32_t* __restrict__ deg) {
+                                                     int32_t* __restrict__ deg,
+                                                     const TimPrep* __restrict__ prep, double beta) {
+  // prep != null: only the problems that ran the FP64 body inside the matrix-core K1 (the others got
+  // their degrees from K1's atomics)
+  if (prep && mfma_consts(beta, prep[blockIdx.y].r2_bits).use_mfma) return;
   const ProbDesc d = descs[blockIdx.y];
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= d.n) return;
@@ -1008,7 +1053,8 @@ void launch_degrees(hipStream_t s, const ProbDesc* d_desc, int batch, int max_n,
                     const uint64_t* d_bitmap, int32_t* d_deg, ProbState* d_state) {
   if (batch <= 0 || max_n <= 0) return;
   dim3 grid((max_n + 3) / 4, batch);
-  hipLaunchKernelGGL(degree_kernel, grid, dim3(256), 0, s, d_desc, d_bitmap, d_deg);
+  hipLaunchKernelGGL(degree_kernel, grid, dim3(256), 0, s, d_desc, d_bitmap, d_deg,
+                     static_cast<const TimPrep*>(nullptr), 0.0);
 }
 
 // ------------------------------------------------------------------------------------------

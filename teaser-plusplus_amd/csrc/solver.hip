@@ -696,7 +696,7 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
     HIPCHK(h, h->d_alive_b.ensure(8 * (size_t)std::max<int64_t>(wo, 1)));
     // K1 on the matrix cores (worklist items index 64-row tiles with 10 bits: n <= 65536)
     if (mfma_k1) {
-      HIPCHK(h, h->d_pk.ensure((size_t)tim_operand_bytes(total_n)));
+      HIPCHK(h, h->d_pk.ensure((size_t)tim_operand_bytes(wo)));
       HIPCHK(h, h->d_work.ensure(8 * (size_t)tim_work_items(n, batch) + 64));
     }
   }
@@ -747,8 +747,9 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
         }
         {
           StageScope sc(h, phase == 1 ? ST_TIM : ST_TIMAUX, s1);
-          launch_tim_graph_mfma(s1, phase, dd, batch, max_n, total_n, d_src, d_dst, h->d_pk.p, h->d_prep.p,
-                                h->d_work.p, cap, h->d_bitmap.as<uint64_t>(), ds, P.noise_bound, P.cbar2);
+          launch_tim_graph_mfma(s1, phase, dd, batch, max_n, wo, d_src, d_dst, h->d_pk.p, h->d_prep.p,
+                                h->d_work.p, cap, h->d_bitmap.as<uint64_t>(), ds, h->d_deg.as<int32_t>(),
+                                P.noise_bound, P.cbar2);
         }
         if (phase == 1 && h->k1_done && s1 == s) {
           HIPCHK(h, hipEventRecord(h->k1_done, s));
@@ -765,7 +766,7 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
       h->prof.tim_graph_pairs += nn * (nn - 1) / 2;
       h->prof.tim_graph_bytes += 48 * nn + 8 * nn * ((nn + 63) / 64);
     }
-    {
+    if (!mfma_k1) {  // (the matrix-core K1 accumulates the degrees itself)
       StageScope sc(h, ST_DEG);
       launch_degrees(s, dd, batch, max_n, h->d_bitmap.as<uint64_t>(), h->d_deg.as<int32_t>(), ds);
     }
