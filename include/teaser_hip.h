@@ -239,6 +239,12 @@ TEASER_HIP_API int32_t teaser_hip_solve_for_translation(teaser_hip_solver* h, co
                                          uint8_t* inlier_mask);
 TEASER_HIP_API int32_t teaser_hip_scalar_tls(teaser_hip_solver* h, const double* x, const double* ranges,
                               int32_t n, double* estimate, uint8_t* inlier_mask);
+/*   solveForScale      -> the scale solver the Params select (registration.h:584, :847-853):
+ *                         TLSScaleSolver::solveForScale (registration.cc:410-425) when estimate_scaling,
+ *                         else ScaleInliersSelector::solveForScale (registration.cc:427-443, scale = 1),
+ *                         on caller-supplied TIMs v1, v2 (3 x m column-major). */
+TEASER_HIP_API int32_t teaser_hip_solve_for_scale(teaser_hip_solver* h, const double* v1, const double* v2,
+                                   int64_t m, double* scale, uint8_t* inlier_mask);
 
 /* MaxCliqueSolver::findMaxClique (graph.cc:12-125) on a caller-supplied adjacency bitmap
  * (host pointer, n rows of (n+63)/64 words).  clique: capacity n; sorted on return. */

@@ -123,6 +123,7 @@ EXPORTED_SYMBOLS = [
     "teaser_hip_synth_problem", "teaser_hip_submit_batch", "teaser_hip_wait",
     "teaser_hip_set_pipeline_depth", "teaser_hip_multi_create", "teaser_hip_multi_destroy",
     "teaser_hip_multi_solve_batch", "teaser_hip_multi_route", "teaser_hip_multi_device_count",
+    "teaser_hip_solve_for_scale",
 ]
 
 
@@ -170,6 +171,7 @@ def lib():
     L.teaser_hip_solve_for_rotation.argtypes = [_vp, _dp, _dp, C.c_int32, C.c_double, _dp, _u8p, _dp, _ip]
     L.teaser_hip_solve_for_translation.argtypes = [_vp, _dp, _dp, C.c_int32, _dp, _u8p]
     L.teaser_hip_scalar_tls.argtypes = [_vp, _dp, _dp, C.c_int32, _dp, _u8p]
+    L.teaser_hip_solve_for_scale.argtypes = [_vp, _dp, _dp, C.c_int64, _dp, _u8p]
     L.teaser_hip_max_clique.argtypes = [_vp, _u64p, C.c_int32, _ip, _ip, _ip]
     L.teaser_hip_submit_batch.argtypes = [_vp, _vp, _vp, _i64p, _ip, C.c_int32, C.c_int32, _ip]
     L.teaser_hip_wait.argtypes = [_vp, C.c_int32, C.POINTER(SolutionC)]
@@ -575,6 +577,19 @@ class RobustRegistrationSolver:
     dst_tims_map = property(lambda self: self.getScaleInliersMap())
 
     # --- stage entry points (registration.h:584-601) ---------------------------------------
+    def solveForScale(self, v1, v2):
+        """registration.h:584: the scale solver selected by Params.estimate_scaling on 3xM TIMs; returns
+        the scale, keeps the inlier mask (1 x M) as `scale_inliers_mask_of_last_stage`."""
+        a, b = _colmajor(v1, "v1"), _colmajor(v2, "v2")
+        if a.shape != b.shape:
+            raise ValueError("v1 and v2 must have the same shape")
+        sc = C.c_double()
+        mask = np.zeros(max(a.shape[0], 1), dtype=np.uint8)
+        self._check(self._lib.teaser_hip_solve_for_scale(self._h, _ptr(a), _ptr(b), a.shape[0], C.byref(sc),
+                                                         _ptr(mask, _u8p)))
+        self.scale_inliers_mask_of_last_stage = mask[:a.shape[0]].astype(bool)
+        return sc.value
+
     def solveForRotation(self, v1, v2, noise_bound=None):
         a, b = _colmajor(v1, "v1"), _colmajor(v2, "v2")
         R = np.zeros(9)

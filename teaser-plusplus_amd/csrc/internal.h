@@ -170,4 +170,8 @@ hipError_t launch_tls_scale_large(hipStream_t s, const double* d_src, const doub
                                   double beta, double* d_raw, double* d_alpha, char* d_workspace,
                                   double* d_scale);
 
+// solveForScale on caller-supplied TIMs: TRIM terms (estimate != 0) or the fixed-scale mask
+void launch_tim_scale_terms(hipStream_t s, const double* d_v1, const double* d_v2, int64_t m, double beta,
+                            int estimate, double* d_raw, double* d_alpha, uint8_t* d_mask);
+
 }  // namespace thip

@@ -9,6 +9,7 @@
 //
 // Compiled with -ffp-contract=off: the pruning predicate must round every product and add
 // individually, as the reference's default (non-FMA) build does.  FMAs below are explicit.
+#include <algorithm>
 #include <utility>
 
 #include <cstdio>
@@ -638,8 +639,14 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma_kernel(
   const int n = d.n, W = d.W;
   const int T = W;
   // block = kMfmaRowTiles consecutive row tiles (one per wave) x kMfmaColTiles column tiles; row group
-  // fastest, so the blocks in flight share a column group
-  const int Ig = blockIdx.x % gyr, X = blockIdx.x / gyr;
+  // fastest, so the blocks in flight share a column group.  Only the blocks that touch the upper triangle
+  // are launched: column group X has min(gyr, 2X + 2) row groups (I0 = 4 Ig <= 8X + 7); blockIdx.x
+  // enumerates them group after group (tim_mfma_grid_blocks is the host-side count).
+  int Ig = blockIdx.x, X = 0;
+  while (Ig >= min(gyr, 2 * X + 2)) {
+    Ig -= min(gyr, 2 * X + 2);
+    ++X;
+  }
   const int I0 = Ig * kMfmaRowTiles, Jbase = X * kMfmaColTiles;
   if (I0 >= T || Jbase >= T || Jbase + kMfmaColTiles - 1 < I0) return;  // outside / below the diagonal
   const int lane = threadIdx.x & 63;
@@ -998,11 +1005,13 @@ void launch_tim_graph_mfma(hipStream_t s, int phase, const ProbDesc* d_desc, int
                        d_src, d_dst, prep, op_src, op_dst, d_deg);
   } else if (phase == 1) {
     const int gxc = (T + kMfmaColTiles - 1) / kMfmaColTiles, gyr = (T + kMfmaRowTiles - 1) / kMfmaRowTiles;
+    int nblk = 0;  // blocks touching the upper triangle (see the kernel's decode of blockIdx.x)
+    for (int X = 0; X < gxc; ++X) nblk += std::min(gyr, 2 * X + 2);
     // scheduling variant of the same kernel (diagnostics; read per launch so that a probe can switch)
     const char* ev = getenv("TEASER_K1_VARIANT");
     const int variant = ev ? atoi(ev) : 1;
 #define TIM_K1_LAUNCH(V, OCC)                                                                            \
-  hipLaunchKernelGGL((tim_graph_mfma_kernel<V, OCC>), dim3(gxc * gyr, batch), dim3(256), 0, s, d_desc, d_src, \
+  hipLaunchKernelGGL((tim_graph_mfma_kernel<V, OCC>), dim3(nblk, batch), dim3(256), 0, s, d_desc, d_src, \
                      d_dst, op_src, op_dst, prep, d_bitmap, beta, gyr, work, work_count,                 \
                      (unsigned int)work_cap, d_state, d_deg)
     switch (variant) {
@@ -1014,7 +1023,7 @@ void launch_tim_graph_mfma(hipStream_t s, int phase, const ProbDesc* d_desc, int
   } else {
     // problems whose geometry the filter cannot handle ran the FP64 body inside K1 (no degree atomics
     // there): their degrees come from the row-popcount pass, which skips every other problem
-    hipLaunchKernelGGL(degree_kernel, dim3((max_n + 3) / 4, batch), dim3(256), 0, s, d_desc, d_bitmap, d_deg,
+    hipLaunchKernelGGL(degree_kernel, dim3(batch >= 64 ? 8 : 64, batch), dim3(256), 0, s, d_desc, d_bitmap, d_deg,
                        prep, beta);
     hipLaunchKernelGGL(tim_fixup_kernel, dim3(512), dim3(256), 0, s, d_desc, batch, d_src, d_dst, d_bitmap,
                        beta, work, work_count, (unsigned int)work_cap, d_state, d_deg);
@@ -1036,17 +1045,17 @@ __global__ __launch_bounds__(256) void degree_kernel(const ProbDesc* __restrict_
                                                      int32_t* __restrict__ deg,
                                                      const TimPrep* __restrict__ prep, double beta) {
   // prep != null: only the problems that ran the FP64 body inside the matrix-core K1 (the others got
-  // their degrees from K1's atomics)
+  // their degrees from K1's atomics); that launch uses a small grid (gridDim.x row groups per problem)
   if (prep && mfma_consts(beta, prep[blockIdx.y].r2_bits).use_mfma) return;
   const ProbDesc d = descs[blockIdx.y];
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= d.n) return;
   const int lane = threadIdx.x & 63;
-  const uint64_t* r = bitmap + d.bm_off + (int64_t)row * d.W;
-  int c = 0;
-  for (int w = lane; w < d.W; w += 64) c += __popcll(r[w]);
-  c = wave_sum_i(c);
-  if (lane == 0) deg[d.pt_off + row] = c;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < d.n; row += gridDim.x * 4) {
+    const uint64_t* r = bitmap + d.bm_off + (int64_t)row * d.W;
+    int c = 0;
+    for (int w = lane; w < d.W; w += 64) c += __popcll(r[w]);
+    c = wave_sum_i(c);
+    if (lane == 0) deg[d.pt_off + row] = c;
+  }
 }
 
 void launch_degrees(hipStream_t s, const ProbDesc* d_desc, int batch, int max_n,

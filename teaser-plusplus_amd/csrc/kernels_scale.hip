@@ -433,4 +433,35 @@ hipError_t launch_tls_scale_large(hipStream_t s, const double* d_src, const doub
   return sort_and_sweep(s, w, d_raw, d_alpha, M, d_scale);
 }
 
+// Stage entry point solveForScale(v1, v2) on caller-supplied TIMs (registration.h:584, registration.cc
+// 410-443): per TIM k the two norms, then either the TRIM terms of TLSScaleSolver (raw = |v2|/|v1|,
+// alpha = beta * (1/|v1|), :415-422) or the mask of ScaleInliersSelector (| |v1| - |v2| | <= beta, :442).
+// Norms as the reference's colwise sums: (x^2 + y^2) + z^2, individually rounded, IEEE sqrt.
+__global__ __launch_bounds__(256) void tim_scale_terms_kernel(const double* __restrict__ v1,
+                                                              const double* __restrict__ v2, int64_t m,
+                                                              double beta, int estimate,
+                                                              double* __restrict__ raw,
+                                                              double* __restrict__ alpha,
+                                                              uint8_t* __restrict__ mask) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= m) return;
+  const double ax = v1[3 * k], ay = v1[3 * k + 1], az = v1[3 * k + 2];
+  const double bx = v2[3 * k], by = v2[3 * k + 1], bz = v2[3 * k + 2];
+  const double n1 = __builtin_sqrt((ax * ax + ay * ay) + az * az);
+  const double n2 = __builtin_sqrt((bx * bx + by * by) + bz * bz);
+  if (estimate) {
+    raw[k] = n2 / n1;
+    alpha[k] = beta * (1.0 / n1);
+  } else {
+    mask[k] = __builtin_fabs(n1 - n2) <= beta ? 1 : 0;
+  }
+}
+
+void launch_tim_scale_terms(hipStream_t s, const double* d_v1, const double* d_v2, int64_t m, double beta,
+                            int estimate, double* d_raw, double* d_alpha, uint8_t* d_mask) {
+  if (m <= 0) return;
+  hipLaunchKernelGGL(tim_scale_terms_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, d_v1, d_v2, m,
+                     beta, estimate, d_raw, d_alpha, d_mask);
+}
+
 }  // namespace thip

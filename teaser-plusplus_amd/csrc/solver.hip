@@ -1429,6 +1429,52 @@ int32_t teaser_hip_scalar_tls(teaser_hip_solver* h, const double* x, const doubl
   return TEASER_HIP_OK;
 }
 
+int32_t teaser_hip_solve_for_scale(teaser_hip_solver* h, const double* v1, const double* v2, int64_t m,
+                                   double* scale, uint8_t* inlier_mask) {
+  if (!h || !v1 || !v2 || m <= 0 || !scale) return TEASER_HIP_ERR_BAD_ARG;
+  if (m > ((int64_t)1 << 30)) {  // the reference's `int nr_centers = 2 * N` (registration.cc:47)
+    h->err = "solveForScale: at most 2^30 TIMs (as the reference)";
+    return TEASER_HIP_ERR_UNSUPPORTED;
+  }
+  (void)hipSetDevice(h->device);
+  hipStream_t s = h->stream;
+  const int estimate = h->params.estimate_scaling ? 1 : 0;
+  const double beta = 2 * h->params.noise_bound * std::sqrt(h->params.cbar2);  // registration.cc:421 / :438
+  HIPCHK(h, h->s_a.ensure((size_t)m * 24));
+  HIPCHK(h, h->s_b.ensure((size_t)m * 24));
+  HIPCHK(h, h->s_e.ensure((size_t)m + 16));
+  HIPCHK(h, h->s_d.ensure(64));
+  HIPCHK(h, hipMemcpyAsync(h->s_a.p, v1, (size_t)m * 24, hipMemcpyHostToDevice, s));
+  HIPCHK(h, hipMemcpyAsync(h->s_b.p, v2, (size_t)m * 24, hipMemcpyHostToDevice, s));
+  *scale = 1.0;  // ScaleInliersSelector, registration.cc:432
+  if (estimate) {
+    // raw / alpha reuse the TIM buffers' tails?  No: separate arrays (the sweep gathers from them)
+    const bool large = m > (1 << 18);
+    int64_t P2 = 2;
+    while (P2 < 2 * m) P2 <<= 1;
+    HIPCHK(h, h->x_src.ensure((size_t)m * 8));
+    HIPCHK(h, h->x_dst.ensure((size_t)m * 8));
+    HIPCHK(h, h->s_c.ensure(large ? (size_t)scalar_tls_large_workspace_bytes(m) : (size_t)P2 * 12 + 64));
+    launch_tim_scale_terms(s, h->s_a.as<double>(), h->s_b.as<double>(), m, beta, 1, h->x_src.as<double>(),
+                           h->x_dst.as<double>(), nullptr);
+    if (large)
+      HIPCHK(h, launch_scalar_tls_large(s, h->x_src.as<double>(), h->x_dst.as<double>(), m, h->s_c.as<char>(),
+                                        h->s_d.as<double>(), h->s_e.as<uint8_t>()));
+    else
+      launch_scalar_tls(s, h->x_src.as<double>(), h->x_dst.as<double>(), (int32_t)m, h->s_c.as<char>(),
+                        h->s_d.as<double>(), h->s_e.as<uint8_t>());
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(scale, h->s_d.p, 8, hipMemcpyDeviceToHost, s));
+  } else {
+    launch_tim_scale_terms(s, h->s_a.as<double>(), h->s_b.as<double>(), m, beta, 0, nullptr, nullptr,
+                           h->s_e.as<uint8_t>());
+    HIPCHK(h, hipGetLastError());
+  }
+  if (inlier_mask) HIPCHK(h, hipMemcpyAsync(inlier_mask, h->s_e.p, (size_t)m, hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  return TEASER_HIP_OK;
+}
+
 int32_t teaser_hip_max_clique(teaser_hip_solver* h, const uint64_t* bitmap, int32_t n,
                               int32_t* clique, int32_t* clique_size, int32_t* exact_run) {
   if (!h || !bitmap || n <= 0 || !clique || !clique_size) return TEASER_HIP_ERR_BAD_ARG;
@@ -1474,6 +1520,17 @@ int32_t teaser_hip_max_clique(teaser_hip_solver* h, const uint64_t* bitmap, int3
                    h->d_start_cliques.as<int32_t>(), n, nullptr, h->d_clique.as<int32_t>());
   launch_select_best(s, dd, 1, W, h->d_deg.as<int32_t>(), ds, h->d_start_cliques.as<int32_t>(), n,
                      h->d_clique.as<int32_t>(), h->d_alive_a.as<uint64_t>(), exact ? 1 : 0);
+  if (mode == TEASER_INLIER_KCORE_HEU) {  // graph.cc:58-81
+    if (n > 65536) {
+      h->err = "KCORE_HEU supports at most 65536 vertices";
+      return TEASER_HIP_ERR_UNSUPPORTED;
+    }
+    HIPCHK(h, h->c_colour.ensure(4 * (size_t)n));
+    HIPCHK(h, h->c_tent.ensure(4 * (size_t)n));
+    launch_kcore_heuristic(s, dd, 1, h->d_bitmap.as<uint64_t>(), h->d_deg.as<int32_t>(), ds,
+                           h->c_colour.as<int32_t>(), h->c_tent.as<int32_t>(), h->d_clique.as<int32_t>(),
+                           h->params.kcore_heuristic_threshold);
+  }
   if (exact)
     launch_peel_rounds(s, dd, 1, W, h->d_bitmap.as<uint64_t>(), ds, h->d_alive_a.as<uint64_t>(),
                        h->d_alive_b.as<uint64_t>(), h->d_next_count.as<int32_t>(), kPeelRounds);

@@ -276,6 +276,32 @@ def test_solve_estimate_scaling_full_size_vs_oracle_fixture():
             assert np.linalg.norm(sol.translation - g["dst_scale"] * pr["t"]) < 0.05
 
 
+def test_solve_for_scale_stage_vs_oracle():
+    """solveForScale(v1, v2) (registration.h:584) on caller-supplied TIMs, both scale solvers, against the
+    oracle's restatement of registration.cc:410-443; scale-solver-test.cc:71-130's all-in / one-out masks."""
+    src = G["object_in"].astype(np.float64)  # 3 x 168, scale-solver-test.cc uses objectIn.csv
+    rng = np.random.default_rng(7)
+    tims, _ = oracle.compute_tims(src)
+    tims = np.asarray(tims if tims.shape[0] == 3 else tims.T)
+    # fixed scale (ScaleInliersSelector): identical TIMs -> all in; one TIM stretched -> exactly that one out
+    s = make_solver(noise_bound=0.01, estimate_scaling=False)
+    assert s.solveForScale(tims, tims) == 1.0 and s.scale_inliers_mask_of_last_stage.all()
+    t2 = tims.copy()
+    t2[:, 5] *= 3.0
+    assert s.solveForScale(tims, t2) == 1.0
+    want = np.ones(tims.shape[1], dtype=bool)
+    want[5] = np.abs(np.linalg.norm(tims[:, 5]) - np.linalg.norm(t2[:, 5])) <= 0.02
+    assert (s.scale_inliers_mask_of_last_stage == want).all() and not want[5]
+    # TLS scale: random scale with noise, vs the oracle (scale to 1e-9, identical masks)
+    for scale in (1.0, 0.73, 2.5):
+        noisy = scale * tims + rng.uniform(-0.004, 0.004, size=tims.shape)
+        s = make_solver(noise_bound=0.01, estimate_scaling=True)
+        got = s.solveForScale(tims, noisy)
+        ref_scale, ref_mask = oracle.scale_inliers_mask(tims, noisy, 0.01, 1.0, True)
+        assert abs(got - ref_scale) <= 1e-9 * max(1.0, ref_scale) and abs(got - scale) < 0.05 * scale
+        assert (s.scale_inliers_mask_of_last_stage == ref_mask).all()
+
+
 def test_translation_known_answer():
     s = make_solver(noise_bound=float(G["trans_noise_bound"]))
     t = s.solveForTranslation(G["trans_v1"], G["trans_v2"])
