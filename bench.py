@@ -66,11 +66,12 @@ def parse(argv=None):
     ap.add_argument("--pool", type=int, default=0,
                     help="distinct batches (0: steps + warmup, capped at 48: every step sees new problems)")
     ap.add_argument("--seed", type=int, default=20250523)
-    ap.add_argument("--depth", type=int, default=3,
+    ap.add_argument("--depth", type=int, default=2,
                     help="batches in flight (teaser_hip_submit_batch / teaser_hip_wait lanes, one HIP stream "
                          "each, fed from ONE host thread): the host enqueues batch k+1 while the GPU runs batch "
                          "k, and the latency-bound tail of batch k (clique, GNC, TLS: one workgroup per problem) "
-                         "shares the GPU with batch k+1's K1.  1 = strictly one batch at a time")
+                         "shares the GPU with batch k+1's K1 (2 is that pattern exactly; more only adds contention).  "
+                         "1 = strictly one batch at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-resident", action="store_true",
                     help="skip the second timed loop fed from page-locked host memory")

@@ -11,6 +11,7 @@
 // converted too); extra vertex properties (confidence, intensity, normals, colours) are ignored.
 #pragma once
 
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <fstream>
@@ -95,7 +96,18 @@ class PLYReader {
 
   // Appends the file's vertices to `cloud`.  0 on success, -1 on any failure (missing file,
   // malformed header, no vertex element with x / y / z, truncated data).
+  // 0 on success, -1 on any malformed / unreadable input (never throws: allocation failures caused by
+  // hostile headers are reported the same way)
   int read(const std::string& file_name, PointCloud& cloud) {
+    try {
+      return read_impl(file_name, cloud);
+    } catch (...) {
+      return -1;
+    }
+  }
+
+ private:
+  int read_impl(const std::string& file_name, PointCloud& cloud) {
     using namespace ply_detail;
     std::ifstream in(file_name, std::ios::binary);
     if (!in) return -1;
@@ -159,7 +171,9 @@ class PLYReader {
         }
       const bool want = e.name == "vertex" && ix >= 0 && iy >= 0 && iz >= 0;
       if (e.name == "vertex" && !want) return -1;
-      if (want) cloud.reserve(cloud.size() + e.count);
+      // the count comes from an untrusted header: reserve at most what a well-formed file of that many
+      // vertices could need here (the loop below stops with -1 at the first missing value anyway)
+      if (want) cloud.reserve(cloud.size() + std::min<size_t>(e.count, (size_t)1 << 22));
       for (size_t r = 0; r < e.count; ++r) {
         double xyz[3] = {0, 0, 0};
         for (size_t k = 0; k < e.props.size(); ++k) {

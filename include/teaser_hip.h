@@ -168,9 +168,9 @@ TEASER_HIP_API int32_t teaser_hip_solve_batch_device(teaser_hip_solver* h, const
 
 /* Asynchronous batches (no reference equivalent).  submit enqueues everything of a batched solve
  * that needs no host sync on one of the handle's LANES (child contexts with their own HIP stream
- * and arenas, used round-robin; teaser_hip_set_pipeline_depth, default 3) and returns a ticket;
+ * and arenas, used round-robin; teaser_hip_set_pipeline_depth, default 2) and returns a ticket;
  * wait blocks on that lane's one host sync, finishes the rare bound-closing work and writes the
- * solutions.  With 2-3 batches in flight the host enqueues batch k+1 while the GPU runs batch k,
+ * solutions.  With 2 batches in flight the host enqueues batch k+1 while the GPU runs batch k,
  * and the latency-bound tail of batch k (clique, GNC, TLS: one workgroup per problem) shares the GPU
  * with batch k+1's K1.  Results are identical to teaser_hip_solve_batch_device (same kernels).
  *   flags = TEASER_HIP_INPUT_DEVICE: src/dst are packed DEVICE arrays (as solve_batch_device), which

@@ -163,16 +163,17 @@ struct teaser_hip_solver {
   hipEvent_t k1_done = nullptr;            // recorded after this handle's K1 kernel
   hipEvent_t wait_before_k1 = nullptr;     // the previously submitted lane's k1_done (staggers the K1s)
   bool k1_recorded = false;
-  int depth = 3;                           // lanes (TEASER_HIP_DEPTH / teaser_hip_set_pipeline_depth)
+  int depth = 2;                           // lanes (TEASER_HIP_DEPTH / teaser_hip_set_pipeline_depth)
   int next_lane = 0, last_lane = -1;
   bool stagger_k1 = true;                  // TEASER_HIP_STAGGER=0 lets the K1 kernels of the lanes co-run
-  // The K1 phase (header upload, pre-pass, K1, fix-up) of EVERY lane runs on ONE low-priority stream
-  // owned by the parent (in order: the K1 kernels follow each other back to back and keep the CUs
-  // full), the latency-bound tail of each lane on the lane's own HIGH-priority stream: whenever a K1
-  // workgroup retires, the dispatcher serves the waiting tail workgroups first.  TEASER_HIP_K1_STREAM=0
-  // falls back to one stream per lane for everything (+ the event stagger above).
+  // Alternative schedule, TEASER_HIP_K1_STREAM=1 (off by default): the K1 phase (header upload,
+  // pre-pass, K1, fix-up) of EVERY lane on ONE low-priority stream owned by the parent, the
+  // latency-bound tail of each lane on the lane's own HIGH-priority stream.  Measured on one MI355X
+  // (profiles/r2d): 34.5 k registrations/s against 39.4 k for the default (one stream per lane for
+  // everything + the event stagger above, two lanes) -- the dispatcher's priority handling starves the
+  // K1 stream whenever several tails are in flight.
   hipStream_t k1_stream = nullptr;         // parent: owner; lane: borrowed from the parent
-  bool shared_k1_stream = true;
+  bool shared_k1_stream = false;
   hipEvent_t k1_phase_done = nullptr;      // recorded on k1_stream after the fix-up
   hipEvent_t inputs_ready = nullptr;       // host inputs copied (lane stream) -> K1 phase may start
   bool inputs_pending = false;

@@ -39,6 +39,40 @@ def test_facade_solves_on_gpu():
     assert out.returncode == 0, out.stdout + out.stderr
 
 
+# --- the rest of the reference's C++ surface: graph.h, stage solvers, set*Estimator, M-sized getters -----
+SURF_SRC = os.path.join(ROOT, "tests", "cxx", "facade_surface.cpp")
+SURF_EXE = os.path.join(ROOT, "tests", "cxx", "facade_surface")
+
+
+def build_surface():
+    if not os.path.exists(os.path.join(LIBDIR, "libteaser_hip.so")):
+        pytest.skip("libteaser_hip.so not built (run __graft_entry__.build())")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           SURF_SRC, "-o", SURF_EXE, "-L" + LIBDIR, "-lteaser_hip", "-Wl,-rpath," + LIBDIR,
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    return SURF_EXE
+
+
+def test_surface_compiles_and_fails_loudly_without_gpu():
+    """teaser/graph.h + the stage-solver classes + set*Estimator + the lazily rebuilt TIM getters compile
+    against the Eigen-less value types; teaser::Graph (host-only) behaves like the reference's
+    (graph-test.cc:60-129); everything that needs the device throws without one (exit code 77)."""
+    exe = build_surface()
+    rc = subprocess.call([exe], stdout=subprocess.DEVNULL)
+    import importlib
+    tp = importlib.import_module("teaser-plusplus_amd")
+    assert rc == (0 if tp.device_count() > 0 else 77)
+
+
+@pytest.mark.gpu
+def test_surface_on_gpu():
+    """MaxCliqueSolver on the reference's toy graphs (graph-test.cc:131-305), solveForScale, stage solvers,
+    a custom scale estimator inside solve() (staged path == default path), solve() never throwing."""
+    exe = build_surface()
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0, out.stdout + out.stderr
+
+
 # --- examples/teaser_hip_ply.cpp: the reference's teaser_cpp_ply workflow through the facade ---------
 EX_SRC = os.path.join(ROOT, "examples", "teaser_hip_ply.cpp")
 EX_EXE = os.path.join(ROOT, "tests", "cxx", "teaser_hip_ply")
