@@ -246,6 +246,25 @@ TEASER_HIP_API int32_t teaser_hip_scalar_tls(teaser_hip_solver* h, const double*
 TEASER_HIP_API int32_t teaser_hip_solve_for_scale(teaser_hip_solver* h, const double* v1, const double* v2,
                                    int64_t m, double* scale, uint8_t* inlier_mask);
 
+/* Correspondence front-end (the stage BEFORE solve()).
+ *   compute_fpfh   -> teaser::FPFHEstimation::computeFPFHFeatures (teaser/src/fpfh.cc:15-43,
+ *                     teaser/include/teaser/fpfh.h:40-42): PCL-semantics normals (radius search, viewpoint
+ *                     0,0,0) and 33-bin FPFH descriptors.  cloud_xyz: n x 3 floats (teaser::PointXYZ);
+ *                     fpfh_out: n x 33 floats (pcl::FPFHSignature33::histogram); normals_out: n x 3 or NULL
+ *                     (FPFHEstimation::getNormals, fpfh.h:56).
+ *   match_features -> teaser::Matcher::calculateCorrespondences (teaser/src/matcher.cc:21-301,
+ *                     matcher.h:40-44) for use_tuple_test = false: exact L2 nearest neighbours both ways,
+ *                     optional cross check, sorted unique (src, dst) pairs.  pairs: room for *n_pairs
+ *                     pairs on entry (n_src + n_dst always suffices), count on return.  The tuple test of
+ *                     the reference draws from rand() seeded with time(NULL) (matcher.cc:214): not
+ *                     reproducible by construction and unused by every reference caller -- not offered. */
+TEASER_HIP_API int32_t teaser_hip_compute_fpfh(teaser_hip_solver* h, const float* cloud_xyz, int32_t n,
+                                double normal_radius, double fpfh_radius, float* fpfh_out,
+                                float* normals_out);
+TEASER_HIP_API int32_t teaser_hip_match_features(teaser_hip_solver* h, const float* src_feat, int32_t n_src,
+                                  const float* dst_feat, int32_t n_dst, int32_t dim, int32_t use_crosscheck,
+                                  int32_t* pairs, int64_t* n_pairs);
+
 /* MaxCliqueSolver::findMaxClique (graph.cc:12-125) on a caller-supplied adjacency bitmap
  * (host pointer, n rows of (n+63)/64 words).  clique: capacity n; sorted on return. */
 TEASER_HIP_API int32_t teaser_hip_max_clique(teaser_hip_solver* h, const uint64_t* bitmap, int32_t n,

@@ -32,7 +32,7 @@ def estimate_normals(points, radius, centred=False):
     """pcl::NormalEstimation with setRadiusSearch(radius), viewpoint (0, 0, 0); points n x 3 -> n x 3."""
     p = _f32(points)
     out = np.zeros_like(p)
-    rc = lib().feat_estimate_normals(p.ctypes.data_as(_fp), C.c_int32(p.shape[0]), C.c_float(radius),
+    rc = lib().feat_estimate_normals(p.ctypes.data_as(_fp), C.c_int32(p.shape[0]), C.c_double(radius),
                                      C.c_int32(int(centred)), out.ctypes.data_as(_fp))
     assert rc == 0
     return out
@@ -43,7 +43,7 @@ def compute_fpfh(points, normals, radius):
     p, nv = _f32(points), _f32(normals)
     out = np.zeros((p.shape[0], 33), dtype=np.float32)
     rc = lib().feat_compute_fpfh(p.ctypes.data_as(_fp), nv.ctypes.data_as(_fp), C.c_int32(p.shape[0]),
-                                 C.c_float(radius), out.ctypes.data_as(_fp))
+                                 C.c_double(radius), out.ctypes.data_as(_fp))
     assert rc == 0
     return out
 

@@ -86,8 +86,8 @@ static int cmp_nbr(const void* a, const void* b) {
  * x, y, z; neighbours with d2 < r^2... FLANN's RadiusResultSet keeps dist <= radius?  KDTreeSingleIndex
  * prunes with `worst_dist` = radius^2 and RadiusResultSet::addPoint keeps `dist < radius`; points exactly on
  * the sphere are measure-zero for the fixtures.  Sorted ascending by distance (sorted_results_ = true). */
-static int radius_search(const float* pts, int n, int q, float radius, nbr_t* out) {
-  const float r2 = radius * radius;
+static int radius_search(const float* pts, int n, int q, double radius, nbr_t* out) {
+  const float r2 = (float)(radius * radius); /* pcl::KdTreeFLANN::radiusSearch: static_cast<float>(radius * radius) */
   const float qx = pts[3 * q], qy = pts[3 * q + 1], qz = pts[3 * q + 2];
   int k = 0;
   for (int i = 0; i < n; ++i) {
@@ -186,7 +186,7 @@ static void eigen33_smallest(const float* cov, float* eval, float* evec) {
 /* pcl::NormalEstimation::computeFeature with setRadiusSearch(radius), viewpoint (0, 0, 0).
  * centred != 0: PCL >= 1.10's computeMeanAndCovarianceMatrix (accumulates relative to the first neighbour);
  * 0: the earlier form (raw coordinates).  normals: n x 3 floats (NaN when < 3 neighbours). */
-FEAT_API int feat_estimate_normals(const float* pts, int32_t n, float radius, int32_t centred, float* normals) {
+FEAT_API int feat_estimate_normals(const float* pts, int32_t n, double radius, int32_t centred, float* normals) {
 #pragma omp parallel
   {
     nbr_t* nb = (nbr_t*)malloc((size_t)n * sizeof(nbr_t));
@@ -287,7 +287,15 @@ static int pair_features(const float* p1, const float* n1, const float* p2, cons
 
 /* pcl::FPFHEstimation::computeFeature with setRadiusSearch(radius): SPFH of every point (11 + 11 + 11
  * bins), then the distance-weighted sum over the neighbours.  out: n x 33 floats. */
-FEAT_API int feat_compute_fpfh(const float* pts, const float* normals, int32_t n, float radius, float* out) {
+/* static_cast<int>(std::floor(x)) clamped to [0, 10]; a NaN feature (NaN normal) gives INT_MIN on x86,
+ * i.e. bin 0 after the clamp -- stated explicitly so that every platform agrees */
+static int fpfh_bin(double x) {
+  if (!(x == x)) return 0;
+  const double fl = floor(x);
+  return fl < 0.0 ? 0 : (fl >= 11.0 ? 10 : (int)fl);
+}
+
+FEAT_API int feat_compute_fpfh(const float* pts, const float* normals, int32_t n, double radius, float* out) {
   float* spfh = (float*)calloc((size_t)n * 33, sizeof(float));
   if (!spfh) return 2;
   const float d_pi = 1.0f / (2.0f * (float)M_PI);
@@ -305,18 +313,9 @@ FEAT_API int feat_compute_fpfh(const float* pts, const float* normals, int32_t n
         if (qi == p) continue;
         float f[4];
         if (!pair_features(pts + 3 * p, normals + 3 * p, pts + 3 * qi, normals + 3 * qi, f)) continue;
-        int hi = (int)floor(11 * (((double)f[0] + M_PI) * (double)d_pi));
-        if (hi < 0) hi = 0;
-        if (hi >= 11) hi = 10;
-        h[hi] += incr;
-        hi = (int)floor(11 * (((double)f[1] + 1.0) * 0.5));
-        if (hi < 0) hi = 0;
-        if (hi >= 11) hi = 10;
-        h[11 + hi] += incr;
-        hi = (int)floor(11 * (((double)f[2] + 1.0) * 0.5));
-        if (hi < 0) hi = 0;
-        if (hi >= 11) hi = 10;
-        h[22 + hi] += incr;
+        h[fpfh_bin(11 * (((double)f[0] + M_PI) * (double)d_pi))] += incr;
+        h[11 + fpfh_bin(11 * (((double)f[1] + 1.0) * 0.5))] += incr;
+        h[22 + fpfh_bin(11 * (((double)f[2] + 1.0) * 0.5))] += incr;
       }
     }
 #pragma omp for schedule(dynamic, 16)

@@ -123,7 +123,7 @@ EXPORTED_SYMBOLS = [
     "teaser_hip_synth_problem", "teaser_hip_submit_batch", "teaser_hip_wait",
     "teaser_hip_set_pipeline_depth", "teaser_hip_multi_create", "teaser_hip_multi_destroy",
     "teaser_hip_multi_solve_batch", "teaser_hip_multi_route", "teaser_hip_multi_device_count",
-    "teaser_hip_solve_for_scale",
+    "teaser_hip_solve_for_scale", "teaser_hip_compute_fpfh", "teaser_hip_match_features",
 ]
 
 
@@ -172,6 +172,9 @@ def lib():
     L.teaser_hip_solve_for_translation.argtypes = [_vp, _dp, _dp, C.c_int32, _dp, _u8p]
     L.teaser_hip_scalar_tls.argtypes = [_vp, _dp, _dp, C.c_int32, _dp, _u8p]
     L.teaser_hip_solve_for_scale.argtypes = [_vp, _dp, _dp, C.c_int64, _dp, _u8p]
+    _fp = C.POINTER(C.c_float)
+    L.teaser_hip_compute_fpfh.argtypes = [_vp, _fp, C.c_int32, C.c_double, C.c_double, _fp, _fp]
+    L.teaser_hip_match_features.argtypes = [_vp, _fp, C.c_int32, _fp, C.c_int32, C.c_int32, C.c_int32, _ip, _i64p]
     L.teaser_hip_max_clique.argtypes = [_vp, _u64p, C.c_int32, _ip, _ip, _ip]
     L.teaser_hip_submit_batch.argtypes = [_vp, _vp, _vp, _i64p, _ip, C.c_int32, C.c_int32, _ip]
     L.teaser_hip_wait.argtypes = [_vp, C.c_int32, C.POINTER(SolutionC)]
@@ -646,6 +649,55 @@ class RobustRegistrationSolver:
         return self._lib.teaser_hip_get_stream(self._h)
 
 
+class FPFHEstimation:
+    """teaser::FPFHEstimation (reference teaser/include/teaser/fpfh.h:22-90, teaser/src/fpfh.cc:15-43) on the
+    GPU: PCL-semantics normals + FPFH.  computeFPFHFeatures(cloud n x 3 float32) -> n x 33 float32."""
+
+    def __init__(self, device=-1):
+        self._solver = RobustRegistrationSolver(device=device)
+        self._normals = None
+
+    def computeFPFHFeatures(self, input_cloud, normal_search_radius=0.03, fpfh_search_radius=0.05):
+        pts = np.ascontiguousarray(np.asarray(input_cloud, dtype=np.float32).reshape(-1, 3))
+        out = np.zeros((pts.shape[0], 33), dtype=np.float32)
+        nrm = np.zeros((pts.shape[0], 3), dtype=np.float32)
+        fp = C.POINTER(C.c_float)
+        s = self._solver
+        s._check(s._lib.teaser_hip_compute_fpfh(s._h, _ptr(pts, fp), pts.shape[0], float(normal_search_radius),
+                                                float(fpfh_search_radius), _ptr(out, fp), _ptr(nrm, fp)))
+        self._normals = nrm
+        return out
+
+    def getNormals(self):  # fpfh.h:56
+        return self._normals
+
+
+class Matcher:
+    """teaser::Matcher (reference teaser/include/teaser/matcher.h:20-61, teaser/src/matcher.cc:21-301) on
+    the GPU: exact L2 nearest neighbours both ways + cross check; returns a list of (src, dst) pairs."""
+
+    def __init__(self, device=-1):
+        self._solver = RobustRegistrationSolver(device=device)
+
+    def calculateCorrespondences(self, source_points, target_points, source_features, target_features,
+                                 use_absolute_scale=True, use_crosscheck=True, use_tuple_test=False,
+                                 tuple_scale=0.0):
+        if use_tuple_test and tuple_scale != 0:
+            raise ValueError("the reference's tuple test draws from rand() seeded with time(NULL) "
+                             "(matcher.cc:214): not reproducible, not offered")
+        a = np.ascontiguousarray(source_features, dtype=np.float32)
+        b = np.ascontiguousarray(target_features, dtype=np.float32)
+        if a.ndim != 2 or b.ndim != 2 or a.shape[1] != b.shape[1]:
+            raise ValueError("features must be n x dim arrays of the same dim")
+        out = np.zeros((a.shape[0] + b.shape[0] + 1, 2), dtype=np.int32)
+        cnt = C.c_int64(out.shape[0])
+        fp = C.POINTER(C.c_float)
+        s = self._solver
+        s._check(s._lib.teaser_hip_match_features(s._h, _ptr(a, fp), a.shape[0], _ptr(b, fp), b.shape[0], a.shape[1],
+                                                  1 if use_crosscheck else 0, _ptr(out, _ip), C.byref(cnt)))
+        return [tuple(int(v) for v in row) for row in out[:cnt.value]]
+
+
 class MultiDeviceSolver:
     """teaser_hip_multi_*: one process, one handle + host thread per listed device; a batch is cut
     into contiguous blocks that run concurrently.  devices=None: every visible device."""
@@ -706,6 +758,6 @@ class MultiDeviceSolver:
 
 from . import batched  # noqa: E402,F401  (sharding + record gather for the multi-GPU batched mode)
 
-__all__ = ["batched", "MultiDeviceSolver", "RobustRegistrationSolver", "RegistrationSolution", "RotationEstimationAlgorithm",
+__all__ = ["batched", "FPFHEstimation", "Matcher", "MultiDeviceSolver", "RobustRegistrationSolver", "RegistrationSolution", "RotationEstimationAlgorithm",
            "InlierSelectionMode", "InlierGraphFormulation", "TeaserHipError", "synth_problem",
            "device_count", "build", "lib", "LIB_PATH", "EXPORTED_SYMBOLS"]

@@ -170,6 +170,24 @@ hipError_t launch_tls_scale_large(hipStream_t s, const double* d_src, const doub
                                   double beta, double* d_raw, double* d_alpha, char* d_workspace,
                                   double* d_scale);
 
+// correspondence front-end (kernels_features.hip): radius neighbour lists (count -> scan -> fill + sort by
+// (distance, index)), PCL-style normals, SPFH + FPFH, exact L2 1-NN
+int64_t feat_nbr_bytes();
+int feat_sort_capacity();
+void launch_feat_radius_count(hipStream_t s, const float* d_pts, int n, float r2, int32_t* d_counts);
+void launch_feat_scan(hipStream_t s, const int32_t* d_counts, int n, int64_t* d_offsets /* n + 1 */,
+                      int64_t* d_total_max /* 2 */);
+void launch_feat_radius_fill_sort(hipStream_t s, const float* d_pts, int n, float r2, const int32_t* d_counts,
+                                  const int64_t* d_offsets, void* d_list);
+void launch_feat_normals(hipStream_t s, const float* d_pts, int n, const int64_t* d_offsets, const int32_t* d_counts,
+                         const void* d_list, float* d_normals);
+void launch_feat_fpfh(hipStream_t s, const float* d_pts, const float* d_normals, int n, const int64_t* d_offsets,
+                      const int32_t* d_counts, const void* d_list, float* d_spfh, float* d_out);
+int feat_nn_chunks(int nd);
+int feat_nn_max_dim();
+void launch_feat_nn1(hipStream_t s, const float* d_data, int nd, const float* d_query, int nq, int dim,
+                     float* d_part_d, int32_t* d_part_i, int32_t* d_nn);
+
 // solveForScale on caller-supplied TIMs: TRIM terms (estimate != 0) or the fixed-scale mask
 void launch_tim_scale_terms(hipStream_t s, const double* d_v1, const double* d_v2, int64_t m, double beta,
                             int estimate, double* d_raw, double* d_alpha, uint8_t* d_mask);

@@ -143,6 +143,9 @@ struct teaser_hip_solver {
   DevBuf x_order, x_src, x_dst, x_bitmap, x_desc, x_state, x_ctrl, x_clique, x_arena;
   // stand-alone stages
   DevBuf s_a, s_b, s_c, s_d, s_e;
+  // correspondence front-end (FPFH, matcher)
+  DevBuf f_pts, f_counts, f_offsets, f_list, f_normals, f_spfh, f_out, f_meta, f_feat_a, f_feat_b, f_part_d,
+      f_part_i, f_nn_a, f_nn_b;
 
   PinnedBuf pin_states;  // D2H landing zone of the problem states
   PinnedBuf pin_in;      // H2D staging of the problem descriptors / initial states
@@ -1007,7 +1010,9 @@ void release_handle_resources(teaser_hip_solver* h) {
                     &h->d_tls_scratch, &h->d_tim_off, &h->d_pk, &h->d_prep, &h->d_work, &h->hdr, &h->x_order,
                     &h->x_src, &h->x_dst, &h->x_bitmap, &h->x_desc, &h->x_state, &h->x_ctrl,
                     &h->x_clique, &h->x_arena, &h->c_sel, &h->c_colour, &h->c_tent, &h->c_xlist,
-                    &h->s_a, &h->s_b, &h->s_c, &h->s_d, &h->s_e};
+                    &h->s_a, &h->s_b, &h->s_c, &h->s_d, &h->s_e, &h->f_pts, &h->f_counts, &h->f_offsets, &h->f_list,
+                    &h->f_normals, &h->f_spfh, &h->f_out, &h->f_meta, &h->f_feat_a, &h->f_feat_b, &h->f_part_d,
+                    &h->f_part_i, &h->f_nn_a, &h->f_nn_b};
   for (DevBuf* b : bufs) b->release();
   h->pin_states.release();
   h->pin_in.release();
@@ -1711,6 +1716,125 @@ int32_t teaser_hip_multi_route(teaser_hip_multi* mh, int32_t problem, teaser_hip
       return TEASER_HIP_OK;
     }
   return TEASER_HIP_ERR_BAD_ARG;
+}
+
+// ---- correspondence front-end -----------------------------------------------------------------------
+namespace {
+// neighbour lists of every point for one radius: counts, offsets, sorted (d2, idx) lists in h->f_list
+int32_t feat_neighbours(teaser_hip_solver* h, int n, double radius) {
+  hipStream_t s = h->stream;
+  const float r2 = (float)(radius * radius);  // pcl::KdTreeFLANN::radiusSearch: static_cast<float>(radius * radius)
+  HIPCHK(h, h->f_counts.ensure((size_t)n * 4));
+  HIPCHK(h, h->f_offsets.ensure((size_t)(n + 1) * 8));
+  HIPCHK(h, h->f_meta.ensure(16));
+  launch_feat_radius_count(s, h->f_pts.as<float>(), n, r2, h->f_counts.as<int32_t>());
+  launch_feat_scan(s, h->f_counts.as<int32_t>(), n, h->f_offsets.as<int64_t>(), h->f_meta.as<int64_t>());
+  HIPCHK(h, hipGetLastError());
+  int64_t meta[2] = {0, 0};
+  HIPCHK(h, hipMemcpyAsync(meta, h->f_meta.p, 16, hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  if (meta[1] > feat_sort_capacity()) {
+    h->err = "FPFH: a point has " + std::to_string(meta[1]) + " neighbours inside the search radius (limit " +
+             std::to_string(feat_sort_capacity()) + "): use a smaller radius or a down-sampled cloud";
+    return TEASER_HIP_ERR_UNSUPPORTED;
+  }
+  HIPCHK(h, h->f_list.ensure((size_t)std::max<int64_t>(meta[0], 1) * (size_t)feat_nbr_bytes()));
+  launch_feat_radius_fill_sort(s, h->f_pts.as<float>(), n, r2, h->f_counts.as<int32_t>(),
+                               h->f_offsets.as<int64_t>(), h->f_list.p);
+  HIPCHK(h, hipGetLastError());
+  return TEASER_HIP_OK;
+}
+}  // namespace
+
+int32_t teaser_hip_compute_fpfh(teaser_hip_solver* h, const float* cloud_xyz, int32_t n, double normal_radius,
+                                double fpfh_radius, float* fpfh_out, float* normals_out) {
+  if (!h || n < 0 || (n > 0 && (!cloud_xyz || !fpfh_out)) || !(normal_radius > 0) || !(fpfh_radius > 0))
+    return TEASER_HIP_ERR_BAD_ARG;
+  if (n == 0) return TEASER_HIP_OK;
+  (void)hipSetDevice(h->device);
+  hipStream_t s = h->stream;
+  HIPCHK(h, h->f_pts.ensure((size_t)n * 12));
+  HIPCHK(h, h->f_normals.ensure((size_t)n * 12));
+  HIPCHK(h, h->f_spfh.ensure((size_t)n * 33 * 4));
+  HIPCHK(h, h->f_out.ensure((size_t)n * 33 * 4));
+  HIPCHK(h, hipMemcpyAsync(h->f_pts.p, cloud_xyz, (size_t)n * 12, hipMemcpyHostToDevice, s));
+  int32_t rc = feat_neighbours(h, n, normal_radius);  // fpfh.cc:27-33
+  if (rc != TEASER_HIP_OK) return rc;
+  launch_feat_normals(s, h->f_pts.as<float>(), n, h->f_offsets.as<int64_t>(), h->f_counts.as<int32_t>(),
+                      h->f_list.p, h->f_normals.as<float>());
+  rc = feat_neighbours(h, n, fpfh_radius);  // fpfh.cc:36-40
+  if (rc != TEASER_HIP_OK) return rc;
+  launch_feat_fpfh(s, h->f_pts.as<float>(), h->f_normals.as<float>(), n, h->f_offsets.as<int64_t>(),
+                   h->f_counts.as<int32_t>(), h->f_list.p, h->f_spfh.as<float>(), h->f_out.as<float>());
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(fpfh_out, h->f_out.p, (size_t)n * 33 * 4, hipMemcpyDeviceToHost, s));
+  if (normals_out) HIPCHK(h, hipMemcpyAsync(normals_out, h->f_normals.p, (size_t)n * 12, hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  return TEASER_HIP_OK;
+}
+
+int32_t teaser_hip_match_features(teaser_hip_solver* h, const float* src_feat, int32_t n_src,
+                                  const float* dst_feat, int32_t n_dst, int32_t dim, int32_t use_crosscheck,
+                                  int32_t* pairs, int64_t* n_pairs) {
+  if (!h || !n_pairs || n_src < 0 || n_dst < 0 || dim <= 0 || dim > feat_nn_max_dim()) return TEASER_HIP_ERR_BAD_ARG;
+  const int64_t cap = *n_pairs;
+  *n_pairs = 0;
+  if (n_src == 0 || n_dst == 0) return TEASER_HIP_OK;
+  if (!src_feat || !dst_feat || !pairs) return TEASER_HIP_ERR_BAD_ARG;
+  (void)hipSetDevice(h->device);
+  hipStream_t s = h->stream;
+  // matcher.cc:123-133: i = the larger cloud, j = the smaller one
+  const bool swapped = n_dst > n_src;
+  const float* fi = swapped ? dst_feat : src_feat;
+  const float* fj = swapped ? src_feat : dst_feat;
+  const int ni = swapped ? n_dst : n_src, nj = swapped ? n_src : n_dst;
+  HIPCHK(h, h->f_feat_a.ensure((size_t)ni * dim * 4));
+  HIPCHK(h, h->f_feat_b.ensure((size_t)nj * dim * 4));
+  HIPCHK(h, h->f_nn_a.ensure((size_t)nj * 4));
+  HIPCHK(h, h->f_nn_b.ensure((size_t)ni * 4));
+  const int chunks = std::max(feat_nn_chunks(ni), feat_nn_chunks(nj));
+  HIPCHK(h, h->f_part_d.ensure((size_t)chunks * (size_t)std::max(ni, nj) * 4));
+  HIPCHK(h, h->f_part_i.ensure((size_t)chunks * (size_t)std::max(ni, nj) * 4));
+  HIPCHK(h, hipMemcpyAsync(h->f_feat_a.p, fi, (size_t)ni * dim * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(h, hipMemcpyAsync(h->f_feat_b.p, fj, (size_t)nj * dim * 4, hipMemcpyHostToDevice, s));
+  // :162 for every j its nearest i;  :165 for every i its nearest j (the reference evaluates these lazily)
+  launch_feat_nn1(s, h->f_feat_a.as<float>(), ni, h->f_feat_b.as<float>(), nj, dim, h->f_part_d.as<float>(),
+                  h->f_part_i.as<int32_t>(), h->f_nn_a.as<int32_t>());
+  std::vector<int32_t> j_to_i((size_t)nj), i_nn((size_t)ni);
+  HIPCHK(h, hipMemcpyAsync(j_to_i.data(), h->f_nn_a.p, (size_t)nj * 4, hipMemcpyDeviceToHost, s));
+  launch_feat_nn1(s, h->f_feat_b.as<float>(), nj, h->f_feat_a.as<float>(), ni, dim, h->f_part_d.as<float>(),
+                  h->f_part_i.as<int32_t>(), h->f_nn_b.as<int32_t>());
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(i_nn.data(), h->f_nn_b.p, (size_t)ni * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  // index bookkeeping of matcher.cc:155-233, 281-296 (O(n) on the host)
+  std::vector<int32_t> i_to_j((size_t)ni, -1);
+  for (int j = 0; j < nj; ++j) {
+    const int i = j_to_i[(size_t)j];
+    if (i_to_j[(size_t)i] == -1) i_to_j[(size_t)i] = i_nn[(size_t)i];
+  }
+  std::vector<std::pair<int32_t, int32_t>> corres;
+  if (use_crosscheck) {
+    for (int i = 0; i < ni; ++i) {
+      const int j = i_to_j[(size_t)i];
+      if (j >= 0 && j_to_i[(size_t)j] == i) corres.emplace_back(i, j);
+    }
+  } else {
+    for (int i = 0; i < ni; ++i)
+      if (i_to_j[(size_t)i] != -1) corres.emplace_back(i, i_to_j[(size_t)i]);
+    for (int j = 0; j < nj; ++j) corres.emplace_back(j_to_i[(size_t)j], j);
+  }
+  if (swapped)
+    for (auto& c : corres) std::swap(c.first, c.second);
+  std::sort(corres.begin(), corres.end());
+  corres.erase(std::unique(corres.begin(), corres.end()), corres.end());
+  *n_pairs = (int64_t)corres.size();
+  if ((int64_t)corres.size() > cap) return TEASER_HIP_ERR_BAD_ARG;
+  for (size_t k = 0; k < corres.size(); ++k) {
+    pairs[2 * k] = corres[k].first;
+    pairs[2 * k + 1] = corres[k].second;
+  }
+  return TEASER_HIP_OK;
 }
 
 int32_t teaser_hip_set_profiling(teaser_hip_solver* h, int32_t level) {

@@ -1,0 +1,108 @@
+"""GPU parity tests of the correspondence front-end (FPFH + matcher, csrc/kernels_features.hip) against the
+CPU oracle (oracle/features_oracle.c) and the reference's fixtures (tests/golden/features_golden.npz).
+The bar: the GPU reproduces the oracle BIT FOR BIT (same operation sequence, deterministic elementary
+functions), so correspondences are identical index pairs; the oracle itself is pinned to the reference's
+fixtures in tests/test_features_oracle.py."""
+import importlib
+import os
+
+import numpy as np
+import pytest
+
+from oracle import features as F
+from oracle import oracle
+from util import ROOT
+
+pytestmark = pytest.mark.gpu
+
+tp = importlib.import_module("teaser-plusplus_amd")
+G = np.load(os.path.join(ROOT, "tests", "golden", "features_golden.npz"))
+
+
+def test_fpfh_bunny_bit_exact_vs_oracle_and_fixture():
+    est = tp.FPFHEstimation()
+    f = est.computeFPFHFeatures(G["bunny_pts"], 0.03, 0.05)
+    fo, no = F.fpfh_features(G["bunny_pts"], 0.03, 0.05)
+    assert np.array_equal(est.getNormals(), no)
+    assert np.array_equal(f, fo)
+    d = np.abs(f - G["bunny_fpfh"])  # feature-test.cc:55-90 (see test_features_oracle.py for the f3 ties)
+    assert d[:, :22].max() < 2e-4 and (d.max(1) < 2e-4).sum() >= 0.70 * len(f)
+
+
+@pytest.mark.parametrize("key,rn,rf", [("canstick", 0.03, 0.05), ("matcher_object", 0.02, 0.04)])
+def test_fpfh_other_clouds_bit_exact_vs_oracle(key, rn, rf):
+    est = tp.FPFHEstimation()
+    f = est.computeFPFHFeatures(G[key], rn, rf)
+    fo, no = F.fpfh_features(G[key], rn, rf)
+    assert np.array_equal(est.getNormals(), no, equal_nan=True)
+    assert np.array_equal(f, fo, equal_nan=True)
+
+
+def test_fpfh_sparse_points_and_limits():
+    """Isolated points (< 3 neighbours -> NaN normal, as PCL) and a neighbourhood beyond the sort capacity."""
+    rng = np.random.default_rng(5)
+    pts = np.concatenate([rng.uniform(0, 0.2, size=(300, 3)), [[5, 5, 5], [9, 9, 9]]]).astype(np.float32)
+    est = tp.FPFHEstimation()
+    f = est.computeFPFHFeatures(pts, 0.03, 0.05)
+    fo, no = F.fpfh_features(pts, 0.03, 0.05)
+    assert np.isnan(est.getNormals()[-1]).all() and np.array_equal(est.getNormals(), no, equal_nan=True)
+    assert np.array_equal(f, fo, equal_nan=True)
+    dense = rng.uniform(0, 0.01, size=(5000, 3)).astype(np.float32)
+    with pytest.raises(tp.TeaserHipError):
+        est.computeFPFHFeatures(dense, 0.03, 0.05)  # 5000 neighbours per point: refused, loudly
+
+
+def test_matcher_vs_oracle_and_fixture():
+    """matcher-test.cc:46-85: object (1000 points) against scene (60 865 points), features on the GPU."""
+    est = tp.FPFHEstimation()
+    fo = est.computeFPFHFeatures(G["matcher_object"], 0.02, 0.04)
+    fs = est.computeFPFHFeatures(G["matcher_scene"], 0.02, 0.04)
+    m = tp.Matcher().calculateCorrespondences(G["matcher_object"], G["matcher_scene"], fo, fs, False, True, False, 0.95)
+    assert m == [tuple(r) for r in F.match(fo, fs, crosscheck=True).tolist()]
+    ref = set(map(tuple, G["matcher_matches"].tolist()))
+    assert len(ref & set(m)) >= 0.9 * len(ref) and abs(len(m) - len(ref)) <= 0.1 * len(ref)
+    # without the cross check, and with the roles swapped (matcher.cc:123-133, 281-287)
+    m2 = tp.Matcher().calculateCorrespondences(None, None, fo, fs, False, False, False, 0)
+    assert m2 == [tuple(r) for r in F.match(fo, fs, crosscheck=False).tolist()]
+    m3 = tp.Matcher().calculateCorrespondences(None, None, fs, fo, False, True, False, 0)
+    assert sorted((b, a) for a, b in m3) == m
+
+
+def test_matcher_self_matching():
+    """matcher-test.cc:21-44."""
+    est = tp.FPFHEstimation()
+    f = est.computeFPFHFeatures(G["canstick"], 0.03, 0.05)
+    m = tp.Matcher().calculateCorrespondences(G["canstick"], G["canstick"], f, f, False, True, False, 0)
+    assert all(a == b for a, b in m) and len(m) >= 0.9 * len(f)
+    assert m == [tuple(r) for r in F.match(f, f, crosscheck=True).tolist()]
+
+
+def test_front_end_to_registration():
+    """examples/teaser_cpp_fpfh/teaser_cpp_fpfh.cc:60-110 end to end on the GPU: a cloud and its transformed,
+    noisy copy -> FPFH (0.02, 0.04) -> matcher (cross check) -> solve(cloud, cloud, correspondences); the
+    registration of the SAME correspondences by the oracle agrees (clique, inliers, R, t)."""
+    rng = np.random.default_rng(11)
+    src = G["matcher_object"].astype(np.float32)
+    T = np.array([[9.96926560e-01, 6.68735757e-02, -4.06664421e-02, -1.15576939e-01],
+                  [-6.61289946e-02, 9.97617877e-01, 1.94008687e-02, -3.87705398e-02],
+                  [4.18675510e-02, -1.66517807e-02, 9.98977765e-01, 1.14874890e-01]])  # teaser_cpp_fpfh.cc:66-70
+    dst = (src.astype(np.float64) @ T[:, :3].T + T[:, 3] + rng.uniform(-0.0005, 0.0005, size=src.shape)).astype(np.float32)
+    est = tp.FPFHEstimation()
+    fs, fd = est.computeFPFHFeatures(src, 0.02, 0.04), est.computeFPFHFeatures(dst, 0.02, 0.04)
+    corr = tp.Matcher().calculateCorrespondences(src, dst, fs, fd, False, True, False, 0.95)
+    assert len(corr) >= 100
+    p = dict(noise_bound=0.001, cbar2=1.0, estimate_scaling=False, rotation_gnc_factor=1.4,
+             rotation_max_iterations=100, rotation_cost_threshold=0.005)
+    s = tp.RobustRegistrationSolver(tp.RobustRegistrationSolver.Params(**p))
+    sol = s.solve_correspondences(src, dst, corr)
+    c = np.array(corr)
+    o = oracle.solve(src[c[:, 0]].astype(np.float64).T, dst[c[:, 1]].astype(np.float64).T,
+                     **dict(p, estimate_scaling=0))
+    assert sol.valid and o["valid"]
+    assert len(s.getInlierMaxClique()) == len(o["max_clique"])
+    if o["clique_unique"]:
+        assert s.getInlierMaxClique() == o["max_clique"].tolist()
+        assert np.linalg.norm(sol.rotation - o["rotation"]) < 1e-4
+        assert np.linalg.norm(sol.translation - o["translation"]) < 1e-4
+    ang = np.arccos(np.clip((np.trace(T[:, :3].T @ sol.rotation) - 1) / 2, -1, 1))
+    assert ang < 0.02 and np.linalg.norm(sol.translation - T[:, 3]) < 0.01
