@@ -1,0 +1,70 @@
+// teaser/matcher.h -- drop-in for the reference's teaser/include/teaser/matcher.h (teaser::Matcher,
+// reference matcher.h:20-61, teaser/src/matcher.cc:21-301) over the MI355X C ABI (teaser_hip_match_features).
+//
+// The reference searches two FLANN kd-trees (exact L2 1-NN in 33 dimensions, matcher.cc:140-170); here both
+// searches are brute-force distance tiles on the GPU, the index bookkeeping (initial matching, cross check,
+// swap, sort + unique: matcher.cc:155-296) is the same.  The reference's normalizePoints (matcher.cc:57-116)
+// only feeds the tuple test; that test draws from rand() seeded with time(NULL) (matcher.cc:214), is not
+// reproducible by construction and is passed `false` by every reference caller: asking for it throws.
+#pragma once
+
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "teaser/fpfh.h"
+#include "teaser/geometry.h"
+#include "teaser_hip.h"
+
+namespace teaser {
+
+class Matcher {
+ public:
+  Matcher() = default;
+  Matcher(const Matcher&) = delete;
+  Matcher& operator=(const Matcher&) = delete;
+  ~Matcher() {
+    if (h_) teaser_hip_solver_destroy(h_);
+  }
+
+  // matcher.h:40-44: (source index, target index) pairs, sorted, unique
+  std::vector<std::pair<int, int>> calculateCorrespondences(const PointCloud& source_points,
+                                                            const PointCloud& target_points,
+                                                            const FPFHCloud& source_features,
+                                                            const FPFHCloud& target_features,
+                                                            bool use_absolute_scale = true, bool use_crosscheck = true,
+                                                            bool use_tuple_test = true, float tuple_scale = 0) {
+    (void)source_points;
+    (void)target_points;
+    (void)use_absolute_scale;
+    if (use_tuple_test && tuple_scale != 0)
+      throw std::invalid_argument("teaser::Matcher: the tuple test (rand() seeded with time(NULL) in the reference) "
+                                  "is not reproducible and not offered; pass use_tuple_test = false");
+    if (!h_) {
+      const int32_t rc = teaser_hip_solver_create(nullptr, /*device=*/-1, &h_);
+      if (rc != TEASER_HIP_OK) {
+        h_ = nullptr;
+        throw std::runtime_error("teaser::Matcher: teaser_hip_solver_create failed (status " + std::to_string(rc) +
+                                 "; 3 = no HIP device)");
+      }
+    }
+    static_assert(sizeof(std::pair<int, int>) == 8, "packed pairs expected");
+    std::vector<std::pair<int, int>> out(source_features.size() + target_features.size() + 1);
+    int64_t cnt = (int64_t)out.size();
+    const int32_t rc = teaser_hip_match_features(
+        h_, reinterpret_cast<const float*>(source_features.data()), (int32_t)source_features.size(),
+        reinterpret_cast<const float*>(target_features.data()), (int32_t)target_features.size(), 33,
+        use_crosscheck ? 1 : 0, reinterpret_cast<int32_t*>(out.data()), &cnt);
+    if (rc != TEASER_HIP_OK)
+      throw std::runtime_error(std::string("teaser_hip_match_features status ") + std::to_string(rc) + ": " +
+                               teaser_hip_last_error(h_));
+    out.resize((size_t)cnt);
+    return out;
+  }
+
+ private:
+  teaser_hip_solver* h_ = nullptr;
+};
+
+}  // namespace teaser

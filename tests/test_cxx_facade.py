@@ -115,3 +115,46 @@ def test_ply_example_registers_the_bunny(tmp_path):
     exe = build_ply_example()
     out = subprocess.run([exe, bunny_ply(str(tmp_path / "bunny.ply"))], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+# --- teaser/fpfh.h + teaser/matcher.h: the reference's teaser_cpp_fpfh workflow ------------------------------
+FP_SRC = os.path.join(ROOT, "tests", "cxx", "fpfh_example.cpp")
+FP_EXE = os.path.join(ROOT, "tests", "cxx", "fpfh_example")
+
+
+def build_fpfh_example():
+    if not os.path.exists(os.path.join(LIBDIR, "libteaser_hip.so")):
+        pytest.skip("libteaser_hip.so not built (run __graft_entry__.build())")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           FP_SRC, "-o", FP_EXE, "-L" + LIBDIR, "-lteaser_hip", "-Wl,-rpath," + LIBDIR,
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    return FP_EXE
+
+
+def object_ply(path):
+    """matcher-test-object-1.ply of the reference's tests (golden `matcher_object`), rewritten as ascii PLY."""
+    import numpy as np
+    pts = np.load(os.path.join(ROOT, "tests", "golden", "features_golden.npz"))["matcher_object"]
+    with open(path, "w") as f:
+        f.write("ply\nformat ascii 1.0\nelement vertex %d\nproperty float x\nproperty float y\nproperty float z\n"
+                "end_header\n" % len(pts))
+        for p in pts:
+            f.write(" ".join(repr(float(v)) for v in p) + "\n")
+    return path
+
+
+def test_fpfh_example_builds_and_fails_loudly_without_gpu(tmp_path):
+    exe = build_fpfh_example()
+    rc = subprocess.call([exe, object_ply(str(tmp_path / "object.ply"))], stdout=subprocess.DEVNULL)
+    import importlib
+    tp = importlib.import_module("teaser-plusplus_amd")
+    assert rc == (0 if tp.device_count() > 0 else 77)
+
+
+@pytest.mark.gpu
+def test_fpfh_example_registers_on_gpu(tmp_path):
+    """examples/teaser_cpp_fpfh/teaser_cpp_fpfh.cc:40-110 through teaser/fpfh.h, teaser/matcher.h and
+    solve(cloud, cloud, correspondences)."""
+    exe = build_fpfh_example()
+    out = subprocess.run([exe, object_ply(str(tmp_path / "object.ply"))], capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0, out.stdout + out.stderr

@@ -106,3 +106,49 @@ def test_front_end_to_registration():
         assert np.linalg.norm(sol.translation - o["translation"]) < 1e-4
     ang = np.arccos(np.clip((np.trace(T[:, :3].T @ sol.rotation) - 1) / 2, -1, 1))
     assert ang < 0.02 and np.linalg.norm(sol.translation - T[:, 3]) < 0.01
+
+
+def test_config5_3dmatch_pair():
+    """BASELINE config 5: the 3DMatch pair of examples/teaser_python_fpfh_icp (cloud_bin_0 / cloud_bin_4, voxel
+    0.05: tests/golden/config5_clouds.npz), real descriptor correspondences: FPFH (radii 2 and 5 voxels, as
+    helpers.py:9-18) and mutual nearest neighbours (helpers.py:27-43 = the matcher's cross check) on the GPU,
+    then solve() with helpers.py:45-60's parameters.  Front-end identical to the oracle's; the registration
+    needs the exact clique search here (max_core + 1 > omega) and matches the oracle's clique size; the pose
+    aligns the overlapping half of the clouds."""
+    import time
+    C5 = np.load(os.path.join(ROOT, "tests", "golden", "config5_clouds.npz"))
+    A, B, vox = C5["cloud_bin_0"], C5["cloud_bin_4"], float(C5["voxel_size"])
+    est = tp.FPFHEstimation()
+    est.computeFPFHFeatures(A, 2 * vox, 5 * vox)  # warm-up (arenas)
+    t0 = time.perf_counter()
+    fa = est.computeFPFHFeatures(A, 2 * vox, 5 * vox)
+    fb = est.computeFPFHFeatures(B, 2 * vox, 5 * vox)
+    corr = tp.Matcher().calculateCorrespondences(A, B, fa, fb, False, True, False, 0)
+    t1 = time.perf_counter()
+    foa, _ = F.fpfh_features(A, 2 * vox, 5 * vox)
+    fob, _ = F.fpfh_features(B, 2 * vox, 5 * vox)
+    assert np.array_equal(fa, foa) and np.array_equal(fb, fob)
+    assert corr == [tuple(r) for r in F.match(foa, fob, crosscheck=True).tolist()] and len(corr) > 300
+    p = dict(noise_bound=vox, cbar2=1.0, estimate_scaling=False, rotation_gnc_factor=1.4,
+             rotation_max_iterations=10000, rotation_cost_threshold=1e-16)
+    s = tp.RobustRegistrationSolver(tp.RobustRegistrationSolver.Params(**p))
+    s.solve_correspondences(A, B, corr)
+    t2 = time.perf_counter()
+    sol = s.solve_correspondences(A, B, corr)
+    t3 = time.perf_counter()
+    c = np.array(corr)
+    o = oracle.solve(A[c[:, 0]].astype(np.float64).T, B[c[:, 1]].astype(np.float64).T, **dict(p, estimate_scaling=0))
+    assert sol.valid and o["valid"] and o["clique_exact_run"]
+    clique = s.getInlierMaxClique()
+    assert len(clique) == len(o["max_clique"]) and s.raw_solution().clique_exact_run == 1
+    assert s.raw_solution().num_edges == o["num_edges"]
+    _, bm = oracle.inlier_bitmap(A[c[:, 0]].astype(np.float64).T, B[c[:, 1]].astype(np.float64).T, vox, 1.0, False)
+    dense = np.unpackbits(bm.view(np.uint8), axis=1, bitorder="little")[:, :len(c)].astype(bool)
+    assert dense[np.ix_(clique, clique)].sum() == len(clique) * (len(clique) - 1)  # a clique of the oracle's graph
+    if o["clique_unique"]:
+        assert clique == o["max_clique"].tolist()
+    from scipy.spatial import cKDTree
+    d, _ = cKDTree(B.astype(np.float64)).query(A.astype(np.float64) @ sol.rotation.T + sol.translation)
+    assert (d < vox).mean() > 0.4  # the clouds overlap by about half
+    print("config5: %d + %d points, %d correspondences, clique %d; front-end %.2f ms, solve %.2f ms"
+          % (len(A), len(B), len(corr), len(clique), 1e3 * (t1 - t0), 1e3 * (t3 - t2)))
