@@ -590,6 +590,11 @@ __device__ __forceinline__ unsigned int spread_nibbles(unsigned int v) {
   return v;
 }
 
+// Offset of a buffer store / atomic that must do nothing: beyond every descriptor's num_records (bitmaps stay
+// below 2^31 bytes for n <= 65536) and ALIGNED -- a misaligned no-return atomic (e.g. 0xffffffff) raises a
+// memory violation instead of being dropped by the range check.
+constexpr unsigned int kOobOffset = 0x80000000u;
+
 // Block = 4 waves = 4 consecutive row tiles (64 rows each) x kMfmaColTiles 64-column tiles.
 constexpr int kMfmaRowTiles = 4;
 constexpr int kMfmaColTiles = 8;
@@ -678,6 +683,18 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma_kernel(
   const TimOperandTile* __restrict__ qs = op_src + d.w_off;  // tile t of this problem: qs[t]
   const TimOperandTile* __restrict__ qd = op_dst + d.w_off;
   const int h = lane >> 5, c = lane & 31;
+  // operands through buffer descriptors over this problem's tiles: scalar tile offset + ONE per-lane byte
+  // offset (lane * 16 = [h][c]) instead of 64-bit per-lane address arithmetic
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t qs_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)qs, 0, (int)((unsigned int)T * (unsigned int)sizeof(TimOperandTile)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t qd_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)qd, 0, (int)((unsigned int)T * (unsigned int)sizeof(TimOperandTile)), 0x00020000);
+  auto load_op = [&](int cloud, int tile, int side, int g, int m) -> uint4 {  // side 0 = a (rows), 1 = b
+    const int soff = tile * (int)sizeof(TimOperandTile) + side * (int)sizeof(TimOperandTile) / 2 + (g * 2 + m) * 1024;
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(cloud ? qd_rsrc : qs_rsrc, lane * 16, soff, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+  };
   unsigned long long* wbuf = reinterpret_cast<unsigned long long*>(cbuf[wave]);  // private to the wave
   int wcount = 0;  // wave-uniform
 
@@ -687,10 +704,10 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma_kernel(
   {
     const int It = min(I, T - 1);
     for (int rt = 0; rt < 2; ++rt) {
-      as[rt][0] = __builtin_bit_cast(bf16x8, qs[It].a[rt][0][h][c]);
-      as[rt][1] = __builtin_bit_cast(bf16x8, qs[It].a[rt][1][h][c]);
-      ad[rt][0] = __builtin_bit_cast(bf16x8, qd[It].a[rt][0][h][c]);
-      ad[rt][1] = __builtin_bit_cast(bf16x8, qd[It].a[rt][1][h][c]);
+      as[rt][0] = __builtin_bit_cast(bf16x8, load_op(0, It, 0, rt, 0));
+      as[rt][1] = __builtin_bit_cast(bf16x8, load_op(0, It, 0, rt, 1));
+      ad[rt][0] = __builtin_bit_cast(bf16x8, load_op(1, It, 0, rt, 0));
+      ad[rt][1] = __builtin_bit_cast(bf16x8, load_op(1, It, 0, rt, 1));
     }
   }
   const bool rowvalid = I < T;  // (T need not be a multiple of the block's row tiles)
@@ -709,8 +726,8 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma_kernel(
   uint4 nb[4];  // next column point: src MFMA 0/1, dst MFMA 0/1
   {
     const int Jf = min(Jfirst, T - 1);
-    nb[0] = qs[Jf].b[0][0][h][c]; nb[1] = qs[Jf].b[0][1][h][c];
-    nb[2] = qd[Jf].b[0][0][h][c]; nb[3] = qd[Jf].b[0][1][h][c];
+    nb[0] = load_op(0, Jf, 1, 0, 0); nb[1] = load_op(0, Jf, 1, 0, 1);
+    nb[2] = load_op(1, Jf, 1, 0, 0); nb[3] = load_op(1, Jf, 1, 0, 1);
   }
   // vertex degrees (row popcounts) are accumulated here instead of by a separate pass over the bitmap:
   // own words per row in a register, transposed words with one fire-and-forget atomic per J
@@ -727,21 +744,46 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma_kernel(
   auto store_tr = [&](int Jp) {
     const int r = 16 * wave + (lane >> 2), k = lane & 3, Ik = I0 + k, jp0 = Jp * 64;
     const bool ok = Jp >= Jbase && Ik < Jp && Ik < T && jp0 + r < n;
-    if (V == 1) {
-      const uint64_t w = lds_tr[(Jp - Jbase) & 1][k][r];
-      const u32x2 dw = {(unsigned int)w, (unsigned int)(w >> 32)};
-      const unsigned int off = ok ? ((unsigned int)(jp0 + r) * (unsigned int)W + (unsigned int)Ik) * 8u : 0xffffffffu;
-      __builtin_amdgcn_raw_buffer_store_b64(dw, bm_rsrc, off, 0, 0);
-    } else if (ok) {
-      bm[(int64_t)(jp0 + r) * W + Ik] = lds_tr[(Jp - Jbase) & 1][k][r];
-    }
+    const uint64_t w = lds_tr[(Jp - Jbase) & 1][k][r];
+    const u32x2 dw = {(unsigned int)w, (unsigned int)(w >> 32)};
+    const unsigned int off = ok ? ((unsigned int)(jp0 + r) * (unsigned int)W + (unsigned int)Ik) * 8u : kOobOffset;
+    __builtin_amdgcn_raw_buffer_store_b64(dw, bm_rsrc, off, 0, 0);
   };
+  // What column tile Jp leaves in global memory besides the own words: the transposed words and the degree
+  // contributions of their bits, always ONE buffer store + ONE no-return buffer atomic per lane (nothing to
+  // do => out-of-range offset, dropped by the hardware), so that the compiler's vmcnt bookkeeping is exact.
+  // Stores and atomics share the in-order vmcnt counter with the loads:
+  //   V = 0 / 2: issued at the end of iteration Jp, i.e. YOUNGER than the operand loads already in flight
+  //              for iteration Jp + 1, whose wait then leaves these two outstanding (the same two dummy
+  //              operations are issued before the loop so that both edges into the loop agree);
+  //   V = 1:     issued in the middle of iteration Jp + 1, behind its first MFMAs; the wave's own word is
+  //              read back from its lds_tr slot.
+  auto flush_tr = [&](int Jp, uint64_t w_own) {
+    const bool have = Jp >= Jbase && rowvalid && Jp > I;  // (Jp == I: diagonal, no transposed copy)
+    const int cnt = have ? __builtin_popcountll(w_own) : 0;
+    if (V != 2) store_tr(Jp);
+    if (V == 2) {
+      // lane = row Jp * 64 + lane of the transposed block, word I: 8 bytes at a stride of W words
+      const u32x2 dw = {(unsigned int)w_own, (unsigned int)(w_own >> 32)};
+      const unsigned int off = (have && Jp * 64 + lane < n)
+                                   ? ((unsigned int)(Jp * 64 + lane) * (unsigned int)W + (unsigned int)I) * 8u
+                                   : kOobOffset;
+      __builtin_amdgcn_raw_buffer_store_b64(dw, bm_rsrc, off, 0, 0);
+    }
+    __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(cnt, deg_rsrc,
+                                                   cnt ? (unsigned int)(Jp * 64 + lane) * 4u : kOobOffset, 0, 0);
+  };
+  auto flush_prev = [&](int Jp) { flush_tr(Jp, lds_tr[(Jp - Jbase) & 1][wave][lane]); };
+  if (V != 1) {
+    __builtin_amdgcn_sched_barrier(0);
+    flush_tr(Jbase - 1, 0ull);  // the two dummies (see above)
+    __builtin_amdgcn_sched_barrier(0);
+  }
   for (int J = Jbase; J < Jend; ++J) {
     const int j0 = J * 64;
     uint64_t trw_out = 0;
     if (!(rowvalid && J >= I)) {
-      if (V == 1) store_tr(J - 1);
-      if (V == 2) continue;
+      if (V == 1) flush_prev(J - 1);
     } else {
     unsigned int tr[2][2];  // [ct][rt]: this lane's 16 column bits
     unsigned int ubits[4];  // per tile 2 ct + rt: this lane's in-band pairs (bit q)
@@ -750,10 +792,12 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma_kernel(
     for (int ct = 0; ct < 2; ++ct) {
       const bf16x8 bs0 = __builtin_bit_cast(bf16x8, nb[0]), bs1 = __builtin_bit_cast(bf16x8, nb[1]);
       const bf16x8 bd0 = __builtin_bit_cast(bf16x8, nb[2]), bd1 = __builtin_bit_cast(bf16x8, nb[3]);
-      {  // prefetch: the other half of this tile, then the first half of the next one
-        const int Jn = (ct == 0 || J + 1 >= Jend) ? J : J + 1, gn = ct ^ 1;
-        nb[0] = qs[Jn].b[gn][0][h][c]; nb[1] = qs[Jn].b[gn][1][h][c];
-        nb[2] = qd[Jn].b[gn][0][h][c]; nb[3] = qd[Jn].b[gn][1][h][c];
+      // prefetch: the other half of this tile, then the first half of the next one.  OCC == 4 (128 VGPRs)
+      // has no room for a second operand set: there the registers are reloaded behind the half tile's last MFMA
+      const int Jn = (ct == 0 || J + 1 >= Jend) ? J : J + 1, gn = ct ^ 1;
+      if (OCC < 4) {
+        nb[0] = load_op(0, Jn, 1, gn, 0); nb[1] = load_op(0, Jn, 1, gn, 1);
+        nb[2] = load_op(1, Jn, 1, gn, 0); nb[3] = load_op(1, Jn, 1, gn, 1);
       }
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) {
@@ -764,12 +808,27 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma_kernel(
         mt.B = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad[rt][0], bd0, z, 0, 0, 0);
         mt.A = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as[rt][1], bs1, mt.A, 0, 0, 0);
         mt.B = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ad[rt][1], bd1, mt.B, 0, 0, 0);
+        if (OCC >= 4 && rt == 1) {
+          __builtin_amdgcn_sched_barrier(0);
+          nb[0] = load_op(0, Jn, 1, gn, 0); nb[1] = load_op(0, Jn, 1, gn, 1);
+          nb[2] = load_op(1, Jn, 1, gn, 0); nb[3] = load_op(1, Jn, 1, gn, 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (V == 1 && ct == 0 && rt == 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          flush_prev(J - 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
         if (J == I && rt == ct) {
           // self pairs (A = B = 0) are masked out of the bitmap below; park them far outside the band
           // and the t <= tau test so that the diagonal tiles are not sent to the FP64 fix-up wholesale
+          // (the lane's column index goes through an empty asm so that the 16 compares stay inside this
+          // rarely taken branch instead of being hoisted into 32 loop-invariant SGPRs)
+          int cq = c - 4 * h;
+          asm volatile("" : "+v"(cq));
 #pragma unroll
           for (int q = 0; q < 16; ++q)
-            mt.A[q] = (c == (q & 3) + 8 * (q >> 2) + 4 * h) ? 1e18f : mt.A[q];
+            mt.A[q] = (cq == (q & 3) + 8 * (q >> 2)) ? 1e18f : mt.A[q];
         }
         mt.colbits = 0;
         mt.lobits = 0;
@@ -784,13 +843,6 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma_kernel(
         ubits[2 * ct + rt] = ub;
 
         tr[ct][rt] = mt.colbits;
-      }
-      if (V == 1 && ct == 0) {
-        // the previous tile's transposed words: issued behind this iteration's operand wait and its
-        // first MFMAs, half an iteration before the next wait needs the counter to drain
-        __builtin_amdgcn_sched_barrier(0);
-        store_tr(J - 1);
-        __builtin_amdgcn_sched_barrier(0);
       }
     }
 #pragma nounroll
@@ -845,7 +897,8 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma_kernel(
         const bool up = (lane & j) != 0;
         // lower lane keeps x & m and takes (p << j) & ~m; upper keeps x & ~m, takes (p >> j) & m
         const unsigned int shifted = __builtin_amdgcn_alignbit(p, p, up ? j : 32 - j);
-        x = (x & tmask[st]) | (shifted & ~tmask[st]);
+        // x = (x & tmask) | (shifted & ~tmask): one v_bfi_b32 (the compiler emits not + and + and_or)
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(x) : "v"(tmask[st]), "v"(x), "v"(shifted));
       }
       ow[rt] = x;  // lane (r, half ct): the 32 column bits (ct) of row 32 rt + r
     }
@@ -858,27 +911,19 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma_kernel(
     if (J == I) ownw &= ~(1ull << lane);
     lds_own[wave][lane][J - Jbase] = ownw;
     degacc += __builtin_popcountll(ownw);
-    trw_out = (J != I) ? (trw & rowmask) : 0ull;
-    // degree of row j0 + lane gains the bits of its transposed word (rows beyond n hold no bits: the
-    // offset is out of range there and the hardware drops the atomic)
-    __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(__builtin_popcountll(trw_out), deg_rsrc,
-                                                   (unsigned int)(j0 + lane) * 4u, 0, 0);
+    // rows beyond n hold no bits (clamped: the padding repeats the last point)
+    trw_out = (J != I && j0 + lane < n) ? (trw & rowmask) : 0ull;
     }  // active
-    if (V == 2) {
-      // lane = row j0 + lane of the transposed block, word I: 8 bytes at a stride of W words
-      const u32x2 dw = {(unsigned int)trw_out, (unsigned int)(trw_out >> 32)};
-      const unsigned int off = (J != I && j0 + lane < n)
-                                   ? ((unsigned int)(j0 + lane) * (unsigned int)W + (unsigned int)I) * 8u
-                                   : 0xffffffffu;
-      __builtin_amdgcn_raw_buffer_store_b64(dw, bm_rsrc, off, 0, 0);
+    if (V == 2) {  // (no LDS staging, no barrier)
+      flush_tr(J, trw_out);
       continue;
     }
     const int buf = (J - Jbase) & 1;
     lds_tr[buf][wave][lane] = trw_out;
     __syncthreads();  // (one barrier per J: the other buffer is rewritten only after the next one)
-    if (V == 0) store_tr(J);
+    if (V == 0) flush_prev(J);  // (own word read back from LDS: nothing live across the barrier)
   }
-  if (V == 1 && Jend > Jbase) store_tr(Jend - 1);
+  if (V == 1 && Jend > Jbase) flush_prev(Jend - 1);
   // own words: lanes 8r..8r+7 store the (up to) 8 consecutive words of one row
   if (rowvalid) {
 #pragma unroll
@@ -1017,6 +1062,7 @@ void launch_tim_graph_mfma(hipStream_t s, int phase, const ProbDesc* d_desc, int
     switch (variant) {
       case 0: TIM_K1_LAUNCH(0, 3); break;
       case 2: TIM_K1_LAUNCH(2, 3); break;
+      case 3: TIM_K1_LAUNCH(2, 4); break;
       default: TIM_K1_LAUNCH(1, 3); break;
     }
 #undef TIM_K1_LAUNCH
