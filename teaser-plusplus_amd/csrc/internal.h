@@ -29,6 +29,14 @@ struct ProbDesc {
 };
 
 // Mutable per-problem device state.
+// The latency-bound tail kernels of a batch run BESIDE the next batch's K1, whose VALU-saturating waves hold
+// three of every SIMD's slots: raising the tail waves' issue priority lets them through (their instruction
+// count is negligible for K1).
+#ifndef TEASER_TAIL_PRIO
+#define TEASER_TAIL_PRIO 3
+#endif
+#define TAIL_WAVE_PRIO() __builtin_amdgcn_s_setprio(TEASER_TAIL_PRIO)
+
 struct ProbState {
   int32_t lb;            // best greedy clique size
   int32_t best_start;    // which start produced it
@@ -43,6 +51,8 @@ struct ProbState {
   int32_t k1_overflow;   // 1: the K1 fix-up worklist overflowed (host reruns the batch on the FP64 K1)
   int32_t max_core;      // KCORE_HEU only: maximum core number of the inlier graph
   int32_t tls_arrive;    // translation stage: axis workgroups of this problem that have finished
+  int32_t heu_closed;    // heuristic: 1 once a start's clique is proven maximum by the degree count
+  int32_t next_start;    // heuristic: next start of the problem's queue (host: workgroups per problem)
   int32_t pad1;
   int32_t start_vertex[kMaxStarts];
   int32_t start_size[kMaxStarts];
@@ -107,6 +117,7 @@ void launch_degrees(hipStream_t s, const ProbDesc* d_desc, int batch, int max_n,
                     const uint64_t* d_bitmap, int32_t* d_deg, ProbState* d_state);
 // greedy multi-start clique heuristic (each workgroup picks its own start vertex; the problem states
 // must arrive zeroed); writes per-start cliques, then the per-problem best
+int heuristic_blocks_per_problem(int batch);
 void launch_heuristic(hipStream_t s, const ProbDesc* d_desc, int batch, int max_W,
                       const uint64_t* d_bitmap, const int32_t* d_deg, ProbState* d_state,
                       int32_t* d_start_cliques /* [kMaxStarts][sum n] */, int64_t total_n,

@@ -541,6 +541,7 @@ __global__ __launch_bounds__(256) void gnc_tls_kernel(const ProbDesc* __restrict
                                                       double* __restrict__ weights,
                                                       int32_t* __restrict__ rot_inliers,
                                                       const int64_t* __restrict__ tim_off) {
+  TAIL_WAVE_PRIO();
   __shared__ double sh[64];
   __shared__ int scan[257];
   const ProbDesc d = descs[blockIdx.x];
@@ -798,6 +799,7 @@ __global__ __launch_bounds__(256) void tls_translation_kernel(
     const double* __restrict__ dst, const int32_t* __restrict__ clique,
     ProbState* __restrict__ states, EstParams ep, char* __restrict__ scratch,
     int64_t scratch_stride, int32_t* __restrict__ trans_inliers) {
+  TAIL_WAVE_PRIO();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int scan[257];
   __shared__ int s_last;

@@ -953,6 +953,7 @@ __global__ __launch_bounds__(256) void tim_fixup_kernel(const ProbDesc* __restri
                                                         const unsigned int* __restrict__ work_count,
                                                         unsigned int cap, ProbState* __restrict__ states,
                                                         int32_t* __restrict__ deg) {
+  TAIL_WAVE_PRIO();
   const unsigned int total = *work_count;
   if (total > cap) {
     const ProbDesc last = descs[batch - 1];
@@ -1158,13 +1159,13 @@ __device__ __forceinline__ unsigned long long blockN_max_u64(unsigned long long 
 // T threads per workgroup: 512 (lowest latency when the GPU is otherwise idle) or 256 (4 waves: a
 // workgroup then fits into the slot ONE retiring K1 workgroup frees, which is what lets the tail of a
 // batch run beside the next batch's K1).
+// One start (index sidx) of problem blockIdx.y; returns the clique size (also left in start_size[sidx]).
 template <int kGreedyThreads>
-__global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
+__device__ __forceinline__ int greedy_one_start(
     const ProbDesc* __restrict__ descs, const uint64_t* __restrict__ bitmap,
     const int32_t* __restrict__ deg, ProbState* __restrict__ states,
-    int32_t* __restrict__ start_cliques, int64_t total_n) {
+    int32_t* __restrict__ start_cliques, int64_t total_n, char* smem, const int sidx) {
   constexpr int kGreedyWaves = kGreedyThreads / 64;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const ProbDesc d = descs[blockIdx.y];
   const int n = d.n, W = d.W;
   const int Wpad = (W + 1) & ~1;
@@ -1179,7 +1180,6 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
   int* misc = red + kGreedyMaxThreads / 64;                             // 8
 
   ProbState* st = states + blockIdx.y;
-  const int sidx = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint64_t* bm = bitmap + d.bm_off;
   const int32_t* dg = deg + d.pt_off;
@@ -1215,7 +1215,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
   }
   if (v0 < 0 || n <= 0) {
     if (threadIdx.x == 0) st->start_size[sidx] = 0;
-    return;
+    return 0;
   }
 
   int csize = 1;
@@ -1471,6 +1471,102 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
     }
   }
   if (tid == 0) st->start_size[sidx] = csize;
+  return csize;
+}
+
+// Grid (B, batch): B workgroups per problem share the kMaxStarts starts.  Workgroup x begins with start x;
+// further starts come from the problem's queue (ProbState.next_start, initialised to B by the host) until it
+// is empty or the problem is CLOSED: a start whose clique of size c leaves at most c vertices in the peel at
+// threshold c (alive = {deg >= c}; repeatedly keep the vertices with >= c alive neighbours: a clique of c + 1
+// vertices survives every round) has found a maximum clique, and no start
+// fetched later can be selected -- the selection takes the largest clique and breaks ties towards the LOWEST
+// start, starts are fetched in increasing order, and a start once fetched always runs to completion.  So the
+// selected clique is the one all kMaxStarts starts would give, whatever the timing, while in the common case
+// (one start already finds the maximum clique) a problem costs B greedy runs instead of kMaxStarts.
+// B = kMaxStarts (small batches: lowest latency) makes the queue empty from the outset.
+template <int kGreedyThreads>
+__global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
+    const ProbDesc* __restrict__ descs, const uint64_t* __restrict__ bitmap,
+    const int32_t* __restrict__ deg, ProbState* __restrict__ states,
+    int32_t* __restrict__ start_cliques, int64_t total_n) {
+  TAIL_WAVE_PRIO();
+  constexpr int kGreedyWaves = kGreedyThreads / 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int next_s;
+  __shared__ int red_c[kGreedyWaves];
+  ProbState* st = states + blockIdx.y;
+  const ProbDesc d = descs[blockIdx.y];
+  int sidx = blockIdx.x;
+  while (sidx < kMaxStarts) {
+    const int csize = greedy_one_start<kGreedyThreads>(descs, bitmap, deg, states, start_cliques, total_n, smem, sidx);
+    if (gridDim.x >= kMaxStarts) break;  // every start has its own workgroup: nothing left to skip
+    // closure test: the peel at threshold csize, in LDS (the start's P / U bitsets are free again)
+    const int W = d.W, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint64_t* Pa = reinterpret_cast<uint64_t*>(smem);
+    uint64_t* Pb = Pa + ((W + 1) & ~1);
+    const uint64_t* bm = bitmap + d.bm_off;
+    int cnt = 0;
+    __syncthreads();
+    for (int w = tid; w < W; w += kGreedyThreads) {
+      uint64_t bits = 0;
+      const int vmax = min(64, d.n - w * 64);
+      for (int b = 0; b < vmax; ++b) bits |= (uint64_t)(deg[d.pt_off + w * 64 + b] >= csize ? 1 : 0) << b;
+      Pa[w] = bits;
+      cnt += __popcll(bits);
+    }
+    cnt = blockN_sum_i<kGreedyWaves>(cnt, red_c);  // (barriers inside: Pa is visible after)
+    // Only worth trying when the survivors are few.  One THREAD per alive vertex (index list in the LDS region
+    // of the start's compact matrix): each lane walks its own bitmap row word by word against the alive
+    // bitset -- 64 rows in flight per wave, every 128-byte line fetched once and reused 16 times from L1 --
+    // instead of one wave per row (a dependent round trip to L2 per row: 0.7 ms beside K1 in the benchmark).
+    constexpr int kClosureCap = 4096;
+    int* alist = reinterpret_cast<int*>(Pb + ((W + 1) & ~1));  // the A region: >= kCap * kCapStride * 8 bytes
+    for (int round = 0; round < 8 && cnt > csize && cnt <= 2 * csize + 256 && cnt <= kClosureCap; ++round) {
+      if (tid == 0) next_s = 0;
+      for (int w = tid; w < W; w += kGreedyThreads) Pb[w] = 0;
+      __syncthreads();
+      for (int w = tid; w < W; w += kGreedyThreads) {  // (order of the list is irrelevant)
+        uint64_t bits = Pa[w];
+        if (bits) {
+          int pos = atomicAdd(&next_s, __popcll(bits));
+          while (bits) {
+            alist[pos++] = w * 64 + __builtin_ctzll(bits);
+            bits &= bits - 1;
+          }
+        }
+      }
+      __syncthreads();
+      for (int k = tid; k < cnt; k += kGreedyThreads) {
+        const int v = alist[k];
+        const uint64_t* row = bm + (int64_t)v * W;
+        int c = 0;
+        for (int x = 0; x < W; ++x) c += __popcll(row[x] & Pa[x]);
+        if (c >= csize) atomicOr(reinterpret_cast<unsigned long long*>(&Pb[v >> 6]), 1ull << (v & 63));
+      }
+      __syncthreads();
+      int c2 = 0;
+      for (int w = tid; w < W; w += kGreedyThreads) {
+        const uint64_t x = Pb[w];
+        Pa[w] = x;
+        c2 += __popcll(x);
+      }
+      c2 = blockN_sum_i<kGreedyWaves>(c2, red_c);
+      if (c2 == cnt) break;  // fixpoint above csize: not closed
+      cnt = c2;
+    }
+    if (threadIdx.x == 0) {
+      int nx = kMaxStarts;
+      if (cnt <= csize) {
+        __hip_atomic_store(&st->heu_closed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else if (!__hip_atomic_load(&st->heu_closed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        nx = atomicAdd(&st->next_start, 1);
+      }
+      next_s = nx;
+    }
+    __syncthreads();
+    sidx = next_s;
+    __syncthreads();
+  }
 }
 
 // Per problem: choose the best start (largest clique, ties to the lowest start), emit it SORTED
@@ -1479,6 +1575,7 @@ __global__ __launch_bounds__(256) void select_best_kernel(
     const ProbDesc* __restrict__ descs, const int32_t* __restrict__ deg,
     ProbState* __restrict__ states, const int32_t* __restrict__ start_cliques, int64_t total_n,
     int32_t* __restrict__ clique, uint64_t* __restrict__ alive_a, int do_peel) {
+  TAIL_WAVE_PRIO();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const ProbDesc d = descs[blockIdx.x];
   const int n = d.n, W = d.W;
@@ -1568,7 +1665,9 @@ __global__ __launch_bounds__(256) void select_best_kernel(
     st->best_start = bs;
     st->clique_size = best;
     st->alive_count = alive;
-    const int closed = do_peel ? (alive <= best) : 0;
+    // (closed by the degree count here, or already by a heuristic start's own peel: its clique is then the
+    // largest one, i.e. the one selected above)
+    const int closed = do_peel ? ((alive <= best) || st->heu_closed) : 0;
     st->proven = closed;
     st->peel_done = do_peel ? closed : 1;
   }
@@ -1580,11 +1679,22 @@ size_t greedy_lds_bytes(int max_W) {
          kGreedyMaxThreads * 4 + (kGreedyMaxThreads / 64) * 4 + 8 * 4;
 }
 
+// workgroups per problem of the heuristic (the host initialises ProbState.next_start with it)
+int heuristic_blocks_per_problem(int batch) {
+  static const char* ev = getenv("TEASER_HEU_BLOCKS");  // diagnostics
+  if (ev && atoi(ev) >= 1 && atoi(ev) <= kMaxStarts) return atoi(ev);
+  // about 128 workgroups in flight: every start in parallel for small batches (lowest latency, the GPU is
+  // otherwise idle), two workgroups per problem from 64 problems on (they run beside the next batch's K1 and
+  // each has to wait for a slot a retiring K1 workgroup frees: 2 measured 6 % faster than 4, 4 % faster than 16)
+  return std::max(2, std::min(kMaxStarts, 128 / std::max(batch, 1)));
+}
+
 void launch_heuristic(hipStream_t s, const ProbDesc* d_desc, int batch, int max_W,
                       const uint64_t* d_bitmap, const int32_t* d_deg, ProbState* d_state,
                       int32_t* d_start_cliques, int64_t total_n, int32_t* d_cand,
                       int32_t* d_clique) {
   if (batch <= 0) return;
+  const int nblk = heuristic_blocks_per_problem(batch);
   const size_t lds = greedy_lds_bytes(max_W);
   // Small batches (<= 16 problems = at most one workgroup per CU) run 512-thread workgroups: nothing
   // competes for the CUs and the gather loops finish sooner (N = 1889: 0.51 vs 0.90 ms).  Larger batches
@@ -1595,11 +1705,11 @@ void launch_heuristic(hipStream_t s, const ProbDesc* d_desc, int batch, int max_
   static DynLdsOptIn optin256, optin512;  // beyond the 64 KB default dynamic-LDS limit once W >= ~300
   if (wide) {
     if (lds > 48 * 1024) optin512.ensure(reinterpret_cast<const void*>(greedy_clique_kernel<512>), (int)lds);
-    hipLaunchKernelGGL(greedy_clique_kernel<512>, dim3(kMaxStarts, batch), dim3(512), lds, s, d_desc, d_bitmap,
+    hipLaunchKernelGGL(greedy_clique_kernel<512>, dim3(nblk, batch), dim3(512), lds, s, d_desc, d_bitmap,
                        d_deg, d_state, d_start_cliques, total_n);
   } else {
     if (lds > 48 * 1024) optin256.ensure(reinterpret_cast<const void*>(greedy_clique_kernel<256>), (int)lds);
-    hipLaunchKernelGGL(greedy_clique_kernel<256>, dim3(kMaxStarts, batch), dim3(256), lds, s, d_desc, d_bitmap,
+    hipLaunchKernelGGL(greedy_clique_kernel<256>, dim3(nblk, batch), dim3(256), lds, s, d_desc, d_bitmap,
                        d_deg, d_state, d_start_cliques, total_n);
   }
 }
@@ -1613,33 +1723,37 @@ __global__ __launch_bounds__(256) void peel_round_kernel(const ProbDesc* __restr
                                                          const uint64_t* __restrict__ cur_mask,
                                                          uint64_t* __restrict__ nxt_mask,
                                                          int32_t* __restrict__ next_count) {
+  TAIL_WAVE_PRIO();
   __shared__ unsigned long long neww;
   const ProbDesc d = descs[blockIdx.y];
-  const int tile = blockIdx.x;
-  if (tile >= d.W) return;
   const ProbState* st = states + blockIdx.y;
   if (st->peel_done) return;
   const uint64_t* cur = cur_mask + d.w_off;
-  const uint64_t aw = cur[tile];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) neww = 0;
-  __syncthreads();
-  if (aw) {
-    const int lb = st->lb;
-    const uint64_t* bm = bitmap + d.bm_off;
-    for (int r = wave; r < 64; r += 4) {
-      if (!((aw >> r) & 1ull)) continue;
-      const uint64_t* row = bm + (int64_t)(tile * 64 + r) * d.W;
-      int c = 0;
-      for (int w = lane; w < d.W; w += 64) c += __popcll(row[w] & cur[w]);
-      c = wave_sum_i(c);
-      if (lane == 0 && c >= lb) atomicOr(&neww, 1ull << r);
+  // (a workgroup walks several 64-vertex tiles: the grid is kept small for large batches, where most
+  // problems are closed already and every workgroup of a launch has to wait for a free slot beside K1)
+  for (int tile = blockIdx.x; tile < d.W; tile += gridDim.x) {
+    const uint64_t aw = cur[tile];
+    if (threadIdx.x == 0) neww = 0;
+    __syncthreads();
+    if (aw) {
+      const int lb = st->lb;
+      const uint64_t* bm = bitmap + d.bm_off;
+      for (int r = wave; r < 64; r += 4) {
+        if (!((aw >> r) & 1ull)) continue;
+        const uint64_t* row = bm + (int64_t)(tile * 64 + r) * d.W;
+        int c = 0;
+        for (int w = lane; w < d.W; w += 64) c += __popcll(row[w] & cur[w]);
+        c = wave_sum_i(c);
+        if (lane == 0 && c >= lb) atomicOr(&neww, 1ull << r);
+      }
     }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    nxt_mask[d.w_off + tile] = neww;
-    if (neww) atomicAdd(next_count + blockIdx.y, __popcll(neww));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      nxt_mask[d.w_off + tile] = neww;
+      if (neww) atomicAdd(next_count + blockIdx.y, __popcll(neww));
+    }
+    __syncthreads();
   }
 }
 
@@ -1675,8 +1789,9 @@ void launch_peel_rounds(hipStream_t s, const ProbDesc* d_desc, int batch, int ma
   if (batch <= 0) return;
   uint64_t* cur = d_alive_a;
   uint64_t* nxt = d_alive_b;
+  const int gx = std::min(max_W, std::max(8, 2048 / batch));
   for (int r = 0; r < rounds; ++r) {
-    hipLaunchKernelGGL(peel_round_kernel, dim3(max_W, batch), dim3(256), 0, s, d_desc, d_bitmap,
+    hipLaunchKernelGGL(peel_round_kernel, dim3(gx, batch), dim3(256), 0, s, d_desc, d_bitmap,
                        d_state, cur, nxt, d_next_count);
     hipLaunchKernelGGL(peel_finish_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, d_state,
                        d_next_count, batch);

@@ -178,6 +178,8 @@ struct teaser_hip_solver {
   // K1 stream whenever several tails are in flight.
   hipStream_t k1_stream = nullptr;         // parent: owner; lane: borrowed from the parent
   bool shared_k1_stream = false;
+  int tail_cus = 0;            // > 0: CU partition between the K1 stream and the lanes' tail streams (make_lane)
+  bool tail_cu_block = false;  // which units: false = spread over the device, true = one contiguous block
   hipEvent_t k1_phase_done = nullptr;      // recorded on k1_stream after the fix-up
   hipEvent_t inputs_ready = nullptr;       // host inputs copied (lane stream) -> K1 phase may start
   bool inputs_pending = false;
@@ -649,6 +651,7 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
     st.scale = 1.0;
     st.R[0] = st.R[4] = st.R[8] = 1.0;
     st.gnc_cost = INFINITY;
+    st.next_start = heuristic_blocks_per_problem(batch);  // (the heuristic's start queue begins behind its workgroups)
     for (int k = 0; k < kMaxStarts; ++k) st.start_vertex[k] = -1;
   }
   if (tims > ((int64_t)1 << 31)) {
@@ -980,12 +983,36 @@ int32_t make_lane(teaser_hip_solver* h, teaser_hip_solver** out) {
   memset(&lane->prof, 0, sizeof(lane->prof));
   int prio_least = 0, prio_greatest = 0;
   (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-  if (h->shared_k1_stream && !h->k1_stream &&
-      hipStreamCreateWithPriority(&h->k1_stream, hipStreamNonBlocking, prio_least) != hipSuccess)
+  // CU partition (tail_cus > 0): the K1 phases of all lanes run on one stream confined to all but tail_cus
+  // compute units, the lanes' own streams (everything behind K1) on those tail_cus units -- the latency-bound
+  // tail kernels then never wait for a K1 workgroup to retire, and K1 is not slowed down by them.
+  std::vector<uint32_t> mask_k1, mask_tail;
+  if (h->tail_cus > 0) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, h->device) == hipSuccess && prop.multiProcessorCount > h->tail_cus) {
+      const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
+      mask_k1.assign((size_t)words, 0u);
+      mask_tail.assign((size_t)words, 0u);
+      for (int i = 0; i < ncu; ++i) {
+        // spread: every (ncu / tail_cus)-th unit; block: the last tail_cus units
+        const bool tail = h->tail_cu_block ? (i >= ncu - h->tail_cus)
+                                           : ((int64_t)(i + 1) * h->tail_cus / ncu != (int64_t)i * h->tail_cus / ncu);
+        (tail ? mask_tail : mask_k1)[(size_t)(i >> 5)] |= 1u << (i & 31);
+      }
+    }
+  }
+  if (!mask_k1.empty()) {
+    if (!h->k1_stream && hipExtStreamCreateWithCUMask(&h->k1_stream, (uint32_t)mask_k1.size(), mask_k1.data()) != hipSuccess)
+      h->k1_stream = nullptr;
+  } else if (h->shared_k1_stream && !h->k1_stream &&
+             hipStreamCreateWithPriority(&h->k1_stream, hipStreamNonBlocking, prio_least) != hipSuccess) {
     h->k1_stream = nullptr;  // no shared K1 stream: every lane keeps all of its work on its own stream
-  const hipError_t es = h->k1_stream
-                            ? hipStreamCreateWithPriority(&lane->stream, hipStreamNonBlocking, prio_greatest)
-                            : hipStreamCreateWithFlags(&lane->stream, hipStreamNonBlocking);
+  }
+  const hipError_t es =
+      (!mask_tail.empty() && h->k1_stream)
+          ? hipExtStreamCreateWithCUMask(&lane->stream, (uint32_t)mask_tail.size(), mask_tail.data())
+          : h->k1_stream ? hipStreamCreateWithPriority(&lane->stream, hipStreamNonBlocking, prio_greatest)
+                         : hipStreamCreateWithFlags(&lane->stream, hipStreamNonBlocking);
   if (es != hipSuccess || hipEventCreateWithFlags(&lane->k1_done, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&lane->k1_phase_done, hipEventDisableTiming) != hipSuccess ||
       hipEventCreateWithFlags(&lane->inputs_ready, hipEventDisableTiming) != hipSuccess) {
@@ -1203,6 +1230,8 @@ int32_t teaser_hip_solver_create(const teaser_params_c* params, int32_t device,
   }
   if (const char* e = getenv("TEASER_HIP_STAGGER")) h->stagger_k1 = atoi(e) != 0;
   if (const char* e = getenv("TEASER_HIP_K1_STREAM")) h->shared_k1_stream = atoi(e) != 0;
+  if (const char* e = getenv("TEASER_HIP_TAIL_CUS")) h->tail_cus = std::max(0, atoi(e));
+  if (const char* e = getenv("TEASER_HIP_TAIL_CU_BLOCK")) h->tail_cu_block = atoi(e) != 0;
   *out = h;
   return TEASER_HIP_OK;
 }
@@ -1544,6 +1573,7 @@ int32_t teaser_hip_max_clique(teaser_hip_solver* h, const uint64_t* bitmap, int3
   d.w_off = 0;
   ProbState& st = h->states[0];
   memset(&st, 0, sizeof(st));
+  st.next_start = heuristic_blocks_per_problem(1);
   for (int k = 0; k < kMaxStarts; ++k) st.start_vertex[k] = -1;
   HIPCHK(h, h->d_desc.ensure(sizeof(ProbDesc)));
   HIPCHK(h, h->d_state.ensure(sizeof(ProbState)));
