@@ -2,6 +2,6 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r2h
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r2h
-python scripts/probe/h2d_bw.py
-timeout 300 python bench.py --no-cpu-baseline > $OUT/bench2.log 2>&1; tail -1 $OUT/bench2.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['config']['single_problem_latency_ms'], d['config']['host_resident'])"
-timeout 300 python -m pytest tests/test_gpu_parity.py -m gpu -q --timeout=300 -x -k "max_clique or heur or clique" > $OUT/tests_clique.log 2>&1; echo "clique tests rc=$?"; tail -2 $OUT/tests_clique.log
+cd /tmp
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_d3 -o bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-host-resident --no-latency --steps 12 --warmup 3 --depth 3 > $OUT/trace_d3.log 2>&1; tail -1 $OUT/trace_d3.log | cut -c75-200
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_d2 -o bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-host-resident --no-latency --steps 12 --warmup 3 --depth 2 > $OUT/trace_d2.log 2>&1; tail -1 $OUT/trace_d2.log | cut -c75-200
