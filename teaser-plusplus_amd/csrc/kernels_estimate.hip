@@ -881,6 +881,66 @@ __global__ __launch_bounds__(256) void scalar_tls_kernel(const double* __restric
   if (threadIdx.x == 0) *est_out = est;
 }
 
+// ------------------------------------------------------------------------------------------
+// estimate_scaling = true for a BATCH of small problems (n <= 724: at most 2^19 interval endpoints, sorted by
+// one workgroup each): every problem's TRIMs in one launch, every problem's scalar TLS in another -- instead
+// of two launches per problem one after the other (each single-workgroup sort leaves 255 CUs idle).
+// sel[k] = problem index; off[2k] = offset (in doubles) of problem k's TRIM arrays, off[2k+1] = byte offset of
+// its sort scratch.  Same arithmetic and pair order as trims_kernel / scalar_tls_kernel.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void trims_batch_kernel(const ProbDesc* __restrict__ descs,
+                                                          const int32_t* __restrict__ sel,
+                                                          const int64_t* __restrict__ off,
+                                                          const double* __restrict__ src,
+                                                          const double* __restrict__ dst, double beta,
+                                                          double* __restrict__ raw, double* __restrict__ alpha) {
+  const ProbDesc d = descs[sel[blockIdx.y]];
+  const int n = d.n, i = blockIdx.x;
+  if (i >= n - 1) return;
+  const double* ps = src + 3 * d.pt_off;
+  const double* pd = dst + 3 * d.pt_off;
+  double* rw = raw + off[2 * blockIdx.y];
+  double* al = alpha + off[2 * blockIdx.y];
+  const int64_t seg = (int64_t)i * n - (int64_t)i * (i + 1) / 2;
+  const double six = ps[3 * i], siy = ps[3 * i + 1], siz = ps[3 * i + 2];
+  const double dix = pd[3 * i], diy = pd[3 * i + 1], diz = pd[3 * i + 2];
+  for (int j = i + 1 + threadIdx.x; j < n; j += 256) {
+    const double ax = ps[3 * j] - six, ay = ps[3 * j + 1] - siy, az = ps[3 * j + 2] - siz;
+    const double bx = pd[3 * j] - dix, by = pd[3 * j + 1] - diy, bz = pd[3 * j + 2] - diz;
+    const double v1 = __builtin_sqrt((ax * ax + ay * ay) + az * az);
+    const double v2 = __builtin_sqrt((bx * bx + by * by) + bz * bz);
+    const int64_t k = seg + (j - i - 1);
+    rw[k] = v2 / v1;
+    al[k] = beta * (1.0 / v1);
+  }
+}
+
+__global__ __launch_bounds__(256) void scalar_tls_batch_kernel(const ProbDesc* __restrict__ descs,
+                                                               const int32_t* __restrict__ sel,
+                                                               const int64_t* __restrict__ off,
+                                                               const double* __restrict__ raw,
+                                                               const double* __restrict__ alpha,
+                                                               char* __restrict__ scratch,
+                                                               ProbState* __restrict__ states) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int p = sel[blockIdx.x];
+  const int n = descs[p].n;
+  const int m = (int)((int64_t)n * (n - 1) / 2);
+  TlsScratch sc = tls_scratch(smem, scratch + off[2 * blockIdx.x + 1], m);
+  const double est = scalar_tls_group(raw + off[2 * blockIdx.x], alpha + off[2 * blockIdx.x], 0.0, m, sc, threadIdx.x);
+  if (threadIdx.x == 0) states[p].scale = est;
+}
+
+void launch_scale_small_batch(hipStream_t s, const ProbDesc* d_desc, const int32_t* d_sel, const int64_t* d_off,
+                              int count, int max_n, const double* d_src, const double* d_dst, double beta,
+                              double* d_raw, double* d_alpha, char* d_scratch, ProbState* d_state) {
+  if (count <= 0 || max_n < 2) return;
+  hipLaunchKernelGGL(trims_batch_kernel, dim3(max_n - 1, count), dim3(256), 0, s, d_desc, d_sel, d_off, d_src,
+                     d_dst, beta, d_raw, d_alpha);
+  hipLaunchKernelGGL(scalar_tls_batch_kernel, dim3(count), dim3(256), kTlsGroupLds, s, d_desc, d_sel, d_off, d_raw,
+                     d_alpha, d_scratch, d_state);
+}
+
 void launch_scalar_tls(hipStream_t s, const double* d_x, const double* d_r, int32_t n,
                        char* d_scratch, double* d_est, uint8_t* d_mask) {
   hipLaunchKernelGGL(scalar_tls_kernel, dim3(1), dim3(256), kTlsGroupLds, s, d_x, d_r, n, d_scratch,

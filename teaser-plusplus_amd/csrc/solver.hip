@@ -30,6 +30,9 @@ void launch_gather_bitmap(hipStream_t s, const uint64_t* d_in, int W_in, const i
 void launch_gnc_tls_raw(hipStream_t s, const double* d_src, const double* d_dst, int K,
                         double noise_bound, EstParams ep, double* d_w, double* d_out,
                         int32_t* d_iters);
+void launch_scale_small_batch(hipStream_t s, const ProbDesc* d_desc, const int32_t* d_sel, const int64_t* d_off,
+                              int count, int max_n, const double* d_src, const double* d_dst, double beta,
+                              double* d_raw, double* d_alpha, char* d_scratch, ProbState* d_state);
 void launch_trims(hipStream_t s, const double* d_src, const double* d_dst, int n, double beta,
                   double* d_raw, double* d_alpha);
 void launch_fill_identity_clique(hipStream_t s, const ProbDesc* d_desc, int batch, int max_n,
@@ -456,8 +459,25 @@ int32_t exact_stage(teaser_hip_solver* h, int p, const uint64_t* d_final_alive,
 // reference fixture is in this range); above, kernels_scale.hip: fused TRIM/endpoint kernel ->
 // device radix sort -> three-pass sweep.  The reference's `int nr_centers = 2*N`
 // (registration.cc:47) overflows for M > 2^30, i.e. n > 46341: refused here rather than undefined.
-constexpr int kSmallScaledN = 724;
+constexpr int kSmallScaledN = 724;  // capability of the single-workgroup sort (2^19 endpoints)
+// ... but one workgroup sorting M log^2 M takes 8.6 ms at n = 200 and 137 ms at n = 724 (profiles/r2j), against
+// ~0.22 ms of launch-bound kernels on the radix-sort path: a problem on its own takes the single-workgroup path
+// only while that is the faster one; batches weigh the two (scale_stage_batch).
+constexpr int kSingleSmallN = 64;
+constexpr double kLargePathMs = 0.22;  // measured: 64 x n = 724 in 13.7 ms (profiles/r2j)
 constexpr int kMaxScaledN = 46341;
+
+// measured model of the single-workgroup path: bitonic sort of P2 >= 2 M endpoints, L (L + 1) / 2 passes
+static double small_path_ms(int n) {
+  const int64_t M = (int64_t)n * (n - 1) / 2;
+  int64_t P2 = 2;
+  int L = 1;
+  while (P2 < 2 * M) {
+    P2 <<= 1;
+    ++L;
+  }
+  return 8.6 * ((double)P2 * L * (L + 1) / 2) / (65536.0 * 136.0) + 0.05;
+}
 
 int32_t scale_stage(teaser_hip_solver* h, int p) {
   hipStream_t s = h->stream;
@@ -473,7 +493,7 @@ int32_t scale_stage(teaser_hip_solver* h, int p) {
   double* d_scale = &(h->d_state.as<ProbState>()[p].scale);
   HIPCHK(h, h->s_a.ensure((size_t)M * 8));
   HIPCHK(h, h->s_b.ensure((size_t)M * 8));
-  if (n > kSmallScaledN) {
+  if (n > kSingleSmallN) {
     HIPCHK(h, h->s_c.ensure((size_t)scalar_tls_large_workspace_bytes(M)));
     HIPCHK(h, launch_tls_scale_large(s, h->cur_src + 3 * d.pt_off, h->cur_dst + 3 * d.pt_off, n, beta,
                                      h->s_a.as<double>(), h->s_b.as<double>(), h->s_c.as<char>(),
@@ -487,6 +507,80 @@ int32_t scale_stage(teaser_hip_solver* h, int p) {
                h->s_a.as<double>(), h->s_b.as<double>());
   launch_scalar_tls(s, h->s_a.as<double>(), h->s_b.as<double>(), (int32_t)M, h->s_c.as<char>(),
                     d_scale, nullptr);
+  return TEASER_HIP_OK;
+}
+
+// The whole batch: problems of up to kSmallScaledN points (one sorting workgroup each) go through TWO launches
+// per chunk -- all their TRIMs, all their scalar TLS problems -- instead of two launches per problem one after
+// the other; chunks bound the scratch (TRIM arrays + sort scratch) to ~8 GB.  Larger problems keep the
+// device-wide radix sort path, one problem at a time (each saturates the GPU on its own).
+int32_t scale_stage_batch(teaser_hip_solver* h, int batch) {
+  hipStream_t s = h->stream;
+  const double beta = 2 * h->params.noise_bound * std::sqrt(h->params.cbar2);
+  // candidates for the shared launches, smallest first; the largest ones are dropped while one such workgroup
+  // alone would take longer than the radix-sort path needs for all the candidates (up to ~512 workgroups run
+  // side by side, so a chunk costs about its slowest member)
+  std::vector<int32_t> small;
+  for (int b = 0; b < batch; ++b) {
+    const int n = h->descs[(size_t)b].n;
+    if (n >= 2 && n <= kSmallScaledN) small.push_back(b);
+  }
+  std::sort(small.begin(), small.end(),
+            [&](int32_t a, int32_t b) { return h->descs[(size_t)a].n < h->descs[(size_t)b].n; });
+  while (!small.empty()) {
+    const double waves = (double)((small.size() + 511) / 512);
+    if (small_path_ms(h->descs[(size_t)small.back()].n) * waves <= kLargePathMs * (double)small.size()) break;
+    small.pop_back();
+  }
+  constexpr int64_t kChunkBytes = (int64_t)8 << 30;
+  static const char* ev = getenv("TEASER_SCALE_BATCH");  // diagnostics: 0 = one problem at a time
+  if (ev && atoi(ev) == 0) small.clear();
+  size_t at = 0;
+  while (small.size() - at >= 2) {  // (a single small problem takes the per-problem path below)
+    std::vector<int32_t> sel;
+    std::vector<int64_t> off;
+    int64_t trims = 0, scratch = 0;
+    int max_n = 0;
+    while (at < small.size()) {
+      const int n = h->descs[(size_t)small[at]].n;
+      const int64_t M = (int64_t)n * (n - 1) / 2;
+      int64_t P2 = 2;
+      while (P2 < 2 * M) P2 <<= 1;
+      const int64_t sb = (P2 * 12 + 64 + 255) & ~(int64_t)255;
+      if (!sel.empty() && 16 * (trims + M) + scratch + sb > kChunkBytes) break;
+      sel.push_back(small[at]);
+      off.push_back(trims);
+      off.push_back(scratch);
+      trims += (M + 31) & ~(int64_t)31;
+      scratch += sb;
+      max_n = std::max(max_n, n);
+      ++at;
+    }
+    const size_t meta = 4 * sel.size() + 8 * off.size() + 64;
+    HIPCHK(h, h->s_a.ensure((size_t)trims * 8));
+    HIPCHK(h, h->s_b.ensure((size_t)trims * 8));
+    HIPCHK(h, h->s_c.ensure((size_t)scratch));
+    HIPCHK(h, h->s_d.ensure(meta));
+    char* dm = h->s_d.as<char>();
+    const size_t o_off = (4 * sel.size() + 63) & ~(size_t)63;
+    // (pageable sources: the runtime stages them before returning, the vectors may die)
+    HIPCHK(h, hipMemcpyAsync(dm, sel.data(), 4 * sel.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(dm + o_off, off.data(), 8 * off.size(), hipMemcpyHostToDevice, s));
+    launch_scale_small_batch(s, h->d_desc.as<ProbDesc>(), reinterpret_cast<const int32_t*>(dm),
+                             reinterpret_cast<const int64_t*>(dm + o_off), (int)sel.size(), max_n, h->cur_src,
+                             h->cur_dst, beta, h->s_a.as<double>(), h->s_b.as<double>(), h->s_c.as<char>(),
+                             h->d_state.as<ProbState>());
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(s));  // (sel / off are stack vectors; the next chunk reuses the scratch)
+  }
+  for (int b = 0; b < batch; ++b) {
+    const int n = h->descs[(size_t)b].n;
+    const bool done = n >= 2 && n <= kSmallScaledN && small.size() >= 2 &&
+                      std::find(small.begin(), small.begin() + (std::ptrdiff_t)at, b) != small.begin() + (std::ptrdiff_t)at;
+    if (done) continue;
+    const int32_t rc = scale_stage(h, b);
+    if (rc != TEASER_HIP_OK) return rc;
+  }
   return TEASER_HIP_OK;
 }
 
@@ -733,10 +827,8 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
 
   if (P.estimate_scaling) {
     StageScope sc(h, ST_TIM);
-    for (int b = 0; b < batch; ++b) {
-      int32_t rc = scale_stage(h, b);
-      if (rc != TEASER_HIP_OK) return rc;
-    }
+    int32_t rc = scale_stage_batch(h, batch);
+    if (rc != TEASER_HIP_OK) return rc;
   }
   if (need_graph) {
     if (!mfma_k1) {

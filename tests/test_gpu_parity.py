@@ -254,6 +254,36 @@ def test_solve_estimate_scaling_large_vs_oracle(n, rho, scale, seed):
         check_solution_parity(s, sol, o)
 
 
+def test_estimate_scaling_batch_small_problems():
+    """estimate_scaling = true over a ragged batch: the problems of up to 724 points share two launches (all
+    TRIMs, all scalar TLS problems), larger ones keep the radix-sort path; every problem is bit-identical to
+    its own single solve, and two of them are checked against the oracle."""
+    nb = 0.01
+    sizes = [60, 300, 724, 2, 511, 900, 128, 725, 1]
+    probs = []
+    for i, n in enumerate(sizes):
+        q = tp.synth_problem(500 + i, n, 0.5, nb)
+        sc = 1.0 + 0.25 * i
+        probs.append((q["src"], q["dst"] * sc))
+    p = bench_params(estimate_scaling=True, noise_bound=nb * 3.25)  # (covers the largest scaled noise)
+    s = make_solver(**p)
+    sols = s.solve_batch([q[0] for q in probs], [q[1] for q in probs])
+    batch = [(bool(o.valid), o.scale, o.rotation.copy(), o.translation.copy(), s.getInlierMaxClique(b))
+             for b, o in enumerate(sols)]
+    one = make_solver(**p)
+    for b, q in enumerate(probs):
+        o = one.solve(q[0], q[1])
+        assert bool(o.valid) == batch[b][0]
+        assert one.getInlierMaxClique() == batch[b][4], sizes[b]
+        if o.valid:
+            assert o.scale == batch[b][1], sizes[b]
+            assert (o.rotation == batch[b][2]).all() and (o.translation == batch[b][3]).all()
+    for b in (1, 4):
+        ref = oracle.solve(probs[b][0], probs[b][1], **oracle_params(p))
+        assert abs(batch[b][1] - ref["scale"]) <= 1e-9 * max(1.0, abs(ref["scale"]))
+        assert batch[b][4] == ref["max_clique"].tolist() or not ref["clique_unique"]
+
+
 def test_solve_estimate_scaling_full_size_vs_oracle_fixture():
     """Full-size estimate_scaling = true (N = 10 000: M = 5e7 TRIMs, 1e8 endpoints through the
     radix sort) against the oracle's result committed in tests/golden/scale_golden.json (made by
