@@ -142,7 +142,10 @@ struct ExactArgs {
   int32_t n_waves;
   int32_t n_roots;          // roots 0..n_roots-1 are searched (n: all; colouring bound: |X|)
   int64_t deadline_ticks;   // wall_clock64 ticks allowed (0 = unlimited)
+  int32_t lds_bitmap;       // set by launch_exact_clique: the adjacency fits in LDS and is staged there
+  int32_t pad;
 };
+constexpr int64_t kExactLdsBitmapBytes = 128 * 1024;  // n <= 1024 compact vertices
 void launch_exact_clique(hipStream_t s, const ExactArgs& a);
 // global colouring bound on the peel survivors of the selected problems (kernels_clique.hip)
 constexpr int kColourMaxLb = 4096;  // palette limit (64 LDS words per wave)

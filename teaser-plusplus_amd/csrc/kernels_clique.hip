@@ -47,19 +47,22 @@ __device__ int colour_sort(const uint64_t* __restrict__ bitmap, int W, const uin
     ++k;
     for (int w = lane; w < W; w += 64) Qc[w] = Q[w];
     __syncthreads();
-    int wcur = 0;
+    // Colour classes are filled from the HIGHEST vertex index down: the search order is ascending degree, so
+    // the colouring visits the largest degrees first (Welsh-Powell order: markedly fewer colours on dense
+    // descriptor graphs than lowest-degree-first, i.e. tighter bounds at every node).
+    int wcur = W - 1;
     while (true) {
-      // first set bit of Qc at or after word wcur
+      // last set bit of Qc at or before word wcur
       int u = -1, wsel = 0, bit = 0;
-      for (int base = wcur; base < W; base += 64) {
-        const int w = base + lane;
-        const uint64_t word = (w < W) ? Qc[w] : 0ull;
+      for (int top = wcur; top >= 0; top -= 64) {
+        const int w = top - lane;
+        const uint64_t word = (w >= 0) ? Qc[w] : 0ull;
         const uint64_t mask = __ballot(word != 0ull);
         if (mask) {
-          const int fl = __builtin_ctzll(mask);
+          const int fl = __builtin_ctzll(mask);  // lane 0 holds the highest word of this group
           const uint64_t ws = __shfl(word, fl, 64);
-          wsel = base + fl;
-          bit = __builtin_ctzll(ws);
+          wsel = top - fl;
+          bit = 63 - __builtin_clzll(ws);
           u = wsel * 64 + bit;
           break;
         }
@@ -67,7 +70,7 @@ __device__ int colour_sort(const uint64_t* __restrict__ bitmap, int W, const uin
       if (u < 0) break;
       wcur = wsel;
       const uint64_t* ru = bitmap + (int64_t)u * W;
-      for (int w = wcur + lane; w < W; w += 64) {
+      for (int w = wcur - lane; w >= 0; w -= 64) {
         uint64_t x = Qc[w] & ~ru[w];
         if (w == wsel) {
           x &= ~(1ull << bit);
@@ -97,6 +100,18 @@ __global__ __launch_bounds__(64) void exact_clique_kernel(ExactArgs a, int32_t* 
   const int lane = threadIdx.x;
   uint64_t* Q = reinterpret_cast<uint64_t*>(smem);
   uint64_t* Qc = Q + ((W + 1) & ~1);
+  // Compact problems of up to 1024 vertices (the regime of real descriptor graphs: BASELINE config 5, 626
+  // vertices, omega 91): the whole adjacency, n x W words <= 128 KB, is staged in LDS once per workgroup and
+  // every row the colouring / branching steps touch comes from there -- those steps are a chain of dependent
+  // row fetches (one per coloured vertex), ~1 us each from L2, ~0.1 us from LDS.
+  const uint64_t* bmrows = a.bitmap;
+  if (a.lds_bitmap) {
+    uint64_t* bl = Qc + ((W + 1) & ~1);
+    const int64_t words = (int64_t)n * W;
+    for (int64_t k = lane; k < words; k += 64) bl[k] = a.bitmap[k];
+    __syncthreads();
+    bmrows = bl;
+  }
   char* arena = a.arena + (int64_t)blockIdx.x * a.arena_bytes;
   int32_t* C = reinterpret_cast<int32_t*>(arena);
   const int64_t stack0 = align16((int64_t)(n + 1) * 4);
@@ -111,7 +126,11 @@ __global__ __launch_bounds__(64) void exact_clique_kernel(ExactArgs a, int32_t* 
       if (lane == 0) atomicMax(a.status, 2);
       break;
     }
-    const int v = r;
+    // roots from the END of the search order (highest degree first): their later-neighbour sets are the
+    // smallest and densest, so a maximum clique shows up in the first few roots and every other root is
+    // searched against a tight incumbent (the ascending order kept the whole device busy on the loosest
+    // subproblems first: config 5 took minutes instead of milliseconds)
+    const int v = a.n_roots - 1 - r;
     int best = __hip_atomic_load(a.best_size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // level 0: P = later neighbours of v
     int64_t off = stack0;
@@ -124,7 +143,7 @@ __global__ __launch_bounds__(64) void exact_clique_kernel(ExactArgs a, int32_t* 
     }
     LevelHdr* L = reinterpret_cast<LevelHdr*>(arena + off);
     uint64_t* P = reinterpret_cast<uint64_t*>(arena + off + align16(sizeof(LevelHdr)));
-    const uint64_t* rv = a.bitmap + (int64_t)v * W;
+    const uint64_t* rv = bmrows + (int64_t)v * W;
     int pc = 0;
     for (int w = lane; w < W; w += 64) {
       uint64_t x = rv[w];
@@ -147,7 +166,7 @@ __global__ __launch_bounds__(64) void exact_clique_kernel(ExactArgs a, int32_t* 
     int32_t* order = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(P) + align16((int64_t)W * 8));
     int32_t* colour = order + (align16((int64_t)pc * 4) / 4);
     __syncthreads();
-    int m = colour_sort(a.bitmap, W, P, pc, best - csize, Q, Qc, order, colour);
+    int m = colour_sort(bmrows, W, P, pc, best - csize, Q, Qc, order, colour);
     if (lane == 0) {
       L->pcount = pc;
       L->m = m;
@@ -158,7 +177,13 @@ __global__ __launch_bounds__(64) void exact_clique_kernel(ExactArgs a, int32_t* 
     __syncthreads();
     int depth = 0;
     bool overflow = false;
+    unsigned int steps = 0;
     while (depth >= 0) {
+      // the time limit also holds INSIDE a root's subtree (checked every 256 steps), not only between roots
+      if (a.deadline_ticks > 0 && (++steps & 255u) == 0u && wall_clock64() - t_start > a.deadline_ticks) {
+        if (lane == 0) atomicMax(a.status, 2);
+        break;
+      }
       L = reinterpret_cast<LevelHdr*>(arena + off);
       P = reinterpret_cast<uint64_t*>(arena + off + align16(sizeof(LevelHdr)));
       const int lpc = L->pcount;
@@ -187,7 +212,7 @@ __global__ __launch_bounds__(64) void exact_clique_kernel(ExactArgs a, int32_t* 
       }
       LevelHdr* NL = reinterpret_cast<LevelHdr*>(arena + noff);
       uint64_t* NP = reinterpret_cast<uint64_t*>(arena + noff + hdr_b);
-      const uint64_t* ru = a.bitmap + (int64_t)u * W;
+      const uint64_t* ru = bmrows + (int64_t)u * W;
       int cnt = 0;
       for (int w = lane; w < W; w += 64) {
         const uint64_t x = P[w] & ru[w];
@@ -227,7 +252,7 @@ __global__ __launch_bounds__(64) void exact_clique_kernel(ExactArgs a, int32_t* 
         int32_t* norder = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(NP) + p_b);
         int32_t* ncolour = norder + (align16((int64_t)cnt * 4) / 4);
         ++csize;
-        const int nm = colour_sort(a.bitmap, W, NP, cnt, best - csize, Q, Qc, norder, ncolour);
+        const int nm = colour_sort(bmrows, W, NP, cnt, best - csize, Q, Qc, norder, ncolour);
         if (lane == 0) {
           NL->pcount = cnt;
           NL->m = nm;
@@ -249,8 +274,15 @@ __global__ __launch_bounds__(64) void exact_clique_kernel(ExactArgs a, int32_t* 
 
 void launch_exact_clique(hipStream_t s, const ExactArgs& a) {
   // best_size[0] = incumbent, best_size[1] = recorded size, best_size[2] = lock
-  const size_t lds = (size_t)2 * ((a.W + 1) & ~1) * 8;
-  hipLaunchKernelGGL(exact_clique_kernel, dim3(a.n_waves), dim3(64), lds, s, a, a.best_size + 1,
+  size_t lds = (size_t)2 * ((a.W + 1) & ~1) * 8;
+  ExactArgs b = a;
+  b.lds_bitmap = ((int64_t)a.n * a.W * 8 <= kExactLdsBitmapBytes) ? 1 : 0;
+  if (b.lds_bitmap) {
+    lds += (size_t)a.n * (size_t)a.W * 8;
+    static DynLdsOptIn optin;
+    if (lds > 48 * 1024) optin.ensure(reinterpret_cast<const void*>(exact_clique_kernel), (int)lds);
+  }
+  hipLaunchKernelGGL(exact_clique_kernel, dim3(a.n_waves), dim3(64), lds, s, b, a.best_size + 1,
                      a.best_size + 2);
 }
 

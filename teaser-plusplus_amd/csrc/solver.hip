@@ -13,6 +13,8 @@
 #include <thread>
 #include <vector>
 
+#include <chrono>
+
 #include "internal.h"
 
 namespace thip {
@@ -342,10 +344,18 @@ int32_t run_exact_on_compact(teaser_hip_solver* h, const uint64_t* d_cbitmap, in
     a.n_roots = n_roots;
     const double lim = h->params.max_clique_time_limit;
     a.deadline_ticks = (lim > 0 && lim < 1e7) ? (int64_t)(lim * 1e8) : 0;  // 100 MHz counter
+    static const bool dbg = getenv("TEASER_K4_DEBUG") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     launch_exact_clique(s, a);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(ctrl, h->x_ctrl.p, sizeof(ctrl), hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
+    if (dbg)  // diagnostics only
+      fprintf(stderr, "[teaser_hip] exact search: n %d W %d incumbent %d roots %d waves %d arena %lld B attempt %d: "
+              "%.1f ms, best %d recorded %d roots taken %d status %d\n", n2, W2, lb, n_roots, n_waves,
+              (long long)arena, attempt,
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), ctrl[0],
+              ctrl[1], ctrl[3], ctrl[4]);
     if (ctrl[4] == 1) {  // arena overflow: keep the incumbent, retry with a larger arena
       arena *= 4;
       ctrl[0] = ctrl[1];
