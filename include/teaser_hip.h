@@ -265,6 +265,30 @@ TEASER_HIP_API int32_t teaser_hip_match_features(teaser_hip_solver* h, const flo
                                   const float* dst_feat, int32_t n_dst, int32_t dim, int32_t use_crosscheck,
                                   int32_t* pairs, int64_t* n_pairs);
 
+/* DRS rotation certifier: teaser::DRSCertifier::certify(R, src, dst, theta) (teaser/src/certification.cc:39-190,
+ * teaser/include/teaser/certification.h:53-239).  Parameters as DRSCertifier::Params (certification.h:71-104;
+ * eig_decomposition_solver: the dense solver is always used -- Spectra is an un-vendored dependency).
+ * R: 3 x 3 row-major; src / dst: the 3 x N column-major matrices of the reference (N points, xyz interleaved);
+ * theta: N entries, +1 inlier / -1 outlier (certification.h:133-140).  traj: capacity traj_cap doubles
+ * (max_iterations always suffices) or NULL; out->iterations = length of the sub-optimality trajectory.
+ * TEASER_HIP_ERR_UNSUPPORTED when rocSOLVER / rocBLAS (the symmetric eigensolver) cannot be loaded. */
+typedef struct teaser_certifier_params_c {
+  double noise_bound;     /* 0.01 */
+  double cbar2;           /* 1 */
+  double sub_optimality;  /* 1e-3 */
+  double max_iterations;  /* 2e2 (a double in the reference, too) */
+  double gamma_tau;       /* 1.999999 */
+} teaser_certifier_params_c;
+typedef struct teaser_certification_c {
+  int32_t is_optimal;          /* CertificationResult::is_optimal */
+  int32_t iterations;          /* suboptimality_traj.size() */
+  double best_suboptimality;   /* CertificationResult::best_suboptimality */
+} teaser_certification_c;
+TEASER_HIP_API int32_t teaser_hip_certifier_params_default(teaser_certifier_params_c* p);
+TEASER_HIP_API int32_t teaser_hip_certify(teaser_hip_solver* h, const teaser_certifier_params_c* p, const double* R,
+                           const double* src, const double* dst, const double* theta, int32_t n,
+                           teaser_certification_c* out, double* traj, int32_t traj_cap);
+
 /* MaxCliqueSolver::findMaxClique (graph.cc:12-125) on a caller-supplied adjacency bitmap
  * (host pointer, n rows of (n+63)/64 words).  clique: capacity n; sorted on return. */
 TEASER_HIP_API int32_t teaser_hip_max_clique(teaser_hip_solver* h, const uint64_t* bitmap, int32_t n,

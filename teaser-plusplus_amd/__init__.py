@@ -124,6 +124,7 @@ EXPORTED_SYMBOLS = [
     "teaser_hip_set_pipeline_depth", "teaser_hip_multi_create", "teaser_hip_multi_destroy",
     "teaser_hip_multi_solve_batch", "teaser_hip_multi_route", "teaser_hip_multi_device_count",
     "teaser_hip_solve_for_scale", "teaser_hip_compute_fpfh", "teaser_hip_match_features",
+    "teaser_hip_certifier_params_default", "teaser_hip_certify",
 ]
 
 
@@ -175,6 +176,7 @@ def lib():
     _fp = C.POINTER(C.c_float)
     L.teaser_hip_compute_fpfh.argtypes = [_vp, _fp, C.c_int32, C.c_double, C.c_double, _fp, _fp]
     L.teaser_hip_match_features.argtypes = [_vp, _fp, C.c_int32, _fp, C.c_int32, C.c_int32, C.c_int32, _ip, _i64p]
+    L.teaser_hip_certify.argtypes = [_vp, C.c_void_p, _dp, _dp, _dp, _dp, C.c_int32, C.c_void_p, _dp, C.c_int32]
     L.teaser_hip_max_clique.argtypes = [_vp, _u64p, C.c_int32, _ip, _ip, _ip]
     L.teaser_hip_submit_batch.argtypes = [_vp, _vp, _vp, _i64p, _ip, C.c_int32, C.c_int32, _ip]
     L.teaser_hip_wait.argtypes = [_vp, C.c_int32, C.POINTER(SolutionC)]
@@ -696,6 +698,65 @@ class Matcher:
         s._check(s._lib.teaser_hip_match_features(s._h, _ptr(a, fp), a.shape[0], _ptr(b, fp), b.shape[0], a.shape[1],
                                                   1 if use_crosscheck else 0, _ptr(out, _ip), C.byref(cnt)))
         return [tuple(int(v) for v in row) for row in out[:cnt.value]]
+
+
+class CertifierParamsC(C.Structure):
+    _fields_ = [("noise_bound", C.c_double), ("cbar2", C.c_double), ("sub_optimality", C.c_double),
+                ("max_iterations", C.c_double), ("gamma_tau", C.c_double)]
+
+
+class CertificationC(C.Structure):
+    _fields_ = [("is_optimal", C.c_int32), ("iterations", C.c_int32), ("best_suboptimality", C.c_double)]
+
+
+class CertificationResult:
+    """teaser::CertificationResult (reference teaser/include/teaser/certification.h:21-25)."""
+
+    def __init__(self, is_optimal, best_suboptimality, suboptimality_traj):
+        self.is_optimal = bool(is_optimal)
+        self.best_suboptimality = float(best_suboptimality)
+        self.suboptimality_traj = suboptimality_traj
+
+
+class DRSCertifier:
+    """teaser::DRSCertifier (reference teaser/include/teaser/certification.h:53-239,
+    teaser/src/certification.cc:22-190) on the GPU: Douglas-Rachford splitting on the (4 + 4N)-square dual
+    matrix, eigendecompositions by rocSOLVER, projections by hand-written kernels."""
+
+    class Params:  # certification.h:71-104
+        def __init__(self, noise_bound=0.01, cbar2=1.0, sub_optimality=1e-3, max_iterations=2e2,
+                     gamma_tau=1.999999):
+            self.noise_bound = noise_bound
+            self.cbar2 = cbar2
+            self.sub_optimality = sub_optimality
+            self.max_iterations = max_iterations
+            self.gamma_tau = gamma_tau
+
+    def __init__(self, params=None, device=-1, **kw):
+        self.params = params if params is not None else DRSCertifier.Params(**kw)
+        self._solver = RobustRegistrationSolver(device=device)
+
+    def certify(self, R_solution, src, dst, theta):
+        """src, dst: 3 x N; theta: N entries (+1 inlier, -1 outlier) or a boolean inlier mask
+        (certification.cc:22-37 converts the mask the same way)."""
+        R = np.ascontiguousarray(R_solution, dtype=np.float64)
+        a, b = _colmajor(src, "src"), _colmajor(dst, "dst")
+        th = np.asarray(theta)
+        if th.dtype == np.bool_:
+            th = np.where(th, 1.0, -1.0)
+        th = np.ascontiguousarray(th, dtype=np.float64).reshape(-1)
+        n = a.shape[0]
+        if R.shape != (3, 3) or b.shape[0] != n or th.shape[0] != n:
+            raise ValueError("R must be 3 x 3; src, dst 3 x N; theta N")
+        p = self.params
+        pc = CertifierParamsC(p.noise_bound, p.cbar2, p.sub_optimality, p.max_iterations, p.gamma_tau)
+        out = CertificationC()
+        cap = max(int(p.max_iterations), 1)
+        traj = np.zeros(cap, dtype=np.float64)
+        s = self._solver
+        s._check(s._lib.teaser_hip_certify(s._h, C.byref(pc), _ptr(R), _ptr(a), _ptr(b), _ptr(th), n,
+                                           C.byref(out), _ptr(traj), cap))
+        return CertificationResult(out.is_optimal, out.best_suboptimality, traj[:out.iterations].copy())
 
 
 class MultiDeviceSolver:

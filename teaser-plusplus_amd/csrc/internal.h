@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <vector>
 
 #include "teaser_hip.h"
 
@@ -147,6 +148,10 @@ struct ExactArgs {
 };
 constexpr int64_t kExactLdsBitmapBytes = 128 * 1024;  // n <= 1024 compact vertices
 void launch_exact_clique(hipStream_t s, const ExactArgs& a);
+// DRS certifier (kernels_certify.hip): 0, or -1 rocSOLVER / rocBLAS not loadable, -2 HIP error, -3 library call failed
+int certify_on_device(hipStream_t s, const double* R, const double* src, const double* dst, const double* theta, int N,
+                      double noise_bound, double cbar2, double sub_optimality, double max_iterations,
+                      double gamma_tau, int* is_optimal, double* best_suboptimality, std::vector<double>* traj);
 // global colouring bound on the peel survivors of the selected problems (kernels_clique.hip)
 constexpr int kColourMaxLb = 4096;  // palette limit (64 LDS words per wave)
 constexpr int kColourRounds = 10;

@@ -1,0 +1,359 @@
+// kernels_certify.hip -- the DRS rotation certifier (reference teaser/src/certification.cc:39-190) on gfx950.
+//
+// certify() runs Douglas-Rachford splitting on an (4 + 4N) x (4 + 4N) dual matrix M: per iteration one
+// projection onto the PSD cone (symmetric eigendecomposition), one projection onto the affine dual
+// subspace (getOptimalDualProjection: a structured O(N^2) map) and the sub-optimality gap (smallest
+// eigenvalue of M_affine).  Design:
+//   * the O(N) set-up -- Q_cost, D_omega, Q_bar, mu, lambda_guess (certification.cc:233-321, 454-536) -- is
+//     done on the host in double: M_init = Q_bar - mu J - lambda is non-zero only in its first block row /
+//     column and its 4 x 4 diagonal blocks, so only those blocks are uploaded and M_init is never stored
+//     dense (`minit()` below);
+//   * the inverse map A_inv of getLinearProjection (certification.cc:538-657: an N(N+1)/2-square sparse
+//     matrix, 2.5e7 entries at N = 100) is never built: its action on b_W is evaluated from its defining
+//     pattern, O(N) per pair (ainv_apply_kernel; checked against the dense matrix by
+//     tests/test_certifier_oracle.py::test_structured_inverse_map);
+//   * the two eigendecompositions per iteration are rocSOLVER's dsyevd and the reconstruction
+//     V max(D, 0) V^T one rocBLAS dgemm (plain library calls, loaded with dlopen on first use so that the
+//     registration path does not depend on them); everything else is hand-written elementwise / block kernels
+//     on column-major FP64 matrices that stay in HBM for the whole run (7 n^2 doubles; n = 4004 at N = 1000:
+//     0.9 GB).
+// One host sync per iteration (the gap decides termination, as in the reference).
+#include <dlfcn.h>
+
+#include <rocblas/rocblas.h>
+#include <rocsolver/rocsolver.h>
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "cert_setup.h"
+#include "internal.h"
+
+namespace thip {
+
+namespace {
+
+struct CertLibs {
+  void* blas = nullptr;
+  void* solver = nullptr;
+  decltype(&rocblas_create_handle) create_handle = nullptr;
+  decltype(&rocblas_destroy_handle) destroy_handle = nullptr;
+  decltype(&rocblas_set_stream) set_stream = nullptr;
+  decltype(&rocblas_dgemm) dgemm = nullptr;
+  decltype(&rocsolver_dsyevd) dsyevd = nullptr;
+  bool ok = false;
+};
+
+void* open_first(const char* const* names) {
+  for (int i = 0; names[i]; ++i)
+    if (void* p = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL)) return p;
+  return nullptr;
+}
+
+CertLibs& cert_libs() {
+  static CertLibs L = [] {
+    CertLibs l;
+    static const char* const blas_names[] = {"librocblas.so.5", "librocblas.so", "/opt/rocm/lib/librocblas.so", nullptr};
+    static const char* const solver_names[] = {"librocsolver.so.0", "librocsolver.so", "/opt/rocm/lib/librocsolver.so",
+                                               nullptr};
+    l.blas = open_first(blas_names);
+    l.solver = open_first(solver_names);
+    if (!l.blas || !l.solver) return l;
+    l.create_handle = reinterpret_cast<decltype(l.create_handle)>(dlsym(l.blas, "rocblas_create_handle"));
+    l.destroy_handle = reinterpret_cast<decltype(l.destroy_handle)>(dlsym(l.blas, "rocblas_destroy_handle"));
+    l.set_stream = reinterpret_cast<decltype(l.set_stream)>(dlsym(l.blas, "rocblas_set_stream"));
+    l.dgemm = reinterpret_cast<decltype(l.dgemm)>(dlsym(l.blas, "rocblas_dgemm"));
+    l.dsyevd = reinterpret_cast<decltype(l.dsyevd)>(dlsym(l.solver, "rocsolver_dsyevd"));
+    l.ok = l.create_handle && l.destroy_handle && l.set_stream && l.dgemm && l.dsyevd;
+    return l;
+  }();
+  return L;
+}
+
+// M_init blocks (4 x 4, column-major): diag[(N+1)][16], row0[N][16] = block (0, k), col0[N][16] = block (k, 0)
+struct InitBlocks {
+  const double* diag;
+  const double* row0;
+  const double* col0;
+};
+__device__ __forceinline__ double minit(const InitBlocks& b, int r, int c) {
+  const int br = r >> 2, bc = c >> 2, e = (c & 3) * 4 + (r & 3);
+  if (br == bc) return b.diag[br * 16 + e];
+  if (br == 0) return b.row0[(bc - 1) * 16 + e];
+  if (bc == 0) return b.col0[(br - 1) * 16 + e];
+  return 0.0;
+}
+
+__global__ void cert_init_kernel(InitBlocks b, int n, double* __restrict__ M) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= (int64_t)n * n) return;
+  M[k] = minit(b, (int)(k % n), (int)(k / n));
+}
+// A = (M + M^T) / 2
+__global__ void cert_sym_kernel(const double* __restrict__ M, int n, double* __restrict__ A) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= (int64_t)n * n) return;
+  const int r = (int)(k % n), c = (int)(k / n);
+  A[k] = (M[k] + M[(int64_t)r * n + c]) / 2;
+}
+// T[:, k] = V[:, k] * max(D[k], 0)
+__global__ void cert_scale_kernel(const double* __restrict__ V, const double* __restrict__ D, int n,
+                                  double* __restrict__ T) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= (int64_t)n * n) return;
+  const double d = D[k / n];
+  T[k] = V[k] * (d < 0 ? 0.0 : d);
+}
+// W = 2 M_psd - M - M_init
+__global__ void cert_w_kernel(const double* __restrict__ Mpsd, const double* __restrict__ M, InitBlocks b, int n,
+                              double* __restrict__ W) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= (int64_t)n * n) return;
+  W[k] = 2 * Mpsd[k] - M[k] - minit(b, (int)(k % n), (int)(k / n));
+}
+// pair (i, j), i < j, of N1 = N + 1 items -> row of b_W
+__device__ __forceinline__ int64_t pair_index(int i, int j, int N1) {
+  return (int64_t)i * N1 - (int64_t)i * (i + 1) / 2 + (j - i - 1);
+}
+// b_W rows (certification.cc:339-378): one thread per pair (i < N, j in (i, N])
+__global__ void cert_bw_kernel(const double* __restrict__ W, const double* __restrict__ thp, int N, int n,
+                               double* __restrict__ bW) {
+  const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y;
+  if (j <= i || j > N) return;
+  const int r0 = 4 * i, r3 = r0 + 3, c0 = 4 * j, c3 = c0 + 3;
+  const double tij = thp[i] * thp[j];
+  double* o = bW + 3 * pair_index(i, j, N + 1);
+  for (int k = 0; k < 3; ++k) {
+    const double C_ = W[(int64_t)(r0 + k) * n + r3], D_ = W[(int64_t)(r0 + k) * n + c3];
+    const double E_ = W[(int64_t)(c0 + k) * n + r3], F_ = W[(int64_t)(c0 + k) * n + c3];
+    o[k] = (-tij * C_ + D_) + (-E_ + tij * F_);
+  }
+}
+// b_W_dual = A_inv b_W without A_inv (certification.cc:538-657 defines column (i, j) of A_inv: rows (p, i) /
+// (i, p) carry +- y theta_j theta_p, rows (p, j) / (j, p) -+ y theta_i theta_p, the diagonal x).  Row (a, c):
+//   x b[(a,c)] + y theta_a sum_{j>c} theta_j b[(c,j)] - y theta_c sum_{j>a, j!=c} theta_j b[(a,j)]
+//   - y theta_a sum_{i<c, i!=a} theta_i b[(i,c)] + y theta_c sum_{i<a} theta_i b[(i,a)]
+__global__ void cert_ainv_apply_kernel(const double* __restrict__ bW, const double* __restrict__ thp, int N,
+                                       double* __restrict__ out) {
+  const int c = blockIdx.x * 64 + threadIdx.x, a = blockIdx.y;
+  if (c <= a || c > N) return;
+  const int N1 = N + 1;
+  const double y = 1.0 / (2 * (double)N + 6), x = ((double)N + 1.0) * y;
+  const double ta = thp[a], tc = thp[c];
+  const double* b0 = bW + 3 * pair_index(a, c, N1);
+  double acc[3] = {x * b0[0], x * b0[1], x * b0[2]};
+  for (int j = c + 1; j < N1; ++j) {
+    const double* b = bW + 3 * pair_index(c, j, N1);
+    const double f = y * thp[j] * ta;
+    for (int k = 0; k < 3; ++k) acc[k] += f * b[k];
+  }
+  for (int j = a + 1; j < N1; ++j) {
+    if (j == c) continue;
+    const double* b = bW + 3 * pair_index(a, j, N1);
+    const double f = y * thp[j] * tc;
+    for (int k = 0; k < 3; ++k) acc[k] -= f * b[k];
+  }
+  for (int i = 0; i < c; ++i) {
+    if (i == a) continue;
+    const double* b = bW + 3 * pair_index(i, c, N1);
+    const double f = y * thp[i] * ta;
+    for (int k = 0; k < 3; ++k) acc[k] -= f * b[k];
+  }
+  for (int i = 0; i < a; ++i) {
+    const double* b = bW + 3 * pair_index(i, a, N1);
+    const double f = y * thp[i] * tc;
+    for (int k = 0; k < 3; ++k) acc[k] += f * b[k];
+  }
+  double* o = out + 3 * pair_index(a, c, N1);
+  o[0] = acc[0];
+  o[1] = acc[1];
+  o[2] = acc[2];
+}
+// off-diagonal blocks of W_dual and their transposes (certification.cc:381-419); diagonal blocks zeroed
+__global__ void cert_wdual_offdiag_kernel(const double* __restrict__ W, const double* __restrict__ bWd, int N, int n,
+                                          double* __restrict__ Wd) {
+  const int j = blockIdx.x * 64 + threadIdx.x, i = blockIdx.y;
+  if (j > N) return;
+  if (j == i) {
+    for (int c = 0; c < 4; ++c)
+      for (int r = 0; r < 4; ++r) Wd[(int64_t)(4 * i + c) * n + 4 * i + r] = 0.0;
+    return;
+  }
+  if (j < i) return;
+  const double* y = bWd + 3 * pair_index(i, j, N + 1);
+  for (int c = 0; c < 4; ++c)
+    for (int r = 0; r < 4; ++r) {
+      double v = (W[(int64_t)(4 * j + c) * n + 4 * i + r] - W[(int64_t)(4 * j + r) * n + 4 * i + c]) / 2;
+      if (c == 3 && r < 3) v = y[r];
+      if (r == 3 && c < 3) v = -y[c];
+      Wd[(int64_t)(4 * j + c) * n + 4 * i + r] = v;  // block (i, j)
+      Wd[(int64_t)(4 * i + r) * n + 4 * j + c] = v;  // block (j, i) = transpose
+    }
+}
+// diagonal blocks (certification.cc:421-438): one 64-thread workgroup per block row i
+__global__ __launch_bounds__(64) void cert_wdual_diag_kernel(const double* __restrict__ W,
+                                                             const double* __restrict__ thp, int N, int n,
+                                                             double* __restrict__ Wd, double* __restrict__ w33) {
+  const int i = blockIdx.x, lane = threadIdx.x;
+  double rs[4] = {0, 0, 0, 0};
+  for (int k = lane; k <= N; k += 64) {  // (block (i, i) holds zeros here)
+    const double t = thp[k];
+    for (int r = 0; r < 4; ++r) rs[r] += t * Wd[(int64_t)(4 * k + 3) * n + 4 * i + r];
+  }
+  for (int r = 0; r < 4; ++r)
+    for (int o = 32; o > 0; o >>= 1) rs[r] += __shfl_xor(rs[r], o, 64);
+  __syncthreads();
+  if (lane < 16) {
+    const int r = lane & 3, c = lane >> 2;
+    double v = W[(int64_t)(4 * i + c) * n + 4 * i + r];
+    const double ti = thp[i];
+    if (c == 3) v = -ti * rs[r];
+    if (r == 3) v = -ti * rs[c];
+    Wd[(int64_t)(4 * i + c) * n + 4 * i + r] = v;
+    if (r < 3 && c < 3) w33[9 * i + 3 * c + r] = v;
+  }
+}
+// subtract the mean of the diagonal blocks' top-left 3 x 3 (certification.cc:439-451); sums in block order
+__global__ __launch_bounds__(64) void cert_wdual_mean_kernel(const double* __restrict__ w33, int N, int n,
+                                                             double* __restrict__ Wd) {
+  __shared__ double mean[9];
+  if (threadIdx.x < 9) {
+    double s = 0;
+    for (int i = 0; i <= N; ++i) s += w33[9 * i + threadIdx.x];
+    mean[threadIdx.x] = s / (N + 1);
+  }
+  __syncthreads();
+  for (int i = blockIdx.x * 64 + threadIdx.x; i <= N; i += gridDim.x * 64)
+    for (int c = 0; c < 3; ++c)
+      for (int r = 0; r < 3; ++r) Wd[(int64_t)(4 * i + c) * n + 4 * i + r] -= mean[3 * c + r];
+}
+// M_affine = M_init + W_dual
+__global__ void cert_affine_kernel(const double* __restrict__ Wd, InitBlocks b, int n, double* __restrict__ Maff) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= (int64_t)n * n) return;
+  Maff[k] = minit(b, (int)(k % n), (int)(k / n)) + Wd[k];
+}
+// M += gamma (M_affine - M_psd)
+__global__ void cert_update_kernel(const double* __restrict__ Maff, const double* __restrict__ Mpsd, double gamma,
+                                   int n, double* __restrict__ M) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= (int64_t)n * n) return;
+  M[k] += gamma * (Maff[k] - Mpsd[k]);
+}
+
+}  // namespace
+
+// src / dst: N points, xyz interleaved (= the 3 x N column-major matrices of the reference); R row-major.
+// Returns 0, or -1 (rocSOLVER / rocBLAS not loadable), -2 (HIP error), -3 (library call failed).
+int certify_on_device(hipStream_t s, const double* R, const double* src, const double* dst, const double* theta, int N,
+                      double noise_bound, double cbar2, double sub_optimality, double max_iterations,
+                      double gamma_tau, int* is_optimal, double* best_suboptimality, std::vector<double>* traj) {
+  traj->clear();
+  *is_optimal = 0;
+  *best_suboptimality = INFINITY;
+  if (N < 1) return 0;
+  CertLibs& L = cert_libs();
+  if (!L.ok) return -1;
+  const int n = 4 + 4 * N;
+  // ---- O(N) set-up on the host (cert_setup.h) ---------------------------------------------------------------
+  std::vector<double> thp, diag, row0, col0;
+  double mu = 0;
+  cert_setup(R, src, dst, theta, N, noise_bound, cbar2, &thp, &diag, &row0, &col0, &mu);
+
+  // ---- device buffers ------------------------------------------------------------------------------------
+  const size_t nn = (size_t)n * (size_t)n;
+  const int64_t pairs = (int64_t)(N + 1) * N / 2;
+  double *dM = nullptr, *dPsd = nullptr, *dW = nullptr, *dWd = nullptr, *dAff = nullptr, *dA = nullptr, *dT = nullptr;
+  double *dD = nullptr, *dE = nullptr, *dBlk = nullptr, *dThp = nullptr, *dbW = nullptr, *dbWd = nullptr, *dw33 = nullptr;
+  rocblas_int* dInfo = nullptr;
+  rocblas_handle hb = nullptr;
+  int rc = 0;
+  auto fail = [&](int code) { rc = code; };
+#define CERT_HIP(x)               \
+  do {                            \
+    if (rc == 0 && (x) != hipSuccess) fail(-2); \
+  } while (0)
+  CERT_HIP(hipMalloc(&dM, nn * 8));
+  CERT_HIP(hipMalloc(&dPsd, nn * 8));
+  CERT_HIP(hipMalloc(&dW, nn * 8));
+  CERT_HIP(hipMalloc(&dWd, nn * 8));
+  CERT_HIP(hipMalloc(&dAff, nn * 8));
+  CERT_HIP(hipMalloc(&dA, nn * 8));
+  CERT_HIP(hipMalloc(&dT, nn * 8));
+  CERT_HIP(hipMalloc(&dD, (size_t)n * 8));
+  CERT_HIP(hipMalloc(&dE, (size_t)n * 8));
+  CERT_HIP(hipMalloc(&dInfo, sizeof(rocblas_int)));
+  const size_t blk_doubles = (size_t)(N + 1) * 16 + 2 * (size_t)N * 16;
+  CERT_HIP(hipMalloc(&dBlk, blk_doubles * 8));
+  CERT_HIP(hipMalloc(&dThp, (size_t)(N + 1) * 8));
+  CERT_HIP(hipMalloc(&dbW, (size_t)std::max<int64_t>(pairs, 1) * 24));
+  CERT_HIP(hipMalloc(&dbWd, (size_t)std::max<int64_t>(pairs, 1) * 24));
+  CERT_HIP(hipMalloc(&dw33, (size_t)(N + 1) * 72));
+  if (rc == 0) {
+    CERT_HIP(hipMemcpyAsync(dBlk, diag.data(), diag.size() * 8, hipMemcpyHostToDevice, s));
+    CERT_HIP(hipMemcpyAsync(dBlk + diag.size(), row0.data(), row0.size() * 8, hipMemcpyHostToDevice, s));
+    CERT_HIP(hipMemcpyAsync(dBlk + diag.size() + row0.size(), col0.data(), col0.size() * 8, hipMemcpyHostToDevice, s));
+    CERT_HIP(hipMemcpyAsync(dThp, thp.data(), thp.size() * 8, hipMemcpyHostToDevice, s));
+    CERT_HIP(hipStreamSynchronize(s));  // (the host vectors are pageable)
+  }
+  if (rc == 0 && (L.create_handle(&hb) != rocblas_status_success || L.set_stream(hb, s) != rocblas_status_success)) fail(-3);
+  if (rc == 0) {
+    InitBlocks ib{dBlk, dBlk + diag.size(), dBlk + diag.size() + row0.size()};
+    const dim3 g1((unsigned)((nn + 255) / 256)), b1(256);
+    const dim3 gp((unsigned)((N + 1 + 63) / 64), (unsigned)(N + 1));
+    const double one = 1.0, zero = 0.0;
+    double best = INFINITY;
+    hipLaunchKernelGGL(cert_init_kernel, g1, b1, 0, s, ib, n, dM);
+    const int iters = (int)max_iterations;
+    for (int it = 0; it < iters && rc == 0; ++it) {
+      // nearest PSD matrix of M (linalg.h:85-99)
+      hipLaunchKernelGGL(cert_sym_kernel, g1, b1, 0, s, dM, n, dA);
+      if (L.dsyevd(hb, rocblas_evect_original, rocblas_fill_upper, n, dA, n, dD, dE, dInfo) != rocblas_status_success) {
+        fail(-3);
+        break;
+      }
+      hipLaunchKernelGGL(cert_scale_kernel, g1, b1, 0, s, dA, dD, n, dT);
+      if (L.dgemm(hb, rocblas_operation_none, rocblas_operation_transpose, n, n, n, &one, dT, n, dA, n, &zero, dPsd, n) !=
+          rocblas_status_success) {
+        fail(-3);
+        break;
+      }
+      hipLaunchKernelGGL(cert_w_kernel, g1, b1, 0, s, dPsd, dM, ib, n, dW);
+      // projection onto the affine dual subspace (certification.cc:323-452)
+      hipLaunchKernelGGL(cert_bw_kernel, gp, dim3(64), 0, s, dW, dThp, N, n, dbW);
+      hipLaunchKernelGGL(cert_ainv_apply_kernel, gp, dim3(64), 0, s, dbW, dThp, N, dbWd);
+      hipLaunchKernelGGL(cert_wdual_offdiag_kernel, gp, dim3(64), 0, s, dW, dbWd, N, n, dWd);
+      hipLaunchKernelGGL(cert_wdual_diag_kernel, dim3((unsigned)(N + 1)), dim3(64), 0, s, dW, dThp, N, n, dWd, dw33);
+      hipLaunchKernelGGL(cert_wdual_mean_kernel, dim3((unsigned)std::min(64, (N + 64) / 64)), dim3(64), 0, s, dw33, N, n,
+                         dWd);
+      hipLaunchKernelGGL(cert_affine_kernel, g1, b1, 0, s, dWd, ib, n, dAff);
+      // sub-optimality gap (certification.cc:192-231): smallest eigenvalue of sym(M_affine)
+      hipLaunchKernelGGL(cert_sym_kernel, g1, b1, 0, s, dAff, n, dA);
+      if (L.dsyevd(hb, rocblas_evect_none, rocblas_fill_upper, n, dA, n, dD, dE, dInfo) != rocblas_status_success) {
+        fail(-3);
+        break;
+      }
+      double min_eig = 0;
+      CERT_HIP(hipMemcpyAsync(&min_eig, dD, 8, hipMemcpyDeviceToHost, s));  // ascending order: D[0]
+      CERT_HIP(hipStreamSynchronize(s));
+      if (rc != 0) break;
+      const double gap = (min_eig > 0) ? 0.0 : (-min_eig * (N + 1)) / mu;
+      traj->push_back(gap);
+      if (gap < best) best = gap;
+      if (gap < sub_optimality) break;
+      hipLaunchKernelGGL(cert_update_kernel, g1, b1, 0, s, dAff, dPsd, gamma_tau, n, dM);
+    }
+    if (rc == 0 && hipGetLastError() != hipSuccess) fail(-2);
+    *best_suboptimality = best;
+    *is_optimal = best < sub_optimality ? 1 : 0;
+  }
+#undef CERT_HIP
+  if (hb) (void)L.destroy_handle(hb);
+  for (void* p : {(void*)dM, (void*)dPsd, (void*)dW, (void*)dWd, (void*)dAff, (void*)dA, (void*)dT, (void*)dD, (void*)dE,
+                  (void*)dInfo, (void*)dBlk, (void*)dThp, (void*)dbW, (void*)dbWd, (void*)dw33})
+    if (p) (void)hipFree(p);
+  return rc;
+}
+
+}  // namespace thip

@@ -1532,7 +1532,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
     const int csize = greedy_one_start<kGreedyThreads>(descs, bitmap, deg, states, start_cliques, total_n, smem, sidx);
     if (gridDim.x >= kMaxStarts) break;  // every start has its own workgroup: nothing left to skip
     // closure test: the peel at threshold csize, in LDS (the start's P / U bitsets are free again)
-    const int W = d.W, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int W = d.W, tid = threadIdx.x;
     uint64_t* Pa = reinterpret_cast<uint64_t*>(smem);
     uint64_t* Pb = Pa + ((W + 1) & ~1);
     const uint64_t* bm = bitmap + d.bm_off;

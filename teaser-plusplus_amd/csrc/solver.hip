@@ -1905,6 +1905,46 @@ int32_t teaser_hip_compute_fpfh(teaser_hip_solver* h, const float* cloud_xyz, in
   return TEASER_HIP_OK;
 }
 
+int32_t teaser_hip_certifier_params_default(teaser_certifier_params_c* p) {
+  if (!p) return TEASER_HIP_ERR_BAD_ARG;
+  p->noise_bound = 0.01;  // certification.h:75-99
+  p->cbar2 = 1;
+  p->sub_optimality = 1e-3;
+  p->max_iterations = 2e2;
+  p->gamma_tau = 1.999999;
+  return TEASER_HIP_OK;
+}
+
+int32_t teaser_hip_certify(teaser_hip_solver* h, const teaser_certifier_params_c* p, const double* R,
+                           const double* src, const double* dst, const double* theta, int32_t n,
+                           teaser_certification_c* out, double* traj, int32_t traj_cap) {
+  if (!h || !p || !R || !out || n < 0 || (n > 0 && (!src || !dst || !theta))) return TEASER_HIP_ERR_BAD_ARG;
+  if (n > 8000) {  // (4 + 4n)^2 doubles x 7 matrices beyond ~57 GB; the reference itself is dense O(n^2) memory
+    h->err = "teaser_hip_certify: more than 8000 correspondences";
+    return TEASER_HIP_ERR_UNSUPPORTED;
+  }
+  if (hipSetDevice(h->device) != hipSuccess) return TEASER_HIP_ERR_HIP;
+  std::vector<double> t;
+  int opt = 0;
+  double best = INFINITY;
+  const int rc = thip::certify_on_device(h->stream, R, src, dst, theta, n, p->noise_bound, p->cbar2, p->sub_optimality,
+                                         p->max_iterations, p->gamma_tau, &opt, &best, &t);
+  if (rc == -1) {
+    h->err = "teaser_hip_certify: librocsolver / librocblas could not be loaded (symmetric eigensolver)";
+    return TEASER_HIP_ERR_UNSUPPORTED;
+  }
+  if (rc != 0) {
+    h->err = rc == -2 ? "teaser_hip_certify: HIP error" : "teaser_hip_certify: rocSOLVER / rocBLAS call failed";
+    return TEASER_HIP_ERR_HIP;
+  }
+  out->is_optimal = opt;
+  out->iterations = (int32_t)t.size();
+  out->best_suboptimality = best;
+  if (traj)
+    for (size_t k = 0; k < t.size() && (int32_t)k < traj_cap; ++k) traj[k] = t[k];
+  return TEASER_HIP_OK;
+}
+
 int32_t teaser_hip_match_features(teaser_hip_solver* h, const float* src_feat, int32_t n_src,
                                   const float* dst_feat, int32_t n_dst, int32_t dim, int32_t use_crosscheck,
                                   int32_t* pairs, int64_t* n_pairs) {

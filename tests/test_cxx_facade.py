@@ -158,3 +158,32 @@ def test_fpfh_example_registers_on_gpu(tmp_path):
     exe = build_fpfh_example()
     out = subprocess.run([exe, object_ply(str(tmp_path / "object.ply"))], capture_output=True, text=True, timeout=180)
     assert out.returncode == 0, out.stdout + out.stderr
+
+
+# --- teaser/certification.h ---------------------------------------------------------------------------
+CERT_SRC = os.path.join(ROOT, "tests", "cxx", "certifier_example.cpp")
+CERT_EXE = os.path.join(ROOT, "tests", "cxx", "certifier_example")
+
+
+def build_certifier_example():
+    if not os.path.exists(os.path.join(LIBDIR, "libteaser_hip.so")):
+        pytest.skip("libteaser_hip.so not built (run __graft_entry__.build())")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           CERT_SRC, "-o", CERT_EXE, "-L" + LIBDIR, "-lteaser_hip", "-Wl,-rpath," + LIBDIR,
+                           "-Wl,-rpath,/opt/rocm/lib"])
+    return CERT_EXE
+
+
+def test_certifier_facade_compiles_and_fails_loudly_without_gpu():
+    exe = build_certifier_example()
+    rc = subprocess.call([exe], stdout=subprocess.DEVNULL)
+    import importlib
+    tp = importlib.import_module("teaser-plusplus_amd")
+    assert rc == (0 if tp.device_count() > 0 else 77)
+
+
+@pytest.mark.gpu
+def test_certifier_facade_on_gpu():
+    exe = build_certifier_example()
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0, out.stdout + out.stderr
