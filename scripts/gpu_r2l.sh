@@ -1,7 +1,8 @@
 #!/bin/bash
-# session L: GPU certifier vs the reference's fixtures and the oracle
+# session L (final): the whole GPU suite incl. the certifier, then the bench line
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r2l
 export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/r2l
-timeout 200 python -m pytest tests/test_gpu_certifier.py -m gpu -q --timeout=150 --durations=8 > $OUT/tests_cert.log 2>&1; echo "certifier tests rc=$?"; tail -25 $OUT/tests_cert.log | cut -c1-220
-timeout 60 python -m pytest tests/test_cxx_facade.py -m gpu -q --timeout=60 -k certifier > $OUT/tests_cert_cxx.log 2>&1; echo "cxx rc=$?"; tail -3 $OUT/tests_cert_cxx.log | cut -c1-220
+timeout 120 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $OUT/smoke.log
+timeout 400 python -m pytest tests -m gpu -q --timeout=200 > $OUT/tests.log 2>&1; echo "tests rc=$?"; tail -3 $OUT/tests.log
+timeout 120 python bench.py --no-cpu-baseline --no-host-resident > $OUT/bench.log 2>&1; tail -1 $OUT/bench.log | cut -c1-330
