@@ -709,13 +709,22 @@ class CertificationC(C.Structure):
     _fields_ = [("is_optimal", C.c_int32), ("iterations", C.c_int32), ("best_suboptimality", C.c_double)]
 
 
+class EigSolverType(enum.IntEnum):  # certification.h:62-65, teaserpp_python.cc:71-74
+    EIGEN = 0
+    SPECTRA = 1
+
+
 class CertificationResult:
     """teaser::CertificationResult (reference teaser/include/teaser/certification.h:21-25)."""
 
-    def __init__(self, is_optimal, best_suboptimality, suboptimality_traj):
+    def __init__(self, is_optimal=False, best_suboptimality=-1.0, suboptimality_traj=()):
         self.is_optimal = bool(is_optimal)
         self.best_suboptimality = float(best_suboptimality)
         self.suboptimality_traj = suboptimality_traj
+
+    def __repr__(self):  # teaserpp_python.cc:254-263
+        return ("<CertificationResult \nis_optimal=%s\nbest_suboptimality=%s\n>"
+                % (self.is_optimal, self.best_suboptimality))
 
 
 class DRSCertifier:
@@ -725,12 +734,13 @@ class DRSCertifier:
 
     class Params:  # certification.h:71-104
         def __init__(self, noise_bound=0.01, cbar2=1.0, sub_optimality=1e-3, max_iterations=2e2,
-                     gamma_tau=1.999999):
+                     gamma_tau=1.999999, eig_decomposition_solver=EigSolverType.EIGEN):
             self.noise_bound = noise_bound
             self.cbar2 = cbar2
             self.sub_optimality = sub_optimality
             self.max_iterations = max_iterations
             self.gamma_tau = gamma_tau
+            self.eig_decomposition_solver = eig_decomposition_solver  # accepted; the device solver is dense
 
     def __init__(self, params=None, device=-1, **kw):
         self.params = params if params is not None else DRSCertifier.Params(**kw)

@@ -300,6 +300,12 @@ def test_python_mirror_names_and_tim_helper():
     assert int(t.RotationEstimationAlgorithm.QUATRO) == 2 and int(t.InlierSelectionMode.NONE) == 3
     assert int(t.InlierGraphFormulation.COMPLETE) == 1 and t.OMP_MAX_THREADS >= 1
     assert t.RobustRegistrationSolver.ROTATION_ESTIMATION_ALGORITHM is t.RotationEstimationAlgorithm
+    # the certifier names of teaserpp_python.cc:71-74, 249-291 (defaults: certification.h:71-104)
+    cp = t.DRSCertifier.Params()
+    assert (cp.noise_bound, cp.cbar2, cp.sub_optimality, cp.max_iterations, cp.gamma_tau) == \
+        (0.01, 1, 1e-3, 2e2, 1.999999)
+    assert cp.eig_decomposition_solver == t.EigSolverType.EIGEN and int(t.EigSolverType.SPECTRA) == 1
+    assert "is_optimal=False" in repr(t.CertificationResult())
     rng = np.random.default_rng(5)
     v = rng.normal(size=(3, 37))
     tims, mp = oracle.compute_tims(v)
