@@ -119,7 +119,7 @@ def roofline_object(k1_ms, k1_launches, k1_bytes, k1_pairs, k1_aux_ms, traffic, 
                 "the kernel alone; peak = dense FP64 peak (matrix = vector = 78.6 TFLOP/s).  The kernel computes "
                 "the same decisions with an exact bf16-split MFMA + f32 filter and an FP64 fix-up, so this is "
                 "speed relative to the algorithm as specified, not issued FP64 work (see executed_mfma); it is "
-                "bound by its packed-f32 VALU epilogue (DESIGN.md 3).  With --depth > 1 the kernel shares the GPU "
+                "bound by the per-tile chain MFMA -> f32 epilogue -> bit plumbing of each wave (DESIGN.md 3).  With --depth > 1 the kernel shares the GPU "
                 "with the latency-bound tail kernels of the previous batch, which is included in its time",
         "executed_mfma": {"achieved": mfma_tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                           "frac": mfma_tf / MFMA_BF16_PEAK_TF,
