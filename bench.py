@@ -7,29 +7,37 @@ N > 1: the script re-launches ITSELF as N ranks (one process per GPU) under
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`; when it is
 already running under torch.distributed.run (RANK / WORLD_SIZE set) it uses those ranks.
 
-Workload (BASELINE.json configs[1], the configuration the metric is quoted on): synthetic
-N = 10 000 correspondences, 95 % outliers, noise_bound 0.01, estimate_scaling = false, GNC-TLS
-(SURVEY.md 8(d)).  One STEP = one batched pass of the whole hot path (TIM build + pruning ->
-adjacency bitmap -> max clique -> GNC-TLS rotation -> TLS translation) over `--batch` independent
-problems; EVERY step sees problems it has not seen before (steps + warmup distinct seeded batches).
-`value` is measured with the point arrays already resident in HBM when the timed region starts (the
-bench contract); the same loop fed from page-locked HOST memory, H2D inside the timer (SURVEY.md
-8(d)'s timer scope), is reported next to it as config.host_resident.  Steps are submitted through
-the library's asynchronous batch API (teaser_hip_submit_batch / teaser_hip_wait, `--depth` batches in
-flight from ONE host thread), which is how a throughput caller drives it: the host enqueues batch
-k+1 while the GPU runs batch k.  Multi-GPU: problems are independent, so each rank owns its own
-problems (weak scaling, no data-path collective); the fixed-size result records are all-gathered over
-RCCL at the end, inside the timed region.
+Top-level line = BASELINE.json configs[1] (synthetic N = 10 000 correspondences, 95 % outliers, one MI355X:
+the largest single-GPU configuration the metric is quoted on).  One STEP = one batched pass of the whole hot
+path (TIM build + pruning -> adjacency bitmap -> max clique -> GNC-TLS rotation -> TLS translation) over
+`--batch` independent problems; EVERY step sees problems it has not seen before.  `value` is measured with the
+point arrays already resident in HBM when the timed region starts (the bench contract); the same loop fed from
+page-locked HOST memory, H2D inside the timer (SURVEY.md 8(d)'s timer scope), is reported next to it as
+config.host_resident.  Steps go through the library's asynchronous batch API (teaser_hip_submit_batch /
+teaser_hip_wait, `--depth` batches on the lanes, plus one staged host batch whose copy runs on the copy stream).
+Multi-GPU: problems are independent, so each rank owns its own problems (weak scaling, no data-path
+collective); the fixed-size result records are all-gathered over RCCL at the end, inside the timed region.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline     -- K1 (tim_graph_mfma_kernel, the dominant kernel), from HIP events recorded around
-                  that kernel alone on the stream it runs on, during the timed region: algorithmic
-                  flops (20 FP64 flop per pair) against the dense FP64 peak at the top
-                  level; the issued bf16 MFMA work and the HBM view (algorithmic bytes 48 n +
-                  8 n ceil(n/64) per problem, PMC traffic) are nested beside it.
-  cpu_baseline -- the CPU oracle (a port of the reference path; the reference itself cannot be
-                  built here: no Eigen3 / pmc) timed on a bounded sample of the same workload, in its
-                  streaming form and in the reference-faithful materialising form.
+The `configs` object carries one driver-run line for each of the other GPU configurations of BASELINE.json
+(SURVEY.md 8(d)):
+  config4 -- one GPU's share of the 1024 x N = 5 000 batch, 90 % outliers: 128 problems per step (the metric's
+             "90 % outliers" rate);
+  config3 -- N = 50 000, 99 % outliers, one problem per step (stresses the O(N^2) TIM build and the clique stage);
+  config5 -- the 3DMatch pair of examples/teaser_python_fpfh_icp with real FPFH correspondences, batched: 64
+             perturbed copies of the two clouds per step (front-end on the GPU, timed separately).
+Each line: ms/step and registrations/s as the median of `--repeats` timed regions of its own step count, the
+roofline of K1 from HIP events inside those regions, the per-stage device times of one profiled step, and a
+cpu_baseline (N = 1 only).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with:
+  roofline     -- K1 (tim_graph_mfma_kernel, the dominant kernel), from HIP events recorded around that kernel
+                  alone on the stream it runs on, during the timed region: algorithmic flops (20 FP64 flop per
+                  pair) against the dense FP64 peak at the top level; what the kernel actually
+                  issues (bf16 MFMA + f32 VALU) and the HBM view (algorithmic bytes 48 n + 8 n ceil(n/64) per
+                  problem, PMC traffic) are nested beside it.
+  cpu_baseline -- the CPU oracle (a port of the reference path; the reference itself cannot be built here: no
+                  Eigen3 / pmc) timed on a bounded sample of the same workload, in its streaming form and in
+                  the reference-faithful materialising form.
 """
 import argparse
 import collections
@@ -52,26 +60,30 @@ FP64_PEAK_TF = 78.6        # dense FP64 peak of MI355X (matrix =
 K1_FLOPS_PER_PAIR = 20.0   # algorithmic FP64 flops of the reference predicate
 # executed by K1 per pair: 4 x v_mfma_f32_32x32x16_bf16 (2*32*32*16 flops each) per 1024 pairs
 K1_MFMA_FLOPS_PER_PAIR = 4 * 2 * 32 * 32 * 16 / 1024.0
+DTYPE = "bf16x3-split MFMA + f32 filter with FP64 fix-up for K1 (bitmap bit-identical to FP64); f64 estimators"
 
 
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="independent problems per step and per GPU")
     ap.add_argument("--n", type=int, default=10000)
     ap.add_argument("--outlier-ratio", type=float, default=0.95)
     ap.add_argument("--noise-bound", type=float, default=0.01)
     ap.add_argument("--pool", type=int, default=0,
-                    help="distinct batches (0: steps + warmup, capped at 48: every step sees new problems)")
+                    help="distinct batches (0: steps + warmup, capped at 32: every step sees new problems)")
     ap.add_argument("--seed", type=int, default=20250523)
     ap.add_argument("--depth", type=int, default=2,
-                    help="batches in flight (teaser_hip_submit_batch / teaser_hip_wait lanes, one HIP stream "
-                         "each, fed from ONE host thread): the host enqueues batch k+1 while the GPU runs batch "
-                         "k, and the latency-bound tail of batch k (clique, GNC, TLS: one workgroup per problem) "
-                         "shares the GPU with batch k+1's K1 (2 is that pattern exactly; more only adds contention).  "
+                    help="batches on the lanes (teaser_hip_submit_batch / teaser_hip_wait, one HIP stream each, "
+                         "fed from ONE host thread): the host enqueues batch k+1 while the GPU runs batch k, and "
+                         "the latency-bound tail of batch k (clique, GNC, TLS: one workgroup per problem) shares "
+                         "the GPU with batch k+1's K1 (2 is that pattern exactly; more only adds contention).  "
                          "1 = strictly one batch at a time")
+    ap.add_argument("--configs", default="4,3,5",
+                    help="other BASELINE configurations to run after the top-level one ('' = none)")
+    ap.add_argument("--repeats", type=int, default=3, help="timed regions per `configs` line (median reported)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-resident", action="store_true",
                     help="skip the second timed loop fed from page-locked host memory")
@@ -84,13 +96,14 @@ def parse(argv=None):
     return ap.parse_args(argv)
 
 
-def solver_params(tp, nb):
-    return tp.RobustRegistrationSolver.Params(
-        noise_bound=nb, cbar2=1.0, estimate_scaling=False, rotation_gnc_factor=1.4,
-        rotation_max_iterations=100, rotation_cost_threshold=0.005)
+def solver_params(tp, nb, **kw):
+    p = dict(noise_bound=nb, cbar2=1.0, estimate_scaling=False, rotation_gnc_factor=1.4,
+             rotation_max_iterations=100, rotation_cost_threshold=0.005)
+    p.update(kw)
+    return tp.RobustRegistrationSolver.Params(**p)
 
 
-def roofline_object(k1_ms, k1_launches, k1_bytes, k1_pairs, k1_aux_ms, traffic, traffic_src):
+def roofline_object(k1_ms, k1_launches, k1_bytes, k1_pairs, k1_aux_ms, traffic, traffic_src, issue=None):
     """roofline of the dominant kernel (K1) from the HIP-event totals of the timed region.
 
     Top level, as the bench contract defines it: ALGORITHMIC work per launch (20 FP64
@@ -98,7 +111,7 @@ def roofline_object(k1_ms, k1_launches, k1_bytes, k1_pairs, k1_aux_ms, traffic, 
     FP64 peak (78.6 TFLOP/s on MI355X, matrix = vector).  The kernel is compute-side, so the bound is
     the arithmetic peak, not HBM; it does NOT execute those FP64 flops -- it evaluates the predicate
     as an exact-bf16-split MFMA + f32 filter with an FP64 fix-up -- so what it actually issues is
-    reported next to it (`executed_mfma`), as is the HBM view (`hbm`)."""
+    reported next to it (`executed_mfma`, `issue`), as is the HBM view (`hbm`)."""
     launches = max(k1_launches, 1)
     k1_avg_s = (k1_ms / launches) * 1e-3
     bytes_per_launch = k1_bytes / launches
@@ -116,39 +129,60 @@ def roofline_object(k1_ms, k1_launches, k1_bytes, k1_pairs, k1_aux_ms, traffic, 
         "pairs_per_launch": pairs_per_launch,
         "aux_ms_per_launch": k1_aux_ms / launches,
         "note": "achieved = 20 FP64 flop/pair (SURVEY.md 8(d), the reference predicate) x pairs / HIP-event time of "
-                "the kernel alone; peak = dense FP64 peak (matrix = vector = 78.6 TFLOP/s).  The kernel computes "
-                "the same decisions with an exact bf16-split MFMA + f32 filter and an FP64 fix-up, so this is "
-                "speed relative to the algorithm as specified, not issued FP64 work (see executed_mfma); it is "
-                "bound by the per-tile chain MFMA -> f32 epilogue -> bit plumbing of each wave (DESIGN.md 3).  With --depth > 1 the kernel shares the GPU "
-                "with the latency-bound tail kernels of the previous batch, which is included in its time",
+                "the kernel alone; peak = dense FP64 peak (matrix = vector = 78.6 TFLOP/s): an algorithm-equivalent "
+                "rate.  The kernel issues NO FP64: it decides the same predicate with an exact bf16-split MFMA + f32 "
+                "VALU filter and an FP64 fix-up (bitmap bit-identical), so the pipes it really loads are "
+                "`executed_mfma` (bf16 matrix pipe) and `issue` (VALU instruction issue, its actual bound: "
+                "DESIGN.md 3).  With --depth > 1 the kernel shares the GPU with the latency-bound tail kernels of "
+                "the previous batch, which is included in its time",
         "executed_mfma": {"achieved": mfma_tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                           "frac": mfma_tf / MFMA_BF16_PEAK_TF,
                           "flops_per_launch": K1_MFMA_FLOPS_PER_PAIR * pairs_per_launch,
                           "note": "issued bf16 MFMA flops: 4 x v_mfma_f32_32x32x16_bf16 per 1024 pairs = 128/pair"},
+        "issue": issue,
         "hbm": {"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "traffic_bytes_per_launch": traffic, "traffic_source": traffic_src},
     }
 
 
-def k1_traffic(batch, n):
-    """HBM bytes per K1 launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE are
-    collected in SEPARATE runs of this same command, profiles/<round>/pmc_traffic.json, with the
-    gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md); null when no pass matches this shape."""
+def _latest_profile_json(name, pred):
+    """newest profiles/<round>/<name> whose kernel entries satisfy pred (committed rocprofv3 summaries)."""
     import glob
     best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json"))):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", name))):
         try:
             doc = json.load(open(path))
         except Exception:
             continue
         for k in doc.get("kernels", []):
-            if "tim_graph_mfma_kernel" in k["kernel"] and k.get("batch") == batch and k.get("n") == n:
-                best = (k["hbm_bytes_per_launch"], os.path.relpath(path, ROOT))
-    return best if best else (None, None)
+            if pred(k):
+                best = (k, os.path.relpath(path, ROOT))
+    return best
 
 
-def cpu_baseline(tp, args):
+def k1_traffic(batch, n):
+    """HBM bytes per K1 launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE are
+    collected in SEPARATE runs of this same command, profiles/<round>/pmc_traffic.json, with the
+    gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md); null when no pass matches this shape."""
+    hit = _latest_profile_json("pmc_traffic.json", lambda k: "tim_graph_mfma_kernel" in k["kernel"] and
+                               k.get("batch") == batch and k.get("n") == n)
+    return (hit[0]["hbm_bytes_per_launch"], hit[1]) if hit else (None, None)
+
+
+def k1_issue():
+    """What bounds K1: VALU / matrix-pipe busy fractions from the committed SQ-counter pass
+    (profiles/<round>/k1_sq_counters.json; counters cannot be collected inside a timed run)."""
+    hit = _latest_profile_json("k1_sq_counters.json", lambda k: "tim_graph_mfma_kernel" in k.get("kernel", ""))
+    if not hit:
+        return None
+    k, src = hit
+    keep = {f: k[f] for f in ("valu_busy_frac", "mfma_busy_frac", "valu_insts_per_1024_pairs",
+                              "wave_issue_frac", "wave_wait_frac", "wave_stall_frac") if f in k}
+    return dict(keep, source=src) if keep else None
+
+
+def cpu_baseline(tp, n, outlier_ratio, nb, seed, max_solves, budget_s, problems=None, extra_kw=None):
     """Oracle (kind = port: the reference needs Eigen3 + pmc, absent here) on a bounded sample of the
     same workload, all host cores, built gcc -O3 -fopenmp without -march=native (the reference's
     default flags, CMakeLists.txt:27).  Two forms, SURVEY.md 8(d): (i) STREAMING -- no TIM storage,
@@ -158,36 +192,45 @@ def cpu_baseline(tp, args):
     from oracle import oracle
 
     cores = os.cpu_count() or 1
-    kw = dict(noise_bound=args.noise_bound, cbar2=1.0, estimate_scaling=0, rotation_gnc_factor=1.4,
+    kw = dict(noise_bound=nb, cbar2=1.0, estimate_scaling=0, rotation_gnc_factor=1.4,
               rotation_max_iterations=100, rotation_cost_threshold=0.005, max_clique_num_threads=cores)
+    kw.update(extra_kw or {})
 
-    def run(materialise, max_solves, budget_s):
+    def problem(i):
+        if problems is not None:
+            return problems[i % len(problems)]
+        pr = tp.synth_problem(seed + 100000 + i, n, outlier_ratio, nb)
+        return pr["src"], pr["dst"]
+
+    def run(materialise, count, budget):
         times = []
         t_all = time.perf_counter()
-        for i in range(max_solves):
-            pr = tp.synth_problem(args.seed + 100000 + i, args.n, args.outlier_ratio, args.noise_bound)
+        for i in range(count):
+            s, d = problem(i)
             t0 = time.perf_counter()
-            o = oracle.solve(pr["src"], pr["dst"], materialise=materialise, **kw)
+            o = oracle.solve(s, d, materialise=materialise, **kw)
             times.append(time.perf_counter() - t0)
             assert o["valid"]
-            if time.perf_counter() - t_all > budget_s:
+            if time.perf_counter() - t_all > budget:
                 break
         return times
 
     run(False, 1, 0.0)  # warm-up (OpenMP pool, page faults)
-    ts = run(False, args.cpu_solves, 10.0)
+    ts = run(False, max_solves, budget_s)
     med = float(np.median(ts))
+    what = ("N=%d, %.0f%% outliers" % (n, 100 * outlier_ratio)) if problems is None else \
+        "%d-%d correspondences (real descriptors)" % (min(p[0].shape[1] for p in problems),
+                                                      max(p[0].shape[1] for p in problems))
     out = {"value": 1.0 / med, "unit": "registrations/s", "cores": cores, "kind": "port",
-           "sample": "%d solves of the bench workload (N=%d, %.0f%% outliers), median %.1f ms each, streaming "
-                     "oracle (no TIM storage), gcc -O3 -fopenmp without -march=native, OMP threads = %d"
-                     % (len(ts), args.n, 100 * args.outlier_ratio, 1e3 * med, cores)}
-    pairs = args.n * (args.n - 1) // 2
+           "sample": "%d solves of this workload (%s), median %.1f ms each, streaming oracle (no TIM storage), "
+                     "gcc -O3 -fopenmp without -march=native, OMP threads = %d" % (len(ts), what, 1e3 * med, cores)}
+    pairs = n * (n - 1) // 2
     if pairs * 81 < 24e9:  # the materialised form needs ~81 B per pair of host memory
-        tm = run(True, 2, 8.0)
+        tm = run(True, 2, min(budget_s, 8.0))
         mm = float(np.median(tm))
         out["reference_faithful"] = {
             "value": 1.0 / mm, "unit": "registrations/s",
-            "sample": "%d solves, median %.1f ms each, TIMs materialised (~%.1f GB), serial mask and "
+            "sample": "%d solves, median %.1f ms each, TIMs materialised (~%.2f GB), serial mask and "
                       "vector-of-vectors graph build as the reference" % (len(tm), 1e3 * mm, pairs * 81 / 1e9)}
     else:
         out["reference_faithful"] = {"value": None, "sample": "infeasible: ~%.0f GB of TIM storage" % (pairs * 81 / 1e9)}
@@ -205,23 +248,242 @@ def relaunch_as_ranks(args):
     os.execvpe(cmd[0], cmd, env)
 
 
-def make_pool(tp, args, rank, n_batches):
+def synth_pool(tp, seed0, n_batches, B, n, rho, nb):
     """n_batches distinct seeded batches as packed host arrays [B*n, 3] (+ ground truth)."""
-    B, n = args.batch, args.n
     pool, truth = [], []
     for k in range(n_batches):
         src = np.empty((B * n, 3))
         dst = np.empty((B * n, 3))
         tr = []
         for b in range(B):
-            seed = args.seed + ((rank * 4096 + k) * B + b)
-            pr = tp.synth_problem(seed, n, args.outlier_ratio, args.noise_bound)
+            pr = tp.synth_problem(seed0 + k * B + b, n, rho, nb)
             src[b * n:(b + 1) * n] = pr["src"].T
             dst[b * n:(b + 1) * n] = pr["dst"].T
             tr.append((pr["R"], pr["t"], int(pr["inliers"].sum())))
         pool.append((src, dst))
         truth.append(tr)
     return pool, truth
+
+
+class Runner:
+    """The timed loop: `count` steps through the asynchronous batch API."""
+
+    def __init__(self, torch, dist, solver, depth, gather_dev):
+        self.torch, self.dist, self.solver, self.D, self.gather_dev = torch, dist, solver, depth, gather_dev
+
+    def sync_all(self):
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, seconds):
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device=self.gather_dev)
+        if self.dist is not None:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def run_steps(self, first, count, buffers, offsets, sizes, host, acc=None):
+        """`count` steps, at most D on the lanes (+ one staged host batch whose copy is already running);
+        returns the last outputs.  buffers[k] = (src, dst) tensors; offsets / sizes: one pair, or one per buffer."""
+        solver = self.solver
+        tickets = collections.deque()
+        last = None
+        in_flight = self.D + (1 if host else 0)
+        per_buffer = isinstance(offsets, list)
+
+        def retire():
+            nonlocal last
+            last = solver.wait(tickets.popleft())
+            if acc is not None:
+                pf = solver.get_profile()
+                acc["ms"] += pf["tim_graph_ms"]
+                acc["launches"] += pf["tim_graph_launches"]
+                acc["bytes"] += pf["tim_graph_bytes"]
+                acc["pairs"] += pf["tim_graph_pairs"]
+                acc["aux"] += pf["tim_aux_ms"]
+
+        for k in range(first, first + count):
+            if len(tickets) == in_flight:
+                retire()
+            i = k % len(buffers)
+            s_t, d_t = buffers[i]
+            tickets.append(solver.submit_batch(s_t.data_ptr(), d_t.data_ptr(), offsets[i] if per_buffer else offsets,
+                                               sizes[i] if per_buffer else sizes, host=host))
+        while tickets:
+            retire()
+        return last
+
+    def timed(self, first, count, buffers, offsets, sizes, host, acc=None, tail=None):
+        """barrier + sync, `count` steps (+ tail()), barrier + sync; max over ranks, seconds"""
+        self.sync_all()
+        t0 = time.perf_counter()
+        last = self.run_steps(first, count, buffers, offsets, sizes, host, acc)
+        if tail is not None:
+            tail(last)
+        self.sync_all()
+        return self.max_over_ranks(time.perf_counter() - t0), last
+
+
+def stage_breakdown(solver, s_t, d_t, offsets, sizes):
+    """per-stage device times (HIP events around every stage) of ONE synchronous step; untimed extra"""
+    solver.set_profiling(1)
+    solver.solve_batch_device(s_t.data_ptr(), d_t.data_ptr(), offsets, sizes)
+    pf = solver.get_profile()
+    solver.set_profiling(0)
+    keep = ("h2d_ms", "tim_aux_ms", "tim_graph_ms", "degree_ms", "heuristic_ms", "peel_ms", "colour_ms", "exact_ms",
+            "rotation_ms", "translation_ms", "d2h_ms", "total_ms")
+    return {k: round(float(pf[k]), 4) for k in keep}
+
+
+def run_config(tag, tp, torch, runner, args, dev, world, rank, make_workload, steps, want_cpu):
+    """One `configs` line: median of args.repeats timed regions of `steps` steps each."""
+    solver, wl = make_workload()
+    runner_c = Runner(torch, runner.dist, solver, runner.D, runner.gather_dev)
+    solver.set_pipeline_depth(runner.D)
+    bufs = [(torch.from_numpy(s).to(dev), torch.from_numpy(d).to(dev)) for s, d in wl["pool"]]
+    offsets, sizes = wl["offsets"], wl["sizes"]
+    B = wl["problems_per_step"]
+    runner_c.run_steps(0, max(args.warmup, runner.D), bufs, offsets, sizes, False)
+    last = runner_c.run_steps(0, 1, bufs, offsets, sizes, False)
+    wl["check"](last)  # the work is not skipped and is right
+    solver.set_profiling(2)
+    acc = dict(ms=0.0, launches=0, bytes=0, pairs=0, aux=0.0)
+    times = []
+    for r in range(max(1, args.repeats)):
+        t, _ = runner_c.timed(1 + r * steps, steps, bufs, offsets, sizes, False, acc)
+        times.append(t)
+    solver.set_profiling(0)
+    med = float(np.median(times))
+    line = {
+        "workload": wl["workload"], "problems_per_step_per_gpu": B, "steps": steps, "repeats": len(times),
+        "value": world * B * steps / med, "unit": "registrations/s", "ms_per_step": 1e3 * med / steps,
+        "ms_per_registration": 1e3 * med / (steps * B),
+        "ms_per_step_repeats": [round(1e3 * t / steps, 4) for t in times],
+        "distinct_batches": len(bufs), "inputs": "resident in HBM", "n_gpus": world,
+    }
+    if not args.no_host_resident:
+        pinned = [(torch.from_numpy(s).pin_memory(), torch.from_numpy(d).pin_memory()) for s, d in wl["pool"]]
+        runner_c.run_steps(0, runner.D + 1, pinned, offsets, sizes, True)
+        th = [runner_c.timed(1 + r * steps, steps, pinned, offsets, sizes, True)[0] for r in range(max(1, args.repeats))]
+        mh = float(np.median(th))
+        line["host_resident"] = {"value": world * B * steps / mh, "unit": "registrations/s",
+                                 "ms_per_step": 1e3 * mh / steps}
+        del pinned
+    if acc["launches"]:
+        n_eq = wl.get("n")
+        traffic, traffic_src = k1_traffic(B, n_eq) if n_eq else (None, None)
+        line["roofline"] = roofline_object(acc["ms"], acc["launches"], acc["bytes"], acc["pairs"], acc["aux"],
+                                           traffic, traffic_src)
+        line["roofline"].pop("note", None)
+    else:
+        line["roofline"] = None
+    i0 = 0
+    per_buffer = isinstance(offsets, list)
+    line["stage_ms"] = stage_breakdown(solver, bufs[i0][0], bufs[i0][1], offsets[i0] if per_buffer else offsets,
+                                       sizes[i0] if per_buffer else sizes)
+    line.update(wl.get("extra", {}))
+    if want_cpu and rank == 0:
+        line["cpu_baseline"] = wl["cpu"]()
+    del bufs
+    del solver
+    return line
+
+
+def config5_workload(tp, args, rank, B, n_batches):
+    """BASELINE config 5, batched: per step B perturbed copies of the 3DMatch pair (tests/golden/
+    config5_clouds.npz: cloud_bin_0 / cloud_bin_4 of the reference's examples/teaser_python_fpfh_icp, voxel
+    0.05).  Copy i: the source cloud moved by a seeded random rigid transform, both clouds jittered by
+    N(0, (0.1 voxel)^2) noise; FPFH (radii 2 and 5 voxels) + mutual nearest neighbours on the GPU give its own
+    correspondences (ragged sizes), solve() runs with helpers.py:45-60's parameters."""
+    C5 = np.load(os.path.join(ROOT, "tests", "golden", "config5_clouds.npz"))
+    A0, B0, vox = C5["cloud_bin_0"].astype(np.float64), C5["cloud_bin_4"].astype(np.float64), float(C5["voxel_size"])
+    est, matcher = tp.FPFHEstimation(), tp.Matcher()
+    rng = np.random.default_rng(args.seed + 555 + rank)
+    pool, offs, szs, probs, truth = [], [], [], [], []
+    fe, clouds0 = [], []
+    est.computeFPFHFeatures(A0.astype(np.float32), 2 * vox, 5 * vox)  # warm-up (arenas)
+    for k in range(n_batches):
+        ss, dd, nn, tr = [], [], [], []
+        for b in range(B):
+            q = rng.standard_normal(4)
+            q /= np.linalg.norm(q)
+            w, x, y, z = q
+            Rm = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                           [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                           [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+            tv = rng.uniform(-1, 1, 3)
+            # A_i = Rm^T (A0 - tv): registering A_i onto B_i then composes (Rm, tv) with the pair's own pose
+            Ai = ((A0 + 0.1 * vox * rng.standard_normal(A0.shape) - tv) @ Rm).astype(np.float32)
+            Bi = (B0 + 0.1 * vox * rng.standard_normal(B0.shape)).astype(np.float32)
+            t0 = time.perf_counter()
+            fa = est.computeFPFHFeatures(Ai, 2 * vox, 5 * vox)
+            fb = est.computeFPFHFeatures(Bi, 2 * vox, 5 * vox)
+            corr = np.array(matcher.calculateCorrespondences(Ai, Bi, fa, fb, False, True, False, 0), dtype=np.int64)
+            fe.append(time.perf_counter() - t0)
+            s = Ai[corr[:, 0]].astype(np.float64)
+            d = Bi[corr[:, 1]].astype(np.float64)
+            ss.append(s)
+            dd.append(d)
+            nn.append(len(corr))
+            tr.append((Rm, tv))
+            if k == 0 and b < 16:
+                probs.append((np.ascontiguousarray(s.T), np.ascontiguousarray(d.T)))
+            if k == 0 and b < 3:
+                clouds0.append((Ai, Bi))
+        n_arr = np.array(nn, dtype=np.int32)
+        pool.append((np.ascontiguousarray(np.concatenate(ss)), np.ascontiguousarray(np.concatenate(dd))))
+        offs.append(np.concatenate([[0], np.cumsum(n_arr)[:-1]]).astype(np.int64))
+        szs.append(n_arr)
+        truth.append(tr)
+    kw = dict(rotation_max_iterations=10000, rotation_cost_threshold=1e-16)
+    solver = tp.RobustRegistrationSolver(solver_params(tp, vox, **kw), device=-1)
+
+    def check(out):
+        # every copy is a valid registration with a sizeable clique; the first ones are checked geometrically:
+        # the estimated pose must bring the overlapping half of the source cloud onto the target cloud
+        from scipy.spatial import cKDTree
+        for b in range(B):
+            o = out[b]
+            assert o.valid == 1 and o.clique_size >= 20, (b, o.valid, o.clique_size)
+        for b, (Ai, Bi) in enumerate(clouds0):
+            R = np.array(out[b].rotation[:]).reshape(3, 3)
+            d, _ = cKDTree(Bi.astype(np.float64)).query(Ai.astype(np.float64) @ R.T + np.array(out[b].translation[:]))
+            assert (d < vox).mean() > 0.3, (b, (d < vox).mean())
+
+    sizes_all = np.concatenate(szs)
+    return solver, dict(
+        pool=pool, offsets=offs, sizes=szs, problems_per_step=B, check=check,
+        workload="BASELINE configs[4]: 3DMatch pair of examples/teaser_python_fpfh_icp (voxel 0.05), %d perturbed "
+                 "copies per step, real FPFH correspondences (%d-%d per problem), noise_bound=%g, GNC-TLS 10000 "
+                 "iterations / 1e-16, PMC_EXACT" % (B, sizes_all.min(), sizes_all.max(), vox),
+        extra={"front_end_ms_per_pair": round(1e3 * float(np.median(fe)), 3),
+               "correspondences_per_problem": [int(sizes_all.min()), int(np.median(sizes_all)), int(sizes_all.max())]},
+        cpu=lambda: cpu_baseline(tp, int(np.median(sizes_all)), 0.0, vox, 0, 16, 10.0, problems=probs, extra_kw=kw))
+
+
+def synth_workload(tp, args, rank, tag, B, n, rho, n_batches, cpu_solves, cpu_budget):
+    nb = args.noise_bound
+    pool, truth = synth_pool(tp, args.seed + 7919 * (1 + rank) + {"config4": 1, "config3": 2}[tag] * 1000003, n_batches,
+                             B, n, rho, nb)
+    solver = tp.RobustRegistrationSolver(solver_params(tp, nb), device=-1)
+
+    def check(out):
+        for b in range(B):
+            R, t, n_in = truth[0][b]
+            o = out[b]
+            assert o.valid == 1 and n_in <= o.clique_size <= n_in + 3, (o.valid, o.clique_size, n_in)
+            assert np.linalg.norm(np.array(o.rotation[:]).reshape(3, 3) - R) < 0.05
+            assert np.linalg.norm(np.array(o.translation[:]) - t) < 0.05
+
+    name = {"config4": "BASELINE configs[3]: one GPU's share (%d problems per step) of the 1024 x N=%d batch" % (B, n),
+            "config3": "BASELINE configs[2]: N=%d, one problem per step" % n}[tag]
+    return solver, dict(
+        pool=pool, offsets=np.arange(B, dtype=np.int64) * n, sizes=np.full(B, n, dtype=np.int32), n=n,
+        problems_per_step=B, check=check,
+        workload="%s, %.0f%% outliers; noise_bound=%g, estimate_scaling=false, GNC-TLS, PMC_EXACT, CHAIN"
+                 % (name, 100 * rho, nb),
+        cpu=lambda: cpu_baseline(tp, n, rho, nb, args.seed + 31, cpu_solves, cpu_budget))
 
 
 def main():
@@ -264,50 +526,20 @@ def main():
     D = max(1, args.depth)
     solver = tp.RobustRegistrationSolver(solver_params(tp, args.noise_bound), device=dev_index)
     solver.set_pipeline_depth(D)
+    runner = Runner(torch, dist, solver, D, gather_dev)
 
-    n_batches = args.pool if args.pool > 0 else min(args.steps + args.warmup + 1, 48)
-    host_pool, truth = make_pool(tp, args, rank, n_batches)
+    n_batches = args.pool if args.pool > 0 else min(args.steps + args.warmup + 1, 32)
+    host_pool, truth = synth_pool(tp, args.seed + rank * 4096 * B, n_batches, B, n, args.outlier_ratio, args.noise_bound)
     # HBM-resident copies (the headline loop) and page-locked host copies (the host-resident loop)
     pool = [(torch.from_numpy(s).to(dev), torch.from_numpy(d).to(dev)) for s, d in host_pool]
     offsets = np.arange(B, dtype=np.int64) * n
     sizes = np.full(B, n, dtype=np.int32)
 
-    def sync_all():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def run_steps(first, count, buffers, host, acc=None):
-        """`count` steps through the asynchronous batch API, at most D in flight; returns the last outputs."""
-        tickets = collections.deque()
-        last = None
-
-        def retire():
-            nonlocal last
-            last = solver.wait(tickets.popleft())
-            if acc is not None:
-                pf = solver.get_profile()
-                acc["ms"] += pf["tim_graph_ms"]
-                acc["launches"] += pf["tim_graph_launches"]
-                acc["bytes"] += pf["tim_graph_bytes"]
-                acc["pairs"] += pf["tim_graph_pairs"]
-                acc["aux"] += pf["tim_aux_ms"]
-
-        for k in range(first, first + count):
-            if len(tickets) == D:
-                retire()
-            s_t, d_t = buffers[k % len(buffers)]
-            tickets.append(solver.submit_batch(s_t.data_ptr(), d_t.data_ptr(), offsets, sizes, host=host))
-        while tickets:
-            retire()
-        return last
-
     # warm-up (arenas of every lane sized, kernels loaded), then a correctness guard on a batch the timed
     # region will not see again: the work is not skipped and is right
-    run_steps(0, max(args.warmup, D), pool, False)
+    runner.run_steps(0, max(args.warmup, D), pool, offsets, sizes, False)
     k_chk = args.warmup % n_batches
-    out = run_steps(k_chk, 1, pool, False)
+    out = runner.run_steps(k_chk, 1, pool, offsets, sizes, False)
     for b in range(B):
         R, t, n_in = truth[k_chk][b]
         o = out[b]
@@ -319,40 +551,29 @@ def main():
     # ---- timed region: EXACTLY args.steps steps, inputs resident in HBM -------------------------
     solver.set_profiling(2)  # HIP events around the K1 kernel only (two per step), inside the timed region
     acc = dict(ms=0.0, launches=0, bytes=0, pairs=0, aux=0.0)
-    sync_all()
-    t0 = time.perf_counter()
-    last = run_steps(args.warmup + 1, args.steps, pool, False, acc)
-    # final gather of the fixed-size result records (256 B each; RCCL over xGMI when N > 1)
-    rec = tp.batched.pack_records([last[b] for b in range(B)], first_index=rank * B)
-    allrec = tp.batched.gather_records(rec, world * B, dist if world > 1 else None, device=gather_dev)
-    assert allrec.shape[0] == world * B
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device=gather_dev)
-    if dist is not None:
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-    elapsed = float(t_max.item())
+
+    def gather_tail(last):
+        # final gather of the fixed-size result records (256 B each; RCCL over xGMI when N > 1)
+        rec = tp.batched.pack_records([last[b] for b in range(B)], first_index=rank * B)
+        allrec = tp.batched.gather_records(rec, world * B, dist if world > 1 else None, device=gather_dev)
+        assert allrec.shape[0] == world * B
+
+    elapsed, _ = runner.timed(args.warmup + 1, args.steps, pool, offsets, sizes, False, acc, gather_tail)
     solver.set_profiling(0)
 
     # ---- the same loop fed from page-locked HOST memory: H2D inside the timer ----
     host_line = None
     if not args.no_host_resident:
         pinned = [(torch.from_numpy(s).pin_memory(), torch.from_numpy(d).pin_memory()) for s, d in host_pool]
-        run_steps(0, D, pinned, True)
-        sync_all()
-        th0 = time.perf_counter()
-        run_steps(args.warmup + 1, args.steps, pinned, True)
-        sync_all()
-        th = time.perf_counter() - th0
-        tt = torch.tensor([th], dtype=torch.float64, device=gather_dev)
-        if dist is not None:
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        th = float(tt.item())
+        runner.run_steps(0, D + 1, pinned, offsets, sizes, True)
+        th, _ = runner.timed(args.warmup + 1, args.steps, pinned, offsets, sizes, True, None, gather_tail)
         host_line = {"value": world * B * args.steps / th, "unit": "registrations/s",
                      "ms_per_step": 1e3 * th / args.steps,
                      "h2d_bytes_per_step_per_gpu": 48 * B * n,
-                     "note": "same steps, inputs in page-locked host memory, one H2D copy per cloud and step "
-                             "inside the timed region (PCIe-inclusive rate; never `value`)"}
+                     "note": "same steps, inputs in page-locked host memory, one H2D copy per cloud and step on the "
+                             "library's copy stream inside the timed region, depth + 1 host batches outstanding "
+                             "(the staged one's copy hides behind the batches on the lanes); PCIe-inclusive rate, "
+                             "SURVEY.md 8(d)'s timer scope; never `value`"}
         del pinned
 
     # single-problem latency (not the headline value; reported for the ms/solve half of the metric)
@@ -365,6 +586,24 @@ def main():
         solver.solve_batch_device(s_t.data_ptr(), d_t.data_ptr(), one_off, one_n)
         lat.append(time.perf_counter() - a)
     lat_ms = 1e3 * float(np.median(lat)) if lat else None
+    stages = stage_breakdown(solver, s_t, d_t, offsets, sizes)
+    del pool
+
+    # ---- the other BASELINE configurations (their own solvers, pools and timed regions) -----------
+    want_cpu = world == 1 and not args.no_cpu_baseline
+    cfg_lines = {}
+    for tag in [c.strip() for c in args.configs.split(",") if c.strip()]:
+        if tag == "4":
+            mk = lambda: synth_workload(tp, args, rank, "config4", 128, 5000, 0.90, 8, 24, 10.0)
+            cfg_lines["config4"] = run_config("config4", tp, torch, runner, args, dev, world, rank, mk, 24, want_cpu)
+        elif tag == "3":
+            mk = lambda: synth_workload(tp, args, rank, "config3", 1, 50000, 0.99, 4, 3, 20.0)
+            cfg_lines["config3"] = run_config("config3", tp, torch, runner, args, dev, world, rank, mk, 24, want_cpu)
+        elif tag == "5":
+            mk = lambda: config5_workload(tp, args, rank, 64, 2)
+            cfg_lines["config5"] = run_config("config5", tp, torch, runner, args, dev, world, rank, mk, 12, want_cpu)
+        else:
+            raise SystemExit("bench.py: unknown --configs entry %r (use 3, 4, 5)" % tag)
 
     if rank == 0:
         total_regs = world * B * args.steps
@@ -374,7 +613,7 @@ def main():
             "metric": "registrations/sec at N=%d correspondences, %.0f%% outliers" % (n, 100 * args.outlier_ratio),
             "value": value, "unit": "registrations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE,
             "data": "synthetic",
             "config": {"workload": "synthetic N=%d correspondences, %.0f%% outliers, single-MI355X config "
                                    "(BASELINE configs[1]); noise_bound=%g, estimate_scaling=false, GNC-TLS, "
@@ -383,17 +622,18 @@ def main():
                        "distinct_batches": n_batches,
                        "ms_per_registration": 1e3 * elapsed / (args.steps * B),
                        "single_problem_latency_ms": lat_ms, "inputs": "resident in HBM",
-                       "host_resident": host_line,
+                       "host_resident": host_line, "stage_ms": stages,
                        "arithmetic": "FP64 estimators and FP64 reference expression for every pruning decision the "
                                      "K1 filter (exact bf16 split on MFMA + f32 epilogue with a rigorous error band) "
                                      "cannot make; bitmap bit-identical to the FP64 oracle",
                        "parallelism": "independent problems per GPU, %s all_gather of result records"
                                       % ("gloo (ranks share a GPU: test mode)" if shared else "RCCL")},
             "roofline": roofline_object(acc["ms"], acc["launches"], acc["bytes"], acc["pairs"], acc["aux"],
-                                        traffic, traffic_src),
+                                        traffic, traffic_src, k1_issue()),
+            "configs": cfg_lines,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(tp, args)
+        if want_cpu:
+            line["cpu_baseline"] = cpu_baseline(tp, n, args.outlier_ratio, args.noise_bound, args.seed, args.cpu_solves, 10.0)
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

@@ -177,10 +177,15 @@ TEASER_HIP_API int32_t teaser_hip_solve_batch_device(teaser_hip_solver* h, const
  *           must stay valid and unmodified until the matching wait;
  *   flags = TEASER_HIP_INPUT_HOST:   src/dst are packed HOST arrays of the same layout (problem b =
  *           points [offset[b], offset[b]+n[b])); page-locked memory (hipHostMalloc /
- *           hipHostRegister) is copied asynchronously at PCIe speed, and must stay valid until wait.
- * point_offset / n are host arrays, copied at submit.  Tickets must be waited for in any order,
- * each exactly once; after wait the getters address that batch until the next wait / solve.
- * TEASER_HIP_ERR_BUSY: all lanes are in flight. */
+ *           hipHostRegister) is copied asynchronously at PCIe speed on a dedicated copy stream, and
+ *           must stay valid until wait.  ONE host batch beyond the lanes is accepted (depth + 1 in
+ *           flight): its copy starts at once, hidden behind the kernels of the batches on the lanes,
+ *           and it is enqueued on the first lane that frees up, at the next submit / wait call --
+ *           a throughput caller keeps depth + 1 host batches outstanding and pays no PCIe time.
+ * point_offset / n are host arrays, copied at submit.  Tickets may be waited for in any order
+ * (a batch still staged behind the lanes answers TEASER_HIP_ERR_BUSY until an earlier ticket has been
+ * waited for), each exactly once; after wait the getters address that batch until the next submit /
+ * wait / solve.  TEASER_HIP_ERR_BUSY: all lanes are in flight (and, for host inputs, one batch is staged). */
 enum { TEASER_HIP_INPUT_DEVICE = 0, TEASER_HIP_INPUT_HOST = 1 };
 TEASER_HIP_API int32_t teaser_hip_submit_batch(teaser_hip_solver* h, const double* src, const double* dst,
                                 const int64_t* point_offset, const int32_t* n, int32_t batch,

@@ -23,7 +23,7 @@ _CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(_HERE, "libteaser_hip.so")
 
 STATUS_NAMES = {0: "OK", 1: "BAD_ARG", 2: "HIP", 3: "NO_DEVICE", 4: "UNSUPPORTED", 5: "TIME_LIMIT",
-                6: "SCRATCH", 7: "OOM"}
+                6: "SCRATCH", 7: "OOM", 8: "BUSY"}
 
 
 class TeaserHipError(RuntimeError):
@@ -388,7 +388,8 @@ class RobustRegistrationSolver:
     def submit_batch(self, src_ptr, dst_ptr, point_offsets, n, host=False):
         """Enqueue a batch without waiting (raw pointers to packed [sum n, 3] float64 arrays: device
         memory, or -- host=True -- host memory, ideally page-locked).  Returns a ticket for wait();
-        the arrays must stay valid until then."""
+        the arrays must stay valid until then.  Host batches: one more than the pipeline depth is accepted
+        (it is staged: its copy runs at once, it reaches a lane at the next submit / wait)."""
         off = np.ascontiguousarray(point_offsets, dtype=np.int64)
         nn = np.ascontiguousarray(n, dtype=np.int32)
         t = C.c_int32(-1)
@@ -402,9 +403,10 @@ class RobustRegistrationSolver:
     def wait(self, ticket):
         """Block until the batch behind `ticket` is solved; returns its SolutionC array.  The getters
         (getInlierMaxClique(problem) ...) address this batch afterwards."""
-        B = self._pending.pop(ticket)
+        B = self._pending[ticket]
         out = (SolutionC * B)()
-        self._check(self._lib.teaser_hip_wait(self._h, int(ticket), out))
+        self._check(self._lib.teaser_hip_wait(self._h, int(ticket), out))  # (BUSY: a staged batch stays pending)
+        del self._pending[ticket]
         self._sols = list(out)
         self._sol = RegistrationSolution(out[0]) if B else None
         return out

@@ -43,6 +43,21 @@ void launch_fill_identity_clique(hipStream_t s, const ProbDesc* d_desc, int batc
 
 using namespace thip;
 
+// The per-batch header (descriptors | initial states | TIM offsets | zeroed counters) and the problem states
+// travel between page-locked host memory and HBM inside KERNELS of the batch's own stream, not as
+// hipMemcpyAsync: small copies go to whichever SDMA engine the runtime picks, and an engine's ring is in
+// order -- the header upload of one lane was observed queued behind the other lane's state download, which
+// itself waits for that lane's whole batch (profiles/r3d: a free lane sat idle until the other one had
+// finished whenever page-locked input copies kept the H2D engine busy).  Zero-copy reads / writes of a few
+// tens of KB over PCIe cost the same few microseconds and have no such coupling.
+__global__ __launch_bounds__(256) void hdr_fetch_kernel(const uint4* __restrict__ host, uint4* __restrict__ dev, int n16) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dev[i] = host[i];
+}
+__global__ __launch_bounds__(256) void state_push_kernel(const uint2* __restrict__ dev, uint2* __restrict__ host, int n8) {
+  TAIL_WAVE_PRIO();
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n8; i += gridDim.x * 256) host[i] = dev[i];
+}
+
 namespace {
 
 struct DevBuf {
@@ -195,8 +210,32 @@ struct teaser_hip_solver {
     std::vector<int32_t> n;
     const double* d_src = nullptr;
     const double* d_dst = nullptr;
+    int in_set = -1;                       // parent's input set holding the (host-submitted) points, or -1
+    int32_t ticket = -1;
   } job;
   DevBuf hdr;                              // descs | states | tim offsets | peel counters | K1 prep
+  // ---- host inputs of asynchronous batches (parent only) ------------------------------------------
+  // TEASER_HIP_INPUT_HOST batches are copied on a dedicated copy stream (SDMA: 56 GB/s on MI355X,
+  // unaffected by the kernels in flight -- profiles/r3a) into one of depth + 1 input sets owned by the
+  // PARENT, so that the copy of batch k + depth can run while every lane is still busy: such a batch is
+  // STAGED (copy started, ticket returned) and enqueued on the first lane that frees up, at the next
+  // submit / wait call.  With the copy inside a lane's own stream the lane's serial chain
+  // tail(k) -> H2D(k+2) -> pre-pass -> K1(k+2) was longer than two K1 periods (2.04 vs 1.55 ms per step).
+  struct InSet {
+    DevBuf src, dst;
+    hipEvent_t ready = nullptr;
+    bool in_use = false;
+  };
+  std::vector<InSet> in_sets;
+  hipStream_t copy_stream = nullptr;
+  struct Staged {
+    bool active = false;
+    int32_t ticket = -1;
+    int in_set = -1;
+    std::vector<int64_t> off;
+    std::vector<int32_t> n;
+  } staged;
+  std::vector<int> ticket_lane;            // ticket -> lane index, -1 staged, -2 free (depth + 1 tickets)
 };
 
 // several devices, one process: one handle (and one host thread per solve call) per device
@@ -703,9 +742,11 @@ int32_t enqueue_estimators(teaser_hip_solver* h) {
   HIPCHK(h, hipGetLastError());
   {
     StageScope sc(h, ST_D2H);
+    static_assert(sizeof(ProbState) % 8 == 0, "ProbState is moved in 8-byte pieces");
     HIPCHK(h, h->pin_states.ensure(sizeof(ProbState) * (size_t)batch));
-    HIPCHK(h, hipMemcpyAsync(h->pin_states.p, h->d_state.p, sizeof(ProbState) * (size_t)batch,
-                             hipMemcpyDeviceToHost, s));
+    const int n8 = (int)(sizeof(ProbState) * (size_t)batch / 8);
+    hipLaunchKernelGGL(state_push_kernel, dim3((unsigned)std::min(8, (n8 + 255) / 256)), dim3(256), 0, s,
+                       h->d_state.as<uint2>(), reinterpret_cast<uint2*>(h->pin_states.p), n8);
   }
   return TEASER_HIP_OK;
 }
@@ -830,7 +871,8 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
     memcpy(stage + o_desc, h->descs.data(), b_desc);
     memcpy(stage + o_state, h->states.data(), b_state);
     memcpy(stage + o_off, h->tim_off.data(), b_off);
-    HIPCHK(h, hipMemcpyAsync(h->hdr.p, stage, hdr_bytes, hipMemcpyHostToDevice, s1));
+    hipLaunchKernelGGL(hdr_fetch_kernel, dim3((unsigned)std::min<size_t>(8, (hdr_bytes / 16 + 255) / 256)), dim3(256), 0,
+                       s1, reinterpret_cast<const uint4*>(stage), h->hdr.as<uint4>(), (int)(hdr_bytes / 16));
   }
   const ProbDesc* dd = h->d_desc.as<ProbDesc>();
   ProbState* ds = h->d_state.as<ProbState>();
@@ -1155,6 +1197,17 @@ void release_handle_resources(teaser_hip_solver* h) {
     (void)hipStreamSynchronize(h->k1_stream);
     (void)hipStreamDestroy(h->k1_stream);
   }
+  if (h->copy_stream) {
+    (void)hipStreamSynchronize(h->copy_stream);
+    if (h->copy_stream != h->stream) (void)hipStreamDestroy(h->copy_stream);
+    h->copy_stream = nullptr;
+  }
+  for (auto& is : h->in_sets) {
+    is.src.release();
+    is.dst.release();
+    if (is.ready) (void)hipEventDestroy(is.ready);
+  }
+  h->in_sets.clear();
   if (h->stream) (void)hipStreamDestroy(h->stream);
   h->k1_done = h->k1_phase_done = h->inputs_ready = nullptr;
   h->k1_stream = nullptr;
@@ -1174,75 +1227,180 @@ int32_t ensure_lanes(teaser_hip_solver* h) {
     if (rc != TEASER_HIP_OK) return rc;
     h->lanes.push_back(lane);
   }
+  if ((int)h->ticket_lane.size() != h->depth + 1) h->ticket_lane.assign((size_t)h->depth + 1, -2);
   return TEASER_HIP_OK;
+}
+
+// input sets + copy stream of the host-input path (created on first use)
+int32_t ensure_input_sets(teaser_hip_solver* h) {
+  if (!h->copy_stream) {
+    // HIP multiplexes its streams onto a few hardware queues; a copy stream that lands on the queue of a
+    // lane's stream has its copies ordered behind that lane's kernels (measured: the 0.55 ms copy of a staged
+    // batch started 2.3 ms late, profiles/r3d).  TEASER_HIP_COPY_STREAM: 0 = the parent's own stream (idle
+    // while asynchronous batches are in flight), 1 = a stream of its own, 2 = a high-priority stream of its own.
+    const char* ev = getenv("TEASER_HIP_COPY_STREAM");
+    const int mode = ev ? atoi(ev) : 2;
+    if (mode == 0) {
+      h->copy_stream = h->stream;
+    } else if (mode == 1) {
+      HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+    } else {
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      HIPCHK(h, hipStreamCreateWithPriority(&h->copy_stream, hipStreamNonBlocking, hi));
+    }
+  }
+  while ((int)h->in_sets.size() < h->depth + 1) {
+    h->in_sets.emplace_back();
+    HIPCHK(h, hipEventCreateWithFlags(&h->in_sets.back().ready, hipEventDisableTiming));
+  }
+  return TEASER_HIP_OK;
+}
+
+// everything of a batch that needs no host sync, on lane `idx` (free); src / dst are device pointers
+int32_t enqueue_on_lane(teaser_hip_solver* h, int idx, int32_t ticket, const double* d_src, const double* d_dst,
+                        const int64_t* pt_off, const int32_t* n, int batch, int in_set) {
+  teaser_hip_solver* lane = h->lanes[(size_t)idx];
+  // the getters of an earlier wait() read this lane's buffers: they are about to be overwritten
+  if (!h->route.empty() && h->route[0].first == idx) {
+    h->route.clear();
+    h->batch = 0;
+  }
+  lane->params = h->params;
+  lane->profiling = h->profiling;
+  lane->job.off.assign(pt_off, pt_off + batch);
+  lane->job.n.assign(n, n + batch);
+  lane->job.d_src = d_src;
+  lane->job.d_dst = d_dst;
+  lane->job.in_set = in_set;
+  lane->job.ticket = ticket;
+  profile_begin(lane);
+  if (in_set >= 0) {  // the points arrive on the copy stream
+    HIPCHK(h, hipStreamWaitEvent(lane->stream, h->in_sets[(size_t)in_set].ready, 0));
+    lane->inputs_pending = true;
+  }
+  lane->wait_before_k1 = nullptr;
+  if (h->stagger_k1 && h->last_lane >= 0 && h->last_lane != idx) {
+    teaser_hip_solver* prev = h->lanes[(size_t)h->last_lane];
+    if (prev->k1_recorded) lane->wait_before_k1 = prev->k1_done;
+  }
+  const int32_t rc =
+      solve_packed_enqueue(lane, d_src, d_dst, lane->job.off.data(), lane->job.n.data(), batch, false);
+  if (rc != TEASER_HIP_OK) {
+    h->err = lane->err;
+    if (lane->k1_stream) (void)hipStreamSynchronize(lane->k1_stream);
+    (void)hipStreamSynchronize(lane->stream);
+    if (in_set >= 0) h->in_sets[(size_t)in_set].in_use = false;
+    h->ticket_lane[(size_t)ticket] = -2;
+    return rc;
+  }
+  lane->job.busy = true;
+  h->ticket_lane[(size_t)ticket] = idx;
+  h->last_lane = idx;
+  h->next_lane = (idx + 1) % h->depth;
+  return TEASER_HIP_OK;
+}
+
+// a staged host batch moves to the lane whose turn it is as soon as that lane is free
+int32_t flush_staged(teaser_hip_solver* h) {
+  if (!h->staged.active) return TEASER_HIP_OK;
+  const int idx = h->next_lane;
+  if (h->lanes[(size_t)idx]->job.busy) return TEASER_HIP_OK;
+  h->staged.active = false;
+  const teaser_hip_solver::InSet& is = h->in_sets[(size_t)h->staged.in_set];
+  return enqueue_on_lane(h, idx, h->staged.ticket, is.src.as<double>(), is.dst.as<double>(), h->staged.off.data(),
+                         h->staged.n.data(), (int)h->staged.n.size(), h->staged.in_set);
 }
 
 int32_t submit_impl(teaser_hip_solver* h, const double* src, const double* dst,
                     const int64_t* pt_off, const int32_t* n, int batch, int flags, int32_t* ticket) {
   int32_t rc = ensure_lanes(h);
   if (rc != TEASER_HIP_OK) return rc;
+  rc = flush_staged(h);
+  if (rc != TEASER_HIP_OK) return rc;
   const int idx = h->next_lane;
-  teaser_hip_solver* lane = h->lanes[(size_t)idx];
-  if (lane->job.busy) {
+  const bool lane_free = !h->lanes[(size_t)idx]->job.busy && !h->staged.active;
+  const bool host = (flags & TEASER_HIP_INPUT_HOST) != 0;
+  if (!lane_free && (!host || h->staged.active)) {
     h->err = "every lane holds a submitted batch: call teaser_hip_wait first (or raise the depth)";
     return TEASER_HIP_ERR_BUSY;
   }
-  lane->params = h->params;
-  lane->profiling = h->profiling;
-  lane->job.off.assign(pt_off, pt_off + batch);
-  lane->job.n.assign(n, n + batch);
-  profile_begin(lane);
+  int32_t t = -1;
+  for (size_t k = 0; k < h->ticket_lane.size(); ++k)
+    if (h->ticket_lane[k] == -2) {
+      t = (int32_t)k;
+      break;
+    }
+  if (t < 0) {
+    h->err = "no free ticket";
+    return TEASER_HIP_ERR_BUSY;
+  }
   const double* d_src = src;
   const double* d_dst = dst;
-  if (flags & TEASER_HIP_INPUT_HOST) {
-    // packed host arrays: ONE copy per cloud (page-locked caller memory moves at PCIe speed and the
-    // copy overlaps the previous batch's kernels; pageable memory is staged by the runtime)
+  int set = -1;
+  if (host) {
+    // packed host arrays: ONE copy per cloud on the copy stream (page-locked caller memory moves at PCIe
+    // speed whatever the kernels in flight do; pageable memory is staged by the runtime)
     int64_t tot = 0;
     for (int b = 0; b < batch; ++b) {
       if (n[b] < 0 || pt_off[b] < 0) return TEASER_HIP_ERR_BAD_ARG;
       tot = std::max<int64_t>(tot, pt_off[b] + n[b]);
     }
-    HIPCHK(h, lane->d_src.ensure((size_t)std::max<int64_t>(tot, 1) * 24));
-    HIPCHK(h, lane->d_dst.ensure((size_t)std::max<int64_t>(tot, 1) * 24));
-    if (tot > 0) {
-      StageScope sc(lane, ST_H2D);
-      HIPCHK(h, hipMemcpyAsync(lane->d_src.p, src, (size_t)tot * 24, hipMemcpyHostToDevice, lane->stream));
-      HIPCHK(h, hipMemcpyAsync(lane->d_dst.p, dst, (size_t)tot * 24, hipMemcpyHostToDevice, lane->stream));
-      lane->inputs_pending = true;
+    rc = ensure_input_sets(h);
+    if (rc != TEASER_HIP_OK) return rc;
+    for (size_t k = 0; k < h->in_sets.size(); ++k)
+      if (!h->in_sets[k].in_use) {
+        set = (int)k;
+        break;
+      }
+    if (set < 0) {
+      h->err = "no free input set";
+      return TEASER_HIP_ERR_BUSY;
     }
-    d_src = lane->d_src.as<double>();
-    d_dst = lane->d_dst.as<double>();
+    teaser_hip_solver::InSet& is = h->in_sets[(size_t)set];
+    HIPCHK(h, is.src.ensure((size_t)std::max<int64_t>(tot, 1) * 24));
+    HIPCHK(h, is.dst.ensure((size_t)std::max<int64_t>(tot, 1) * 24));
+    if (tot > 0) {
+      HIPCHK(h, hipMemcpyAsync(is.src.p, src, (size_t)tot * 24, hipMemcpyHostToDevice, h->copy_stream));
+      HIPCHK(h, hipMemcpyAsync(is.dst.p, dst, (size_t)tot * 24, hipMemcpyHostToDevice, h->copy_stream));
+    }
+    HIPCHK(h, hipEventRecord(is.ready, h->copy_stream));
+    is.in_use = true;
+    d_src = is.src.as<double>();
+    d_dst = is.dst.as<double>();
   }
-  lane->job.d_src = d_src;
-  lane->job.d_dst = d_dst;
-  lane->wait_before_k1 = nullptr;
-  if (h->stagger_k1 && h->last_lane >= 0 && h->last_lane != idx) {
-    teaser_hip_solver* prev = h->lanes[(size_t)h->last_lane];
-    if (prev->k1_recorded) lane->wait_before_k1 = prev->k1_done;
+  if (!lane_free) {  // host batch beyond the lanes: copy under way, enqueued when a lane frees up
+    h->staged.active = true;
+    h->staged.ticket = t;
+    h->staged.in_set = set;
+    h->staged.off.assign(pt_off, pt_off + batch);
+    h->staged.n.assign(n, n + batch);
+    h->ticket_lane[(size_t)t] = -1;
+    *ticket = t;
+    return TEASER_HIP_OK;
   }
-  rc = solve_packed_enqueue(lane, d_src, d_dst, lane->job.off.data(), lane->job.n.data(), batch, false);
-  if (rc != TEASER_HIP_OK) {
-    h->err = lane->err;
-    if (lane->k1_stream) (void)hipStreamSynchronize(lane->k1_stream);
-    (void)hipStreamSynchronize(lane->stream);
-    return rc;
-  }
-  lane->job.busy = true;
-  h->last_lane = idx;
-  h->next_lane = (idx + 1) % h->depth;
-  *ticket = idx;
+  rc = enqueue_on_lane(h, idx, t, d_src, d_dst, pt_off, n, batch, set);
+  if (rc != TEASER_HIP_OK) return rc;
+  *ticket = t;
   return TEASER_HIP_OK;
 }
 
 int32_t wait_impl(teaser_hip_solver* h, int32_t ticket, teaser_solution_c* out) {
-  if (ticket < 0 || ticket >= (int32_t)h->lanes.size() || !h->lanes[(size_t)ticket]->job.busy) {
+  if (ticket < 0 || ticket >= (int32_t)h->ticket_lane.size() || h->ticket_lane[(size_t)ticket] == -2) {
     h->err = "teaser_hip_wait: no submitted batch behind this ticket";
     return TEASER_HIP_ERR_BAD_ARG;
   }
-  teaser_hip_solver* lane = h->lanes[(size_t)ticket];
+  int32_t rc = flush_staged(h);
+  if (rc != TEASER_HIP_OK) return rc;
+  if (h->ticket_lane[(size_t)ticket] == -1) {
+    h->err = "teaser_hip_wait: this batch is staged behind the batches in flight; wait for an earlier ticket first";
+    return TEASER_HIP_ERR_BUSY;
+  }
+  const int li = h->ticket_lane[(size_t)ticket];
+  teaser_hip_solver* lane = h->lanes[(size_t)li];
   const int batch = (int)lane->job.n.size();
   bool overflow = false;
-  int32_t rc = solve_packed_finish(lane, out, &overflow);
+  rc = solve_packed_finish(lane, out, &overflow);
   if (rc == TEASER_HIP_OK && overflow)  // K1 fix-up list overflowed: this batch again, all-FP64 K1
     rc = solve_packed_impl(lane, lane->job.d_src, lane->job.d_dst, lane->job.off.data(),
                            lane->job.n.data(), batch, out, true, &overflow);
@@ -1253,9 +1411,12 @@ int32_t wait_impl(teaser_hip_solver* h, int32_t ticket, teaser_solution_c* out) 
   profile_end(lane);
   h->prof = lane->prof;
   lane->job.busy = false;
-  // getters now address this batch
+  if (lane->job.in_set >= 0) h->in_sets[(size_t)lane->job.in_set].in_use = false;
+  lane->job.in_set = -1;
+  h->ticket_lane[(size_t)ticket] = -2;
+  // getters now address this batch (until its lane takes the next one)
   h->route.assign((size_t)batch, std::make_pair(0, 0));
-  for (int b = 0; b < batch; ++b) h->route[(size_t)b] = std::make_pair((int)ticket, b);
+  for (int b = 0; b < batch; ++b) h->route[(size_t)b] = std::make_pair(li, b);
   h->batch = batch;
   h->have_graph = lane->have_graph;
   return rc;
@@ -1749,6 +1910,8 @@ int32_t teaser_hip_set_pipeline_depth(teaser_hip_solver* h, int32_t depth) {
   if (!h || depth < 1 || depth > 16) return TEASER_HIP_ERR_BAD_ARG;
   for (teaser_hip_solver* lane : h->lanes)
     if (lane->job.busy) return TEASER_HIP_ERR_BUSY;
+  if (h->staged.active) return TEASER_HIP_ERR_BUSY;
+  h->ticket_lane.assign((size_t)depth + 1, -2);
   if (depth < (int32_t)h->lanes.size()) {
     (void)hipSetDevice(h->device);
     for (size_t k = (size_t)depth; k < h->lanes.size(); ++k) {

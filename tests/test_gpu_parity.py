@@ -1015,9 +1015,15 @@ def test_async_batches_match_sync():
         for probs in batches[:3]:
             src, dst, off, n = _packed(probs)
             tickets.append(s.submit_batch(put(src), put(dst), off, n, host=host))
-        # all three lanes are in flight: a fourth submit must be refused, loudly
+        # all three lanes are in flight: a fourth DEVICE submit must be refused, loudly; a fourth HOST
+        # batch is staged (its copy starts at once), a fifth one refused
         src, dst, off, n = _packed(batches[3])
         a, b = put(src), put(dst)
+        t3 = None
+        if host:
+            t3 = s.submit_batch(a, b, off, n, host=True)
+            with pytest.raises(tp.TeaserHipError):
+                s.wait(t3)  # still staged behind the lanes: BUSY until an earlier ticket has been waited for
         with pytest.raises(tp.TeaserHipError):
             s.submit_batch(a, b, off, n, host=host)
         for k in (1, 0, 2):  # tickets may be waited for in any order
@@ -1030,7 +1036,8 @@ def test_async_batches_match_sync():
                     assert (np.array(o.rotation[:]).reshape(3, 3) == w[1]).all()
                     assert (np.array(o.translation[:]) == w[2]).all()
                     assert s.getRotationInliers(bi) == w[4] and s.getTranslationInliers(bi) == w[5]
-        t3 = s.submit_batch(a, b, off, n, host=host)
+        if t3 is None:
+            t3 = s.submit_batch(a, b, off, n, host=host)
         out = s.wait(t3)
         for bi, w in enumerate(want[3]):
             assert s.getInlierMaxClique(bi) == w[3]
