@@ -61,3 +61,23 @@ def match(src_feat, dst_feat, crosscheck=True):
     k = lib().feat_match(a.ctypes.data_as(_fp), C.c_int32(a.shape[0]), b.ctypes.data_as(_fp), C.c_int32(b.shape[0]),
                          C.c_int32(a.shape[1]), C.c_int32(int(crosscheck)), out.ctypes.data_as(_ip))
     return out[:k].copy()
+
+
+def tie_hooks(switch_window_ulps=0, bin_window=0.0, flips=None, cap=1 << 16):
+    """Pinning aid (oracle/features_oracle.c, "decisions at the edge of float precision").  Returns a buffer
+    that the next compute_fpfh fills with (p, q, kind, default outcome) quadruples of the near-boundary
+    evaluations: kind 0 = the switch decision with |angle1|, |angle2| within `switch_window_ulps`, kind 1..3 =
+    the bin of feature f1 / f2 / f3 with 11 x within `bin_window` of an integer.  `flips` = (k, 3) int32 array of
+    (p, q, kind) evaluations forced to the other outcome.  tie_hooks() with no arguments switches everything
+    off again."""
+    global _tie_keep
+    out = np.zeros((cap, 4), dtype=np.int32)
+    fl = np.ascontiguousarray(flips if flips is not None else np.zeros((0, 3)), dtype=np.int32).reshape(-1, 3)
+    _tie_keep = (out, fl)  # the C side keeps the pointers
+    lib().feat_tie_hooks(C.c_int32(int(switch_window_ulps)), C.c_double(float(bin_window)), out.ctypes.data_as(_ip),
+                         C.c_int32(cap), fl.ctypes.data_as(_ip), C.c_int32(fl.shape[0]))
+    return out
+
+
+def tie_count():
+    return int(lib().feat_tie_count())

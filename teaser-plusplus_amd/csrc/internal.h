@@ -128,39 +128,64 @@ void launch_peel(hipStream_t s, const ProbDesc* d_desc, int batch, int max_n, in
                  const uint64_t* d_bitmap, const int32_t* d_deg, ProbState* d_state,
                  uint64_t* d_alive_a, uint64_t* d_alive_b);
 
-// exact B&B (kernels_clique.hip).  Works on ONE compact problem: n vertices already renumbered
-// in search order, bitmap rows of W words.
-struct ExactArgs {
-  const uint64_t* bitmap;
-  int32_t n;
-  int32_t W;
-  int32_t* best_size;       // device, initialised to the incumbent size
-  int32_t* best_clique;     // device [n]
-  int32_t* root_counter;    // device, zeroed
-  int32_t* status;          // device, 0 ok / 1 scratch overflow / 2 time limit
-  char* arena;              // device scratch, n_waves * arena_bytes
-  int64_t arena_bytes;      // per wave
-  int32_t n_waves;
-  int32_t n_roots;          // roots 0..n_roots-1 are searched (n: all; colouring bound: |X|)
-  int64_t deadline_ticks;   // wall_clock64 ticks allowed (0 = unlimited)
-  int32_t lds_bitmap;       // set by launch_exact_clique: the adjacency fits in LDS and is staged there
-  int32_t pad;
+// exact B&B (kernels_clique.hip), batched: every open problem of a batch is searched by ONE launch.  Each
+// problem is handed over COMPACT: its candidate vertices renumbered in search order (roots first), adjacency
+// rows of W2 words.  The descriptors live in device memory; ctrl[] is updated by the search with atomics.
+struct ExactProb {
+  int32_t prob;          // index into the batch's ProbDesc / ProbState arrays
+  int32_t n2, W2;        // compact vertices, words per compact row
+  int32_t n_roots;       // roots 0 .. n_roots - 1 are searched (all vertices, or the colouring bound's X)
+  int32_t lb;            // incumbent size at the start (the greedy clique)
+  int32_t n_waves;       // wavefronts (64-thread workgroups) serving this problem
+  int32_t wave0;         // first workgroup index of this problem in the launch
+  int32_t lds_bitmap;    // 1: the compact adjacency is staged in LDS by every workgroup
+  int32_t max_deg;       // largest degree among the candidates (arena sizing)
+  int32_t use_x;         // 1: roots = X (the survivors the colouring bound left without a colour)
+  int64_t order_off;     // compact -> original vertex index, into the order pool (int32)
+  int64_t bm_off;        // compact adjacency, into the bitmap pool (words)
+  int64_t arena_off;     // per-wave DFS arenas, into the arena pool (bytes); wave w: + w * arena_bytes
+  int64_t arena_bytes;
+  int64_t clique_off;    // best clique in compact indices, into the clique pool (int32, n2 + 1 entries)
+  int32_t ctrl[8];       // [0] incumbent size, [1] recorded size, [2] lock, [3] root counter, [4] status
+                         // (0 ok / 1 arena overflow / 2 time limit), [5] raw |X|, [6] kept |X|, [7] spare
 };
-constexpr int64_t kExactLdsBitmapBytes = 128 * 1024;  // n <= 1024 compact vertices
-void launch_exact_clique(hipStream_t s, const ExactArgs& a);
+constexpr int64_t kExactLdsBitmapBytes = 128 * 1024;  // compact adjacency up to 128 KB is staged in LDS
+constexpr int kExactBuildCap = 8192;  // compact vertices the device-side ordering handles (beyond: host path)
+constexpr int kExactXCap = 512;       // |X| up to which only X and its neighbourhood enter the compact problem
+// step 1 (one workgroup per open problem): root filter, candidate set, sizes -> ExactProb.{n2, n_roots, ...}
+void launch_exact_count(hipStream_t s, const ProbDesc* d_desc, ExactProb* d_probs, int nprob, int max_W,
+                        const uint64_t* d_bitmap, const uint64_t* d_alive, const int32_t* d_deg,
+                        const ProbState* d_state, const int32_t* d_xlist, const int32_t* d_keep,
+                        uint64_t* d_cand_bits /* [sum W] by w_off */, uint64_t* d_x_bits /* [sum W] */);
+// step 2: search order (roots first, the rest by ascending degree) + compact adjacency
+void launch_exact_build(hipStream_t s, const ProbDesc* d_desc, const ExactProb* d_probs, int nprob, int max_W,
+                        int max_n2, const uint64_t* d_bitmap, const int32_t* d_deg, const uint64_t* d_cand_bits,
+                        const uint64_t* d_x_bits, int32_t* d_order_pool, unsigned long long* d_key_pool,
+                        uint64_t* d_bitmap_pool);
+// step 3: the search; step 4: best cliques back into the batch's clique arrays (sorted), clique_size updated
+void launch_exact_clique(hipStream_t s, ExactProb* d_probs, int nprob, int total_waves, int max_W2,
+                         int64_t max_lds_bitmap_bytes, const uint64_t* d_bitmap_pool, char* d_arena_pool,
+                         int64_t arena_bytes /* per wave, uniform */, int arena_waves /* >= total_waves */,
+                         int32_t* d_clique_pool, char* d_task_pool, int64_t task_pool_bytes,
+                         int32_t* d_counters /* 4 */, int64_t deadline_ticks);
+void launch_exact_finish(hipStream_t s, const ProbDesc* d_desc, const ExactProb* d_probs, int nprob, int max_W,
+                         const int32_t* d_order_pool, const int32_t* d_clique_pool, int32_t* d_clique,
+                         ProbState* d_state);
 // DRS certifier (kernels_certify.hip): 0, or -1 rocSOLVER / rocBLAS not loadable, -2 HIP error, -3 library call failed
 int certify_on_device(hipStream_t s, const double* R, const double* src, const double* dst, const double* theta, int N,
                       double noise_bound, double cbar2, double sub_optimality, double max_iterations,
                       double gamma_tau, int* is_optimal, double* best_suboptimality, std::vector<double>* traj);
 // global colouring bound on the peel survivors of the selected problems (kernels_clique.hip)
 constexpr int kColourMaxLb = 4096;  // palette limit (64 LDS words per wave)
-constexpr int kColourRounds = 10;
+constexpr int kColourRounds = 16;  // one per vertex class (8) + the all-in rounds
 constexpr int kRootPruneCap = 512;   // leftover roots tested by root_prune_kernel (counts in d_tent)
 constexpr int kRootPruneSlices = 32; // workgroups per root
 void launch_colour_bound(hipStream_t s, const ProbDesc* d_desc, const int32_t* d_sel, int nsel,
                          int max_n, const uint64_t* d_bitmap, const uint64_t* d_alive,
                          const int32_t* d_clique, ProbState* d_state, int32_t* d_colour,
-                         int32_t* d_tent, int32_t* d_xlist, int rounds);
+                         int32_t* d_tent, int32_t* d_xlist, int32_t* d_class_lists /* 8 * total_n */,
+                         int32_t* d_list_a, int32_t* d_list_b, int32_t* d_counts /* nsel * (kColourRounds + 2) */,
+                         uint64_t* d_bits /* 10 * total_w words */, int64_t total_w, int64_t total_n, int rounds);
 
 // KCORE_HEU (graph.cc:58-81): exact core numbers; when max_core > (int)(threshold * n) and
 // threshold != 1 the clique is replaced by every vertex of the maximum core (n <= 65536)

@@ -11,6 +11,9 @@
 // The host hands over a COMPACT problem: vertices already restricted to the peel survivors and
 // renumbered in search order (ascending degree), so "later neighbours of v" is simply the bits
 // above v in row v.
+#include <algorithm>
+#include <utility>
+
 #include "internal.h"
 
 namespace thip {
@@ -93,246 +96,738 @@ __device__ int colour_sort(const uint64_t* __restrict__ bitmap, int W, const uin
   return m;
 }
 
-__global__ __launch_bounds__(64) void exact_clique_kernel(ExactArgs a, int32_t* recorded_size,
-                                                          int32_t* lock) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int n = a.n, W = a.W;
-  const int lane = threadIdx.x;
-  uint64_t* Q = reinterpret_cast<uint64_t*>(smem);
-  uint64_t* Qc = Q + ((W + 1) & ~1);
-  // Compact problems of up to 1024 vertices (the regime of real descriptor graphs: BASELINE config 5, 626
-  // vertices, omega 91): the whole adjacency, n x W words <= 128 KB, is staged in LDS once per workgroup and
-  // every row the colouring / branching steps touch comes from there -- those steps are a chain of dependent
-  // row fetches (one per coloured vertex), ~1 us each from L2, ~0.1 us from LDS.
-  const uint64_t* bmrows = a.bitmap;
-  if (a.lds_bitmap) {
-    uint64_t* bl = Qc + ((W + 1) & ~1);
-    const int64_t words = (int64_t)n * W;
-    for (int64_t k = lane; k < words; k += 64) bl[k] = a.bitmap[k];
-    __syncthreads();
-    bmrows = bl;
-  }
-  char* arena = a.arena + (int64_t)blockIdx.x * a.arena_bytes;
-  int32_t* C = reinterpret_cast<int32_t*>(arena);
-  const int64_t stack0 = align16((int64_t)(n + 1) * 4);
-  const long long t_start = wall_clock64();
+// ------------------------------------------------------------------------------------------
+// The search, in three launches over ALL open problems of a batch (no host round trip in between):
+//   phase 1  one wave per root (waves of a problem pull its roots from a counter): level-0 colouring, every
+//            surviving child becomes a TASK (clique prefix, candidate set, parent's colour bound) in queue 1;
+//   phase 2  persistent waves pull queue-1 tasks in order, colour the node and emit ITS children to queue 2;
+//   phase 3  persistent waves pull queue-2 tasks and run the sequential branch and bound below them.
+// Round 2 searched a root's whole subtree with one wave: BASELINE config 5 batched (64 perturbed 3DMatch
+// pairs) spent 0.86 s in ONE launch because a single root of one problem held 41 000 of the batch's ~100 000
+// search nodes (profiles/r3g) while 2 000 wave slots sat idle.  Depth-2 tasks spread such a tree over hundreds
+// of waves; a task carries its parent's colour bound, so a task whose bound the (shared, steadily improving)
+// incumbent has overtaken is dropped when it is pulled -- the same pruning the sequential order does.
+// A full queue is not an error: the emitting wave searches that child itself.
+// ------------------------------------------------------------------------------------------
+struct ExactTask {   // 32-byte header of a task slot; the candidate bit set (W2 words) follows
+  int32_t q;         // problem index in the launch
+  int32_t csize;     // clique prefix length (<= 4)
+  int32_t cnt;       // |P|
+  int32_t cb;        // a clique through this node has at most this many vertices (parent's colour bound)
+  int32_t C[4];      // the prefix (compact vertex indices)
+};
 
-  while (true) {
-    int r = 0;
-    if (lane == 0) r = atomicAdd(a.root_counter, 1);
-    r = __builtin_amdgcn_readfirstlane(r);
-    if (r >= a.n_roots) break;
-    if (a.deadline_ticks > 0 && wall_clock64() - t_start > a.deadline_ticks) {
-      if (lane == 0) atomicMax(a.status, 2);
-      break;
+struct ExactQueues {
+  char* pool1;
+  char* pool2;
+  int32_t* counters;  // [0] queue-1 count, [1] queue-2 count, [2] queue-1 head, [3] queue-2 head
+  int32_t cap1, cap2;
+  int32_t slot_bytes;  // 32 + 8 * max W2, multiple of 32
+  int32_t pad;
+};
+
+struct WaveCtx {
+  ExactProb* pb;
+  const uint64_t* bmrows;
+  int W;
+  char* arena;
+  int64_t arena_bytes;
+  int32_t* C;
+  int64_t stack0;
+  uint64_t *Q, *Qc;
+  int64_t deadline;
+  long long t_start;
+  unsigned int steps;
+};
+
+// Sequential branch and bound below the node whose candidate set P (pc vertices) sits in the level record at
+// cx.stack0 and whose clique prefix is cx.C[0 .. csize).  Returns 0, or 1 arena overflow / 2 time limit.
+__device__ int dfs_subtree(WaveCtx& cx, int32_t* __restrict__ best_clique, int csize, int pc) {
+  const int lane = threadIdx.x, W = cx.W;
+  char* arena = cx.arena;
+  int32_t* C = cx.C;
+  int32_t* best_size = &cx.pb->ctrl[0];
+  int32_t* recorded_size = &cx.pb->ctrl[1];
+  int32_t* lock = &cx.pb->ctrl[2];
+  int64_t off = cx.stack0;
+  const int64_t hdr_b = align16(sizeof(LevelHdr)), p_b = align16((int64_t)W * 8);
+  int best = __hip_atomic_load(best_size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int64_t lvl_bytes = hdr_b + p_b + 2 * align16((int64_t)pc * 4);
+  if (off + lvl_bytes > cx.arena_bytes) return 1;
+  LevelHdr* L = reinterpret_cast<LevelHdr*>(arena + off);
+  uint64_t* P = reinterpret_cast<uint64_t*>(arena + off + hdr_b);
+  int32_t* order = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(P) + p_b);
+  int32_t* colour = order + (align16((int64_t)pc * 4) / 4);
+  __syncthreads();
+  const int m = colour_sort(cx.bmrows, W, P, pc, best - csize, cx.Q, cx.Qc, order, colour);
+  if (lane == 0) {
+    L->pcount = pc;
+    L->m = m;
+    L->idx = m - 1;
+    L->prev_off = -1;
+    L->bytes = lvl_bytes;
+  }
+  __syncthreads();
+  int depth = 0;
+  while (depth >= 0) {
+    // the time limit also holds INSIDE a subtree (checked every 256 steps)
+    if ((++cx.steps & 255u) == 0u && cx.deadline > 0 && wall_clock64() - cx.t_start > cx.deadline) return 2;
+    L = reinterpret_cast<LevelHdr*>(arena + off);
+    P = reinterpret_cast<uint64_t*>(arena + off + hdr_b);
+    const int lpc = L->pcount;
+    order = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(P) + p_b);
+    colour = order + (align16((int64_t)lpc * 4) / 4);
+    const int idx = L->idx;
+    best = __hip_atomic_load(best_size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool pop = idx < 0;
+    if (!pop && colour[idx] <= best - csize) pop = true;
+    if (pop) {
+      off = L->prev_off;
+      --depth;
+      --csize;
+      __syncthreads();
+      continue;
     }
-    // roots from the END of the search order (highest degree first): their later-neighbour sets are the
-    // smallest and densest, so a maximum clique shows up in the first few roots and every other root is
-    // searched against a tight incumbent (the ascending order kept the whole device busy on the loosest
-    // subproblems first: config 5 took minutes instead of milliseconds)
-    const int v = a.n_roots - 1 - r;
-    int best = __hip_atomic_load(a.best_size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    // level 0: P = later neighbours of v
-    int64_t off = stack0;
-    {
-      const int64_t need_bytes = align16(sizeof(LevelHdr)) + align16((int64_t)W * 8);
-      if (off + need_bytes > a.arena_bytes) {
-        if (lane == 0) atomicMax(a.status, 1);
-        break;
-      }
-    }
-    LevelHdr* L = reinterpret_cast<LevelHdr*>(arena + off);
-    uint64_t* P = reinterpret_cast<uint64_t*>(arena + off + align16(sizeof(LevelHdr)));
-    const uint64_t* rv = bmrows + (int64_t)v * W;
-    int pc = 0;
+    const int u = order[idx];
+    __syncthreads();
+    if (lane == 0) L->idx = idx - 1;
+    // child candidate set NP = P & N(u), built in place at the next arena slot
+    const int64_t noff = off + L->bytes;
+    if (noff + hdr_b + p_b > cx.arena_bytes) return 1;
+    LevelHdr* NL = reinterpret_cast<LevelHdr*>(arena + noff);
+    uint64_t* NP = reinterpret_cast<uint64_t*>(arena + noff + hdr_b);
+    const uint64_t* ru = cx.bmrows + (int64_t)u * W;
+    int cnt = 0;
     for (int w = lane; w < W; w += 64) {
-      uint64_t x = rv[w];
-      const int lo = w * 64;
-      if (lo + 63 <= v) x = 0;
-      else if (lo <= v) x &= ~((2ull << (v - lo)) - 1ull);  // keep bits > v
-      P[w] = x;
-      pc += __popcll(x);
+      const uint64_t x = P[w] & ru[w];
+      NP[w] = x;
+      cnt += __popcll(x);
     }
-    pc = wsum(pc);
-    if (pc < best) continue;  // |C|+|P| = 1+pc must exceed best
-    int csize = 1;
-    if (lane == 0) C[0] = v;
-    // finish level 0
-    int64_t lvl_bytes = align16(sizeof(LevelHdr)) + align16((int64_t)W * 8) + 2 * align16((int64_t)pc * 4);
-    if (off + lvl_bytes > a.arena_bytes) {
-      if (lane == 0) atomicMax(a.status, 1);
-      break;
-    }
-    int32_t* order = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(P) + align16((int64_t)W * 8));
-    int32_t* colour = order + (align16((int64_t)pc * 4) / 4);
-    __syncthreads();
-    int m = colour_sort(bmrows, W, P, pc, best - csize, Q, Qc, order, colour);
+    cnt = wsum(cnt);
     if (lane == 0) {
-      L->pcount = pc;
-      L->m = m;
-      L->idx = m - 1;
-      L->prev_off = -1;
-      L->bytes = lvl_bytes;
+      P[u >> 6] &= ~(1ull << (u & 63));
+      C[csize] = u;
     }
     __syncthreads();
-    int depth = 0;
-    bool overflow = false;
-    unsigned int steps = 0;
-    while (depth >= 0) {
-      // the time limit also holds INSIDE a root's subtree (checked every 256 steps), not only between roots
-      if (a.deadline_ticks > 0 && (++steps & 255u) == 0u && wall_clock64() - t_start > a.deadline_ticks) {
-        if (lane == 0) atomicMax(a.status, 2);
+    if (cnt == 0) {
+      const int size = csize + 1;
+      if (size > best) {
+        if (lane == 0) {
+          atomicMax(best_size, size);
+          while (atomicCAS(lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(2);
+          __threadfence();
+          const int rec = __hip_atomic_load(recorded_size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (size > rec) {
+            for (int k = 0; k < size; ++k)
+              __hip_atomic_store(best_clique + k, C[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(recorded_size, size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          __threadfence();
+          atomicExch(lock, 0);
+        }
+        __syncthreads();
+      }
+    } else if (csize + 1 + cnt > best) {
+      const int64_t nbytes = hdr_b + p_b + 2 * align16((int64_t)cnt * 4);
+      if (noff + nbytes > cx.arena_bytes) return 1;
+      int32_t* norder = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(NP) + p_b);
+      int32_t* ncolour = norder + (align16((int64_t)cnt * 4) / 4);
+      ++csize;
+      const int nm = colour_sort(cx.bmrows, W, NP, cnt, best - csize, cx.Q, cx.Qc, norder, ncolour);
+      if (lane == 0) {
+        NL->pcount = cnt;
+        NL->m = nm;
+        NL->idx = nm - 1;
+        NL->prev_off = off;
+        NL->bytes = nbytes;
+      }
+      __syncthreads();
+      off = noff;
+      ++depth;
+    }
+  }
+  return 0;
+}
+
+// Expands ONE node (prefix cx.C[0 .. csize), candidate set P of pc vertices in the level record at cx.stack0):
+// colours it and turns every child that survives the bounds into a task of `pool` (or, when the pool is full,
+// searches the child at once).  Returns 0 / 1 / 2 like dfs_subtree.
+__device__ int expand_node(WaveCtx& cx, int32_t* __restrict__ best_clique, int q, int csize, int pc, char* pool,
+                           int32_t* pool_count, int cap, int slot_bytes) {
+  const int lane = threadIdx.x, W = cx.W;
+  char* arena = cx.arena;
+  int32_t* C = cx.C;
+  int32_t* best_size = &cx.pb->ctrl[0];
+  const int64_t off = cx.stack0;
+  const int64_t hdr_b = align16(sizeof(LevelHdr)), p_b = align16((int64_t)W * 8);
+  int best = __hip_atomic_load(best_size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int64_t lvl_bytes = hdr_b + p_b + 2 * align16((int64_t)pc * 4);
+  const int64_t noff = off + lvl_bytes;
+  if (noff + hdr_b + p_b > cx.arena_bytes) return 1;
+  uint64_t* P = reinterpret_cast<uint64_t*>(arena + off + hdr_b);
+  int32_t* order = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(P) + p_b);
+  int32_t* colour = order + (align16((int64_t)pc * 4) / 4);
+  uint64_t* NP = reinterpret_cast<uint64_t*>(arena + noff + hdr_b);
+  __syncthreads();
+  const int m = colour_sort(cx.bmrows, W, P, pc, best - csize, cx.Q, cx.Qc, order, colour);
+  __syncthreads();
+  for (int idx = m - 1; idx >= 0; --idx) {
+    best = __hip_atomic_load(best_size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int col = colour[idx];
+    if (col <= best - csize) break;  // colours are listed in non-decreasing order: nothing below can improve
+    const int u = order[idx];
+    const uint64_t* ru = cx.bmrows + (int64_t)u * W;
+    int cnt = 0;
+    for (int w = lane; w < W; w += 64) {
+      const uint64_t x = P[w] & ru[w];
+      NP[w] = x;
+      cnt += __popcll(x);
+    }
+    cnt = wsum(cnt);
+    __syncthreads();
+    if (lane == 0) P[u >> 6] &= ~(1ull << (u & 63));
+    __syncthreads();
+    ++cx.steps;
+    if (cnt == 0) {
+      if (csize + 1 > best) {  // (a clique of prefix + u: only for tiny incumbents)
+        if (lane == 0) {
+          C[csize] = u;
+          int32_t* recorded_size = &cx.pb->ctrl[1];
+          int32_t* lock = &cx.pb->ctrl[2];
+          const int size = csize + 1;
+          atomicMax(best_size, size);
+          while (atomicCAS(lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(2);
+          __threadfence();
+          const int rec = __hip_atomic_load(recorded_size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (size > rec) {
+            for (int k = 0; k < size; ++k)
+              __hip_atomic_store(best_clique + k, C[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(recorded_size, size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          __threadfence();
+          atomicExch(lock, 0);
+        }
+        __syncthreads();
+      }
+      continue;
+    }
+    if (csize + 1 + cnt <= best) continue;
+    int slot = cap;
+    if (csize + 1 <= 4) {
+      if (lane == 0) slot = atomicAdd(pool_count, 1);
+      slot = __builtin_amdgcn_readfirstlane(slot);
+    }
+    if (slot < cap) {
+      ExactTask* t = reinterpret_cast<ExactTask*>(pool + (int64_t)slot * slot_bytes);
+      if (lane == 0) {
+        t->q = q;
+        t->csize = csize + 1;
+        t->cnt = cnt;
+        t->cb = csize + col;
+        for (int k = 0; k < csize; ++k) t->C[k] = C[k];
+        t->C[csize] = u;
+      }
+      uint64_t* tp = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(t) + sizeof(ExactTask));
+      for (int w = lane; w < W; w += 64) tp[w] = NP[w];
+    } else {
+      // queue full (or the prefix does not fit a task): search this child here and now
+      if (lane == 0) {
+        C[csize] = u;
+        if (slot >= cap && csize + 1 <= 4) atomicSub(pool_count, 1);  // give the ticket back (count stays <= cap + waves)
+      }
+      __syncthreads();
+      const int64_t save = cx.stack0;
+      cx.stack0 = noff;
+      const int rc = dfs_subtree(cx, best_clique, csize + 1, cnt);
+      cx.stack0 = save;
+      if (rc) return rc;
+    }
+  }
+  return 0;
+}
+
+__device__ __forceinline__ void stage_problem(WaveCtx& cx, ExactProb* pb, const uint64_t* bitmap_pool,
+                                              char* arena_wave, int64_t arena_bytes, uint64_t* lds_after_q) {
+  const int lane = threadIdx.x;
+  cx.pb = pb;
+  cx.W = pb->W2;
+  cx.bmrows = bitmap_pool + pb->bm_off;
+  cx.arena = arena_wave;
+  cx.arena_bytes = arena_bytes;
+  cx.C = reinterpret_cast<int32_t*>(arena_wave);
+  cx.stack0 = align16((int64_t)(pb->n2 + 1) * 4);
+  if (pb->lds_bitmap) {
+    const int64_t words = (int64_t)pb->n2 * pb->W2;
+    __syncthreads();
+    for (int64_t k = lane; k < words; k += 64) lds_after_q[k] = cx.bmrows[k];
+    __syncthreads();
+    cx.bmrows = lds_after_q;
+  }
+}
+
+// PHASE 1: roots -> queue 1.  Workgroup (= wavefront) g serves problem q with wave0 <= g < wave0 + n_waves.
+// PHASE 2: queue 1 -> queue 2.  PHASE 3: queue 2 -> sequential search.  (Phases 2 and 3: persistent waves.)
+template <int PHASE>
+__global__ __launch_bounds__(64) void exact_clique_kernel(ExactProb* __restrict__ probs, int nprob,
+                                                          const uint64_t* __restrict__ bitmap_pool,
+                                                          char* __restrict__ arena_pool, int64_t arena_bytes,
+                                                          int max_W2, int32_t* __restrict__ clique_pool,
+                                                          ExactQueues qs, int64_t deadline_ticks) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x;
+  WaveCtx cx;
+  cx.Q = reinterpret_cast<uint64_t*>(smem);
+  cx.Qc = cx.Q + ((max_W2 + 1) & ~1);
+  uint64_t* lds_bm = cx.Qc + ((max_W2 + 1) & ~1);
+  cx.deadline = deadline_ticks;
+  cx.t_start = wall_clock64();
+  cx.steps = 0;
+  char* arena_wave = arena_pool + (int64_t)blockIdx.x * arena_bytes;
+  const int64_t hdr_b = align16(sizeof(LevelHdr));
+  int status_rc = 0;
+  ExactProb* pb = nullptr;
+
+  if (PHASE == 1) {
+    int q = -1;
+    for (int base = 0; base < nprob && q < 0; base += 64) {
+      const int k = base + lane;
+      const bool mine = k < nprob && (int)blockIdx.x >= probs[k].wave0 && (int)blockIdx.x < probs[k].wave0 + probs[k].n_waves;
+      const uint64_t m = __ballot(mine);
+      if (m) q = base + __builtin_ctzll(m);
+    }
+    if (q < 0) return;
+    pb = probs + q;
+    stage_problem(cx, pb, bitmap_pool, arena_wave, arena_bytes, lds_bm);
+    const int W = cx.W, n_roots = pb->n_roots;
+    int32_t* best_clique = clique_pool + pb->clique_off;
+    while (true) {
+      int r = 0;
+      if (lane == 0) r = atomicAdd(&pb->ctrl[3], 1);
+      r = __builtin_amdgcn_readfirstlane(r);
+      if (r >= n_roots) break;
+      if (deadline_ticks > 0 && wall_clock64() - cx.t_start > deadline_ticks) {
+        status_rc = 2;
         break;
       }
-      L = reinterpret_cast<LevelHdr*>(arena + off);
-      P = reinterpret_cast<uint64_t*>(arena + off + align16(sizeof(LevelHdr)));
-      const int lpc = L->pcount;
-      order = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(P) + align16((int64_t)W * 8));
-      colour = order + (align16((int64_t)lpc * 4) / 4);
-      const int idx = L->idx;
-      best = __hip_atomic_load(a.best_size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      bool pop = idx < 0;
-      if (!pop && colour[idx] <= best - csize) pop = true;
-      if (pop) {
-        off = L->prev_off;
-        --depth;
-        --csize;
-        __syncthreads();
+      // roots from the END of the search order (highest degree first): their later-neighbour sets are the
+      // smallest and densest, so a maximum clique shows up in the first few roots and every other root is
+      // searched against a tight incumbent
+      const int v = n_roots - 1 - r;
+      const int best = __hip_atomic_load(&pb->ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (cx.stack0 + hdr_b + align16((int64_t)W * 8) > arena_bytes) {
+        status_rc = 1;
+        break;
+      }
+      uint64_t* P = reinterpret_cast<uint64_t*>(cx.arena + cx.stack0 + hdr_b);
+      const uint64_t* rv = cx.bmrows + (int64_t)v * W;
+      int pc = 0;
+      __syncthreads();
+      for (int w = lane; w < W; w += 64) {
+        uint64_t x = rv[w];
+        const int lo = w * 64;
+        if (lo + 63 <= v) x = 0;
+        else if (lo <= v) x &= ~((2ull << (v - lo)) - 1ull);  // keep bits > v
+        P[w] = x;
+        pc += __popcll(x);
+      }
+      pc = wsum(pc);
+      if (pc < best) continue;  // |C| + |P| = 1 + pc must exceed best
+      if (lane == 0) cx.C[0] = v;
+      __syncthreads();
+      ++cx.steps;
+      status_rc = expand_node(cx, best_clique, q, 1, pc, qs.pool1, qs.counters + 0, qs.cap1, qs.slot_bytes);
+      if (status_rc) break;
+    }
+  } else {
+    const char* pool_in = PHASE == 2 ? qs.pool1 : qs.pool2;
+    const int n_in = min(PHASE == 2 ? qs.counters[0] : qs.counters[1], PHASE == 2 ? qs.cap1 : qs.cap2);
+    int32_t* head = qs.counters + (PHASE == 2 ? 2 : 3);
+    int cur_q = -1;
+    while (true) {
+      int i = 0;
+      if (lane == 0) i = atomicAdd(head, 1);
+      i = __builtin_amdgcn_readfirstlane(i);
+      if (i >= n_in) break;
+      const ExactTask* t = reinterpret_cast<const ExactTask*>(pool_in + (int64_t)i * qs.slot_bytes);
+      const int q = t->q, csize = t->csize, cnt = t->cnt, cb = t->cb;
+      ExactProb* tpb = probs + q;
+      const int best = __hip_atomic_load(&tpb->ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (cb <= best || csize + cnt <= best) continue;  // the incumbent has overtaken this subtree
+      if (__hip_atomic_load(&tpb->ctrl[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) continue;  // problem aborted
+      if (deadline_ticks > 0 && wall_clock64() - cx.t_start > deadline_ticks) {
+        if (lane == 0) atomicMax(&tpb->ctrl[4], 2);
         continue;
       }
-      const int u = order[idx];
-      __syncthreads();
-      if (lane == 0) L->idx = idx - 1;
-      // child candidate set NP = P & N(u), built in place at the next arena slot
-      const int64_t noff = off + L->bytes;
-      const int64_t hdr_b = align16(sizeof(LevelHdr)), p_b = align16((int64_t)W * 8);
-      if (noff + hdr_b + p_b > a.arena_bytes) {
-        overflow = true;
-        break;
+      if (q != cur_q) {
+        if (pb && lane == 0 && cx.steps) atomicAdd(&pb->ctrl[7], (int)cx.steps);
+        cx.steps = 0;
+        pb = tpb;
+        stage_problem(cx, pb, bitmap_pool, arena_wave, arena_bytes, lds_bm);
+        cur_q = q;
       }
-      LevelHdr* NL = reinterpret_cast<LevelHdr*>(arena + noff);
-      uint64_t* NP = reinterpret_cast<uint64_t*>(arena + noff + hdr_b);
-      const uint64_t* ru = bmrows + (int64_t)u * W;
-      int cnt = 0;
+      const int W = cx.W;
+      if (cx.stack0 + hdr_b + align16((int64_t)W * 8) > arena_bytes) {
+        if (lane == 0) atomicMax(&pb->ctrl[4], 1);
+        continue;
+      }
+      uint64_t* P = reinterpret_cast<uint64_t*>(cx.arena + cx.stack0 + hdr_b);
+      const uint64_t* tp = reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(t) + sizeof(ExactTask));
+      __syncthreads();
+      for (int w = lane; w < W; w += 64) P[w] = tp[w];
+      if (lane < csize) cx.C[lane] = t->C[lane];
+      __syncthreads();
+      int32_t* best_clique = clique_pool + pb->clique_off;
+      ++cx.steps;
+      int rc;
+      if (PHASE == 2)
+        rc = expand_node(cx, best_clique, q, csize, cnt, qs.pool2, qs.counters + 1, qs.cap2, qs.slot_bytes);
+      else
+        rc = dfs_subtree(cx, best_clique, csize, cnt);
+      if (rc && lane == 0) atomicMax(&pb->ctrl[4], rc);
+    }
+  }
+  if (pb && lane == 0) {
+    if (status_rc) atomicMax(&pb->ctrl[4], status_rc);
+    if (cx.steps) atomicAdd(&pb->ctrl[7], (int)cx.steps);
+  }
+}
+
+void launch_exact_clique(hipStream_t s, ExactProb* d_probs, int nprob, int total_waves, int max_W2,
+                         int64_t max_lds_bitmap_bytes, const uint64_t* d_bitmap_pool, char* d_arena_pool,
+                         int64_t arena_bytes, int arena_waves, int32_t* d_clique_pool, char* d_task_pool,
+                         int64_t task_pool_bytes, int32_t* d_counters /* 4, zeroed here */, int64_t deadline_ticks) {
+  if (nprob <= 0 || total_waves <= 0) return;
+  const size_t lds = (size_t)2 * ((max_W2 + 1) & ~1) * 8 + (size_t)max_lds_bitmap_bytes;
+  static DynLdsOptIn optin1, optin2, optin3;
+  if (lds > 48 * 1024) {
+    optin1.ensure(reinterpret_cast<const void*>(exact_clique_kernel<1>), (int)lds);
+    optin2.ensure(reinterpret_cast<const void*>(exact_clique_kernel<2>), (int)lds);
+    optin3.ensure(reinterpret_cast<const void*>(exact_clique_kernel<3>), (int)lds);
+  }
+  ExactQueues qs;
+  qs.slot_bytes = (int32_t)((sizeof(ExactTask) + 8 * (size_t)max_W2 + 31) & ~(size_t)31);
+  const int64_t slots = task_pool_bytes / qs.slot_bytes;
+  qs.cap1 = (int32_t)std::min<int64_t>(slots / 4, 1 << 22);
+  qs.cap2 = (int32_t)std::min<int64_t>(slots - qs.cap1, 1 << 24);
+  qs.pool1 = d_task_pool;
+  qs.pool2 = d_task_pool + (int64_t)qs.cap1 * qs.slot_bytes;
+  qs.counters = d_counters;
+  qs.pad = 0;
+  (void)hipMemsetAsync(d_counters, 0, 4 * sizeof(int32_t), s);
+  const int w1 = std::min(total_waves, arena_waves);
+  hipLaunchKernelGGL(exact_clique_kernel<1>, dim3(w1), dim3(64), lds, s, d_probs, nprob, d_bitmap_pool, d_arena_pool,
+                     arena_bytes, max_W2, d_clique_pool, qs, deadline_ticks);
+  hipLaunchKernelGGL(exact_clique_kernel<2>, dim3(arena_waves), dim3(64), lds, s, d_probs, nprob, d_bitmap_pool,
+                     d_arena_pool, arena_bytes, max_W2, d_clique_pool, qs, deadline_ticks);
+  hipLaunchKernelGGL(exact_clique_kernel<3>, dim3(arena_waves), dim3(64), lds, s, d_probs, nprob, d_bitmap_pool,
+                     d_arena_pool, arena_bytes, max_W2, d_clique_pool, qs, deadline_ticks);
+}
+
+// ------------------------------------------------------------------------------------------
+// Set-up of the compact problems on the device (what exact_stage used to do on the host with one
+// hipMemcpy per root row, a host sort and a stream sync per problem).
+// ------------------------------------------------------------------------------------------
+// step 1, one workgroup per open problem: the roots the neighbourhood test kept (count >= lb), the candidate
+// set (X and its surviving neighbourhood, or every survivor when there is no usable X), their sizes.
+__global__ __launch_bounds__(256) void exact_count_kernel(const ProbDesc* __restrict__ descs,
+                                                          ExactProb* __restrict__ probs,
+                                                          const uint64_t* __restrict__ bitmap,
+                                                          const uint64_t* __restrict__ alive,
+                                                          const int32_t* __restrict__ deg,
+                                                          const ProbState* __restrict__ states,
+                                                          const int32_t* __restrict__ xlist,
+                                                          const int32_t* __restrict__ keep,
+                                                          uint64_t* __restrict__ cand_bits,
+                                                          uint64_t* __restrict__ x_bits) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int red4[4];
+  __shared__ int kept;
+  ExactProb* pb = probs + blockIdx.x;
+  const int p = pb->prob;
+  const ProbDesc d = descs[p];
+  const int W = d.W, tid = threadIdx.x;
+  const int lb = states[p].lb;
+  const int xc = pb->use_x ? states[p].x_count : -1;  // -1: the colouring bound did not run for this problem
+  uint64_t* Xb = reinterpret_cast<uint64_t*>(smem);  // W
+  uint64_t* Cb = Xb + ((W + 1) & ~1);                // W
+  const uint64_t* al = alive + d.w_off;
+  const uint64_t* bm = bitmap + d.bm_off;
+  for (int w = tid; w < W; w += 256) {
+    Xb[w] = 0;
+    Cb[w] = 0;
+  }
+  if (tid == 0) kept = 0;
+  __syncthreads();
+  bool use_x = xc > 0 && xc <= kExactXCap;
+  if (xc > 0) {
+    // roots the neighbourhood test discarded (fewer than lb qualifying neighbours) are dropped; the counters
+    // are valid for |X| <= kRootPruneCap
+    for (int k = tid; k < xc; k += 256) {
+      const bool ok = xc > kRootPruneCap || keep[d.pt_off + k] >= lb;
+      if (ok) {
+        const int x = xlist[d.pt_off + k];
+        atomicOr(reinterpret_cast<unsigned long long*>(&Xb[x >> 6]), 1ull << (x & 63));
+        atomicAdd(&kept, 1);
+      }
+    }
+  }
+  __syncthreads();
+  const int nx = kept;
+  if (use_x && nx > 0) {
+    // candidates = surviving neighbours of X: one wave per root row
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int k = wave; k < xc; k += 4) {
+      const int x = xlist[d.pt_off + k];
+      if (!((Xb[x >> 6] >> (x & 63)) & 1ull)) continue;
+      const uint64_t* row = bm + (int64_t)x * W;
       for (int w = lane; w < W; w += 64) {
-        const uint64_t x = P[w] & ru[w];
-        NP[w] = x;
-        cnt += __popcll(x);
-      }
-      cnt = wsum(cnt);
-      if (lane == 0) {
-        P[u >> 6] &= ~(1ull << (u & 63));
-        C[csize] = u;
-      }
-      __syncthreads();
-      if (cnt == 0) {
-        const int size = csize + 1;
-        if (size > best) {
-          if (lane == 0) {
-            atomicMax(a.best_size, size);
-            while (atomicCAS(lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(2);
-            __threadfence();
-            const int rec = __hip_atomic_load(recorded_size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (size > rec) {
-              for (int k = 0; k < size; ++k)
-                __hip_atomic_store(a.best_clique + k, C[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              __hip_atomic_store(recorded_size, size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __threadfence();
-            atomicExch(lock, 0);
-          }
-          __syncthreads();
-        }
-      } else if (csize + 1 + cnt > best) {
-        const int64_t nbytes = hdr_b + p_b + 2 * align16((int64_t)cnt * 4);
-        if (noff + nbytes > a.arena_bytes) {
-          overflow = true;
-          break;
-        }
-        int32_t* norder = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(NP) + p_b);
-        int32_t* ncolour = norder + (align16((int64_t)cnt * 4) / 4);
-        ++csize;
-        const int nm = colour_sort(bmrows, W, NP, cnt, best - csize, Q, Qc, norder, ncolour);
-        if (lane == 0) {
-          NL->pcount = cnt;
-          NL->m = nm;
-          NL->idx = nm - 1;
-          NL->prev_off = off;
-          NL->bytes = nbytes;
-        }
-        __syncthreads();
-        off = noff;
-        ++depth;
+        const uint64_t v = row[w] & al[w];
+        if (v) atomicOr(reinterpret_cast<unsigned long long*>(&Cb[w]), v);
       }
     }
-    if (overflow) {
-      if (lane == 0) atomicMax(a.status, 1);
-      break;
+    __syncthreads();
+    for (int w = tid; w < W; w += 256) Cb[w] &= ~Xb[w];
+  } else {
+    for (int w = tid; w < W; w += 256) {
+      Cb[w] = al[w];
+      Xb[w] = 0;
+    }
+    use_x = false;
+  }
+  __syncthreads();
+  int cnt = 0, mdeg = 0;
+  for (int w = tid; w < W; w += 256) {
+    uint64_t bits = Cb[w] | Xb[w];
+    cnt += __popcll(bits);
+    cand_bits[d.w_off + w] = Cb[w];
+    x_bits[d.w_off + w] = Xb[w];
+    while (bits) {
+      mdeg = max(mdeg, deg[d.pt_off + w * 64 + __builtin_ctzll(bits)]);
+      bits &= bits - 1;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    cnt += __shfl_xor(cnt, o, 64);
+    mdeg = max(mdeg, __shfl_xor(mdeg, o, 64));
+  }
+  if ((tid & 63) == 0) red4[tid >> 6] = cnt;
+  __syncthreads();
+  const int n2 = red4[0] + red4[1] + red4[2] + red4[3];
+  __syncthreads();
+  if ((tid & 63) == 0) red4[tid >> 6] = mdeg;
+  __syncthreads();
+  if (tid == 0) {
+    const bool proven = xc == 0 || (xc > 0 && xc <= kRootPruneCap && nx == 0);  // no root can lie in a larger clique
+    pb->n2 = proven ? 0 : n2;
+    pb->W2 = (n2 + 63) / 64;
+    pb->n_roots = use_x ? nx : n2;
+    pb->use_x = use_x ? 1 : 0;
+    pb->lb = lb;
+    pb->max_deg = max(max(red4[0], red4[1]), max(red4[2], red4[3]));
+    pb->ctrl[5] = xc;
+    pb->ctrl[6] = xc > 0 ? nx : xc;
+  }
+}
+
+void launch_exact_count(hipStream_t s, const ProbDesc* d_desc, ExactProb* d_probs, int nprob, int max_W,
+                        const uint64_t* d_bitmap, const uint64_t* d_alive, const int32_t* d_deg,
+                        const ProbState* d_state, const int32_t* d_xlist, const int32_t* d_keep,
+                        uint64_t* d_cand_bits, uint64_t* d_x_bits) {
+  if (nprob <= 0) return;
+  const size_t lds = (size_t)2 * ((max_W + 1) & ~1) * 8;
+  static DynLdsOptIn optin;
+  if (lds > 48 * 1024) optin.ensure(reinterpret_cast<const void*>(exact_count_kernel), (int)lds);
+  hipLaunchKernelGGL(exact_count_kernel, dim3(nprob), dim3(256), lds, s, d_desc, d_probs, d_bitmap, d_alive, d_deg,
+                     d_state, d_xlist, d_keep, d_cand_bits, d_x_bits);
+}
+
+// step 2a, one workgroup per problem: roots (ascending index) to order[0 .. nx), the other candidates as a list
+// of keys (degree << 32 | index) behind them
+__global__ __launch_bounds__(256) void exact_list_kernel(const ProbDesc* __restrict__ descs,
+                                                         const ExactProb* __restrict__ probs,
+                                                         const int32_t* __restrict__ deg,
+                                                         const uint64_t* __restrict__ cand_bits,
+                                                         const uint64_t* __restrict__ x_bits,
+                                                         int32_t* __restrict__ order_pool,
+                                                         unsigned long long* __restrict__ key_pool) {
+  __shared__ int wcnt[256];
+  const ExactProb pb = probs[blockIdx.x];
+  if (pb.n2 <= 0) return;
+  const ProbDesc d = descs[pb.prob];
+  const int W = d.W, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int32_t* order = order_pool + pb.order_off;
+  unsigned long long* keys = key_pool + pb.order_off;
+  const int nx = pb.use_x ? pb.n_roots : 0;
+  for (int pass = 0; pass < 2; ++pass) {
+    const uint64_t* bits = (pass == 0 ? x_bits : cand_bits) + d.w_off;
+    if (pass == 0 && nx == 0) continue;
+    const int wpt = (W + 255) / 256;
+    const int w0 = tid * wpt, w1 = min(W, w0 + wpt);
+    int mycnt = 0;
+    for (int w = w0; w < w1; ++w) mycnt += __popcll(bits[w]);
+    __syncthreads();
+    wcnt[tid] = mycnt;
+    __syncthreads();
+    if (wave == 0) {
+      int a0 = wcnt[4 * lane], a1 = wcnt[4 * lane + 1], a2 = wcnt[4 * lane + 2], a3 = wcnt[4 * lane + 3];
+      int tot = a0 + a1 + a2 + a3, incl = tot;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+      }
+      int ex = incl - tot;
+      wcnt[4 * lane] = ex;
+      wcnt[4 * lane + 1] = ex + a0;
+      wcnt[4 * lane + 2] = ex + a0 + a1;
+      wcnt[4 * lane + 3] = ex + a0 + a1 + a2;
+    }
+    __syncthreads();
+    int pos = wcnt[tid];
+    for (int w = w0; w < w1; ++w) {
+      uint64_t b = bits[w];
+      while (b) {
+        const int v = w * 64 + __builtin_ctzll(b);
+        b &= b - 1;
+        if (pass == 0)
+          order[pos] = v;
+        else
+          keys[nx + pos] = ((unsigned long long)(unsigned int)deg[d.pt_off + v] << 32) | (unsigned int)v;
+        ++pos;
+      }
     }
   }
 }
 
-void launch_exact_clique(hipStream_t s, const ExactArgs& a) {
-  // best_size[0] = incumbent, best_size[1] = recorded size, best_size[2] = lock
-  size_t lds = (size_t)2 * ((a.W + 1) & ~1) * 8;
-  ExactArgs b = a;
-  b.lds_bitmap = ((int64_t)a.n * a.W * 8 <= kExactLdsBitmapBytes) ? 1 : 0;
-  if (b.lds_bitmap) {
-    lds += (size_t)a.n * (size_t)a.W * 8;
-    static DynLdsOptIn optin;
-    if (lds > 48 * 1024) optin.ensure(reinterpret_cast<const void*>(exact_clique_kernel), (int)lds);
+// step 2b: the non-root candidates in ascending (degree, index) order -- rank by counting (every key is unique)
+__global__ __launch_bounds__(256) void exact_rank_kernel(const ExactProb* __restrict__ probs,
+                                                         const unsigned long long* __restrict__ key_pool,
+                                                         int32_t* __restrict__ order_pool) {
+  __shared__ unsigned long long tile[256];
+  const ExactProb pb = probs[blockIdx.y];
+  const int nx = pb.use_x ? pb.n_roots : 0, m = pb.n2 - nx;
+  if (pb.n2 <= 0 || (int)blockIdx.x * 256 >= m) return;
+  const unsigned long long* keys = key_pool + pb.order_off + nx;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const unsigned long long mine = i < m ? keys[i] : ~0ull;
+  int rank = 0;
+  for (int base = 0; base < m; base += 256) {
+    __syncthreads();
+    tile[threadIdx.x] = base + (int)threadIdx.x < m ? keys[base + threadIdx.x] : ~0ull;
+    __syncthreads();
+    const int lim = min(256, m - base);
+    for (int k = 0; k < lim; ++k) rank += tile[k] < mine ? 1 : 0;
   }
-  hipLaunchKernelGGL(exact_clique_kernel, dim3(a.n_waves), dim3(64), lds, s, b, a.best_size + 1,
-                     a.best_size + 2);
+  if (i < m) order_pool[pb.order_off + nx + rank] = (int32_t)(mine & 0xffffffffu);
 }
 
-// ------------------------------------------------------------------------------------------
-// helpers for the compact problem: gather points in search order
-// ------------------------------------------------------------------------------------------
-__global__ void gather_points_kernel(const double* __restrict__ src, const double* __restrict__ dst,
-                                     const int32_t* __restrict__ order, int n,
-                                     double* __restrict__ osrc, double* __restrict__ odst) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int64_t v = order[i];
-  for (int r = 0; r < 3; ++r) {
-    osrc[3 * (int64_t)i + r] = src[3 * v + r];
-    odst[3 * (int64_t)i + r] = dst[3 * v + r];
-  }
-}
-
-void launch_gather_points(hipStream_t s, const double* d_src, const double* d_dst,
-                          const int32_t* d_order, int n, double* d_osrc, double* d_odst) {
-  if (n <= 0) return;
-  hipLaunchKernelGGL(gather_points_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_src, d_dst,
-                     d_order, n, d_osrc, d_odst);
-}
-
-// gather rows/columns of a bitmap into a compact renumbered bitmap (used when the caller supplied
-// the adjacency itself, teaser_hip_max_clique): out[i][j] = in[order[i]][order[j]]
-__global__ __launch_bounds__(64) void gather_bitmap_kernel(const uint64_t* __restrict__ in, int W_in,
-                                                           const int32_t* __restrict__ order, int n,
-                                                           uint64_t* __restrict__ out, int W_out) {
-  const int i = blockIdx.x;
-  const int lane = threadIdx.x;
-  const uint64_t* row = in + (int64_t)order[i] * W_in;
-  for (int wo = 0; wo < W_out; ++wo) {
-    const int j = wo * 64 + lane;
-    bool e = false;
-    if (j < n) {
-      const int v = order[j];
-      e = (row[v >> 6] >> (v & 63)) & 1ull;
+// step 2c: compact adjacency out[i][j] = in[order[i]][order[j]], one wave per compact row
+__global__ __launch_bounds__(256) void exact_gather_kernel(const ProbDesc* __restrict__ descs,
+                                                           const ExactProb* __restrict__ probs,
+                                                           const uint64_t* __restrict__ bitmap,
+                                                           const int32_t* __restrict__ order_pool,
+                                                           uint64_t* __restrict__ bitmap_pool) {
+  const ExactProb pb = probs[blockIdx.y];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n2 = pb.n2, W2 = pb.W2;
+  const ProbDesc d = descs[pb.prob];
+  const int32_t* order = order_pool + pb.order_off;
+  uint64_t* out = bitmap_pool + pb.bm_off;
+  for (int i = blockIdx.x * 4 + wave; i < n2; i += gridDim.x * 4) {
+    const uint64_t* row = bitmap + d.bm_off + (int64_t)order[i] * d.W;
+    for (int wo = 0; wo < W2; ++wo) {
+      const int j = wo * 64 + lane;
+      bool e = false;
+      if (j < n2) {
+        const int v = order[j];
+        e = (row[v >> 6] >> (v & 63)) & 1ull;
+      }
+      const uint64_t m = __ballot(e);
+      if (lane == 0) out[(int64_t)i * W2 + wo] = m;
     }
-    const uint64_t m = __ballot(e);
-    if (lane == 0) out[(int64_t)i * W_out + wo] = m;
   }
 }
 
-void launch_gather_bitmap(hipStream_t s, const uint64_t* d_in, int W_in, const int32_t* d_order,
-                          int n, uint64_t* d_out, int W_out) {
-  if (n <= 0) return;
-  hipLaunchKernelGGL(gather_bitmap_kernel, dim3(n), dim3(64), 0, s, d_in, W_in, d_order, n, d_out,
-                     W_out);
+void launch_exact_build(hipStream_t s, const ProbDesc* d_desc, const ExactProb* d_probs, int nprob, int max_W,
+                        int max_n2, const uint64_t* d_bitmap, const int32_t* d_deg, const uint64_t* d_cand_bits,
+                        const uint64_t* d_x_bits, int32_t* d_order_pool, unsigned long long* d_key_pool,
+                        uint64_t* d_bitmap_pool) {
+  if (nprob <= 0 || max_n2 <= 0) return;
+  hipLaunchKernelGGL(exact_list_kernel, dim3(nprob), dim3(256), 0, s, d_desc, d_probs, d_deg, d_cand_bits, d_x_bits,
+                     d_order_pool, d_key_pool);
+  hipLaunchKernelGGL(exact_rank_kernel, dim3((max_n2 + 255) / 256, nprob), dim3(256), 0, s, d_probs, d_key_pool,
+                     d_order_pool);
+  hipLaunchKernelGGL(exact_gather_kernel, dim3(std::min((max_n2 + 3) / 4, 2048), nprob), dim3(256), 0, s, d_desc,
+                     d_probs, d_bitmap, d_order_pool, d_bitmap_pool);
+}
+
+// step 4, one workgroup per problem: a larger clique found by the search goes back to the batch's clique array
+// in original vertex indices, sorted ascending (registration.cc:636), and the state's clique size follows
+__global__ __launch_bounds__(256) void exact_finish_kernel(const ProbDesc* __restrict__ descs,
+                                                           const ExactProb* __restrict__ probs,
+                                                           const int32_t* __restrict__ order_pool,
+                                                           const int32_t* __restrict__ clique_pool,
+                                                           int32_t* __restrict__ clique,
+                                                           ProbState* __restrict__ states) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int wcnt[256];
+  const ExactProb pb = probs[blockIdx.x];
+  const int size = pb.ctrl[1];
+  if (pb.n2 <= 0 || size <= pb.lb) return;
+  const ProbDesc d = descs[pb.prob];
+  const int W = d.W, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint64_t* memb = reinterpret_cast<uint64_t*>(smem);
+  for (int w = tid; w < W; w += 256) memb[w] = 0;
+  __syncthreads();
+  const int32_t* order = order_pool + pb.order_off;
+  const int32_t* best = clique_pool + pb.clique_off;
+  for (int k = tid; k < size; k += 256) {
+    const int u = order[best[k]];
+    atomicOr(reinterpret_cast<unsigned long long*>(&memb[u >> 6]), 1ull << (u & 63));
+  }
+  __syncthreads();
+  const int wpt = (W + 255) / 256;
+  const int w0 = tid * wpt, w1 = min(W, w0 + wpt);
+  int mycnt = 0;
+  for (int w = w0; w < w1; ++w) mycnt += __popcll(memb[w]);
+  wcnt[tid] = mycnt;
+  __syncthreads();
+  if (wave == 0) {
+    int a0 = wcnt[4 * lane], a1 = wcnt[4 * lane + 1], a2 = wcnt[4 * lane + 2], a3 = wcnt[4 * lane + 3];
+    int tot = a0 + a1 + a2 + a3, incl = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    int ex = incl - tot;
+    wcnt[4 * lane] = ex;
+    wcnt[4 * lane + 1] = ex + a0;
+    wcnt[4 * lane + 2] = ex + a0 + a1;
+    wcnt[4 * lane + 3] = ex + a0 + a1 + a2;
+  }
+  __syncthreads();
+  int pos = wcnt[tid];
+  int32_t* out = clique + d.pt_off;
+  for (int w = w0; w < w1; ++w) {
+    uint64_t b = memb[w];
+    while (b) {
+      out[pos++] = w * 64 + __builtin_ctzll(b);
+      b &= b - 1;
+    }
+  }
+  if (tid == 0) states[pb.prob].clique_size = size;
+}
+
+void launch_exact_finish(hipStream_t s, const ProbDesc* d_desc, const ExactProb* d_probs, int nprob, int max_W,
+                         const int32_t* d_order_pool, const int32_t* d_clique_pool, int32_t* d_clique,
+                         ProbState* d_state) {
+  if (nprob <= 0) return;
+  const size_t lds = (size_t)((max_W + 1) & ~1) * 8;
+  static DynLdsOptIn optin;
+  if (lds > 48 * 1024) optin.ensure(reinterpret_cast<const void*>(exact_finish_kernel), (int)lds);
+  hipLaunchKernelGGL(exact_finish_kernel, dim3(nprob), dim3(256), lds, s, d_desc, d_probs, d_order_pool,
+                     d_clique_pool, d_clique, d_state);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -363,150 +858,225 @@ __device__ __forceinline__ unsigned int colour_hash(int v, int round, unsigned i
   return mix32((unsigned int)v * 0x9E3779B9u + (unsigned int)round * 0x85EBCA6Bu + salt);
 }
 
+// Work lists: after the first rounds only a small fraction of the survivors is still uncoloured, so every
+// round walks a LIST of the uncoloured vertices (two lists per problem, swapped each round, with one counter per
+// round) instead of launching a wave per vertex of the graph that returns at once; the order of a list is
+// irrelevant: every choice is a pure function of (v, round) and of the colours committed in EARLIER rounds.
+// Classes: at N = 50 000 every survivor has ~1600 uncoloured neighbours competing for ~480 free colours -- when
+// all of them pick at once four out of five lose and come back (profiles/r3h: the second round cost as much as
+// the first).  The first kColourClasses rounds therefore admit one hash class of the vertices each (a vertex then
+// competes with 1/8 of its neighbours and wins four times out of five); afterwards everybody left participates.
+// Bit sets: `colbits` = vertices holding a colour, `classbits[k]` = uncoloured survivors of class k; the assign
+// step gathers colours only from neighbours in colbits (round 0: the ~20 adjacent clique members instead of 1600
+// loads that all return "uncoloured"), the resolve step looks only at neighbours that bid in the same round.
+constexpr int kColourClasses = 8;
+static_assert(kColourRounds > kColourClasses, "rounds = one per class + the all-in rounds");
+
+__device__ __forceinline__ int colour_class(int v) { return (int)(mix32((unsigned int)v * 0x9E3779B9u + 0x51ed27u) & (kColourClasses - 1)); }
+
 __global__ __launch_bounds__(256) void colour_init_kernel(const ProbDesc* __restrict__ descs,
                                                           const int32_t* __restrict__ sel,
                                                           const uint64_t* __restrict__ alive,
                                                           const int32_t* __restrict__ clique,
                                                           ProbState* __restrict__ states,
                                                           int32_t* __restrict__ colour,
-                                                          int32_t* __restrict__ tent) {
+                                                          int32_t* __restrict__ tent,
+                                                          int32_t* __restrict__ list0 /* [kColourClasses][sum n] */,
+                                                          int32_t* __restrict__ counts /* [nsel][kColourRounds + 2] */,
+                                                          uint64_t* __restrict__ colbits /* [sum W] */,
+                                                          uint64_t* __restrict__ classbits /* [kColourClasses][sum W] */,
+                                                          int64_t total_w, int64_t total_n) {
   const int p = sel[blockIdx.y];
   const ProbDesc d = descs[p];
-  const int v = blockIdx.x * 256 + threadIdx.x;
-  if (v >= d.n) return;
   const int lb = states[p].lb;
-  const bool al = (alive[d.w_off + (v >> 6)] >> (v & 63)) & 1ull;
-  int c = al ? -1 : -3;
-  if (al) {  // position of v in the sorted clique (binary search)
-    const int32_t* cl = clique + d.pt_off;
-    int lo = 0, hi = lb;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (cl[mid] < v) lo = mid + 1; else hi = mid;
+  const int lane = threadIdx.x & 63;
+  int32_t* cnt = counts + (int64_t)blockIdx.y * (kColourRounds + 2);
+  if (blockIdx.x == 0 && threadIdx.x == 0) states[p].x_count = 0;  // (the rounds that append to X come later)
+  const int npad = d.W * 64;
+  for (int v = blockIdx.x * 256 + threadIdx.x; v < npad; v += gridDim.x * 256) {  // a wave = one 64-vertex word
+    const bool in = v < d.n;
+    const bool al = in && ((alive[d.w_off + (v >> 6)] >> (v & 63)) & 1ull);
+    int c = al ? -1 : -3;
+    if (al) {  // position of v in the sorted clique (binary search)
+      const int32_t* cl = clique + d.pt_off;
+      int lo = 0, hi = lb;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cl[mid] < v) lo = mid + 1; else hi = mid;
+      }
+      if (lo < lb && cl[lo] == v) c = lo;
     }
-    if (lo < lb && cl[lo] == v) c = lo;
+    if (in) {
+      colour[d.pt_off + v] = c;
+      tent[d.pt_off + v] = -1;
+    }
+    const int cls = colour_class(v);
+    const uint64_t mcol = __ballot(c >= 0);
+    if (lane == 0) colbits[d.w_off + (v >> 6)] = mcol;
+#pragma unroll
+    for (int k = 0; k < kColourClasses; ++k) {
+      const uint64_t mk = __ballot(c == -1 && cls == k);
+      if (lane == 0) classbits[(int64_t)k * total_w + d.w_off + (v >> 6)] = mk;
+    }
+    // the class lists: every uncoloured survivor goes to the list of its class (one atomic per wave and class)
+#pragma unroll
+    for (int k = 0; k < kColourClasses; ++k) {
+      const uint64_t m = __ballot(c == -1 && cls == k);
+      if (m) {
+        int base = 0;
+        if (lane == __builtin_ctzll(m)) base = atomicAdd(&cnt[k], __builtin_popcountll(m));
+        base = __shfl(base, __builtin_ctzll(m), 64);
+        if (c == -1 && cls == k)
+          list0[(int64_t)k * total_n + d.pt_off + base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = v;
+      }
+    }
   }
-  colour[d.pt_off + v] = c;
-  tent[d.pt_off + v] = -1;
-  if (v == 0) states[p].x_count = 0;
 }
 
 __global__ __launch_bounds__(256) void colour_assign_kernel(const ProbDesc* __restrict__ descs,
                                                             const int32_t* __restrict__ sel,
                                                             const uint64_t* __restrict__ bitmap,
-                                                            const uint64_t* __restrict__ alive,
-                                                            const ProbState* __restrict__ states,
+                                                            ProbState* __restrict__ states,
                                                             int32_t* __restrict__ colour,
-                                                            int32_t* __restrict__ tent, int round) {
+                                                            int32_t* __restrict__ tent,
+                                                            const int32_t* __restrict__ list,
+                                                            const int32_t* __restrict__ counts,
+                                                            int32_t* __restrict__ xlist,
+                                                            const uint64_t* __restrict__ colbits, int round,
+                                                            int count_idx, const uint64_t* __restrict__ alive,
+                                                            uint64_t* __restrict__ bid_snapshot) {
   __shared__ unsigned long long Fs[4][kColourMaxWords];
   const int p = sel[blockIdx.y];
   const ProbDesc d = descs[p];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int v = blockIdx.x * 4 + wave;
-  if (v >= d.n) return;
+  // all-in rounds: the bidders of this round = the survivors still without a colour NOW (colbits is stable while
+  // the assign step runs; the resolve step, which updates it, reads this snapshot)
+  if (bid_snapshot && blockIdx.x == 0)
+    for (int w = threadIdx.x; w < d.W; w += 256) bid_snapshot[d.w_off + w] = alive[d.w_off + w] & ~colbits[d.w_off + w];
+  const int count = counts[(int64_t)blockIdx.y * (kColourRounds + 2) + count_idx];
   int32_t* col = colour + d.pt_off;
-  if (col[v] != -1) return;
   const int lb = states[p].lb;
   const int nw = (lb + 63) >> 6;
   unsigned long long* F = Fs[wave];
-  F[lane] = 0ull;  // kColourMaxWords == 64 lanes
-  const uint64_t* row = bitmap + d.bm_off + (int64_t)v * d.W;
-  const uint64_t* al = alive + d.w_off;
-  for (int w = lane; w < d.W; w += 64) {
-    uint64_t bits = row[w] & al[w];
-    while (bits) {
-      const int u = w * 64 + __builtin_ctzll(bits);
-      bits &= bits - 1;
-      const int cu = col[u];
-      if (cu >= 0) atomicOr(&F[cu >> 6], 1ull << (cu & 63));
+  const uint64_t* cb = colbits + d.w_off;
+  for (int it = blockIdx.x * 4 + wave; it < count; it += gridDim.x * 4) {
+    const int v = list[d.pt_off + it];
+    F[lane] = 0ull;  // kColourMaxWords == 64 lanes
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    const uint64_t* row = bitmap + d.bm_off + (int64_t)v * d.W;
+    for (int w = lane; w < d.W; w += 64) {
+      uint64_t bits = row[w] & cb[w];  // coloured neighbours only
+      while (bits) {
+        const int u = w * 64 + __builtin_ctzll(bits);
+        bits &= bits - 1;
+        const int cu = col[u];
+        if (cu >= 0) atomicOr(&F[cu >> 6], 1ull << (cu & 63));
+      }
     }
-  }
-  // wave-private LDS, same-wave ordering: no block barrier needed
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  unsigned long long freeb = 0ull;
-  if (lane < nw) {
-    freeb = ~F[lane];
-    const int rem = lb - lane * 64;
-    if (rem < 64) freeb &= (1ull << rem) - 1ull;
-  }
-  const int cnt = __popcll(freeb);
-  int incl = cnt;
+    // wave-private LDS, same-wave ordering: no block barrier needed
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    unsigned long long freeb = 0ull;
+    if (lane < nw) {
+      freeb = ~F[lane];
+      const int rem = lb - lane * 64;
+      if (rem < 64) freeb &= (1ull << rem) - 1ull;
+    }
+    const int cnt = __popcll(freeb);
+    int incl = cnt;
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int t = __shfl_up(incl, o, 64);
-    if (lane >= o) incl += t;
-  }
-  const int total = __shfl(incl, 63, 64);
-  if (total == 0) {
-    if (lane == 0) {
-      col[v] = -2;
-      tent[d.pt_off + v] = -1;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
     }
-    return;
-  }
-  const int target = (int)(colour_hash(v, round, 0x1234567u) % (unsigned int)total);
-  const int excl = incl - cnt;
-  if (target >= excl && target < incl) {
-    int k = target - excl;
-    unsigned long long b = freeb;
-    while (k-- > 0) b &= b - 1;
-    tent[d.pt_off + v] = lane * 64 + __builtin_ctzll(b);
+    const int total = __shfl(incl, 63, 64);
+    if (total == 0) {  // palette exhausted: v belongs to X for good (its neighbours only gain colours)
+      if (lane == 0) {
+        col[v] = -2;
+        tent[d.pt_off + v] = -1;
+        xlist[d.pt_off + atomicAdd(&states[p].x_count, 1)] = v;
+      }
+      continue;
+    }
+    const int target = (int)(colour_hash(v, round, 0x1234567u) % (unsigned int)total);
+    const int excl = incl - cnt;
+    if (target >= excl && target < incl) {
+      int k = target - excl;
+      unsigned long long b = freeb;
+      while (k-- > 0) b &= b - 1;
+      tent[d.pt_off + v] = lane * 64 + __builtin_ctzll(b);
+    }
   }
 }
 
+// winners commit their colour; everybody still uncoloured goes to the next round's list (after the last round:
+// to X)
 __global__ __launch_bounds__(256) void colour_resolve_kernel(const ProbDesc* __restrict__ descs,
                                                              const int32_t* __restrict__ sel,
                                                              const uint64_t* __restrict__ bitmap,
-                                                             const uint64_t* __restrict__ alive,
+                                                             ProbState* __restrict__ states,
                                                              int32_t* __restrict__ colour,
                                                              const int32_t* __restrict__ tent,
-                                                             int round) {
+                                                             const int32_t* __restrict__ list,
+                                                             int32_t* __restrict__ next_list,
+                                                             int32_t* __restrict__ counts,
+                                                             int32_t* __restrict__ xlist,
+                                                             uint64_t* __restrict__ colbits,
+                                                             const uint64_t* __restrict__ bidders /* this round's */,
+                                                             int round, int last, int count_idx, int next_idx) {
   const int p = sel[blockIdx.y];
   const ProbDesc d = descs[p];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int v = blockIdx.x * 4 + wave;
-  if (v >= d.n) return;
+  int32_t* cnt = counts + (int64_t)blockIdx.y * (kColourRounds + 2);
+  const int count = cnt[count_idx];
   int32_t* col = colour + d.pt_off;
   const int32_t* tn = tent + d.pt_off;
-  if (col[v] != -1) return;
-  const int tv = tn[v];
-  if (tv < 0) return;
-  const unsigned int pv = colour_hash(v, round, 0xabcdef1u);
-  const uint64_t* row = bitmap + d.bm_off + (int64_t)v * d.W;
-  const uint64_t* al = alive + d.w_off;
-  bool lose = false;
-  for (int w = lane; w < d.W; w += 64) {
-    uint64_t bits = row[w] & al[w];
-    while (bits) {
-      const int u = w * 64 + __builtin_ctzll(bits);
-      bits &= bits - 1;
-      if (tn[u] == tv) {
-        const unsigned int pu = colour_hash(u, round, 0xabcdef1u);
-        lose |= (pu > pv) | ((pu == pv) & (u > v));
+  const uint64_t* bd = bidders + d.w_off;
+  const uint64_t* cb = colbits + d.w_off;
+  for (int it = blockIdx.x * 4 + wave; it < count; it += gridDim.x * 4) {
+    const int v = list[d.pt_off + it];
+    if (col[v] != -1) continue;  // (-2: already in X)
+    const int tv = tn[v];
+    const unsigned int pv = colour_hash(v, round, 0xabcdef1u);
+    const uint64_t* row = bitmap + d.bm_off + (int64_t)v * d.W;
+    bool lose = false;
+    for (int w = lane; w < d.W; w += 64) {
+      // rivals: neighbours that bid in this round.  (colbits as read here may already hold winners of this very
+      // round -- their bids still count, so it is not used to thin the set; a vertex coloured in an EARLIER
+      // round cannot hold tv: v chose among the colours its coloured neighbours left free.)
+      uint64_t bits = row[w] & bd[w];
+      while (bits) {
+        const int u = w * 64 + __builtin_ctzll(bits);
+        bits &= bits - 1;
+        if (tn[u] == tv) {
+          const unsigned int pu = colour_hash(u, round, 0xabcdef1u);
+          lose |= (pu > pv) | ((pu == pv) & (u > v));
+        }
+      }
+    }
+    const bool lost = __ballot(lose) != 0ull;
+    if (lane == 0) {
+      if (!lost) {
+        col[v] = tv;
+        atomicOr(reinterpret_cast<unsigned long long*>(colbits + d.w_off + (v >> 6)), 1ull << (v & 63));
+      } else if (last) {
+        xlist[d.pt_off + atomicAdd(&states[p].x_count, 1)] = v;
+      } else {
+        next_list[d.pt_off + atomicAdd(&cnt[next_idx], 1)] = v;
       }
     }
   }
-  if (__ballot(lose) == 0ull && lane == 0) col[v] = tv;
+  (void)cb;
 }
 
-// X = survivors left without a colour (-1: still contended after the last round, -2: palette
-// exhausted); unordered append, the host sorts.
-__global__ __launch_bounds__(256) void colour_collect_kernel(const ProbDesc* __restrict__ descs,
-                                                             const int32_t* __restrict__ sel,
-                                                             const int32_t* __restrict__ colour,
-                                                             ProbState* __restrict__ states,
-                                                             int32_t* __restrict__ xlist,
-                                                             int32_t* __restrict__ tent) {
+// the per-root counters of root_prune_kernel (indexed by position in X)
+__global__ __launch_bounds__(256) void colour_finish_kernel(const ProbDesc* __restrict__ descs,
+                                                            const int32_t* __restrict__ sel,
+                                                            const ProbState* __restrict__ states,
+                                                            int32_t* __restrict__ tent) {
   const int p = sel[blockIdx.y];
   const ProbDesc d = descs[p];
-  const int v = blockIdx.x * 256 + threadIdx.x;
-  if (v >= d.n) return;
-  tent[d.pt_off + v] = 0;  // reused as the root_prune counters
-  const int c = colour[d.pt_off + v];
-  if (c == -1 || c == -2) {
-    const int idx = atomicAdd(&states[p].x_count, 1);
-    xlist[d.pt_off + idx] = v;
-  }
+  const int xc = min(states[p].x_count, kRootPruneCap);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < xc; i += gridDim.x * 256) tent[d.pt_off + i] = 0;
 }
 
 // Neighbourhood test for the few roots X the colouring left over.  If x lies in a clique Q with
@@ -562,20 +1132,43 @@ __global__ __launch_bounds__(256) void root_prune_kernel(const ProbDesc* __restr
 void launch_colour_bound(hipStream_t s, const ProbDesc* d_desc, const int32_t* d_sel, int nsel,
                          int max_n, const uint64_t* d_bitmap, const uint64_t* d_alive,
                          const int32_t* d_clique, ProbState* d_state, int32_t* d_colour,
-                         int32_t* d_tent, int32_t* d_xlist, int rounds) {
+                         int32_t* d_tent, int32_t* d_xlist, int32_t* d_class_lists /* kColourClasses * total_n */,
+                         int32_t* d_list_a, int32_t* d_list_b,
+                         int32_t* d_counts /* nsel * (kColourRounds + 2), zeroed here */,
+                         uint64_t* d_bits /* (kColourClasses + 2) * total_w words */, int64_t total_w,
+                         int64_t total_n, int rounds) {
   if (nsel <= 0 || max_n <= 0) return;
-  dim3 gv((max_n + 255) / 256, nsel), gw((max_n + 3) / 4, nsel);
-  hipLaunchKernelGGL(colour_init_kernel, gv, dim3(256), 0, s, d_desc, d_sel, d_alive, d_clique,
-                     d_state, d_colour, d_tent);
+  rounds = std::max(kColourClasses + 1, std::min(rounds, kColourRounds));
+  (void)hipMemsetAsync(d_counts, 0, sizeof(int32_t) * (size_t)nsel * (kColourRounds + 2), s);
+  uint64_t* colbits = d_bits;
+  uint64_t* classbits = d_bits + total_w;
+  const int gi = std::min((max_n + 255) / 256, 1024);
+  hipLaunchKernelGGL(colour_init_kernel, dim3(gi, nsel), dim3(256), 0, s, d_desc, d_sel, d_alive, d_clique,
+                     d_state, d_colour, d_tent, d_class_lists, d_counts, colbits, classbits, total_w, total_n);
+  // counters: [k] = class list k (k < kColourClasses), [kColourClasses + j] = leftover list of all-in round j.
+  // Class round r walks class list r (an eighth of the survivors); its losers go to leftover list 0; all-in
+  // round j walks leftover list j (A / B alternating) and sends its losers to list j + 1, the last one to X.
   for (int r = 0; r < rounds; ++r) {
-    hipLaunchKernelGGL(colour_assign_kernel, gw, dim3(256), 0, s, d_desc, d_sel, d_bitmap, d_alive,
-                       d_state, d_colour, d_tent, r);
-    hipLaunchKernelGGL(colour_resolve_kernel, gw, dim3(256), 0, s, d_desc, d_sel, d_bitmap, d_alive,
-                       d_colour, d_tent, r);
+    const bool cls = r < kColourClasses;
+    const int j = r - kColourClasses;
+    const int32_t* cur = cls ? d_class_lists + (int64_t)r * total_n : ((j & 1) ? d_list_b : d_list_a);
+    int32_t* nxt = cls ? d_list_a : ((j & 1) ? d_list_a : d_list_b);
+    const int count_idx = cls ? r : kColourClasses + j;
+    const int next_idx = cls ? kColourClasses : kColourClasses + j + 1;
+    // (a wave per listed vertex, as many in flight as the GPU holds -- every wave is a chain of dependent
+    // gathers; the all-in rounds see a small fraction of the vertices: a smaller grid starts sooner)
+    const int g = cls ? std::max(1, (max_n / kColourClasses + 3) / 4 + 64) : std::min((max_n + 3) / 4, 1024);
+    uint64_t* snapshot = d_bits + (int64_t)(kColourClasses + 1) * total_w;
+    const uint64_t* bidders = cls ? classbits + (int64_t)r * total_w : snapshot;
+    hipLaunchKernelGGL(colour_assign_kernel, dim3(g, nsel), dim3(256), 0, s, d_desc, d_sel, d_bitmap, d_state,
+                       d_colour, d_tent, cur, d_counts, d_xlist, colbits, r, count_idx, d_alive,
+                       cls ? static_cast<uint64_t*>(nullptr) : snapshot);
+    hipLaunchKernelGGL(colour_resolve_kernel, dim3(g, nsel), dim3(256), 0, s, d_desc, d_sel, d_bitmap, d_state,
+                       d_colour, d_tent, cur, nxt, d_counts, d_xlist, colbits, bidders, r, r == rounds - 1 ? 1 : 0,
+                       count_idx, next_idx);
   }
-  hipLaunchKernelGGL(colour_collect_kernel, gv, dim3(256), 0, s, d_desc, d_sel, d_colour, d_state,
-                     d_xlist, d_tent);
-  // d_tent is free again (zeroed by the collect kernel): per-root counts of qualifying neighbours
+  hipLaunchKernelGGL(colour_finish_kernel, dim3(2, nsel), dim3(256), 0, s, d_desc, d_sel, d_state, d_tent);
+  // d_tent[0 .. |X|) now holds zeroed per-root counts of qualifying neighbours
   const int max_W = (max_n + 63) / 64;
   hipLaunchKernelGGL(root_prune_kernel, dim3(kRootPruneSlices, kRootPruneCap, nsel), dim3(256),
                      (size_t)max_W * 8, s, d_desc, d_sel, d_bitmap, d_alive, d_state, d_xlist, d_tent);

@@ -25,10 +25,6 @@ void launch_select_best(hipStream_t s, const ProbDesc* d_desc, int batch, int ma
 void launch_peel_rounds(hipStream_t s, const ProbDesc* d_desc, int batch, int max_W,
                         const uint64_t* d_bitmap, ProbState* d_state, uint64_t* d_alive_a,
                         uint64_t* d_alive_b, int32_t* d_next_count, int rounds);
-void launch_gather_points(hipStream_t s, const double* d_src, const double* d_dst,
-                          const int32_t* d_order, int n, double* d_osrc, double* d_odst);
-void launch_gather_bitmap(hipStream_t s, const uint64_t* d_in, int W_in, const int32_t* d_order,
-                          int n, uint64_t* d_out, int W_out);
 void launch_gnc_tls_raw(hipStream_t s, const double* d_src, const double* d_dst, int K,
                         double noise_bound, EstParams ep, double* d_w, double* d_out,
                         int32_t* d_iters);
@@ -157,10 +153,10 @@ struct teaser_hip_solver {
       d_alive_b, d_next_count, d_weights, d_rot_inl, d_trans_inl, d_tls_scratch, d_tim_off,
       d_pk, d_prep, d_work;
   // colouring bound
-  DevBuf c_sel, c_colour, c_tent, c_xlist;
+  DevBuf c_sel, c_colour, c_tent, c_xlist, c_list_a, c_list_b, c_counts, c_bits, c_class;
   std::vector<int32_t> colour_x;  // |X| per problem of the last solve (-1: stage not run)
   // exact stage
-  DevBuf x_order, x_src, x_dst, x_bitmap, x_desc, x_state, x_ctrl, x_clique, x_arena;
+  DevBuf x_order, x_src, x_dst, x_bitmap, x_desc, x_state, x_ctrl, x_clique, x_arena, x_probs, x_probs2, x_keys, x_xbits, x_tasks;
   // stand-alone stages
   DevBuf s_a, s_b, s_c, s_d, s_e;
   // correspondence front-end (FPFH, matcher)
@@ -341,167 +337,6 @@ int64_t tls_scratch_bytes(int n) {
 }
 
 // --------------------------------------------------------------------------------------------
-// Exact stage for one problem whose greedy bound the peel could not close (graph.cc:104-122).
-// --------------------------------------------------------------------------------------------
-int32_t run_exact_on_compact(teaser_hip_solver* h, const uint64_t* d_cbitmap, int n2, int W2,
-                             int lb, int max_deg, std::vector<int32_t>& best_local,
-                             int* status_out, int n_roots) {
-  hipStream_t s = h->stream;
-  // control words: [0] incumbent size, [1] recorded size, [2] lock, [3] root counter, [4] status
-  int32_t ctrl[8] = {lb, lb, 0, 0, 0, 0, 0, 0};
-  HIPCHK(h, h->x_ctrl.ensure(sizeof(ctrl)));
-  HIPCHK(h, h->x_clique.ensure((size_t)(n2 + 1) * 4));
-  int n_waves = std::min(2048, std::max(n_roots, 1));
-  int64_t depth_guess = std::min<int64_t>((int64_t)lb + 96, (int64_t)n2 + 1);
-  int64_t arena = (int64_t)(n2 + 1) * 4 + depth_guess * (64 + (int64_t)W2 * 8 + 16) +
-                  8 * (int64_t)max_deg * 8 + (1 << 16);
-  arena = (arena + 255) & ~(int64_t)255;
-  const int64_t kTotalCap = (int64_t)24 << 30;
-  best_local.clear();
-  *status_out = 0;
-  for (int attempt = 0; attempt < 8; ++attempt) {
-    while ((int64_t)n_waves * arena > kTotalCap && n_waves > 64) n_waves /= 2;
-    if ((int64_t)n_waves * arena > kTotalCap) {
-      *status_out = 1;
-      break;
-    }
-    HIPCHK(h, h->x_arena.ensure((size_t)n_waves * (size_t)arena));
-    ctrl[3] = 0;
-    ctrl[4] = 0;
-    HIPCHK(h, hipMemcpyAsync(h->x_ctrl.p, ctrl, sizeof(ctrl), hipMemcpyHostToDevice, s));
-    ExactArgs a;
-    a.bitmap = d_cbitmap;
-    a.n = n2;
-    a.W = W2;
-    a.best_size = h->x_ctrl.as<int32_t>();
-    a.best_clique = h->x_clique.as<int32_t>();
-    a.root_counter = h->x_ctrl.as<int32_t>() + 3;
-    a.status = h->x_ctrl.as<int32_t>() + 4;
-    a.arena = h->x_arena.as<char>();
-    a.arena_bytes = arena;
-    a.n_waves = n_waves;
-    a.n_roots = n_roots;
-    const double lim = h->params.max_clique_time_limit;
-    a.deadline_ticks = (lim > 0 && lim < 1e7) ? (int64_t)(lim * 1e8) : 0;  // 100 MHz counter
-    static const bool dbg = getenv("TEASER_K4_DEBUG") != nullptr;
-    const auto t0 = std::chrono::steady_clock::now();
-    launch_exact_clique(s, a);
-    HIPCHK(h, hipGetLastError());
-    HIPCHK(h, hipMemcpyAsync(ctrl, h->x_ctrl.p, sizeof(ctrl), hipMemcpyDeviceToHost, s));
-    HIPCHK(h, hipStreamSynchronize(s));
-    if (dbg)  // diagnostics only
-      fprintf(stderr, "[teaser_hip] exact search: n %d W %d incumbent %d roots %d waves %d arena %lld B attempt %d: "
-              "%.1f ms, best %d recorded %d roots taken %d status %d\n", n2, W2, lb, n_roots, n_waves,
-              (long long)arena, attempt,
-              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), ctrl[0],
-              ctrl[1], ctrl[3], ctrl[4]);
-    if (ctrl[4] == 1) {  // arena overflow: keep the incumbent, retry with a larger arena
-      arena *= 4;
-      ctrl[0] = ctrl[1];
-      ctrl[2] = 0;
-      continue;
-    }
-    *status_out = ctrl[4];
-    break;
-  }
-  if (ctrl[1] > lb) {
-    best_local.resize((size_t)ctrl[1]);
-    HIPCHK(h, hipMemcpy(best_local.data(), h->x_clique.p, (size_t)ctrl[1] * 4, hipMemcpyDeviceToHost));
-  }
-  return TEASER_HIP_OK;
-}
-
-// X (may be null): the survivors the colouring bound could not colour -- every clique larger
-// than lb contains one of them, so they are the only roots, and only X and its neighbourhood
-// enter the compact problem.
-int32_t exact_stage(teaser_hip_solver* h, int p, const uint64_t* d_final_alive,
-                    const std::vector<int32_t>* X, bool from_points) {
-  hipStream_t s = h->stream;
-  const ProbDesc d = h->descs[(size_t)p];
-  ProbState& st = h->states[(size_t)p];
-  const int n = d.n, W = d.W;
-  std::vector<int32_t> deg((size_t)n);
-  std::vector<uint64_t> alive((size_t)W);
-  HIPCHK(h, hipMemcpy(deg.data(), h->d_deg.as<int32_t>() + d.pt_off, (size_t)n * 4, hipMemcpyDeviceToHost));
-  HIPCHK(h, hipMemcpy(alive.data(), d_final_alive + d.w_off, (size_t)W * 8, hipMemcpyDeviceToHost));
-  std::vector<int32_t> order;
-  int n_roots = -1;
-  if (X && !X->empty() && X->size() <= 512) {
-    // candidates = alive neighbours of X; rows of X fetched from the device bitmap
-    std::vector<uint64_t> un((size_t)W, 0), row((size_t)W);
-    for (int32_t x : *X) {
-      HIPCHK(h, hipMemcpy(row.data(), h->d_bitmap.as<uint64_t>() + d.bm_off + (int64_t)x * W,
-                          (size_t)W * 8, hipMemcpyDeviceToHost));
-      for (int w = 0; w < W; ++w) un[(size_t)w] |= row[(size_t)w] & alive[(size_t)w];
-    }
-    for (int32_t x : *X) un[(size_t)(x >> 6)] &= ~(1ull << (x & 63));
-    order = *X;  // roots first, ascending
-    n_roots = (int)X->size();
-    std::vector<int32_t> rest;
-    for (int v = 0; v < n; ++v)
-      if ((un[(size_t)(v >> 6)] >> (v & 63)) & 1ull) rest.push_back(v);
-    std::stable_sort(rest.begin(), rest.end(),
-                     [&](int32_t a, int32_t b) { return deg[(size_t)a] < deg[(size_t)b]; });
-    order.insert(order.end(), rest.begin(), rest.end());
-  } else {
-    order.reserve((size_t)st.alive_count);
-    for (int v = 0; v < n; ++v)
-      if ((alive[(size_t)(v >> 6)] >> (v & 63)) & 1ull) order.push_back(v);
-    std::stable_sort(order.begin(), order.end(),
-                     [&](int32_t a, int32_t b) { return deg[(size_t)a] < deg[(size_t)b]; });
-    n_roots = (int)order.size();
-  }
-  int max_deg = 0;
-  for (int32_t v : order) max_deg = std::max(max_deg, deg[(size_t)v]);
-  const int n2 = (int)order.size();
-  if (n2 <= st.lb) return TEASER_HIP_OK;
-  const int W2 = (n2 + 63) / 64;
-  HIPCHK(h, h->x_order.ensure((size_t)n2 * 4));
-  HIPCHK(h, h->x_bitmap.ensure((size_t)n2 * (size_t)W2 * 8));
-  HIPCHK(h, hipMemcpyAsync(h->x_order.p, order.data(), (size_t)n2 * 4, hipMemcpyHostToDevice, s));
-  if (from_points) {
-    // the compact adjacency is recomputed from the gathered points (cheaper than a bit gather)
-    HIPCHK(h, h->x_src.ensure((size_t)n2 * 24));
-    HIPCHK(h, h->x_dst.ensure((size_t)n2 * 24));
-    HIPCHK(h, h->x_desc.ensure(sizeof(ProbDesc)));
-    HIPCHK(h, h->x_state.ensure(sizeof(ProbState)));
-    launch_gather_points(s, h->cur_src + 3 * d.pt_off, h->cur_dst + 3 * d.pt_off,
-                         h->x_order.as<int32_t>(), n2, h->x_src.as<double>(), h->x_dst.as<double>());
-    ProbDesc d2;
-    d2.n = n2;
-    d2.W = W2;
-    d2.pt_off = 0;
-    d2.bm_off = 0;
-    d2.w_off = 0;
-    HIPCHK(h, hipMemcpyAsync(h->x_desc.p, &d2, sizeof(d2), hipMemcpyHostToDevice, s));
-    HIPCHK(h, hipMemcpyAsync(h->x_state.p, &st, sizeof(st), hipMemcpyHostToDevice, s));
-    StageScope sc(h, ST_TIM);
-    launch_tim_graph(s, h->x_desc.as<ProbDesc>(), 1, n2, h->x_src.as<double>(), h->x_dst.as<double>(),
-                     h->x_bitmap.as<uint64_t>(), h->params.noise_bound, h->params.cbar2,
-                     h->params.estimate_scaling ? 1 : 0, h->x_state.as<ProbState>());
-  } else {
-    launch_gather_bitmap(s, h->d_bitmap.as<uint64_t>() + d.bm_off, W, h->x_order.as<int32_t>(), n2,
-                         h->x_bitmap.as<uint64_t>(), W2);
-  }
-  std::vector<int32_t> best_local;
-  int xstatus = 0;
-  int32_t rc = run_exact_on_compact(h, h->x_bitmap.as<uint64_t>(), n2, W2, st.lb, max_deg,
-                                    best_local, &xstatus, n_roots);
-  if (rc != TEASER_HIP_OK) return rc;
-  if (xstatus == 1) h->prob_status[(size_t)p] = TEASER_HIP_ERR_SCRATCH;
-  if (xstatus == 2) h->prob_status[(size_t)p] = TEASER_HIP_ERR_TIME_LIMIT;
-  if (!best_local.empty()) {
-    std::vector<int32_t> cl(best_local.size());
-    for (size_t k = 0; k < best_local.size(); ++k) cl[k] = order[(size_t)best_local[k]];
-    std::sort(cl.begin(), cl.end());  // registration.cc:636
-    HIPCHK(h, hipMemcpy(h->d_clique.as<int32_t>() + d.pt_off, cl.data(), cl.size() * 4,
-                        hipMemcpyHostToDevice));
-    st.clique_size = (int32_t)cl.size();
-  }
-  return TEASER_HIP_OK;
-}
-
-// --------------------------------------------------------------------------------------------
 // estimate_scaling = true: TRIMs + scalar TLS over all M pairs (registration.cc:410-425)
 // --------------------------------------------------------------------------------------------
 // Up to kSmallScaledN points the M <= 2^18 TRIMs are sorted by ONE workgroup (lowest latency; every
@@ -637,83 +472,200 @@ int32_t scale_stage_batch(teaser_hip_solver* h, int batch) {
 // After the greedy + peel stages (host copies of the states are fresh): for every problem whose
 // bound is still open run the global colouring bound, then the exact search from the roots it
 // could not colour (graph.cc:104-122 is the reference's counterpart: pmc's exact search).
+// Everything is batched over the open problems and stays on the device: colouring bound -> root filter,
+// candidate sets and sizes (exact_count) -> ONE host sync for the sizes -> search order + compact adjacency
+// (exact_build) -> ONE search launch for all problems -> cliques back into the batch (exact_finish) -> one sync.
+// (Round 2 did this per problem on the host: a hipMemcpy per root row, a host sort, a stream sync per attempt --
+// 20 ms per problem at BASELINE config 5, one problem after the other.)
 // --------------------------------------------------------------------------------------------
-int32_t close_clique_bounds(teaser_hip_solver* h, int batch, int64_t total_n, bool from_points,
-                            bool* changed) {
+int32_t close_clique_bounds(teaser_hip_solver* h, int batch, int64_t total_n, bool* changed) {
   hipStream_t s = h->stream;
   const ProbDesc* dd = h->d_desc.as<ProbDesc>();
   ProbState* ds = h->d_state.as<ProbState>();
-  int32_t rc = TEASER_HIP_OK;
-  {
-    const uint64_t* final_alive =
-        (kPeelRounds % 2 == 0) ? h->d_alive_a.as<uint64_t>() : h->d_alive_b.as<uint64_t>();
-    // problems whose greedy bound the peel did not close: first the global colouring bound
-    std::vector<int32_t> unproven, csel;
-    for (int b = 0; b < batch; ++b) {
-      const ProbState& st = h->states[(size_t)b];
-      if (st.proven || h->descs[(size_t)b].n < 2) continue;
-      unproven.push_back(b);
-      if (st.lb >= 2 && st.lb <= kColourMaxLb) csel.push_back(b);
+  const uint64_t* final_alive =
+      (kPeelRounds % 2 == 0) ? h->d_alive_a.as<uint64_t>() : h->d_alive_b.as<uint64_t>();
+  uint64_t* spare_alive = (kPeelRounds % 2 == 0) ? h->d_alive_b.as<uint64_t>() : h->d_alive_a.as<uint64_t>();
+  // problems whose greedy bound the peel did not close: first the global colouring bound
+  std::vector<int32_t> unproven, csel;
+  for (int b = 0; b < batch; ++b) {
+    const ProbState& st = h->states[(size_t)b];
+    if (st.proven || h->descs[(size_t)b].n < 2) continue;
+    unproven.push_back(b);
+    if (st.lb >= 2 && st.lb <= kColourMaxLb) csel.push_back(b);
+  }
+  h->colour_x.assign((size_t)batch, -1);
+  if (unproven.empty()) return TEASER_HIP_OK;
+  int max_n = 0;
+  for (int32_t b : unproven) max_n = std::max(max_n, h->descs[(size_t)b].n);
+  const int max_W = (max_n + 63) / 64;
+  HIPCHK(h, h->c_colour.ensure(4 * (size_t)total_n));
+  HIPCHK(h, h->c_tent.ensure(4 * (size_t)total_n));
+  HIPCHK(h, h->c_xlist.ensure(4 * (size_t)total_n));
+  if (!csel.empty()) {
+    StageScope sc(h, ST_COLOUR);
+    HIPCHK(h, h->c_sel.ensure(4 * csel.size()));
+    HIPCHK(h, h->c_list_a.ensure(4 * (size_t)total_n));
+    HIPCHK(h, h->c_list_b.ensure(4 * (size_t)total_n));
+    HIPCHK(h, h->c_counts.ensure(4 * csel.size() * (size_t)(kColourRounds + 2)));
+    HIPCHK(h, h->c_bits.ensure(8 * 10 * (size_t)std::max<int64_t>(h->total_w, 1)));
+    HIPCHK(h, h->c_class.ensure(4 * 8 * (size_t)total_n));
+    HIPCHK(h, hipMemcpyAsync(h->c_sel.p, csel.data(), 4 * csel.size(), hipMemcpyHostToDevice, s));
+    int cmax_n = 0;
+    for (int32_t b : csel) cmax_n = std::max(cmax_n, h->descs[(size_t)b].n);
+    launch_colour_bound(s, dd, h->c_sel.as<int32_t>(), (int)csel.size(), cmax_n,
+                        h->d_bitmap.as<uint64_t>(), final_alive, h->d_clique.as<int32_t>(), ds,
+                        h->c_colour.as<int32_t>(), h->c_tent.as<int32_t>(),
+                        h->c_xlist.as<int32_t>(), h->c_class.as<int32_t>(), h->c_list_a.as<int32_t>(),
+                        h->c_list_b.as<int32_t>(), h->c_counts.as<int32_t>(), h->c_bits.as<uint64_t>(),
+                        std::max<int64_t>(h->total_w, 1), total_n, kColourRounds);
+    HIPCHK(h, hipGetLastError());
+  }
+  StageScope sc_exact(h, ST_EXACT);
+  // root filter, candidate sets, sizes: one descriptor per open problem
+  std::vector<ExactProb> ep(unproven.size());
+  memset(ep.data(), 0, sizeof(ExactProb) * ep.size());
+  for (size_t k = 0; k < unproven.size(); ++k) {
+    ep[k].prob = unproven[k];
+    ep[k].use_x = std::find(csel.begin(), csel.end(), unproven[k]) != csel.end() ? 1 : 0;
+  }
+  HIPCHK(h, h->x_probs.ensure(sizeof(ExactProb) * ep.size()));
+  HIPCHK(h, h->x_xbits.ensure(8 * (size_t)std::max<int64_t>(h->total_w, 1)));
+  HIPCHK(h, hipMemcpyAsync(h->x_probs.p, ep.data(), sizeof(ExactProb) * ep.size(), hipMemcpyHostToDevice, s));
+  launch_exact_count(s, dd, h->x_probs.as<ExactProb>(), (int)ep.size(), max_W, h->d_bitmap.as<uint64_t>(), final_alive,
+                     h->d_deg.as<int32_t>(), ds, h->c_xlist.as<int32_t>(), h->c_tent.as<int32_t>(), spare_alive,
+                     h->x_xbits.as<uint64_t>());
+  HIPCHK(h, hipGetLastError());
+  HIPCHK(h, hipMemcpyAsync(ep.data(), h->x_probs.p, sizeof(ExactProb) * ep.size(), hipMemcpyDeviceToHost, s));
+  HIPCHK(h, hipStreamSynchronize(s));
+  std::vector<ExactProb> open;
+  for (const ExactProb& e : ep) {
+    const int b = e.prob;
+    ProbState& st = h->states[(size_t)b];
+    const int xc_raw = e.ctrl[5], xc_kept = e.ctrl[6];
+    h->colour_x[(size_t)b] = (xc_raw > 0 && xc_kept == 0) ? 0 : xc_raw;
+    if (e.n2 == 0) {  // lb colours suffice for every survivor / no root can lie in a larger clique
+      st.proven = 1;
+      continue;
     }
-    h->colour_x.assign((size_t)batch, -1);
-    if (!csel.empty()) {
-      StageScope sc(h, ST_COLOUR);
-      HIPCHK(h, h->c_sel.ensure(4 * csel.size()));
-      HIPCHK(h, h->c_colour.ensure(4 * (size_t)total_n));
-      HIPCHK(h, h->c_tent.ensure(4 * (size_t)total_n));
-      HIPCHK(h, h->c_xlist.ensure(4 * (size_t)total_n));
-      HIPCHK(h, hipMemcpyAsync(h->c_sel.p, csel.data(), 4 * csel.size(), hipMemcpyHostToDevice, s));
-      int cmax_n = 0;
-      for (int32_t b : csel) cmax_n = std::max(cmax_n, h->descs[(size_t)b].n);
-      launch_colour_bound(s, dd, h->c_sel.as<int32_t>(), (int)csel.size(), cmax_n,
-                          h->d_bitmap.as<uint64_t>(), final_alive, h->d_clique.as<int32_t>(), ds,
-                          h->c_colour.as<int32_t>(), h->c_tent.as<int32_t>(),
-                          h->c_xlist.as<int32_t>(), kColourRounds);
-      HIPCHK(h, hipGetLastError());
-      for (int32_t b : csel)
-        HIPCHK(h, hipMemcpyAsync(&h->colour_x[(size_t)b], &ds[b].x_count, 4, hipMemcpyDeviceToHost, s));
-      HIPCHK(h, hipStreamSynchronize(s));
+    h->exact_run[(size_t)b] = 1;
+    if (e.n2 > st.lb) open.push_back(e);
+  }
+  if (open.empty()) return TEASER_HIP_OK;
+  // pools: search order (+ sort keys), compact adjacency, best cliques, per-wave DFS arenas
+  const int64_t kArenaCap = (int64_t)24 << 30;
+  const int kMaxWaves = 16384;
+  int64_t o_order = 0, o_bm = 0, o_cl = 0;
+  int max_n2 = 0;
+  int total_roots = 0;
+  for (const ExactProb& e : open) total_roots += std::min(2048, std::max(e.n_roots, 1));
+  for (ExactProb& e : open) {
+    e.order_off = o_order;
+    e.bm_off = o_bm;
+    e.clique_off = o_cl;
+    o_order += (e.n2 + 63) & ~63;
+    o_bm += (int64_t)e.n2 * e.W2;
+    o_cl += (e.n2 + 1 + 63) & ~63;
+    max_n2 = std::max(max_n2, e.n2);
+    int nw = std::min(2048, std::max(e.n_roots, 1));
+    if (total_roots > kMaxWaves) nw = std::max(1, (int)((int64_t)nw * kMaxWaves / total_roots));
+    e.n_waves = nw;
+    const int64_t depth_guess = std::min<int64_t>((int64_t)e.lb + 96, (int64_t)e.n2 + 1);
+    int64_t arena = (int64_t)(e.n2 + 1) * 4 + depth_guess * (64 + (int64_t)e.W2 * 8 + 16) + 8 * (int64_t)e.max_deg * 8 + (1 << 16);
+    e.arena_bytes = (arena + 255) & ~(int64_t)255;
+    e.lds_bitmap = ((int64_t)e.n2 * e.W2 * 8 <= kExactLdsBitmapBytes) ? 1 : 0;
+    e.ctrl[0] = e.ctrl[1] = e.lb;
+    e.ctrl[2] = e.ctrl[3] = e.ctrl[4] = 0;
+  }
+  HIPCHK(h, h->x_order.ensure(4 * (size_t)o_order));
+  HIPCHK(h, h->x_keys.ensure(8 * (size_t)o_order));
+  HIPCHK(h, h->x_bitmap.ensure(8 * (size_t)o_bm));
+  HIPCHK(h, h->x_clique.ensure(4 * (size_t)o_cl));
+  HIPCHK(h, h->x_probs2.ensure(sizeof(ExactProb) * open.size()));
+  const double lim = h->params.max_clique_time_limit;
+  const int64_t deadline = (lim > 0 && lim < 1e7) ? (int64_t)(lim * 1e8) : 0;  // 100 MHz counter
+  static const bool dbg = getenv("TEASER_K4_DEBUG") != nullptr;
+  bool built = false;
+  std::vector<ExactProb> run = open;
+  for (int attempt = 0; attempt < 8 && !run.empty(); ++attempt) {
+    // per-wave arenas of this attempt, one size for the launch (an overflowed problem comes back with a larger one)
+    int total_waves = 0, max_W2 = 0;
+    int64_t max_lds = 0, arena_bytes = 0;
+    for (ExactProb& e : run) {
+      e.arena_off = 0;
+      e.wave0 = total_waves;
+      total_waves += e.n_waves;
+      max_W2 = std::max(max_W2, e.W2);
+      arena_bytes = std::max(arena_bytes, e.arena_bytes);
+      if (e.lds_bitmap) max_lds = std::max<int64_t>(max_lds, (int64_t)e.n2 * e.W2 * 8);
     }
-    for (int32_t b : unproven) {
-      ProbState& st = h->states[(size_t)b];
-      std::vector<int32_t> X;
-      const int xc = h->colour_x[(size_t)b];
-      if (xc == 0) {  // lb colours suffice for every survivor: the greedy clique is maximum
-        st.proven = 1;
-        continue;
-      }
-      if (xc > 0) {
-        X.resize((size_t)xc);
-        HIPCHK(h, hipMemcpy(X.data(), h->c_xlist.as<int32_t>() + h->descs[(size_t)b].pt_off,
-                            (size_t)xc * 4, hipMemcpyDeviceToHost));
-        if (xc <= kRootPruneCap) {  // drop the roots the neighbourhood test discarded
-          std::vector<int32_t> keep((size_t)xc);
-          HIPCHK(h, hipMemcpy(keep.data(), h->c_tent.as<int32_t>() + h->descs[(size_t)b].pt_off,
-                              (size_t)xc * 4, hipMemcpyDeviceToHost));
-          size_t m = 0;
-          for (size_t k = 0; k < X.size(); ++k)
-            if (keep[k] >= st.lb) X[m++] = X[k];  // >= lb qualifying neighbours: still a root
-          X.resize(m);
-          if (X.empty()) {  // no root can lie in a clique larger than lb
-            h->colour_x[(size_t)b] = 0;
-            st.proven = 1;
-            continue;
-          }
+    // phases 2 and 3 run persistent waves pulling tasks: enough of them to fill the GPU, as far as the arenas allow
+    int arena_waves = std::max(total_waves, 4096);
+    while ((int64_t)arena_waves * arena_bytes > kArenaCap && arena_waves > total_waves) arena_waves = std::max(total_waves, arena_waves / 2);
+    if ((int64_t)arena_waves * arena_bytes > kArenaCap) {
+      // shrink the root waves of the largest problems until the arenas fit
+      bool fits = false;
+      for (int round = 0; round < 16 && !fits; ++round) {
+        total_waves = 0;
+        for (ExactProb& e : run) {
+          e.n_waves = std::max(1, e.n_waves / 2);
+          e.wave0 = total_waves;
+          total_waves += e.n_waves;
         }
-        std::sort(X.begin(), X.end());
+        arena_waves = total_waves;
+        fits = (int64_t)arena_waves * arena_bytes <= kArenaCap;
       }
-      h->exact_run[(size_t)b] = 1;
-      const int before = st.clique_size;
-      {
-        StageScope sc(h, ST_EXACT);
-        rc = exact_stage(h, b, final_alive, xc > 0 ? &X : nullptr, from_points);
-      }
-      if (rc != TEASER_HIP_OK) return rc;
-      if (st.clique_size != before) {
-        *changed = true;
-        HIPCHK(h, hipMemcpy(&ds[b].clique_size, &st.clique_size, 4, hipMemcpyHostToDevice));
+      if (!fits) {
+        for (const ExactProb& e : run) h->prob_status[(size_t)e.prob] = TEASER_HIP_ERR_SCRATCH;
+        break;
       }
     }
+    HIPCHK(h, h->x_arena.ensure((size_t)arena_waves * (size_t)arena_bytes));
+    const int64_t task_bytes = std::min<int64_t>((int64_t)1 << 30, std::max<int64_t>((int64_t)64 << 20, (int64_t)(64 + 8 * max_W2) * 65536));
+    HIPCHK(h, h->x_tasks.ensure((size_t)task_bytes));
+    HIPCHK(h, h->x_ctrl.ensure(64));
+    HIPCHK(h, hipMemcpyAsync(h->x_probs2.p, run.data(), sizeof(ExactProb) * run.size(), hipMemcpyHostToDevice, s));
+    if (!built) {
+      launch_exact_build(s, dd, h->x_probs2.as<ExactProb>(), (int)run.size(), max_W, max_n2, h->d_bitmap.as<uint64_t>(),
+                         h->d_deg.as<int32_t>(), spare_alive, h->x_xbits.as<uint64_t>(), h->x_order.as<int32_t>(),
+                         h->x_keys.as<unsigned long long>(), h->x_bitmap.as<uint64_t>());
+      built = true;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    launch_exact_clique(s, h->x_probs2.as<ExactProb>(), (int)run.size(), total_waves, max_W2, max_lds,
+                        h->x_bitmap.as<uint64_t>(), h->x_arena.as<char>(), arena_bytes, arena_waves,
+                        h->x_clique.as<int32_t>(), h->x_tasks.as<char>(), task_bytes, h->x_ctrl.as<int32_t>(), deadline);
+    launch_exact_finish(s, dd, h->x_probs2.as<ExactProb>(), (int)run.size(), max_W, h->x_order.as<int32_t>(),
+                        h->x_clique.as<int32_t>(), h->d_clique.as<int32_t>(), ds);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(run.data(), h->x_probs2.p, sizeof(ExactProb) * run.size(), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    std::vector<ExactProb> again;
+    for (ExactProb& e : run) {
+      ProbState& st = h->states[(size_t)e.prob];
+      if (dbg)  // diagnostics only
+        fprintf(stderr, "[teaser_hip] exact search: problem %d n2 %d W2 %d incumbent %d roots %d (X %d) waves %d arena %lld B "
+                "attempt %d lds %d: best %d recorded %d roots taken %d status %d nodes %d (launch of %zu problems: %.2f ms)\n",
+                e.prob, e.n2, e.W2, e.lb, e.n_roots, e.use_x, e.n_waves, (long long)e.arena_bytes, attempt, e.lds_bitmap,
+                e.ctrl[0], e.ctrl[1], e.ctrl[3], e.ctrl[4], e.ctrl[7], run.size(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+      if (e.ctrl[1] > st.clique_size) {
+        st.clique_size = e.ctrl[1];
+        *changed = true;
+      }
+      if (e.ctrl[4] == 1) {  // arena overflow: keep the incumbent, retry with a larger arena
+        if (attempt == 7) {
+          h->prob_status[(size_t)e.prob] = TEASER_HIP_ERR_SCRATCH;
+          continue;
+        }
+        e.arena_bytes *= 4;
+        e.ctrl[0] = e.ctrl[1];
+        e.ctrl[2] = e.ctrl[3] = e.ctrl[4] = 0;
+        again.push_back(e);
+      } else if (e.ctrl[4] == 2) {
+        h->prob_status[(size_t)e.prob] = TEASER_HIP_ERR_TIME_LIMIT;
+      }
+    }
+    run.swap(again);
   }
   return TEASER_HIP_OK;
 }
@@ -978,7 +930,7 @@ int32_t solve_packed_finish(teaser_hip_solver* h, teaser_solution_c* out, bool* 
   for (int b = 0; b < batch; ++b) h->heu_size[(size_t)b] = h->states[(size_t)b].lb;
   if (h->pend.need_graph && h->pend.mode == TEASER_INLIER_PMC_EXACT) {
     bool changed = false;
-    int32_t rc = close_clique_bounds(h, batch, h->pend.total_n, /*from_points=*/true, &changed);
+    int32_t rc = close_clique_bounds(h, batch, h->pend.total_n, &changed);
     if (rc != TEASER_HIP_OK) return rc;
     if (changed) {
       rc = enqueue_estimators(h);
@@ -1180,7 +1132,8 @@ void release_handle_resources(teaser_hip_solver* h) {
                     &h->d_next_count, &h->d_weights, &h->d_rot_inl, &h->d_trans_inl,
                     &h->d_tls_scratch, &h->d_tim_off, &h->d_pk, &h->d_prep, &h->d_work, &h->hdr, &h->x_order,
                     &h->x_src, &h->x_dst, &h->x_bitmap, &h->x_desc, &h->x_state, &h->x_ctrl,
-                    &h->x_clique, &h->x_arena, &h->c_sel, &h->c_colour, &h->c_tent, &h->c_xlist,
+                    &h->x_clique, &h->x_arena, &h->x_probs, &h->x_probs2, &h->x_keys, &h->x_xbits, &h->x_tasks, &h->c_sel, &h->c_colour, &h->c_tent, &h->c_xlist, &h->c_list_a, &h->c_list_b,
+                    &h->c_counts, &h->c_bits, &h->c_class,
                     &h->s_a, &h->s_b, &h->s_c, &h->s_d, &h->s_e, &h->f_pts, &h->f_counts, &h->f_offsets, &h->f_list,
                     &h->f_normals, &h->f_spfh, &h->f_out, &h->f_meta, &h->f_feat_a, &h->f_feat_b, &h->f_part_d,
                     &h->f_part_i, &h->f_nn_a, &h->f_nn_b};
@@ -1834,6 +1787,9 @@ int32_t teaser_hip_max_clique(teaser_hip_solver* h, const uint64_t* bitmap, int3
   d.pt_off = 0;
   d.bm_off = 0;
   d.w_off = 0;
+  h->total_n = n;
+  h->total_w = W;
+  h->total_bm = (int64_t)n * W;
   ProbState& st = h->states[0];
   memset(&st, 0, sizeof(st));
   st.next_start = heuristic_blocks_per_problem(1);
@@ -1878,7 +1834,7 @@ int32_t teaser_hip_max_clique(teaser_hip_solver* h, const uint64_t* bitmap, int3
   HIPCHK(h, hipStreamSynchronize(s));
   if (exact && n >= 2) {
     bool changed = false;
-    int32_t rc = close_clique_bounds(h, 1, n, /*from_points=*/false, &changed);
+    int32_t rc = close_clique_bounds(h, 1, n, &changed);
     if (rc != TEASER_HIP_OK) return rc;
   }
   if (exact_run) *exact_run = h->exact_run[0];
