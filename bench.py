@@ -566,9 +566,12 @@ def main():
     if not args.no_host_resident:
         pinned = [(torch.from_numpy(s).pin_memory(), torch.from_numpy(d).pin_memory()) for s, d in host_pool]
         runner.run_steps(0, D + 1, pinned, offsets, sizes, True)
-        th, _ = runner.timed(args.warmup + 1, args.steps, pinned, offsets, sizes, True, None, gather_tail)
+        ths = [runner.timed(args.warmup + 1 + r * args.steps, args.steps, pinned, offsets, sizes, True, None, gather_tail)[0]
+               for r in range(max(1, args.repeats))]
+        th = float(np.median(ths))
         host_line = {"value": world * B * args.steps / th, "unit": "registrations/s",
                      "ms_per_step": 1e3 * th / args.steps,
+                     "ms_per_step_repeats": [round(1e3 * t / args.steps, 4) for t in ths],
                      "h2d_bytes_per_step_per_gpu": 48 * B * n,
                      "note": "same steps, inputs in page-locked host memory, one H2D copy per cloud and step on the "
                              "library's copy stream inside the timed region, depth + 1 host batches outstanding "

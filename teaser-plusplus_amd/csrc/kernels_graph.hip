@@ -11,6 +11,7 @@
 // individually, as the reference's default (non-FMA) build does.  FMAs below are explicit.
 #include <algorithm>
 #include <utility>
+#include <vector>
 
 #include <cstdio>
 #include <cstdlib>
@@ -620,22 +621,28 @@ constexpr int kMfmaRowTiles = 4;
 constexpr int kMfmaColTiles = 8;
 
 constexpr int kWorkBuf = 64 * 6;  // per-wave LDS staging (the FP64 path's column buffer): 384 items
+constexpr int kRegionWords = 32;  // u / w kernel: every wave owns a region of the worklist: a count word + 31 items
+constexpr int kRegionItems = kRegionWords - 1;
 
-// item = prob << 32 | row << 16 | col  (n <= 65536); cap[0] = capacity of the global list
+// item = prob << 32 | row << 16 | col  (n <= 65536).  The worklist is cut into one segment of `cap` items per
+// problem, each with its own counter: work_count[prob] / work + prob * cap.  (One counter for the whole launch
+// meant ~100 000 returning atomics -- one per wave -- on a single word per 64 x 10 k launch: that word, not the
+// arithmetic, set the kernel's time at ~1.2 ms whatever the epilogue did; profiles/r3k.)
 __device__ __forceinline__ int flush_work(const unsigned long long* wbuf, int wcount,
                                           unsigned long long* __restrict__ work,
                                           unsigned int* __restrict__ work_count, unsigned int cap,
                                           ProbState* __restrict__ st, int lane) {
   if (wcount == 0) return 0;
   unsigned int base = 0;
-  if (lane == 0) base = atomicAdd(work_count, (unsigned int)wcount);
+  if (lane == 0) base = atomicAdd(work_count + blockIdx.y, (unsigned int)wcount);
   base = __builtin_amdgcn_readfirstlane(base);
   if (base + (unsigned int)wcount > cap) {  // cannot resolve everything: the host reruns on FP64
     if (lane == 0) st->k1_overflow = 1;
     return 0;
   }
+  unsigned long long* seg = work + (size_t)blockIdx.y * cap;
 #pragma nounroll
-  for (int k = lane; k < wcount; k += 64) work[base + k] = wbuf[k];
+  for (int k = lane; k < wcount; k += 64) seg[base + k] = wbuf[k];
   return 0;
 }
 
@@ -965,6 +972,615 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma_kernel(
   flush_work(wbuf, wcount, work, work_count, work_cap, states + blockIdx.y, lane);
 }
 
+
+// ==========================================================================================
+// K1, second formulation ("u / w"): the epilogue shrinks from 5.5 packed to 4 plain f32 VALU per pair.
+//
+// With A = |s_j - s_i|^2 (src), B = |d_j - d_i|^2 (dst):   | sqrt A - sqrt B | <= beta
+//   <=>  sqrt A + sqrt B <= beta   or   d := u^2 + w <= 0,   u = B - A - beta^2,  w = -4 beta^2 A
+// (d = (x^2 - beta^2)(S^2 - beta^2) with x = sqrt B - sqrt A, S = sqrt A + sqrt B).  Both u and w are LINEAR in
+// the Gram terms, so they come straight out of the matrix pipe: u over 42 K slots (18 + 18 coordinate products of
+// the exact three-way bf16 split, 6 for the per-point constants m_i - n_i - beta^2 and m_j - n_j) = three chained
+// v_mfma_f32_32x32x16_bf16, w over 13 slots (two-piece operands: w is multiplied by nothing and only needs
+// ~1e-4 relative accuracy) = one more -- four MFMAs per 32 x 32 tile as before.  The points are centred AND scaled
+// per problem by g in (1, sqrt 2] such that 4 (g beta)^2 is a power of two: the factor of w is then an exponent
+// shift of the column operands, exact.  Per pair the VALU does d = fma(u, u, w), one v_alignbit for sign(d) (the
+// edge bit), e = fma(w, K2, |d|) and running min3(e) / max3(w); a tile whose min e <= K0 (a pair inside the error
+// band) or max w >= wtau (a short pair: A <= beta^2) -- about one tile in five -- recomputes its 16 values to
+// find the pairs for the FP64 fix-up list.
+//
+// Error budget in the scaled system (u = 2^-24, R = max |scaled centred point|, beta = g beta_0):
+//   eps_u = kEpsU2 u R^2 bounds |u~ - u*|: f32 rounding of the scaled centred coordinates 16 u R^2 (8 per cloud),
+//     rounding of the per-point constants 2, split residuals / dropped products 2, accumulation: 3 x 16 products
+//     + 3 accumulator adds = 51 additions, each erring by at most one f32 ulp (2u) of a magnitude <= the sum of
+//     |terms| <= 6 R^2 + beta^2 <= 6.17 R^2 (beta <= R/ 2.4 is required) => 629; total 649 -> kEpsU2 = 680;
+//   eps_A = kEpsA2 u R^2 bounds |A~ - A*| inside w: coordinates 8, dropped low pieces of the norms 256, dropped
+//     products (m m', h l', l h', ...) 820, accumulation 17 x 2u x 4 R^2 = 136; total 1220 -> kEpsA2 = 1300;
+//   with lam = 2 beta R, eta = eps_u / lam:  |d~ - d*| <= [ (eta + u) |d~| + eta |w~| + K0' ] / (1 - eta),
+//     K0' = eps_u lam + eps_u^2 + kappa eps_A (1 + eta) (kappa = 4 beta^2), so sign(d~) is trusted iff
+//     |d~| > K2 |w~| + K0,  K2 = eta / (1 - 2 eta - 2u),  K0 = (K0' + G) / (1 - 2 eta - 2u) + 2 K2 kappa eps_A
+//     (G: the gap between the reference's rounded double predicate and the exact one, as in the first
+//     formulation), both x 1.001 and rounded outwards;
+//   short pairs: S <= beta implies A <= beta^2 and u <= 0, flagged by w~ >= wtau = -kappa (beta^2 (1 + 8u) +
+//     1.1 eps_A) and u~ <= utau = 1.1 eps_u; they go to the fix-up individually.
+// eta > 1/8, beta > R / 2.4, non-finite input, R^2 or beta^2 out of range => the problem runs the FP64 body.
+// ==========================================================================================
+constexpr float kEpsU2 = 680.0f;
+constexpr float kEpsA2 = 1300.0f;
+
+// per 64 correspondences: row (a) and column (b) operands of the four MFMAs, [32-point group][MFMA][lane half][point]
+struct TimOperandTile2 {
+  uint4 a[2][4][2][32];
+  uint4 b[2][4][2][32];
+};
+static_assert(sizeof(TimOperandTile2) == 2 * sizeof(TimOperandTile), "both layouts take 256 B per correspondence");
+
+// scale g and kappa = 4 (g beta)^2 = 2^kexp (the smallest power of two above 4 beta^2)
+__device__ __forceinline__ double pow2_d(int e) {  // 2^e for -1022 <= e <= 1023
+  return __longlong_as_double((long long)(e + 1023) << 52);
+}
+__device__ __forceinline__ void tim2_scale(double beta_d, double* g, int* kexp) {
+  const double x = 4.0 * beta_d * beta_d;
+  int e = 0;
+  const bool ok = x > 1e-300 && x < 1e300;
+  if (ok) e = (int)((__double_as_longlong(x) >> 52) & 0x7ff) - 1023 + 1;  // floor(log2 x) + 1
+  *kexp = e;
+  *g = ok ? __builtin_sqrt(pow2_d(e) / x) : 1.0;
+}
+
+// bf16 bits of +-(value * 2^j) (exact; underflow flushes to zero, which the error band absorbs: such pieces are
+// below 2^-126)
+__device__ __forceinline__ unsigned int bf16_mul_pow2(unsigned int b, int j, bool negate) {
+  const unsigned int mag = b & 0x7fffu;
+  int e = (int)(mag >> 7);
+  if (e == 0) return 0u;
+  e += j;
+  if (e <= 0) return 0u;
+  if (e > 254) e = 254;  // (excluded by the range checks of mfma2_consts)
+  return (mag & 0x7fu) | ((unsigned int)e << 7) | ((b & 0x8000u) ^ (negate ? 0x8000u : 0u));
+}
+
+__global__ __launch_bounds__(256) void tim_prep_pack2_kernel(const ProbDesc* __restrict__ descs,
+                                                             const double* __restrict__ src,
+                                                             const double* __restrict__ dst,
+                                                             TimPrep* __restrict__ prep,
+                                                             TimOperandTile2* __restrict__ ops,
+                                                             int32_t* __restrict__ deg, double beta) {
+  const ProbDesc d = descs[blockIdx.y];
+  const int ip = blockIdx.x * 256 + threadIdx.x;  // padded point index
+  float mx = 0.f;
+  if (ip < d.W * 64 && d.n > 0) {
+    double g;
+    int kexp;
+    tim2_scale(beta, &g, &kexp);
+    const int i = min(ip, d.n - 1);
+    const TimPrep* pr = prep + blockIdx.y;
+    const double* a = src + 3 * (d.pt_off + i);
+    const double* b = dst + 3 * (d.pt_off + i);
+    const float sx = (float)((a[0] - prep_centre(pr, 0, 0)) * g), sy = (float)((a[1] - prep_centre(pr, 0, 1)) * g),
+                sz = (float)((a[2] - prep_centre(pr, 0, 2)) * g);
+    const float dx = (float)((b[0] - prep_centre(pr, 1, 0)) * g), dy = (float)((b[1] - prep_centre(pr, 1, 1)) * g),
+                dz = (float)((b[2] - prep_centre(pr, 1, 2)) * g);
+    // squared norms of the f32 points, exact in double up to its own rounding
+    const double na_d = ((double)sx * sx + (double)sy * sy) + (double)sz * sz;
+    const double nb_d = ((double)dx * dx + (double)dy * dy) + (double)dz * dz;
+    const float na = (float)na_d, nb = (float)nb_d;
+    const double beta2s = pow2_d(kexp - 2);  // (g beta)^2 = kappa / 4, exact
+    const float delta_row = (float)(nb_d - na_d - beta2s);  // m_i - n_i - beta^2 (this point as a ROW)
+    const float delta_col = (float)(nb_d - na_d);           // m_j - n_j          (this point as a COLUMN)
+    unsigned short A[64], B[64];  // K slots 0..47: the u chain, 48..63: the w MFMA
+    for (int k = 0; k < 64; ++k) { A[k] = 0; B[k] = 0; }
+    const float cs[3] = {sx, sy, sz}, cd[3] = {dx, dy, dz};
+    for (int c = 0; c < 3; ++c) {
+      unsigned int h, m, l;
+      bf16_split3(cs[c], &h, &m, &l);  // -A contributes +2 s.s'
+      unsigned short* ua = A + 6 * c;
+      unsigned short* ub = B + 6 * c;
+      ua[0] = h; ua[1] = h; ua[2] = m; ua[3] = h; ua[4] = l; ua[5] = m;
+      ub[0] = bf16_mul_pow2(h, 1, false); ub[1] = bf16_mul_pow2(m, 1, false); ub[2] = ub[0];
+      ub[3] = bf16_mul_pow2(l, 1, false); ub[4] = ub[0]; ub[5] = ub[1];
+      // w = -kappa n_i - kappa n_j + 2 kappa s.s': products (h,h') (h,m') (m,h')
+      unsigned short* wa = A + 48 + 3 * c;
+      unsigned short* wb = B + 48 + 3 * c;
+      wa[0] = h; wa[1] = h; wa[2] = m;
+      wb[0] = bf16_mul_pow2(h, kexp + 1, false); wb[1] = bf16_mul_pow2(m, kexp + 1, false); wb[2] = wb[0];
+      bf16_split3(cd[c], &h, &m, &l);  // +B contributes -2 d.d'
+      ua = A + 18 + 6 * c;
+      ub = B + 18 + 6 * c;
+      ua[0] = h; ua[1] = h; ua[2] = m; ua[3] = h; ua[4] = l; ua[5] = m;
+      ub[0] = bf16_mul_pow2(h, 1, true); ub[1] = bf16_mul_pow2(m, 1, true); ub[2] = ub[0];
+      ub[3] = bf16_mul_pow2(l, 1, true); ub[4] = ub[0]; ub[5] = ub[1];
+    }
+    const unsigned short one = 0x3f80;
+    unsigned int h, m, l;
+    bf16_split3(delta_row, &h, &m, &l);
+    A[36] = h; A[37] = m; A[38] = l; B[36] = one; B[37] = one; B[38] = one;
+    bf16_split3(delta_col, &h, &m, &l);
+    A[39] = one; A[40] = one; A[41] = one; B[39] = h; B[40] = m; B[41] = l;
+    bf16_split3(na, &h, &m, &l);
+    const unsigned short mk = (unsigned short)bf16_mul_pow2(one, kexp, true);  // -kappa
+    A[57] = h; A[58] = m; B[57] = mk; B[58] = mk;
+    A[59] = one; A[60] = one;
+    B[59] = (unsigned short)bf16_mul_pow2(h, kexp, true); B[60] = (unsigned short)bf16_mul_pow2(m, kexp, true);
+    TimOperandTile2* tile = ops + d.w_off + (ip >> 6);
+    const int gq = (ip >> 5) & 1, cc = ip & 31;
+    for (int mf = 0; mf < 4; ++mf)
+      for (int hh = 0; hh < 2; ++hh) {
+        const unsigned short* pa = A + 16 * mf + 8 * hh;
+        const unsigned short* pb = B + 16 * mf + 8 * hh;
+        tile->a[gq][mf][hh][cc] = make_uint4(pa[0] | ((unsigned int)pa[1] << 16), pa[2] | ((unsigned int)pa[3] << 16),
+                                             pa[4] | ((unsigned int)pa[5] << 16), pa[6] | ((unsigned int)pa[7] << 16));
+        tile->b[gq][mf][hh][cc] = make_uint4(pb[0] | ((unsigned int)pb[1] << 16), pb[2] | ((unsigned int)pb[3] << 16),
+                                             pb[4] | ((unsigned int)pb[5] << 16), pb[6] | ((unsigned int)pb[7] << 16));
+      }
+    mx = na > nb ? na : nb;
+    if (!(mx == mx)) mx = INFINITY;  // NaN coordinates: force the FP64 path
+    if (ip < d.n) deg[d.pt_off + ip] = 0;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const float t = __shfl_xor(mx, o, 64);
+    mx = t > mx ? t : mx;
+  }
+  if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(&prep[blockIdx.y].r2_bits, __float_as_uint(mx));
+}
+
+struct Mfma2Const {
+  float K2, K0, K0k, wtau, utau;  // K0k: K0 as used by the cold path's fused form (a hair wider)
+  int use_mfma;
+};
+
+// Band constants in f32, every step rounded towards "wider" by a relative 2^-20 inflation.  r2_bits = max
+// squared norm of the SCALED centred f32 points.
+__device__ __forceinline__ Mfma2Const mfma2_consts(double beta_d, unsigned int r2_bits) {
+  Mfma2Const c;
+  double g;
+  int kexp;
+  tim2_scale(beta_d, &g, &kexp);
+  const float u = 5.9604644775390625e-8f;  // 2^-24
+  const float up = 1.000001f;
+  const float beta = (float)(beta_d * g) * up;                 // scaled beta
+  const float kappa = (float)pow2_d(kexp);      // 4 beta^2, exact
+  const float R2 = __uint_as_float(r2_bits) * up;
+  const float R = __builtin_sqrtf(R2) * up;
+  const float b2 = 0.25f * kappa;                              // beta^2, exact
+  const float eps_u = kEpsU2 * u * R2 * up;
+  const float eps_a = kEpsA2 * u * R2 * up;
+  const float lam_lo = 2.0f * (float)(beta_d * g) * __builtin_sqrtf(__uint_as_float(r2_bits)) * 0.999999f;  // divisor
+  const float lam_hi = 2.0f * beta * R * up;
+  const float eta = eps_u / lam_lo * up;
+  const bool ok = (R2 > 1e-30f) && (R2 < 1e12f) && (beta_d > 0) && (eta <= 0.125f) && (eta == eta) && (kexp > -60) &&
+                  (kexp < 40) && (b2 * 5.76f <= R2);
+  const float den = 1.0f - 2.0f * (ok ? eta : 0.0f) - 2.0f * u;
+  const float K2 = eta / den * up;
+  const float G = (1.3e-13f * beta * R2 * R + 8e-15f * b2 * R2) * up;
+  const float K0p = (eps_u * lam_hi + eps_u * eps_u + kappa * eps_a * (1.0f + eta) + G) * up;
+  const float K0 = (K0p / den + 2.0f * K2 * kappa * eps_a) * up;
+  c.K2 = K2 * 1.001f * up;
+  // Short pairs (S <= beta: the one region where the sign of d misleads) have A <= beta^2 and B <= beta^2, hence
+  // u in [-2 beta^2, 0], w in [-4 beta^4, 0] and |d| = |u^2 + w| <= 4 beta^4: with K0 at least that (plus what
+  // the computed u~, w~ can add: 4 beta^2 eps_u + eps_u^2 + kappa eps_A) they all count as "inside the band" and
+  // reach the FP64 fix-up -- no separate test.  (At the bench geometry 4 beta^4 is 1.09 x the error term.)
+  const float short_d = (4.0f * b2 * b2 * (1.0f + 16.0f * u) + 4.0f * b2 * eps_u + eps_u * eps_u + kappa * eps_a) * 1.001f * up;
+  const float K0e = K0 * 1.001f * up;
+  c.K0 = (K0e > short_d ? K0e : short_d) * 1.00001f;  // (+ the f32 roundings of x = fma(w, K2, |d| - K0))
+  c.K0k = c.K0;
+  c.wtau = 0.f;
+  c.utau = 0.f;
+  // a band dominated by the short-pair term (beta close to the size of the cloud) would send most pairs to FP64
+  c.use_mfma = (ok && c.K0 == c.K0 && c.K0 < 1e30f && short_d <= 16.0f * K0e) ? 1 : 0;
+  return c;
+}
+
+// Cold path of the u / w kernel (one tile in five): the tile's u and w RECOMPUTED from its operands, and the
+// per-lane mask of the pairs (accumulator registers q) that go to the FP64 fix-up -- inside the error band, or
+// short-pair candidates.  Deliberately NOT inlined: as part of the kernel body its 32 accumulators and temporaries
+// pushed the hot loop into scratch spills (whose reloads wait for every operand prefetch in flight on the in-order
+// vmcnt counter: 1.43 instead of 1.18 ms); as a call, the registers live around it are saved on the cold path only.
+__device__ __attribute__((noinline)) unsigned int tim2_inband_mask(bf16x8 a0, bf16x8 a1, bf16x8 a2, bf16x8 a3, bf16x8 b0,
+                                                                   bf16x8 b1, bf16x8 b2, bf16x8 b3, float K2, float K0,
+                                                                   float wtau, float utau) {
+  f32x16 z;
+  for (int k = 0; k < 16; ++k) z[k] = 0.f;
+  f32x16 U2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, z, 0, 0, 0);
+  f32x16 W2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b3, z, 0, 0, 0);
+  U2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, U2, 0, 0, 0);
+  U2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, U2, 0, 0, 0);
+  unsigned int ub = 0;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const float u = U2[q], w = W2[q];
+    const float dq = __builtin_fmaf(u, u, w);
+    const float eq = __builtin_fmaf(w, K2, __builtin_fabsf(dq));
+    const bool mine = !(eq > K0) || (!(w < wtau) && !(u > utau));
+    ub |= mine ? (1u << q) : 0u;
+  }
+  return ub;
+}
+
+template <int V, int OCC, bool EARLY, int COLD>
+__global__ __launch_bounds__(256, OCC) void tim_graph_mfma2_kernel(
+    const ProbDesc* __restrict__ descs, const double* __restrict__ src,
+    const double* __restrict__ dst, const TimOperandTile2* __restrict__ ops, const TimPrep* __restrict__ prep,
+    uint64_t* __restrict__ bitmap, double beta, int gyr,
+    unsigned long long* __restrict__ work, unsigned int* __restrict__ work_count, unsigned int work_cap,
+    ProbState* __restrict__ states, int32_t* __restrict__ deg, unsigned long long* __restrict__ regions) {
+  const ProbDesc d = descs[blockIdx.y];
+  const int n = d.n, W = d.W;
+  const int T = W;
+  // block = kMfmaRowTiles consecutive row tiles (one per wave) x kMfmaColTiles column tiles; row group
+  // fastest, so the blocks in flight share a column group.  Only the blocks that touch the upper triangle
+  // are launched: column group X has min(gyr, 2X + 2) row groups (I0 = 4 Ig <= 8X + 7); blockIdx.x
+  // enumerates them group after group (tim_mfma_grid_blocks is the host-side count).
+  int Ig = blockIdx.x, X = 0;
+  while (Ig >= min(gyr, 2 * X + 2)) {
+    Ig -= min(gyr, 2 * X + 2);
+    ++X;
+  }
+  const int I0 = Ig * kMfmaRowTiles, Jbase = X * kMfmaColTiles;
+  if (I0 >= T || Jbase >= T || Jbase + kMfmaColTiles - 1 < I0) {  // outside / below the diagonal
+    if (COLD == 1 && (threadIdx.x & 63) == 0)
+      regions[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kMfmaRowTiles + (threadIdx.x >> 6)) * kRegionWords] = 0ull;
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int I = I0 + wave;
+
+  const double* __restrict__ ps = src + 3 * d.pt_off;
+  const double* __restrict__ pd = dst + 3 * d.pt_off;
+  uint64_t* __restrict__ bm = bitmap + d.bm_off;
+  __shared__ __attribute__((aligned(16))) double cbuf[kMfmaRowTiles][64 * 6];
+  // write staging: transposed words of the 4 row tiles (double-buffered over J), and the wave's own
+  // words of all its column tiles -- so that every global store covers whole 32 / 64-byte runs
+  __shared__ uint64_t lds_tr[2][kMfmaRowTiles][64];
+  __shared__ uint64_t lds_own[kMfmaRowTiles][64][kMfmaColTiles + 1];  // +1: conflict-free column reads
+  __shared__ uint2 lds_xb[kMfmaRowTiles][kMfmaColTiles][64];  // per wave and column tile: the lanes' in-band masks
+  const Mfma2Const mc = mfma2_consts(beta, prep[blockIdx.y].r2_bits);
+  const f32x2 k2v = {mc.K2, mc.K2}, nk0v = {-mc.K0, -mc.K0};
+  if (!__builtin_amdgcn_readfirstlane(mc.use_mfma)) {  // per problem: uniform over the block
+    EdgeConst kc;
+    kc.beta = beta;
+    kc.beta2 = beta * beta;
+    kc.m2beta2 = -2.0 * kc.beta2;
+    kc.beta4 = kc.beta2 * kc.beta2;
+    kc.s_hat = 1.0;
+    if (I < T)
+      for (int jb = Jbase; jb < Jbase + kMfmaColTiles; jb += kColTilesPerWave)
+        if (!(jb + kColTilesPerWave - 1 < I || jb >= T))
+          tim_wave_fp64<0>(ps, pd, bm, n, W, I, jb, kc, cbuf[wave]);
+    if (COLD == 1 && lane == 0)
+      regions[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kMfmaRowTiles + wave) * kRegionWords] = 0ull;
+    return;
+  }
+  const TimOperandTile2* __restrict__ qt = ops + d.w_off;  // tile t of this problem: qt[t]
+  const int h = lane >> 5, c = lane & 31;
+  // operands through a buffer descriptor over this problem's tiles: scalar tile offset + ONE per-lane byte
+  // offset (lane * 16 = [h][c]) instead of 64-bit per-lane address arithmetic
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t q_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)qt, 0, (int)((unsigned int)T * (unsigned int)sizeof(TimOperandTile2)), 0x00020000);
+  auto load_op = [&](int tile, int side, int g, int m) -> uint4 {  // side 0 = a (rows), 1 = b; m = MFMA 0..3
+    const int soff = tile * (int)sizeof(TimOperandTile2) + side * (int)sizeof(TimOperandTile2) / 2 + (g * 4 + m) * 1024;
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(q_rsrc, lane * 16, soff, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+  };
+  unsigned long long* wbuf = reinterpret_cast<unsigned long long*>(cbuf[wave]);  // private to the wave
+  int wcount = 0;  // wave-uniform
+  unsigned int xdummy = 0;
+
+  // row operands (A side) of the wave's two 32-row halves, the four MFMAs (three of the u chain, one for w):
+  // every load is 1 KB of consecutive memory per wave (lane = (h, c))
+  bf16x8 ar[2][4];
+  {
+    const int It = min(I, T - 1);
+    for (int rt = 0; rt < 2; ++rt)
+      for (int m = 0; m < 4; ++m) ar[rt][m] = __builtin_bit_cast(bf16x8, load_op(It, 0, rt, m));
+  }
+  const bool rowvalid = I < T;  // (T need not be a multiple of the block's row tiles)
+  const uint64_t rowmask = !rowvalid ? 0ull : (n - I * 64 >= 64) ? ~0ull : ((1ull << (n - I * 64)) - 1ull);
+  // column operands are prefetched one half-block (32 columns) ahead: the loads of the next half
+  // are in flight while the current one is on the matrix / vector pipes
+  // a wave is active for J >= I (a suffix of the block's column range); every wave walks the whole
+  // range because the staged stores are block-wide
+  const int Jfirst = max(Jbase, I), Jend = min(Jbase + kMfmaColTiles, T);
+  uint4 nb[4];  // next column points: MFMA 0..3
+  {
+    const int Jf = min(Jfirst, T - 1);
+    nb[0] = load_op(Jf, 1, 0, 0); nb[1] = load_op(Jf, 1, 0, 1);
+    nb[2] = load_op(Jf, 1, 0, 2); nb[3] = load_op(Jf, 1, 0, 3);
+  }
+  // vertex degrees (row popcounts) are accumulated here instead of by a separate pass over the bitmap:
+  // own words per row in a register, transposed words with one fire-and-forget atomic per J
+  const __amdgpu_buffer_rsrc_t deg_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(deg + d.pt_off), 0, (int)((unsigned int)n * 4u), 0x00020000);
+  int degacc = 0;
+  // transposed words of column tile Jp, staged in lds_tr by all 4 waves: the 4 waves' words I0..I0+3
+  // of row j are 32 contiguous bytes -> one lane group
+  // V = 1 stores through a buffer descriptor with NO branch: lanes (and whole iterations) that have
+  // nothing to store use an out-of-range offset, which the hardware drops -- so the compiler can count
+  // the store in its vmcnt bookkeeping exactly instead of assuming the worst at every wait.
+  const __amdgpu_buffer_rsrc_t bm_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)bm, 0, (int)((unsigned int)n * (unsigned int)W * 8u), 0x00020000);
+  auto store_tr = [&](int Jp) {
+    const int r = 16 * wave + (lane >> 2), k = lane & 3, Ik = I0 + k, jp0 = Jp * 64;
+    const bool ok = Jp >= Jbase && Ik < Jp && Ik < T && jp0 + r < n;
+    const uint64_t w = lds_tr[(Jp - Jbase) & 1][k][r];
+    const u32x2 dw = {(unsigned int)w, (unsigned int)(w >> 32)};
+    unsigned int off = ok ? ((unsigned int)(jp0 + r) * (unsigned int)W + (unsigned int)Ik) * 8u : kOobOffset;
+    __builtin_amdgcn_raw_buffer_store_b64(dw, bm_rsrc, off, 0, 0);
+  };
+  // What column tile Jp leaves in global memory besides the own words: the transposed words and the degree
+  // contributions of their bits, always ONE buffer store + ONE no-return buffer atomic per lane (nothing to
+  // do => out-of-range offset, dropped by the hardware), so that the compiler's vmcnt bookkeeping is exact.
+  // Stores and atomics share the in-order vmcnt counter with the loads:
+  //   V = 0 / 2: issued at the end of iteration Jp, i.e. YOUNGER than the operand loads already in flight
+  //              for iteration Jp + 1, whose wait then leaves these two outstanding (the same two dummy
+  //              operations are issued before the loop so that both edges into the loop agree);
+  //   V = 1:     issued in the middle of iteration Jp + 1, behind its first MFMAs; the wave's own word is
+  //              read back from its lds_tr slot.
+  auto flush_tr = [&](int Jp, uint64_t w_own) {
+    const bool have = Jp >= Jbase && rowvalid && Jp > I;  // (Jp == I: diagonal, no transposed copy)
+    const int cnt = have ? __builtin_popcountll(w_own) : 0;
+    if (V != 2) store_tr(Jp);
+    if (V == 2) {
+      // lane = row Jp * 64 + lane of the transposed block, word I: 8 bytes at a stride of W words
+      const u32x2 dw = {(unsigned int)w_own, (unsigned int)(w_own >> 32)};
+      unsigned int off = (have && Jp * 64 + lane < n)
+                             ? ((unsigned int)(Jp * 64 + lane) * (unsigned int)W + (unsigned int)I) * 8u
+                             : kOobOffset;
+      __builtin_amdgcn_raw_buffer_store_b64(dw, bm_rsrc, off, 0, 0);
+    }
+    unsigned int aoff = cnt ? (unsigned int)(Jp * 64 + lane) * 4u : kOobOffset;
+    __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(cnt, deg_rsrc, aoff, 0, 0);
+  };
+  auto flush_prev = [&](int Jp) { flush_tr(Jp, lds_tr[(Jp - Jbase) & 1][wave][lane]); };
+  if (V != 1) {
+    __builtin_amdgcn_sched_barrier(0);
+    flush_tr(Jbase - 1, 0ull);  // the two dummies (see above)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  for (int J = Jbase; J < Jend; ++J) {
+    const int j0 = J * 64;
+    uint64_t trw_out = 0;
+    if (!(rowvalid && J >= I)) {
+      if (V == 1) flush_prev(J - 1);
+    } else {
+    unsigned int tr[2][2];  // [ct][rt]: this lane's 16 column bits
+    unsigned int xb[2] = {0u, 0u};  // [ct]: this lane's pairs inside the error band, rt 0 in the low half (bit q = register q)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const bf16x8 b0 = __builtin_bit_cast(bf16x8, nb[0]), b1 = __builtin_bit_cast(bf16x8, nb[1]);
+      const bf16x8 b2 = __builtin_bit_cast(bf16x8, nb[2]), b3 = __builtin_bit_cast(bf16x8, nb[3]);
+      // EARLY: prefetch the other half of this tile / the first half of the next one now (a second operand set in
+      // registers); otherwise the registers are reloaded behind the half tile's last MFMA
+      const int Jn = (ct == 0 || J + 1 >= Jend) ? J : J + 1, gn = ct ^ 1;
+      if (EARLY) {
+        nb[0] = load_op(Jn, 1, gn, 0); nb[1] = load_op(Jn, 1, gn, 1);
+        nb[2] = load_op(Jn, 1, gn, 2); nb[3] = load_op(Jn, 1, gn, 3);
+      }
+      // u = B - A - beta^2 over 48 K slots (three chained MFMAs), w = -4 beta^2 A over 16 (one MFMA), for BOTH
+      // 32-row halves at once and interleaved: every MFMA that accumulates onto another one is issued two
+      // instructions (64 matrix-pipe cycles) behind it, so the chain never waits for its own result (issued tile
+      // by tile the three dependent MFMAs stalled the wave: 1.28 instead of 1.19 ms)
+      f32x16 z;
+      for (int k = 0; k < 16; ++k) z[k] = 0.f;
+      f32x16 UU[2], WW[2];
+      // (sched_barrier: the machine scheduler otherwise puts each chain back to back again)
+      UU[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[0][0], b0, z, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      UU[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[1][0], b0, z, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      UU[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[0][1], b1, UU[0], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      UU[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[1][1], b1, UU[1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      UU[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[0][2], b2, UU[0], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      UU[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[1][2], b2, UU[1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      WW[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[0][3], b3, z, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      WW[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[1][3], b3, z, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!EARLY) {
+        __builtin_amdgcn_sched_barrier(0);
+        nb[0] = load_op(Jn, 1, gn, 0); nb[1] = load_op(Jn, 1, gn, 1);
+        nb[2] = load_op(Jn, 1, gn, 2); nb[3] = load_op(Jn, 1, gn, 3);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (V == 1 && ct == 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        flush_prev(J - 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const f32x16 Uv = UU[rt], Wv = WW[rt];
+        // epilogue, no branch, 8 VALU per accumulator PAIR (packed f32: measured here, a v_pk_* issues like one
+        // plain instruction): d = u^2 + w, -band = K2 w - K0 (w <= 0), both band edges d -+ band, and one
+        // v_alignbit per edge and pair collecting sign(d + band) (the edge bit: certainly an edge) and
+        // sign(d - band); the signs differ <=> inside the error band (K0 >= 4 beta^4 puts every short pair there)
+        unsigned int colbits = 0, lobits = 0;
+#pragma unroll
+        for (int qp = 7; qp >= 0; --qp) {  // descending q: bit q of the words = register q
+          const f32x2 u2 = {Uv[2 * qp], Uv[2 * qp + 1]}, w2 = {Wv[2 * qp], Wv[2 * qp + 1]};
+          const f32x2 d2 = __builtin_elementwise_fma(u2, u2, w2);
+          const f32x2 nb2 = __builtin_elementwise_fma(w2, k2v, nk0v);
+          const f32x2 dlo = d2 + nb2, dhi = d2 - nb2;
+          colbits = __builtin_amdgcn_alignbit(colbits, __float_as_uint(dhi.y), 31);
+          lobits = __builtin_amdgcn_alignbit(lobits, __float_as_uint(dlo.y), 31);
+          colbits = __builtin_amdgcn_alignbit(colbits, __float_as_uint(dhi.x), 31);
+          lobits = __builtin_amdgcn_alignbit(lobits, __float_as_uint(dlo.x), 31);
+        }
+        xb[ct] |= ((colbits ^ lobits) & 0xffffu) << (16 * rt);
+        tr[ct][rt] = colbits;
+      }
+    }
+    // the in-band masks of this block are parked in LDS: they are looked at behind the loop (a branch here, taken
+    // for four blocks in ten, splits the loop body into scheduling regions and cost 0.38 ms of a 1.25 ms launch,
+    // however cheap the code behind it: profiles/r3j)
+    lds_xb[wave][J - Jbase][lane] = make_uint2(xb[0], xb[1]);
+    // transposed words: lane (c, h) holds rows 4h + (q&3) + 8(q>>2) of column (ct, c); after the
+    // half swap lanes 0-31 hold column (0, c) and lanes 32-63 column (1, c) = column `lane`
+    unsigned int tw[2], ow[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      unsigned int s0 = spread_nibbles(tr[0][rt]) << (4 * h);
+      unsigned int s1 = spread_nibbles(tr[1][rt]) << (4 * h);
+      const auto r = __builtin_amdgcn_permlane32_swap(s0, s1, false, false);
+      tw[rt] = r[0] | r[1];
+      // The row-major words are the 32 x 32 bit transpose of the column words inside each half
+      // (lane c: bits over rows -> lane r: bits over columns): 5 butterfly stages, each one
+      // ds_swizzle (lane ^ j), one v_alignbit (rotate towards the kept blocks) and one v_bfi.
+      unsigned int x = tw[rt];
+#pragma unroll
+      for (int st = 0; st < 5; ++st) {
+        const int j = 16 >> st;
+        unsigned int p;
+        switch (st) {  // BitMode swizzle: and_mask 0x1f, or_mask 0, xor_mask j
+          case 0: p = __builtin_amdgcn_ds_swizzle(x, (16 << 10) | 0x1f); break;
+          case 1: p = __builtin_amdgcn_ds_swizzle(x, (8 << 10) | 0x1f); break;
+          case 2: p = __builtin_amdgcn_ds_swizzle(x, (4 << 10) | 0x1f); break;
+          case 3: p = __builtin_amdgcn_ds_swizzle(x, (2 << 10) | 0x1f); break;
+          default: p = __builtin_amdgcn_ds_swizzle(x, (1 << 10) | 0x1f); break;
+        }
+        const bool up = (lane & j) != 0;
+        // lower lane keeps x & m and takes (p << j) & ~m; upper keeps x & ~m, takes (p >> j) & m
+        const unsigned int shifted = __builtin_amdgcn_alignbit(p, p, up ? j : 32 - j);
+        // x = (x & tmask) | (shifted & ~tmask): one v_bfi_b32 (the compiler emits not + and + and_or)
+        // keep mask of the stage: m for the lower lane of a pair, ~m for the upper (one v_cndmask of two constants)
+        const unsigned int km[5] = {0x0000FFFFu, 0x00FF00FFu, 0x0F0F0F0Fu, 0x33333333u, 0x55555555u};
+        const unsigned int keep = up ? ~km[st] : km[st];
+        asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(x) : "v"(keep), "v"(x), "v"(shifted));
+      }
+      ow[rt] = x;  // lane (r, half ct): the 32 column bits (ct) of row 32 rt + r
+    }
+    // lanes L: rows L of the block; low word = ct 0, high word = ct 1
+    const auto ro = __builtin_amdgcn_permlane32_swap(ow[0], ow[1], false, false);
+    uint64_t ownw = ((uint64_t)ro[1] << 32) | ro[0];
+    const uint64_t trw = ((uint64_t)tw[1] << 32) | tw[0];
+    const uint64_t colmask = (n - j0 >= 64) ? ~0ull : ((1ull << (n - j0)) - 1ull);
+    ownw &= colmask;
+    if (J == I) ownw &= ~(1ull << lane);
+    lds_own[wave][lane][J - Jbase] = ownw;
+    degacc += __builtin_popcountll(ownw);
+    // rows beyond n hold no bits (clamped: the padding repeats the last point)
+    trw_out = (J != I && j0 + lane < n) ? (trw & rowmask) : 0ull;
+    }  // active
+    if (V == 2) {  // (no LDS staging, no barrier)
+      flush_tr(J, trw_out);
+      continue;
+    }
+    const int buf = (J - Jbase) & 1;
+    lds_tr[buf][wave][lane] = trw_out;
+    __syncthreads();  // (one barrier per J: the other buffer is rewritten only after the next one)
+    if (V == 0) flush_prev(J);  // (own word read back from LDS: nothing live across the barrier)
+  }
+  if (V == 1 && Jend > Jbase) flush_prev(Jend - 1);
+  // ---- the (rare) pairs inside the band go to the FP64 fix-up list.  One pass over the block's column tiles, outside
+  // the hot loop; the lanes holding set bits work in parallel.  Self pairs (u = -beta^2, w = 0: always "inside the
+  // band") and the padding beyond n (copies of the last point) are dropped.  A 64 x 64 block holding more in-band
+  // pairs than the staging buffer (adversarial geometry) flags the problem like a worklist overflow: the host
+  // reruns the batch on the FP64 kernel.
+  if (COLD == 1 && rowvalid) {
+#pragma nounroll
+    for (int J = max(Jbase, I); J < Jend; ++J) {
+      const uint2 xv = lds_xb[wave][J - Jbase][lane];
+      if (__builtin_amdgcn_ballot_w64((xv.x | xv.y) != 0u) == 0ull) continue;
+      const int j0 = J * 64;
+      unsigned int m0 = xv.x, m1 = xv.y;  // ct 0 / ct 1; rt 0 in the low half
+      if (J == I) {  // diagonal block: tile (ct, rt) with ct == rt holds the self pairs
+        const int cq = c - 4 * h;
+        unsigned int selfbit = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) selfbit |= (cq == (q & 3) + 8 * (q >> 2)) ? (1u << q) : 0u;
+        m0 &= ~selfbit;
+        m1 &= ~(selfbit << 16);
+      }
+      if (j0 + c >= n) m0 = 0u;
+      if (j0 + 32 + c >= n) m1 = 0u;
+      if (I * 64 + 64 > n) {  // last row tile only
+        unsigned int rowok = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int r = I * 64 + (q & 3) + 8 * (q >> 2) + 4 * h;
+          rowok |= (r < n ? (1u << q) : 0u) | (r + 32 < n ? (0x10000u << q) : 0u);
+        }
+        m0 &= rowok;
+        m1 &= rowok;
+      }
+      const int mine = __builtin_popcount(m0) + __builtin_popcount(m1);
+      // exclusive prefix of `mine` over the lanes (only a few lanes hold anything: scalar walk over those)
+      int total = 0, base = 0;
+      uint64_t left = __builtin_amdgcn_ballot_w64(mine != 0);
+#pragma nounroll
+      while (left) {
+        const int l = __builtin_ctzll(left);
+        left &= left - 1ull;
+        base = (lane == l) ? total : base;
+        total += __builtin_amdgcn_readlane(mine, l);
+      }
+      if (total > kWorkBuf) {
+        if (lane == 0) states[blockIdx.y].k1_overflow = 1;
+      } else if (total > 0) {
+        if (wcount + total > kWorkBuf)
+          wcount = flush_work(wbuf, wcount, work, work_count, work_cap, states + blockIdx.y, lane);
+        int kk = wcount + base;
+        const unsigned long long hi = (unsigned long long)blockIdx.y << 32;
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          unsigned int bits = ct ? m1 : m0;
+          const unsigned int colp = (unsigned int)(j0 + 32 * ct + c);
+#pragma nounroll
+          while (bits) {
+            const int pos = __builtin_ctz(bits);
+            bits &= bits - 1u;
+            const int q = pos & 15, rt = pos >> 4;
+            const unsigned int rowp = (unsigned int)(I * 64 + 32 * rt + (q & 3) + 8 * (q >> 2) + 4 * h);
+            wbuf[kk++] = hi | ((unsigned long long)rowp << 16) | (unsigned long long)colp;
+          }
+        }
+        wcount += total;
+      }
+    }
+  }
+  // own words: lanes 8r..8r+7 store the (up to) 8 consecutive words of one row
+  if (rowvalid) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int r = it * 8 + (lane >> 3), k = lane & 7, J = Jbase + k;
+      if (J >= I && J < Jend && I * 64 + r < n) bm[(int64_t)(I * 64 + r) * W + J] = lds_own[wave][r][k];
+    }
+  }
+  if (rowvalid)
+    __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(degacc, deg_rsrc, (unsigned int)(I * 64 + lane) * 4u, 0, 0);
+  // The wave's items go to ITS OWN region of the worklist (kRegionItems slots behind a count word, addressed by the
+  // wave's index in the launch): plain stores, no atomic, nothing to wait for -- a returning atomic plus dependent
+  // stores at the very end of every wave, where nothing is left to overlap the ~2 us round trip, cost a quarter of
+  // the launch (0.95 -> 1.20 ms: profiles/r3j, r3k).  Only a wave with more items (adversarial geometry) sends the
+  // rest through the problem's counted segment.
+  if (COLD == 1) {
+    unsigned long long* region = regions + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kMfmaRowTiles + wave) * kRegionWords;
+    const int nreg = wcount < kRegionItems ? wcount : kRegionItems;
+    if (lane == 0) region[0] = (unsigned long long)nreg;
+    if (lane < nreg) region[1 + lane] = wbuf[lane];
+    if (wcount > kRegionItems) {
+      const int extra = wcount - kRegionItems;
+      unsigned int base = 0;
+      if (lane == 0) base = atomicAdd(work_count + blockIdx.y, (unsigned int)extra);
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (base + (unsigned int)extra > work_cap) {
+        if (lane == 0) states[blockIdx.y].k1_overflow = 1;
+      } else {
+        unsigned long long* seg = work + (size_t)blockIdx.y * work_cap;
+#pragma nounroll
+        for (int k2 = lane; k2 < extra; k2 += 64) seg[base + k2] = wbuf[kRegionItems + k2];
+      }
+    }
+  }
+  if (COLD == 2 && xdummy == 0xdeadbeefu) bm[0] = 1;
+}
+
 // FP64 resolution of the worklist: one thread per pair, bits rewritten with atomics (a row word
 // can receive several patches).  Diagonal blocks evaluate (r, c) and (c, r) as separate pairs, each
 // patching only its own bit; elsewhere one pair patches both the row-major and the transposed bit.
@@ -980,26 +1596,41 @@ __global__ __launch_bounds__(256) void tim_fixup_kernel(const ProbDesc* __restri
                                                         const unsigned long long* __restrict__ work,
                                                         const unsigned int* __restrict__ work_count,
                                                         unsigned int cap, ProbState* __restrict__ states,
-                                                        int32_t* __restrict__ deg) {
+                                                        int32_t* __restrict__ deg,
+                                                        const unsigned long long* __restrict__ regions,
+                                                        unsigned int regions_per_problem) {
   TAIL_WAVE_PRIO();
-  const unsigned int total = *work_count;
-  if (total > cap) {
-    const ProbDesc last = descs[batch - 1];
-    const int64_t words = last.bm_off + (int64_t)last.n * last.W;
-    for (int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x; w < words; w += (int64_t)gridDim.x * 256)
-      bitmap[w] = 0;
-    for (int p = blockIdx.x * 256 + threadIdx.x; p < batch; p += gridDim.x * 256) states[p].k1_overflow = 1;
+  const int prob = blockIdx.y;
+  const unsigned int total = work_count[prob];
+  const ProbDesc d = descs[prob];
+  const int n = d.n, W = d.W;
+  if (total > cap) {  // this problem's segment overflowed: empty graph + flag (the host reruns the batch on FP64)
+    const int64_t words = (int64_t)n * W;
+    uint64_t* bm = bitmap + d.bm_off;
+    for (int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x; w < words; w += (int64_t)gridDim.x * 256) bm[w] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) states[prob].k1_overflow = 1;
     return;
   }
-  for (unsigned int w = blockIdx.x * 256 + threadIdx.x; w < total; w += gridDim.x * 256) {
-    const unsigned long long it = work[w];
-    const int prob = (int)(it >> 32), r = (int)((it >> 16) & 0xffff), col = (int)(it & 0xffff);
-    const ProbDesc d = descs[prob];
-    const int n = d.n, W = d.W;
+  const unsigned long long* seg = work + (size_t)prob * cap;
+  const double* ps = src + 3 * d.pt_off;
+  const double* pd = dst + 3 * d.pt_off;
+  unsigned int* bm32 = reinterpret_cast<unsigned int*>(bitmap + d.bm_off);
+  // items: first the per-wave regions of this problem (u / w kernel: slot k of region r, valid iff 1 <= k <= count),
+  // then the problem's counted segment
+  const unsigned int nslots = regions ? regions_per_problem * (unsigned int)kRegionWords : 0u;
+  const unsigned long long* reg = regions ? regions + (size_t)prob * regions_per_problem * kRegionWords : nullptr;
+  for (unsigned int w = blockIdx.x * 256 + threadIdx.x; w < nslots + total; w += gridDim.x * 256) {
+    unsigned long long it;
+    if (w < nslots) {
+      const unsigned int k = w & (kRegionWords - 1);
+      const unsigned int cnt = (unsigned int)reg[w - k];
+      if (k == 0 || k > cnt) continue;
+      it = reg[w];
+    } else {
+      it = seg[w - nslots];
+    }
+    const int r = (int)((it >> 16) & 0xffff), col = (int)(it & 0xffff);
     if (r >= n || col >= n || r == col) continue;  // masked bits: already zero
-    const double* ps = src + 3 * d.pt_off;
-    const double* pd = dst + 3 * d.pt_off;
-    unsigned int* bm32 = reinterpret_cast<unsigned int*>(bitmap + d.bm_off);
     const bool e = tim_edge_exact(ps[3 * col] - ps[3 * r], ps[3 * col + 1] - ps[3 * r + 1],
                                   ps[3 * col + 2] - ps[3 * r + 2], pd[3 * col] - pd[3 * r],
                                   pd[3 * col + 1] - pd[3 * r + 1], pd[3 * col + 2] - pd[3 * r + 2], beta);
@@ -1037,20 +1668,37 @@ void launch_tim_graph(hipStream_t s, const ProbDesc* d_desc, int batch, int max_
 
 // MODE 0 on the matrix cores: pre-pass (centres, packed f32 points, R^2) + tim_graph_mfma_kernel.
 // d_pk: 2 * total_pts float4 (src then dst); d_prep: batch * sizeof(TimPrep) bytes.
-int64_t tim_prep_bytes(int batch) { return (int64_t)batch * (int64_t)sizeof(TimPrep) + 64; }
+int64_t tim_prep_bytes(int batch) { return (int64_t)batch * ((int64_t)sizeof(TimPrep) + 4) + 64; }  // + one worklist counter per problem
 __global__ void degree_kernel(const ProbDesc* __restrict__ descs, const uint64_t* __restrict__ bitmap,
-                              int32_t* __restrict__ deg, const TimPrep* __restrict__ prep, double beta);
+                              int32_t* __restrict__ deg, const TimPrep* __restrict__ prep, double beta, int form2);
 
 int64_t tim_operand_bytes(int64_t total_tiles) { return 2 * total_tiles * (int64_t)sizeof(TimOperandTile); }
 
-// worklist capacity: 1/64 of all pairs of the launch (>= 2^20); typical use is ~2e-4 of the pairs
+// blocks of the matrix-core kernels for a problem of T 64-point tiles: those touching the upper triangle
+static int tim_mfma_blocks(int T) {
+  const int gxc = (T + kMfmaColTiles - 1) / kMfmaColTiles, gyr = (T + kMfmaRowTiles - 1) / kMfmaRowTiles;
+  int nblk = 0;
+  for (int X = 0; X < gxc; ++X) nblk += std::min(gyr, 2 * X + 2);
+  return nblk;
+}
+
+// worklist capacity in 8-byte words: one counted segment per problem, each 1/64 of the pairs of the LARGEST problem
+// (>= 2^16 items; typical use is ~1e-4 of the pairs), followed by the per-wave regions of the u / w kernel
+// (kRegionWords per wave of every block, sized for the largest problem).  Returns the total.
+static int64_t tim_region_words(int max_n) {
+  return (int64_t)tim_mfma_blocks((max_n + 63) / 64) * kMfmaRowTiles * kRegionWords;
+}
 int64_t tim_work_items(const int32_t* n, int batch) {
-  int64_t pairs = 0;
-  for (int b = 0; b < batch; ++b) pairs += (int64_t)n[b] * (n[b] - 1) / 2;
-  int64_t items = pairs / 64;
-  if (items < (1 << 20)) items = 1 << 20;
-  if (items > 0x7fffffffll) items = 0x7fffffffll;
-  return items;
+  int64_t mx = 0;
+  int max_n = 0;
+  for (int b = 0; b < batch; ++b) {
+    mx = std::max<int64_t>(mx, (int64_t)n[b] * (n[b] - 1) / 2);
+    max_n = std::max(max_n, n[b]);
+  }
+  int64_t seg = mx / 64;
+  if (seg < (1 << 16)) seg = 1 << 16;
+  if (seg > 0x7fffffffll) seg = 0x7fffffffll;
+  return (seg + tim_region_words(max_n)) * std::max(batch, 1);
 }
 
 // phase 0 pre-pass (bbox, centred bf16 operands, R^2, degrees zeroed), 1 the matrix-core kernel (bitmap
@@ -1070,24 +1718,36 @@ void launch_tim_graph_mfma(hipStream_t s, int phase, const ProbDesc* d_desc, int
   TimPrep* prep = reinterpret_cast<TimPrep*>(d_prep);
   unsigned long long* work = reinterpret_cast<unsigned long long*>(d_work);
   unsigned int* work_count = reinterpret_cast<unsigned int*>(reinterpret_cast<char*>(d_prep) +
-                                                            sizeof(TimPrep) * (size_t)batch);
+                                                            sizeof(TimPrep) * (size_t)batch);  // [batch]
+  const int64_t reg_words = tim_region_words(max_n);  // per problem
+  const int64_t seg_cap = work_cap / std::max(batch, 1) - reg_words;  // items per problem in the counted segments
+  unsigned long long* regions = work + (size_t)seg_cap * (size_t)batch;
+  // scheduling variant / formulation of the kernel (diagnostics; read per launch so that a probe can switch):
+  // 0..6 the first formulation (A, B from the matrix pipe), 7 / 8 the u / w formulation (staged / unstaged stores)
+  const char* ev = getenv("TEASER_K1_VARIANT");
+  const int variant = ev ? atoi(ev) : 11;
+  const bool form2 = variant >= 7;
   if (phase == 0) {
     // prep (and the worklist counter behind it) arrive zeroed: part of the solve's header upload
     hipLaunchKernelGGL(tim_prep_bbox_kernel, dim3((max_n + 1023) / 1024, batch), dim3(256), 0, s, d_desc,
                        d_src, d_dst, prep);
-    hipLaunchKernelGGL(tim_prep_pack_kernel, dim3((T * 64 + 255) / 256, batch), dim3(256), 0, s, d_desc,
-                       d_src, d_dst, prep, op_src, op_dst, d_deg);
+    if (form2)
+      hipLaunchKernelGGL(tim_prep_pack2_kernel, dim3((T * 64 + 255) / 256, batch), dim3(256), 0, s, d_desc, d_src,
+                         d_dst, prep, reinterpret_cast<TimOperandTile2*>(d_pk), d_deg, beta);
+    else
+      hipLaunchKernelGGL(tim_prep_pack_kernel, dim3((T * 64 + 255) / 256, batch), dim3(256), 0, s, d_desc,
+                         d_src, d_dst, prep, op_src, op_dst, d_deg);
   } else if (phase == 1) {
-    const int gxc = (T + kMfmaColTiles - 1) / kMfmaColTiles, gyr = (T + kMfmaRowTiles - 1) / kMfmaRowTiles;
-    int nblk = 0;  // blocks touching the upper triangle (see the kernel's decode of blockIdx.x)
-    for (int X = 0; X < gxc; ++X) nblk += std::min(gyr, 2 * X + 2);
-    // scheduling variant of the same kernel (diagnostics; read per launch so that a probe can switch)
-    const char* ev = getenv("TEASER_K1_VARIANT");
-    const int variant = ev ? atoi(ev) : 1;
+    const int gyr = (T + kMfmaRowTiles - 1) / kMfmaRowTiles;
+    const int nblk = tim_mfma_blocks(T);  // blocks touching the upper triangle (see the kernel's decode of blockIdx.x)
 #define TIM_K1_LAUNCH(V, OCC, PK)                                                                            \
   hipLaunchKernelGGL((tim_graph_mfma_kernel<V, OCC, PK>), dim3(nblk, batch), dim3(256), 0, s, d_desc, d_src, \
                      d_dst, op_src, op_dst, prep, d_bitmap, beta, gyr, work, work_count,                     \
-                     (unsigned int)work_cap, d_state, d_deg)
+                     (unsigned int)seg_cap, d_state, d_deg)
+#define TIM_K1_LAUNCH2(V, OCC, EARLY, COLD)                                                                                 \
+  hipLaunchKernelGGL((tim_graph_mfma2_kernel<V, OCC, EARLY, COLD>), dim3(nblk, batch), dim3(256), 0, s, d_desc, d_src, d_dst, \
+                     reinterpret_cast<const TimOperandTile2*>(d_pk), prep, d_bitmap, beta, gyr, work, work_count, \
+                     (unsigned int)seg_cap, d_state, d_deg, regions)
     switch (variant) {
       case 0: TIM_K1_LAUNCH(0, 3, true); break;
       case 2: TIM_K1_LAUNCH(2, 3, true); break;
@@ -1095,22 +1755,38 @@ void launch_tim_graph_mfma(hipStream_t s, int phase, const ProbDesc* d_desc, int
       case 4: TIM_K1_LAUNCH(1, 3, false); break;
       case 5: TIM_K1_LAUNCH(2, 3, false); break;
       case 6: TIM_K1_LAUNCH(2, 4, false); break;
-      default: TIM_K1_LAUNCH(1, 3, true); break;
+      case 7: TIM_K1_LAUNCH2(1, 3, true, 1); break;
+      case 8: TIM_K1_LAUNCH2(2, 3, true, 1); break;
+      case 9: TIM_K1_LAUNCH2(2, 4, false, 1); break;
+      case 10: TIM_K1_LAUNCH2(1, 3, false, 1); break;
+      case 11: TIM_K1_LAUNCH2(2, 3, false, 1); break;
+      case 12: TIM_K1_LAUNCH2(2, 3, true, 3); break;   // timing only: everything but the final flush
+      case 13: TIM_K1_LAUNCH2(2, 3, true, 2); break;   // timing only: full hot path, no push loop
+      case 14: TIM_K1_LAUNCH2(2, 4, false, 0); break;
+      case 15: TIM_K1_LAUNCH2(1, 2, true, 1); break;   // occupancy 2
+      case 16: TIM_K1_LAUNCH2(2, 2, true, 1); break;
+      case 1: TIM_K1_LAUNCH(1, 3, true); break;
+      default: TIM_K1_LAUNCH2(2, 3, false, 1); break;
     }
 #undef TIM_K1_LAUNCH
+#undef TIM_K1_LAUNCH2
   } else {
     // problems whose geometry the filter cannot handle ran the FP64 body inside K1 (no degree atomics
     // there): their degrees come from the row-popcount pass, which skips every other problem
     hipLaunchKernelGGL(degree_kernel, dim3(batch >= 64 ? 8 : 64, batch), dim3(256), 0, s, d_desc, d_bitmap, d_deg,
-                       prep, beta);
-    hipLaunchKernelGGL(tim_fixup_kernel, dim3(512), dim3(256), 0, s, d_desc, batch, d_src, d_dst, d_bitmap,
-                       beta, work, work_count, (unsigned int)work_cap, d_state, d_deg);
+                       prep, beta, form2 ? 1 : 0);
+    hipLaunchKernelGGL(tim_fixup_kernel, dim3(std::max(4, std::min(512, 1024 / std::max(batch, 1))), batch), dim3(256), 0, s, d_desc, batch, d_src, d_dst, d_bitmap,
+                       beta, work, work_count, (unsigned int)seg_cap, d_state, d_deg,
+                       form2 ? regions : static_cast<const unsigned long long*>(nullptr),
+                       (unsigned int)(reg_words / kRegionWords));
     static const bool dbg = getenv("TEASER_K1_DEBUG") != nullptr;
     if (dbg) {  // diagnostics only: pairs sent to the FP64 fix-up
-      unsigned int cnt = 0;
+      std::vector<unsigned int> cnt((size_t)batch);
       (void)hipStreamSynchronize(s);
-      (void)hipMemcpy(&cnt, work_count, 4, hipMemcpyDeviceToHost);
-      fprintf(stderr, "[teaser_hip] K1 fix-up items: %u (batch %d, max_n %d)\n", cnt, batch, max_n);
+      (void)hipMemcpy(cnt.data(), work_count, 4 * (size_t)batch, hipMemcpyDeviceToHost);
+      unsigned long long tot = 0;
+      for (unsigned int c : cnt) tot += c;
+      fprintf(stderr, "[teaser_hip] K1 fix-up items: %llu (batch %d, max_n %d)\n", tot, batch, max_n);
     }
   }
 }
@@ -1121,10 +1797,12 @@ void launch_tim_graph_mfma(hipStream_t s, int phase, const ProbDesc* d_desc, int
 __global__ __launch_bounds__(256) void degree_kernel(const ProbDesc* __restrict__ descs,
                                                      const uint64_t* __restrict__ bitmap,
                                                      int32_t* __restrict__ deg,
-                                                     const TimPrep* __restrict__ prep, double beta) {
+                                                     const TimPrep* __restrict__ prep, double beta, int form2) {
   // prep != null: only the problems that ran the FP64 body inside the matrix-core K1 (the others got
   // their degrees from K1's atomics); that launch uses a small grid (gridDim.x row groups per problem)
-  if (prep && mfma_consts(beta, prep[blockIdx.y].r2_bits).use_mfma) return;
+  if (prep && (form2 ? mfma2_consts(beta, prep[blockIdx.y].r2_bits).use_mfma
+                     : mfma_consts(beta, prep[blockIdx.y].r2_bits).use_mfma))
+    return;
   const ProbDesc d = descs[blockIdx.y];
   const int lane = threadIdx.x & 63;
   for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < d.n; row += gridDim.x * 4) {
@@ -1141,7 +1819,7 @@ void launch_degrees(hipStream_t s, const ProbDesc* d_desc, int batch, int max_n,
   if (batch <= 0 || max_n <= 0) return;
   dim3 grid((max_n + 3) / 4, batch);
   hipLaunchKernelGGL(degree_kernel, grid, dim3(256), 0, s, d_desc, d_bitmap, d_deg,
-                     static_cast<const TimPrep*>(nullptr), 0.0);
+                     static_cast<const TimPrep*>(nullptr), 0.0, 0);
 }
 
 // ------------------------------------------------------------------------------------------
