@@ -283,7 +283,7 @@ int certify_on_device(hipStream_t s, const double* R, const double* src, const d
   CERT_HIP(hipMalloc(&dT, nn * 8));
   CERT_HIP(hipMalloc(&dD, (size_t)n * 8));
   CERT_HIP(hipMalloc(&dE, (size_t)n * 8));
-  CERT_HIP(hipMalloc(&dInfo, sizeof(rocblas_int)));
+  CERT_HIP(hipMalloc(&dInfo, 2 * sizeof(rocblas_int)));
   const size_t blk_doubles = (size_t)(N + 1) * 16 + 2 * (size_t)N * 16;
   CERT_HIP(hipMalloc(&dBlk, blk_doubles * 8));
   CERT_HIP(hipMalloc(&dThp, (size_t)(N + 1) * 8));
@@ -313,6 +313,7 @@ int certify_on_device(hipStream_t s, const double* R, const double* src, const d
         fail(-3);
         break;
       }
+      CERT_HIP(hipMemcpyAsync(dInfo + 1, dInfo, sizeof(rocblas_int), hipMemcpyDeviceToDevice, s));  // kept for the check below
       hipLaunchKernelGGL(cert_scale_kernel, g1, b1, 0, s, dA, dD, n, dT);
       if (L.dgemm(hb, rocblas_operation_none, rocblas_operation_transpose, n, n, n, &one, dT, n, dA, n, &zero, dPsd, n) !=
           rocblas_status_success) {
@@ -335,10 +336,16 @@ int certify_on_device(hipStream_t s, const double* R, const double* src, const d
         break;
       }
       double min_eig = 0;
+      rocblas_int info = 0;
       CERT_HIP(hipMemcpyAsync(&min_eig, dD, 8, hipMemcpyDeviceToHost, s));  // ascending order: D[0]
+      rocblas_int info2[2] = {0, 0};
+      CERT_HIP(hipMemcpyAsync(info2, dInfo, sizeof(info2), hipMemcpyDeviceToHost, s));  // both dsyevd calls of this iteration
       CERT_HIP(hipStreamSynchronize(s));
       if (rc != 0) break;
-      const double gap = (min_eig > 0) ? 0.0 : (-min_eig * (N + 1)) / mu;
+      // a non-converged eigendecomposition gives no usable gap: +inf, as the reference does (certification.cc:192-231
+      // returns infinity when eigensolver.info() != Success)
+      info = info2[0] | info2[1];
+      const double gap = info != 0 ? INFINITY : (min_eig > 0) ? 0.0 : (-min_eig * (N + 1)) / mu;
       traj->push_back(gap);
       if (gap < best) best = gap;
       if (gap < sub_optimality) break;

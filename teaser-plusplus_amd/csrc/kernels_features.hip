@@ -437,31 +437,68 @@ __global__ __launch_bounds__(128) void feat_fpfh_kernel(int n, const int64_t* __
 // grid (query blocks of 64, data chunks of kNnChunk): a thread owns one query (its `dim` values staged in
 // LDS, one row per thread), walks the chunk's data points through an LDS tile, accumulating
 // (q_c - d_c)^2 over c in order in float; first strict minimum = lowest index on ties.
-constexpr int kNnChunk = 4096;
+// Exact L2 1-NN, brute force.  The arithmetic of one distance is fixed by the oracle (flann::L2<float> order:
+// d += (q_c - x_c)^2 for c = 0 .. dim-1, float), so the speed has to come from the layout: the query vector of a
+// thread lives in REGISTERS (dim is a template parameter for the 33-bin FPFH signature; other dims take the generic
+// instantiation with the query in LDS), a tile of kNnTile data points is staged in LDS and read back as broadcast
+// ds_read_b128, and the data set is cut into chunks of kNnChunk points so that a 5 000 x 5 000 match fills the GPU
+// (1 700 waves instead of the 164 of the first version, which took 6 ms per direction -- 0.3 TFLOP/s).
+constexpr int kNnChunk = 256;
 constexpr int kNnTile = 64;
 constexpr int kNnMaxDim = 64;
+template <int DIM>
 __global__ __launch_bounds__(64) void feat_nn_partial_kernel(const float* __restrict__ data, int nd,
-                                                             const float* __restrict__ query, int nq, int dim,
+                                                             const float* __restrict__ query, int nq, int dim_rt,
                                                              float* __restrict__ part_d,
                                                              int32_t* __restrict__ part_i) {
-  __shared__ float qs[64 * (kNnMaxDim + 1)];
-  __shared__ float tile[kNnTile * kNnMaxDim];
+  constexpr int kPad = DIM > 0 ? ((DIM + 3) & ~3) : kNnMaxDim;  // floats per staged point (16-byte rows)
+  __shared__ __attribute__((aligned(16))) float tile[kNnTile * kPad];
+  __shared__ float qs[DIM > 0 ? 1 : 64 * (kNnMaxDim + 1)];
+  const int dim = DIM > 0 ? DIM : dim_rt;
   const int q = blockIdx.x * 64 + threadIdx.x;
   const bool live = q < nq;
-  for (int c = 0; c < dim; ++c) qs[threadIdx.x * (kNnMaxDim + 1) + c] = live ? query[(size_t)q * dim + c] : 0.f;
+  float qr[DIM > 0 ? kPad : 1];
+  if (DIM > 0) {
+#pragma unroll
+    for (int c = 0; c < kPad; ++c) qr[c] = (live && c < DIM) ? query[(size_t)q * DIM + c] : 0.f;
+  } else {
+    for (int c = 0; c < dim; ++c) qs[threadIdx.x * (kNnMaxDim + 1) + c] = live ? query[(size_t)q * dim + c] : 0.f;
+  }
   const int lo = blockIdx.y * kNnChunk, hi = min(nd, lo + kNnChunk);
   float best = __builtin_inff();
   int bi = -1;
   for (int base = lo; base < hi; base += kNnTile) {
     const int m = min(kNnTile, hi - base);
     __syncthreads();
-    for (int k = threadIdx.x; k < m * dim; k += 64) tile[k] = data[(size_t)base * dim + k];
+    if (DIM > 0) {
+      for (int k = threadIdx.x; k < m * kPad; k += 64) {
+        const int pt = k / kPad, c = k - pt * kPad;
+        tile[k] = c < DIM ? data[(size_t)(base + pt) * DIM + c] : 0.f;
+      }
+    } else {
+      for (int k = threadIdx.x; k < m * dim; k += 64) tile[(k / dim) * kPad + (k % dim)] = data[(size_t)base * dim + k];
+    }
     __syncthreads();
     for (int k = 0; k < m; ++k) {
       float d = 0;
-      for (int c = 0; c < dim; ++c) {
-        const float t = qs[threadIdx.x * (kNnMaxDim + 1) + c] - tile[k * dim + c];
-        d += t * t;
+      if (DIM > 0) {
+        const float4* row = reinterpret_cast<const float4*>(tile + k * kPad);
+#pragma unroll
+        for (int c4 = 0; c4 < kPad / 4; ++c4) {
+          const float4 x = row[c4];  // broadcast: every lane reads the same 16 bytes
+          const float xs[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (4 * c4 + e < DIM) {  // (the padding is skipped: d + 0 * 0 would still be a float operation)
+              const float t = qr[4 * c4 + e] - xs[e];
+              d += t * t;
+            }
+        }
+      } else {
+        for (int c = 0; c < dim; ++c) {
+          const float t = qs[threadIdx.x * (kNnMaxDim + 1) + c] - tile[k * kPad + c];
+          d += t * t;
+        }
       }
       if (d < best) {
         best = d;
@@ -532,8 +569,12 @@ void launch_feat_nn1(hipStream_t s, const float* d_data, int nd, const float* d_
                      float* d_part_d, int32_t* d_part_i, int32_t* d_nn) {
   if (nq <= 0 || nd <= 0) return;
   const int chunks = feat_nn_chunks(nd);
-  hipLaunchKernelGGL(feat_nn_partial_kernel, dim3((nq + 63) / 64, chunks), dim3(64), 0, s, d_data, nd, d_query, nq,
-                     dim, d_part_d, d_part_i);
+  if (dim == 33)  // pcl::FPFHSignature33
+    hipLaunchKernelGGL(feat_nn_partial_kernel<33>, dim3((nq + 63) / 64, chunks), dim3(64), 0, s, d_data, nd, d_query, nq,
+                       dim, d_part_d, d_part_i);
+  else
+    hipLaunchKernelGGL(feat_nn_partial_kernel<0>, dim3((nq + 63) / 64, chunks), dim3(64), 0, s, d_data, nd, d_query, nq,
+                       dim, d_part_d, d_part_i);
   hipLaunchKernelGGL(feat_nn_final_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, d_part_d, d_part_i, nq, chunks,
                      d_nn);
 }

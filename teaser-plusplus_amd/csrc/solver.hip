@@ -2098,6 +2098,18 @@ int32_t teaser_hip_match_features(teaser_hip_solver* h, const float* src_feat, i
   HIPCHK(h, hipGetLastError());
   HIPCHK(h, hipMemcpyAsync(i_nn.data(), h->f_nn_b.p, (size_t)ni * 4, hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipStreamSynchronize(s));
+  // A query whose distances are all NaN / +inf (non-finite caller features) has no nearest neighbour: the
+  // kernel reports -1.  FLANN would return garbage there; an error is the honest answer.
+  for (int j = 0; j < nj; ++j)
+    if (j_to_i[(size_t)j] < 0 || j_to_i[(size_t)j] >= ni) {
+      h->err = "teaser_hip_match_features: non-finite feature values (no nearest neighbour for a point)";
+      return TEASER_HIP_ERR_BAD_ARG;
+    }
+  for (int i = 0; i < ni; ++i)
+    if (i_nn[(size_t)i] < 0 || i_nn[(size_t)i] >= nj) {
+      h->err = "teaser_hip_match_features: non-finite feature values (no nearest neighbour for a point)";
+      return TEASER_HIP_ERR_BAD_ARG;
+    }
   // index bookkeeping of matcher.cc:155-233, 281-296 (O(n) on the host)
   std::vector<int32_t> i_to_j((size_t)ni, -1);
   for (int j = 0; j < nj; ++j) {

@@ -140,3 +140,171 @@ def test_band_random_and_adversarial():
     src = rng.uniform(size=(1000, 3)) + np.array([1e4, -2e4, 3e4])
     dst = src @ Rm.T + 50.0
     check(src, dst, 0.02, rng, 300_000)
+
+
+# ---------------------------------------------------------------------------------------------
+# second formulation (csrc/kernels_graph.hip, "u / w"): u = B - A - beta^2 over 42 K slots in three chained
+# MFMAs, w = -4 beta^2 A over 13 slots in one, points scaled so that 4 beta^2 is a power of two; epilogue
+# d = fma(u, u, w), -band = fma(w, K2, -K0), edges d -+ band; a pair is trusted iff both edges have one sign.
+# ---------------------------------------------------------------------------------------------
+K_EPS_U2 = np.float32(680.0)
+K_EPS_A2 = np.float32(1300.0)
+
+
+def scale2(beta):
+    x = 4.0 * beta * beta
+    kexp = int(np.floor(np.log2(x))) + 1
+    return np.sqrt(2.0 ** kexp / x), kexp
+
+
+def operands2(src64, dst64, beta):
+    """per point: A-side / B-side f32 arrays [n, 64] of bf16-representable values (slots 0..47 the u chain,
+    48..63 the w MFMA) and the largest squared norm of the scaled centred f32 points."""
+    g, kexp = scale2(beta)
+    kappa = np.float32(2.0 ** kexp)
+
+    def centred(p):
+        lo, hi = p.astype(np.float32).min(0), p.astype(np.float32).max(0)
+        c = 0.5 * (lo.astype(np.float64) + hi.astype(np.float64))
+        return ((p - c) * g).astype(np.float32)
+
+    s, d = centred(src64), centred(dst64)
+    na = (s.astype(np.float64) ** 2).sum(1)
+    nb = (d.astype(np.float64) ** 2).sum(1)
+    n = len(s)
+    A, B = np.zeros((n, 64), np.float32), np.zeros((n, 64), np.float32)
+    for k in range(3):
+        h, m, l = split3(s[:, k])
+        A[:, 6 * k:6 * k + 6] = np.stack([h, h, m, h, l, m], 1)
+        B[:, 6 * k:6 * k + 6] = np.float32(2) * np.stack([h, m, h, l, h, m], 1)
+        A[:, 48 + 3 * k:48 + 3 * k + 3] = np.stack([h, h, m], 1)
+        B[:, 48 + 3 * k:48 + 3 * k + 3] = np.float32(2) * kappa * np.stack([h, m, h], 1)
+        h, m, l = split3(d[:, k])
+        A[:, 18 + 6 * k:18 + 6 * k + 6] = np.stack([h, h, m, h, l, m], 1)
+        B[:, 18 + 6 * k:18 + 6 * k + 6] = np.float32(-2) * np.stack([h, m, h, l, h, m], 1)
+    beta2s = 2.0 ** (kexp - 2)
+    h, m, l = split3((nb - na - beta2s).astype(np.float32))
+    A[:, 36:39] = np.stack([h, m, l], 1)
+    B[:, 36:39] = 1
+    h, m, l = split3((nb - na).astype(np.float32))
+    A[:, 39:42] = 1
+    B[:, 39:42] = np.stack([h, m, l], 1)
+    h, m, l = split3(na.astype(np.float32))
+    A[:, 57:59] = np.stack([h, m], 1)
+    B[:, 57:59] = -kappa
+    A[:, 59:61] = 1
+    B[:, 59:61] = -kappa * np.stack([h, m], 1)
+    r2 = float(max(na.astype(np.float32).max(), nb.astype(np.float32).max()))
+    return A, B, r2, g, kexp
+
+
+def consts2(beta, r2max):
+    f = np.float32
+    g, kexp = scale2(beta)
+    up = f(1.000001)
+    b = f(beta * g) * up
+    kappa = f(2.0 ** kexp)
+    R2 = f(r2max) * up
+    R = np.sqrt(R2) * up
+    b2 = f(0.25) * kappa
+    eps_u = K_EPS_U2 * U * R2 * up
+    eps_a = K_EPS_A2 * U * R2 * up
+    lam_lo = f(2) * f(beta * g) * np.sqrt(f(r2max)) * f(0.999999)
+    lam_hi = f(2) * b * R * up
+    eta = eps_u / lam_lo * up
+    assert eta <= 0.125 and b2 * f(5.76) <= R2
+    den = f(1) - f(2) * eta - f(2) * U
+    K2 = eta / den * up
+    G = (f(1.3e-13) * b * R2 * R + f(8e-15) * b2 * R2) * up
+    K0p = (eps_u * lam_hi + eps_u * eps_u + kappa * eps_a * (f(1) + eta) + G) * up
+    K0 = (K0p / den + f(2) * K2 * kappa * eps_a) * up
+    short_d = (f(4) * b2 * b2 * (f(1) + f(16) * U) + f(4) * b2 * eps_u + eps_u * eps_u + kappa * eps_a) * f(1.001) * up
+    K0e = K0 * f(1.001) * up
+    return dict(K2=K2 * f(1.001) * up, K0=max(K0e, short_d) * f(1.00001))
+
+
+def check2(src, dst, beta, rng, npairs):
+    n = len(src)
+    A, B, r2, g, kexp = operands2(src, dst, beta)
+    kc = consts2(beta, r2)
+    i = rng.integers(0, n, size=npairs)
+    j = rng.integers(0, n, size=npairs)
+    keep = i != j
+    i, j = i[keep], j[keep]
+    ref = reference_edge(src, dst, i, j, beta)
+    fma = lambda x, y, z: (np.asarray(x, np.float64) * np.asarray(y, np.float64) + np.asarray(z, np.float64)).astype(np.float32)
+    trusted_total = 0
+    for order_u, order_w in ((list(range(48)), list(range(48, 64))),
+                             (list(range(47, -1, -1)), list(range(63, 47, -1))),
+                             (list(rng.permutation(48)), list(48 + rng.permutation(16)))):
+        u = accumulate(A[i], B[j], order_u)
+        w = accumulate(A[i], B[j], order_w)
+        d = fma(u, u, w)
+        nb = fma(w, kc["K2"], -kc["K0"])
+        dlo, dhi = (d + nb).astype(np.float32), (d - nb).astype(np.float32)
+        slo, shi = np.signbit(dlo), np.signbit(dhi)
+        trusted = slo == shi
+        # a trusted pair: edge <=> sign bit of d + band (both edges negative); short pairs must never be trusted
+        assert (shi[trusted] == ref[trusted]).all(), "u / w filter trusted a wrong sign"
+        trusted_total += int(trusted.sum())
+    return trusted_total / (3.0 * len(i))
+
+
+def test_band2_random_and_adversarial():
+    rng = np.random.default_rng(2026)
+    n = 3000
+    src = rng.uniform(size=(n, 3))
+    Rm = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+    dst = src @ Rm.T + rng.uniform(-1, 1, size=3)
+    out = rng.uniform(size=n) < 0.95
+    dst[out] = rng.uniform(-1, 1, size=(int(out.sum()), 3))
+    dst[~out] += rng.uniform(-0.0057, 0.0057, size=(int((~out).sum()), 3))
+    frac = check2(src, dst, 0.02, rng, 1_000_000)
+    assert frac > 0.9995  # the filter decides almost everything (fewer pairs in the band than the first formulation)
+    # pairs engineered onto the boundary: dst lengths = src lengths +- beta (1 + delta)
+    for scale, beta in ((1.0, 0.02), (300.0, 0.1), (0.05, 2e-4)):
+        n = 1500
+        src = rng.uniform(-1, 1, size=(n, 3)) * scale
+        Rm = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+        dst = src @ Rm.T
+        off = rng.choice([0.0, 1.0, -1.0], size=n) * beta * (
+            1 + rng.choice([0, 1e-15, 1e-12, 1e-9, 1e-7, 1e-6, 1e-5, 1e-4, 1e-3], size=n))
+        d = dst / np.linalg.norm(dst, axis=1, keepdims=True)
+        dst = dst + d * (off * rng.uniform(0.3, 1.0, size=n))[:, None]
+        check2(src, dst, beta, rng, 600_000)
+    # large offsets are absorbed by the centring
+    src = rng.uniform(size=(1000, 3)) + np.array([1e4, -2e4, 3e4])
+    dst = src @ Rm.T + 50.0
+    check2(src, dst, 0.02, rng, 300_000)
+
+
+def test_band2_short_pairs_are_never_trusted():
+    """S = |a| + |b| <= beta is the one region where the sign of d misleads: every such pair must land inside the
+    band (K0 >= 4 beta^4 + margins).  Clusters of near-coincident correspondences at several beta / size ratios."""
+    rng = np.random.default_rng(7)
+    for scale, beta in ((1.0, 0.02), (1.0, 0.2), (10.0, 0.05), (0.05, 2e-4)):
+        n = 1200
+        centres = rng.uniform(-1, 1, size=(40, 3)) * scale
+        which = rng.integers(0, 40, size=n)
+        src = centres[which] + rng.uniform(-1, 1, size=(n, 3)) * beta * rng.choice([0.05, 0.3, 0.6], size=(n, 1))
+        Rm = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+        dst = src @ Rm.T + rng.uniform(-1, 1, size=(n, 3)) * beta * rng.choice([0.0, 0.05, 0.3], size=(n, 1))
+        A, B, r2, g, kexp = operands2(src, dst, beta)
+        kc = consts2(beta, r2)
+        i = rng.integers(0, n, size=400_000)
+        j = rng.integers(0, n, size=400_000)
+        keep = (i != j) & (which[i] == which[j])
+        i, j = i[keep], j[keep]
+        a = np.linalg.norm(src[j] - src[i], axis=1)
+        b = np.linalg.norm(dst[j] - dst[i], axis=1)
+        short = a + b <= beta * (1 + 1e-9)
+        assert short.sum() > 1000
+        fma = lambda x, y, z: (np.asarray(x, np.float64) * np.asarray(y, np.float64) + np.asarray(z, np.float64)).astype(np.float32)
+        u = accumulate(A[i], B[j], list(range(48)))
+        w = accumulate(A[i], B[j], list(range(48, 64)))
+        d = fma(u, u, w)
+        nb = fma(w, kc["K2"], -kc["K0"])
+        trusted = np.signbit((d + nb).astype(np.float32)) == np.signbit((d - nb).astype(np.float32))
+        assert not trusted[short].any()
+        ref = reference_edge(src, dst, i, j, beta)
+        assert (np.signbit((d - nb).astype(np.float32))[trusted] == ref[trusted]).all()
