@@ -210,6 +210,30 @@ TEASER_HIP_API int32_t teaser_hip_multi_route(teaser_hip_multi* mh, int32_t prob
                                int32_t* local_problem);
 TEASER_HIP_API int32_t teaser_hip_multi_device_count(const teaser_hip_multi* mh);
 
+/* Rank mode: one PROCESS per GPU, the problems of a job cut into contiguous shards, every rank
+ * solving its shard with teaser_hip_solve_batch on its own handle, and ONE all-gather of the fixed-size solution
+ * records over RCCL (xGMI inside a node) -- the compiled-caller counterpart of the Python host's
+ * batched.solve_sharded (torch.distributed).  The reference has no multi-process mode (one problem per
+ * RobustRegistrationSolver object, registration.cc:568-737); there is no data-path collective.
+ *   comm_shard      rank r of `world` owns problems [first, last): contiguous, balanced (the first total % world
+ *                   ranks own one more)
+ *   comm_unique_id  rank 0 makes the RCCL id (TEASER_HIP_COMM_ID_BYTES bytes) and hands it to the other ranks by
+ *                   whatever the job already has (MPI_Bcast, a file, a socket)
+ *   comm_create     collective over all ranks; device < 0: the current device
+ *   comm_gather_solutions  collective: `local` = this rank's records in shard order (n_local = last - first),
+ *                   `all` [total] receives every rank's records in problem order, the same on every rank
+ * librccl is loaded on first use: TEASER_HIP_ERR_UNSUPPORTED when it is absent. */
+#define TEASER_HIP_COMM_ID_BYTES 128
+typedef struct teaser_hip_comm teaser_hip_comm;
+TEASER_HIP_API int32_t teaser_hip_comm_shard(int64_t total, int32_t rank, int32_t world, int64_t* first, int64_t* last);
+TEASER_HIP_API int32_t teaser_hip_comm_unique_id(uint8_t* id /* [TEASER_HIP_COMM_ID_BYTES] */);
+TEASER_HIP_API int32_t teaser_hip_comm_create(const uint8_t* id, int32_t rank, int32_t world, int32_t device,
+                               teaser_hip_comm** out);
+TEASER_HIP_API int32_t teaser_hip_comm_destroy(teaser_hip_comm* c);
+TEASER_HIP_API int32_t teaser_hip_comm_gather_solutions(teaser_hip_comm* c, const teaser_solution_c* local,
+                                         int64_t n_local, int64_t total, teaser_solution_c* all /* [total] */);
+TEASER_HIP_API const char* teaser_hip_comm_last_error(const teaser_hip_comm* c);
+
 /* Getters on the last solve call; `problem` indexes the batch (0 for single solves).  Each copies
  * into buf when buf != NULL and *len (capacity in elements on entry) suffices, and always writes
  * the required length to *len.

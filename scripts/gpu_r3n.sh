@@ -1,6 +1,6 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r3n
-OUT=$GRAFT_REPO_ROOT/gpurun_out/r3n
+export OUT=$GRAFT_REPO_ROOT/gpurun_out/r3n
 export TMPDIR=/tmp
 timeout 200 python -m pytest tests/test_gpu_features.py -m gpu -q -x > $OUT/tests_feat.log 2>&1; echo "feat rc=$?"; tail -3 $OUT/tests_feat.log
 cd /tmp

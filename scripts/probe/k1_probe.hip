@@ -93,11 +93,11 @@ int main(int argc, char** argv) {
     const char* variants_all[] = {"-1", "1", "7", "8", "11"};
     std::vector<std::string> vs;
     if (mode == "one")
-      vs.push_back(getenv("TEASER_K1_VARIANT") ? getenv("TEASER_K1_VARIANT") : "1");
+      vs.push_back(getenv("TEASER_K1_VARIANT") ? getenv("TEASER_K1_VARIANT") : "");  // "": the library's default
     else
       for (const char* v : variants_all) vs.push_back(v);
     for (const std::string& v : vs) {
-      setenv("TEASER_K1_VARIANT", v.c_str(), 1);
+      if (!v.empty()) setenv("TEASER_K1_VARIANT", v.c_str(), 1);
       teaser_hip_solver* h = nullptr;
       CK(teaser_hip_solver_create(&prm, 0, &h));
       for (int w = 0; w < 2; ++w)
@@ -126,7 +126,7 @@ int main(int argc, char** argv) {
       }
       printf("{\"probe\":\"k1\",\"variant\":%s,\"batch\":%d,\"n\":%d,\"k1_ms\":%.4f,\"aux_ms\":%.4f,\"launches\":%d,"
              "\"step_ms_sync\":%.4f,\"clique0\":%d,\"valid0\":%d,\"bitmap_hash\":\"%016llx\"}\n",
-             v.c_str(), B, n, launches ? k1 / launches : (mode == "one" ? 0.0 : k1 / iters), aux / iters, launches,
+             v.empty() ? "\"default\"" : v.c_str(), B, n, launches ? k1 / launches : (mode == "one" ? 0.0 : k1 / iters), aux / iters, launches,
              (t1 - t0) / iters, out[0].clique_size, out[0].valid, (unsigned long long)hsh);
       fflush(stdout);
       teaser_hip_solver_destroy(h);

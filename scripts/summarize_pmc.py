@@ -37,12 +37,12 @@ def main():
                      "hbm_bytes_per_launch": 2.0 * fetch_kb * 1024 + write_kb * 1024})
     if len(sys.argv) >= 6:
         batch, n = int(sys.argv[4]), int(sys.argv[5])
-        T = (n + 63) // 64
-        gxc, gyr = (T + 7) // 8, (T + 3) // 4  # tim_graph_mfma_kernel: 4 row x 8 column tiles / block,
-        grid = sum(min(gyr, 2 * X + 2) for X in range(gxc)) * 256 * batch  # upper-triangle blocks only
-        for r in rows:
-            if "tim_graph_mfma_kernel" in r["kernel"] and r["grid_size"] == grid:
-                r["batch"], r["n"] = batch, n
+        # the batched K1 launch = the largest grid of tim_graph_mfma*_kernel in the pass (the probe / bench run
+        # one shape only)
+        k1 = [r for r in rows if "tim_graph_mfma" in r["kernel"]]
+        if k1:
+            top = max(k1, key=lambda r: r["grid_size"])
+            top["batch"], top["n"] = batch, n
     json.dump({"note": __doc__.strip().split("usage")[0].strip(), "kernels": rows},
               open(sys.argv[3], "w"), indent=1)
     for r in rows:

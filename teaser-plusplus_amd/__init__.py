@@ -125,6 +125,8 @@ EXPORTED_SYMBOLS = [
     "teaser_hip_multi_solve_batch", "teaser_hip_multi_route", "teaser_hip_multi_device_count",
     "teaser_hip_solve_for_scale", "teaser_hip_compute_fpfh", "teaser_hip_match_features",
     "teaser_hip_certifier_params_default", "teaser_hip_certify",
+    "teaser_hip_comm_shard", "teaser_hip_comm_unique_id", "teaser_hip_comm_create", "teaser_hip_comm_destroy",
+    "teaser_hip_comm_gather_solutions", "teaser_hip_comm_last_error",
 ]
 
 

@@ -1,0 +1,179 @@
+// comm.hip -- rank mode of the batched solver for compiled callers: one process per GPU, the
+// problems cut into contiguous shards, every rank solving its shard through teaser_hip_solve_batch, and ONE
+// all-gather of the fixed-size teaser_solution_c records over RCCL (xGMI between the GPUs of a node).  No
+// data-path collective: the problems are independent (the reference itself has no multi-process mode, one problem
+// per RobustRegistrationSolver object, registration.cc:568-737).  The Python host side does the same through
+// torch.distributed (batched.py); this is the entry a C / C++ multi-process caller binds.
+// librccl is dlopen'ed on first use, so the library loads (and every other entry works) without it.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "teaser_hip.h"
+
+namespace {
+struct Rccl {
+  void* lib = nullptr;
+  decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+  decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+  decltype(&ncclAllGather) all_gather = nullptr;
+  decltype(&ncclCommDestroy) comm_destroy = nullptr;
+  decltype(&ncclGetErrorString) error_string = nullptr;
+  bool ok = false;
+};
+Rccl& rccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (r.lib) break;
+    }
+    if (!r.lib) return;
+    r.get_unique_id = reinterpret_cast<decltype(r.get_unique_id)>(dlsym(r.lib, "ncclGetUniqueId"));
+    r.comm_init_rank = reinterpret_cast<decltype(r.comm_init_rank)>(dlsym(r.lib, "ncclCommInitRank"));
+    r.all_gather = reinterpret_cast<decltype(r.all_gather)>(dlsym(r.lib, "ncclAllGather"));
+    r.comm_destroy = reinterpret_cast<decltype(r.comm_destroy)>(dlsym(r.lib, "ncclCommDestroy"));
+    r.error_string = reinterpret_cast<decltype(r.error_string)>(dlsym(r.lib, "ncclGetErrorString"));
+    r.ok = r.get_unique_id && r.comm_init_rank && r.all_gather && r.comm_destroy && r.error_string;
+  });
+  return r;
+}
+}  // namespace
+
+struct teaser_hip_comm {
+  ncclComm_t comm = nullptr;
+  int rank = 0, world = 1, device = 0;
+  hipStream_t stream = nullptr;
+  void *d_send = nullptr, *d_recv = nullptr;
+  size_t send_cap = 0, recv_cap = 0;
+  std::string err;
+};
+
+static_assert(sizeof(ncclUniqueId) == TEASER_HIP_COMM_ID_BYTES, "teaser_hip.h: TEASER_HIP_COMM_ID_BYTES");
+
+extern "C" {
+
+int32_t teaser_hip_comm_shard(int64_t total, int32_t rank, int32_t world, int64_t* first, int64_t* last) {
+  if (total < 0 || world <= 0 || rank < 0 || rank >= world || !first || !last) return TEASER_HIP_ERR_BAD_ARG;
+  // contiguous and balanced: the first total % world ranks own one problem more (batched.py shard_bounds)
+  const int64_t base = total / world, extra = total % world;
+  *first = rank * base + (rank < extra ? rank : extra);
+  *last = *first + base + (rank < extra ? 1 : 0);
+  return TEASER_HIP_OK;
+}
+
+int32_t teaser_hip_comm_unique_id(uint8_t* id) {
+  if (!id) return TEASER_HIP_ERR_BAD_ARG;
+  Rccl& r = rccl();
+  if (!r.ok) return TEASER_HIP_ERR_UNSUPPORTED;
+  ncclUniqueId u;
+  if (r.get_unique_id(&u) != ncclSuccess) return TEASER_HIP_ERR_HIP;
+  std::memcpy(id, &u, sizeof(u));
+  return TEASER_HIP_OK;
+}
+
+int32_t teaser_hip_comm_create(const uint8_t* id, int32_t rank, int32_t world, int32_t device,
+                               teaser_hip_comm** out) {
+  if (!id || !out || world <= 0 || rank < 0 || rank >= world) return TEASER_HIP_ERR_BAD_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return TEASER_HIP_ERR_NO_DEVICE;
+  if (device < 0 && hipGetDevice(&device) != hipSuccess) return TEASER_HIP_ERR_NO_DEVICE;
+  if (device >= count) return TEASER_HIP_ERR_BAD_ARG;
+  Rccl& r = rccl();
+  if (!r.ok) return TEASER_HIP_ERR_UNSUPPORTED;
+  if (hipSetDevice(device) != hipSuccess) return TEASER_HIP_ERR_HIP;
+  teaser_hip_comm* c = new teaser_hip_comm;
+  c->rank = rank;
+  c->world = world;
+  c->device = device;
+  ncclUniqueId u;
+  std::memcpy(&u, id, sizeof(u));
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+      r.comm_init_rank(&c->comm, world, u, rank) != ncclSuccess) {
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return TEASER_HIP_ERR_HIP;
+  }
+  *out = c;
+  return TEASER_HIP_OK;
+}
+
+int32_t teaser_hip_comm_destroy(teaser_hip_comm* c) {
+  if (!c) return TEASER_HIP_OK;
+  (void)hipSetDevice(c->device);
+  if (c->comm) (void)rccl().comm_destroy(c->comm);
+  if (c->d_send) (void)hipFree(c->d_send);
+  if (c->d_recv) (void)hipFree(c->d_recv);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return TEASER_HIP_OK;
+}
+
+const char* teaser_hip_comm_last_error(const teaser_hip_comm* c) { return c ? c->err.c_str() : ""; }
+
+int32_t teaser_hip_comm_gather_solutions(teaser_hip_comm* c, const teaser_solution_c* local, int64_t n_local,
+                                         int64_t total, teaser_solution_c* all) {
+  if (!c || total < 0 || n_local < 0 || (n_local > 0 && !local) || (total > 0 && !all)) return TEASER_HIP_ERR_BAD_ARG;
+  int64_t first = 0, last = 0;
+  (void)teaser_hip_comm_shard(total, c->rank, c->world, &first, &last);
+  if (n_local != last - first) {
+    c->err = "teaser_hip_comm_gather_solutions: this rank's shard of " + std::to_string(total) + " problems holds " +
+             std::to_string(last - first) + " records, not " + std::to_string(n_local);
+    return TEASER_HIP_ERR_BAD_ARG;
+  }
+  if (total == 0) return TEASER_HIP_OK;
+  if (hipSetDevice(c->device) != hipSuccess) return TEASER_HIP_ERR_HIP;
+  // shards are ragged by at most one record: every rank sends a block of the largest shard's size
+  const int64_t cap = (total + c->world - 1) / c->world;
+  const size_t block = (size_t)cap * sizeof(teaser_solution_c);
+  auto fail = [&](const char* what, hipError_t e) {
+    c->err = std::string(what) + ": " + hipGetErrorString(e);
+    return TEASER_HIP_ERR_HIP;
+  };
+  if (c->send_cap < block) {
+    if (c->d_send) (void)hipFree(c->d_send);
+    c->d_send = nullptr;
+    c->send_cap = 0;
+    hipError_t e = hipMalloc(&c->d_send, block);
+    if (e != hipSuccess) return fail("hipMalloc", e);
+    c->send_cap = block;
+  }
+  if (c->recv_cap < block * (size_t)c->world) {
+    if (c->d_recv) (void)hipFree(c->d_recv);
+    c->d_recv = nullptr;
+    c->recv_cap = 0;
+    hipError_t e = hipMalloc(&c->d_recv, block * (size_t)c->world);
+    if (e != hipSuccess) return fail("hipMalloc", e);
+    c->recv_cap = block * (size_t)c->world;
+  }
+  std::vector<teaser_solution_c> stage((size_t)cap);
+  std::memset(stage.data(), 0, block);
+  if (n_local > 0) std::memcpy(stage.data(), local, (size_t)n_local * sizeof(teaser_solution_c));
+  hipError_t e = hipMemcpyAsync(c->d_send, stage.data(), block, hipMemcpyHostToDevice, c->stream);
+  if (e != hipSuccess) return fail("hipMemcpyAsync", e);
+  const ncclResult_t nr = rccl().all_gather(c->d_send, c->d_recv, block, ncclUint8, c->comm, c->stream);
+  if (nr != ncclSuccess) {
+    c->err = std::string("ncclAllGather: ") + rccl().error_string(nr);
+    return TEASER_HIP_ERR_HIP;
+  }
+  std::vector<teaser_solution_c> got((size_t)cap * (size_t)c->world);
+  e = hipMemcpyAsync(got.data(), c->d_recv, block * (size_t)c->world, hipMemcpyDeviceToHost, c->stream);
+  if (e != hipSuccess) return fail("hipMemcpyAsync", e);
+  e = hipStreamSynchronize(c->stream);
+  if (e != hipSuccess) return fail("hipStreamSynchronize", e);
+  for (int r = 0; r < c->world; ++r) {
+    int64_t f = 0, l = 0;
+    (void)teaser_hip_comm_shard(total, r, c->world, &f, &l);
+    if (l > f) std::memcpy(all + f, got.data() + (size_t)r * (size_t)cap, (size_t)(l - f) * sizeof(teaser_solution_c));
+  }
+  return TEASER_HIP_OK;
+}
+
+}  // extern "C"

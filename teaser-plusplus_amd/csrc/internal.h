@@ -210,6 +210,22 @@ void launch_scalar_tls(hipStream_t s, const double* d_x, const double* d_r, int3
 int64_t scalar_tls_large_workspace_bytes(int64_t n);
 hipError_t launch_scalar_tls_large(hipStream_t s, const double* d_x, const double* d_r, int64_t n,
                                    char* d_workspace, double* d_est, uint8_t* d_mask);
+// one problem of a batched scale stage (kernels_scale.hip, "a batch of problems through ONE value sort")
+struct ScaleSeg {
+  int64_t e_off, m;        // first endpoint, endpoints (2 M)
+  int64_t nblk, blk_off;   // sweep chunks of this segment, first chunk in the per-chunk arrays
+  int64_t pt_off;          // first point in the batch's src / dst
+  int64_t trim_off;        // first TRIM in raw / alpha
+  int32_t prob, n;         // problem index (ProbState record), points
+};
+// fills e_off / m / nblk / blk_off / trim_off from (prob, n, pt_off) in order
+void scale_batch_plan(ScaleSeg* segs, int count, int64_t* total_trims, int64_t* total_blocks, int* max_n,
+                      int64_t* max_nblk);
+int64_t scale_batch_workspace_bytes(int64_t trims, int64_t blocks, int count);
+hipError_t launch_tls_scale_batch(hipStream_t s, const double* d_src, const double* d_dst, const ScaleSeg* h_segs,
+                                  int count, int64_t trims, int64_t blocks, int max_n, int64_t max_nblk, double beta,
+                                  double* d_raw, double* d_alpha, char* d_workspace, double* d_scale0,
+                                  int64_t scale_stride);
 hipError_t launch_tls_scale_large(hipStream_t s, const double* d_src, const double* d_dst, int n,
                                   double beta, double* d_raw, double* d_alpha, char* d_workspace,
                                   double* d_scale);
@@ -222,6 +238,7 @@ void launch_feat_radius_count(hipStream_t s, const float* d_pts, int n, float r2
 void launch_feat_scan(hipStream_t s, const int32_t* d_counts, int n, int64_t* d_offsets /* n + 1 */,
                       int64_t* d_total_max /* 2 */);
 void launch_feat_radius_fill_sort(hipStream_t s, const float* d_pts, int n, float r2, const int32_t* d_counts,
+                                  int32_t* d_cursor /* n, scratch */,
                                   const int64_t* d_offsets, void* d_list);
 void launch_feat_normals(hipStream_t s, const float* d_pts, int n, const int64_t* d_offsets, const int32_t* d_counts,
                          const void* d_list, float* d_normals);

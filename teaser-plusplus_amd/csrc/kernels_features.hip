@@ -39,7 +39,7 @@ __device__ double fdet_atan_d(double x) {  // |x| <= 1: two argument halvings, t
   t = t / (1.0 + __builtin_sqrt(1.0 + t * t));
   const double t2 = t * t;
   double s = 0.0;
-#pragma unroll 1
+#pragma unroll  // (the quotients 1 / (2k + 1) fold to constants: correctly rounded at compile time as at run time)
   for (int k = 24; k >= 0; --k) s = 1.0 / (double)(2 * k + 1) - t2 * s;
   return 4.0 * (t * s);
 }
@@ -79,39 +79,45 @@ __device__ __forceinline__ float feat_d2(float qx, float qy, float qz, float x, 
 }
 
 // ---- radius neighbour lists: count pass / fill pass over LDS tiles of the cloud ------------------
-constexpr int kFeatTile = 1024;
+// grid (blocks of 64 queries, chunks of kFeatChunk data points): a wave owns 64 queries and one chunk, so that a
+// 5 000-point cloud is 800 waves (the first version's 20 workgroups left 236 of the 256 CUs idle: 0.39 ms for
+// 25 M distance evaluations).  The lists are SORTED by (d2, idx) afterwards (feat_sort_kernel), so the chunks
+// may append in any order: the count pass adds into counts[q], the fill pass reserves its run of the list with
+// one atomic per (query, chunk).
+constexpr int kFeatChunk = 512;
 
-// FILL == 0: counts[q] = |{ i : d2(q, i) < r2 }|;  FILL == 1: the neighbours (d2, i) in index order into
-// list[offset[q] ...]
+// FILL == 0: counts[q] += |{ i in chunk : d2(q, i) < r2 }| (counts zeroed by the launcher);
+// FILL == 1: the chunk's neighbours (d2, i) into list[offset[q] + cursor[q] ...] (cursor zeroed by the launcher)
 template <int FILL>
-__global__ __launch_bounds__(256) void feat_radius_kernel(const float* __restrict__ pts, int n, float r2,
-                                                          int32_t* __restrict__ counts,
-                                                          const int64_t* __restrict__ offsets,
-                                                          Nbr* __restrict__ list) {
-  __shared__ float tile[kFeatTile * 3];
-  const int q = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(64) void feat_radius_kernel(const float* __restrict__ pts, int n, float r2,
+                                                         int32_t* __restrict__ counts,
+                                                         const int64_t* __restrict__ offsets,
+                                                         Nbr* __restrict__ list) {
+  __shared__ float tile[kFeatChunk * 3];
+  const int q = blockIdx.x * 64 + threadIdx.x;
   const bool live = q < n;
   const float qx = live ? pts[3 * q] : 0.f, qy = live ? pts[3 * q + 1] : 0.f, qz = live ? pts[3 * q + 2] : 0.f;
+  const int base = blockIdx.y * kFeatChunk;
+  const int m = min(kFeatChunk, n - base);
+  for (int k = threadIdx.x; k < 3 * m; k += 64) tile[k] = pts[3 * base + k];
+  __syncthreads();
+  if (!live) return;
   int cnt = 0;
-  Nbr* out = (FILL && live) ? list + offsets[q] : nullptr;
-  for (int base = 0; base < n; base += kFeatTile) {
-    const int m = min(kFeatTile, n - base);
-    __syncthreads();
-    for (int k = threadIdx.x; k < 3 * m; k += 256) tile[k] = pts[3 * base + k];
-    __syncthreads();
-    if (live)
-      for (int k = 0; k < m; ++k) {
-        const float d2 = feat_d2(qx, qy, qz, tile[3 * k], tile[3 * k + 1], tile[3 * k + 2]);
-        if (d2 < r2) {
-          if (FILL) {
-            out[cnt].d2 = d2;
-            out[cnt].idx = base + k;
-          }
-          ++cnt;
-        }
-      }
+#pragma unroll 4
+  for (int k = 0; k < m; ++k) cnt += feat_d2(qx, qy, qz, tile[3 * k], tile[3 * k + 1], tile[3 * k + 2]) < r2 ? 1 : 0;
+  if (cnt == 0) return;
+  const int pos = atomicAdd(&counts[q], cnt);
+  if (!FILL) return;
+  Nbr* out = list + offsets[q] + pos;
+  int c = 0;
+  for (int k = 0; k < m; ++k) {
+    const float d2 = feat_d2(qx, qy, qz, tile[3 * k], tile[3 * k + 1], tile[3 * k + 2]);
+    if (d2 < r2) {
+      out[c].d2 = d2;
+      out[c].idx = base + k;
+      ++c;
+    }
   }
-  if (!FILL && live) counts[q] = cnt;
 }
 
 // exclusive scan of the counts (one workgroup; n <= a few million) + the largest count
@@ -361,76 +367,98 @@ __device__ __forceinline__ int feat_bin(double x) {
   return hi;
 }
 
-// computePointSPFHSignature: one thread per point (33 private bins)
-__global__ __launch_bounds__(128) void feat_spfh_kernel(const float* __restrict__ pts,
+// computePointSPFHSignature: one WAVE per point, its lanes over the neighbours.  Every contributing pair adds
+// the SAME float (incr) to one bin of each of the three histograms, so a bin's value is incr added count times
+// in float -- whatever the order of the neighbours: the lanes count into LDS, then lane b replays the additions
+// of bin b.  (One thread per point, the first version, was 79 waves on 1 024 SIMDs and 1.98 ms at n = 5 000.)
+__global__ __launch_bounds__(256) void feat_spfh_kernel(const float* __restrict__ pts,
                                                         const float* __restrict__ normals, int n,
                                                         const int64_t* __restrict__ offsets,
                                                         const int32_t* __restrict__ counts,
                                                         const Nbr* __restrict__ list, float* __restrict__ spfh) {
-  const int p = blockIdx.x * 128 + threadIdx.x;
-  if (p >= n) return;
-  float h[33];
-  for (int i = 0; i < 33; ++i) h[i] = 0.0f;
-  const int k = counts[p];
-  const Nbr* nb = list + offsets[p];
-  const float incr = 100.0f / (float)(k - 1);
-  const float d_pi = 1.0f / (2.0f * 3.14159274101257324f);  // 1.0f / (2.0f * static_cast<float>(M_PI))
-  const double pi = 3.14159265358979323846;
-  const float P[3] = {pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]};
-  const float N[3] = {normals[3 * p], normals[3 * p + 1], normals[3 * p + 2]};
-  for (int j = 0; j < k; ++j) {
-    const int qi = nb[j].idx;
-    if (qi == p) continue;
-    const float Q[3] = {pts[3 * qi], pts[3 * qi + 1], pts[3 * qi + 2]};
-    const float M[3] = {normals[3 * qi], normals[3 * qi + 1], normals[3 * qi + 2]};
-    float f[4];
-    if (!feat_pair_features(P, N, Q, M, f)) continue;
-    const int b1 = feat_bin(11 * (((double)f[0] + pi) * (double)d_pi));
-    const int b2 = feat_bin(11 * (((double)f[1] + 1.0) * 0.5));
-    const int b3 = feat_bin(11 * (((double)f[2] + 1.0) * 0.5));
-    // (dynamic indexing of a private array would go to scratch: select instead)
-#pragma unroll
-    for (int i = 0; i < 11; ++i) {
-      h[i] += (i == b1) ? incr : 0.0f;
-      h[11 + i] += (i == b2) ? incr : 0.0f;
-      h[22 + i] += (i == b3) ? incr : 0.0f;
+  __shared__ int bins[4][33];
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int p = blockIdx.x * 4 + w;
+  if (lane < 33) bins[w][lane] = 0;
+  __syncthreads();
+  const int k = p < n ? counts[p] : 0;
+  if (p < n) {
+    const Nbr* nb = list + offsets[p];
+    const float d_pi = 1.0f / (2.0f * 3.14159274101257324f);  // 1.0f / (2.0f * static_cast<float>(M_PI))
+    const double pi = 3.14159265358979323846;
+    const float P[3] = {pts[3 * p], pts[3 * p + 1], pts[3 * p + 2]};
+    const float N[3] = {normals[3 * p], normals[3 * p + 1], normals[3 * p + 2]};
+    for (int j = lane; j < k; j += 64) {
+      const int qi = nb[j].idx;
+      if (qi == p) continue;
+      const float Q[3] = {pts[3 * qi], pts[3 * qi + 1], pts[3 * qi + 2]};
+      const float M[3] = {normals[3 * qi], normals[3 * qi + 1], normals[3 * qi + 2]};
+      float f[4];
+      if (!feat_pair_features(P, N, Q, M, f)) continue;
+      atomicAdd(&bins[w][feat_bin(11 * (((double)f[0] + pi) * (double)d_pi))], 1);
+      atomicAdd(&bins[w][11 + feat_bin(11 * (((double)f[1] + 1.0) * 0.5))], 1);
+      atomicAdd(&bins[w][22 + feat_bin(11 * (((double)f[2] + 1.0) * 0.5))], 1);
     }
   }
-  for (int i = 0; i < 33; ++i) spfh[(size_t)p * 33 + i] = h[i];
+  __syncthreads();
+  if (p < n && lane < 33) {
+    const float incr = 100.0f / (float)(k - 1);
+    const int c = bins[w][lane];
+    float h = 0.0f;
+    for (int i = 0; i < c; ++i) h += incr;
+    spfh[(size_t)p * 33 + lane] = h;
+  }
 }
 
-// weightPointSPFHSignature: one thread per point, neighbours in order of increasing distance
-__global__ __launch_bounds__(128) void feat_fpfh_kernel(int n, const int64_t* __restrict__ offsets,
+// weightPointSPFHSignature: one wave per point, lane b = bin b; the neighbours in order of increasing distance
+// (the float sums depend on it).  Per neighbour the bin values val_b = spfh[b] * weight are one coalesced row;
+// the group sums add them in the reference's order (j outer, bin inner), every lane of a group carrying its
+// group's running sum and fetching the eleven addends across the lanes.  A skipped neighbour (d2 == 0)
+// contributes +0, which leaves the non-negative sums unchanged bit for bit.  Neighbour records are wave-uniform
+// (scalar loads), fetched one block of kFpfhBlock ahead of the rows they index.
+constexpr int kFpfhBlock = 8;
+__global__ __launch_bounds__(256) void feat_fpfh_kernel(int n, const int64_t* __restrict__ offsets,
                                                         const int32_t* __restrict__ counts,
                                                         const Nbr* __restrict__ list,
                                                         const float* __restrict__ spfh, float* __restrict__ out) {
-  const int p = blockIdx.x * 128 + threadIdx.x;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int p = blockIdx.x * 4 + w;
   if (p >= n) return;
-  float o[33];
-  for (int i = 0; i < 33; ++i) o[i] = 0.0f;
-  float sum[3] = {0, 0, 0};
   const int k = counts[p];
   const Nbr* nb = list + offsets[p];
-  for (int j = 0; j < k; ++j) {
-    const float d2 = nb[j].d2;
-    if (d2 == 0.0f) continue;
-    const float weight = 1.0f / d2;
-    const float* h = spfh + (size_t)nb[j].idx * 33;
+  const int b = lane < 33 ? lane : 32;  // (lanes 33 .. 63 shadow bin 32; they do not store)
+  const int g0 = 11 * (b / 11);
+  float o = 0.0f, sum = 0.0f;
+  Nbr cur[kFpfhBlock], nxt[kFpfhBlock];
 #pragma unroll
-    for (int g = 0; g < 3; ++g)
-#pragma unroll
-      for (int i = 0; i < 11; ++i) {
-        const float val = h[11 * g + i] * weight;
-        sum[g] += val;
-        o[11 * g + i] += val;
-      }
+  for (int u = 0; u < kFpfhBlock; ++u) {
+    cur[u].d2 = u < k ? nb[u].d2 : 0.0f;
+    cur[u].idx = u < k ? nb[u].idx : p;
   }
+  for (int j0 = 0; j0 < k; j0 += kFpfhBlock) {
+    float hv[kFpfhBlock];
 #pragma unroll
-  for (int g = 0; g < 3; ++g) {
-    if (sum[g] != 0) sum[g] = 100.0f / sum[g];
+    for (int u = 0; u < kFpfhBlock; ++u) hv[u] = spfh[(size_t)cur[u].idx * 33 + b];
 #pragma unroll
-    for (int i = 0; i < 11; ++i) out[(size_t)p * 33 + 11 * g + i] = o[11 * g + i] * sum[g];
+    for (int u = 0; u < kFpfhBlock; ++u) {
+      const int j = j0 + kFpfhBlock + u;
+      nxt[u].d2 = j < k ? nb[j].d2 : 0.0f;
+      nxt[u].idx = j < k ? nb[j].idx : p;
+    }
+#pragma unroll
+    for (int u = 0; u < kFpfhBlock; ++u) {
+      const float d2 = cur[u].d2;
+      const float weight = 1.0f / d2;
+      const float val = d2 == 0.0f ? 0.0f : hv[u] * weight;
+      o += val;
+#pragma unroll
+      for (int i = 0; i < 11; ++i) sum += __shfl(val, g0 + i);
+    }
+#pragma unroll
+    for (int u = 0; u < kFpfhBlock; ++u) cur[u] = nxt[u];
   }
+  if (sum != 0) sum = 100.0f / sum;
+  if (lane < 33) out[(size_t)p * 33 + lane] = o * sum;
 }
 
 // ---- exact L2 1-NN in `dim` dimensions (the matcher's two searches) -------------------------------
@@ -535,17 +563,19 @@ int64_t feat_nbr_bytes() { return (int64_t)sizeof(Nbr); }
 
 void launch_feat_radius_count(hipStream_t s, const float* d_pts, int n, float r2, int32_t* d_counts) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(feat_radius_kernel<0>, dim3((n + 255) / 256), dim3(256), 0, s, d_pts, n, r2, d_counts,
-                     static_cast<const int64_t*>(nullptr), static_cast<Nbr*>(nullptr));
+  (void)hipMemsetAsync(d_counts, 0, (size_t)n * 4, s);
+  hipLaunchKernelGGL(feat_radius_kernel<0>, dim3((n + 63) / 64, (n + kFeatChunk - 1) / kFeatChunk), dim3(64), 0, s, d_pts,
+                     n, r2, d_counts, static_cast<const int64_t*>(nullptr), static_cast<Nbr*>(nullptr));
 }
 void launch_feat_scan(hipStream_t s, const int32_t* d_counts, int n, int64_t* d_offsets, int64_t* d_total_max) {
   hipLaunchKernelGGL(feat_scan_kernel, dim3(1), dim3(1024), 0, s, d_counts, n, d_offsets, d_total_max);
 }
 void launch_feat_radius_fill_sort(hipStream_t s, const float* d_pts, int n, float r2, const int32_t* d_counts,
-                                  const int64_t* d_offsets, void* d_list) {
+                                  int32_t* d_cursor, const int64_t* d_offsets, void* d_list) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(feat_radius_kernel<1>, dim3((n + 255) / 256), dim3(256), 0, s, d_pts, n, r2,
-                     static_cast<int32_t*>(nullptr), d_offsets, reinterpret_cast<Nbr*>(d_list));
+  (void)hipMemsetAsync(d_cursor, 0, (size_t)n * 4, s);
+  hipLaunchKernelGGL(feat_radius_kernel<1>, dim3((n + 63) / 64, (n + kFeatChunk - 1) / kFeatChunk), dim3(64), 0, s, d_pts,
+                     n, r2, d_cursor, d_offsets, reinterpret_cast<Nbr*>(d_list));
   hipLaunchKernelGGL(feat_sort_kernel, dim3(n), dim3(256), 0, s, d_offsets, d_counts, reinterpret_cast<Nbr*>(d_list));
 }
 int feat_sort_capacity() { return kFeatSortCap; }
@@ -558,9 +588,9 @@ void launch_feat_normals(hipStream_t s, const float* d_pts, int n, const int64_t
 void launch_feat_fpfh(hipStream_t s, const float* d_pts, const float* d_normals, int n, const int64_t* d_offsets,
                       const int32_t* d_counts, const void* d_list, float* d_spfh, float* d_out) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(feat_spfh_kernel, dim3((n + 127) / 128), dim3(128), 0, s, d_pts, d_normals, n, d_offsets,
-                     d_counts, reinterpret_cast<const Nbr*>(d_list), d_spfh);
-  hipLaunchKernelGGL(feat_fpfh_kernel, dim3((n + 127) / 128), dim3(128), 0, s, n, d_offsets, d_counts,
+  hipLaunchKernelGGL(feat_spfh_kernel, dim3((n + 3) / 4), dim3(256), 0, s, d_pts, d_normals, n, d_offsets, d_counts,
+                     reinterpret_cast<const Nbr*>(d_list), d_spfh);
+  hipLaunchKernelGGL(feat_fpfh_kernel, dim3((n + 3) / 4), dim3(256), 0, s, n, d_offsets, d_counts,
                      reinterpret_cast<const Nbr*>(d_list), d_spfh, d_out);
 }
 int feat_nn_chunks(int nd) { return (nd + kNnChunk - 1) / kNnChunk; }

@@ -1197,28 +1197,38 @@ __device__ __attribute__((noinline)) unsigned int tim2_inband_mask(bf16x8 a0, bf
   return ub;
 }
 
-template <int V, int OCC, bool EARLY, int COLD>
+template <int V, int OCC, bool EARLY>
 __global__ __launch_bounds__(256, OCC) void tim_graph_mfma2_kernel(
     const ProbDesc* __restrict__ descs, const double* __restrict__ src,
     const double* __restrict__ dst, const TimOperandTile2* __restrict__ ops, const TimPrep* __restrict__ prep,
     uint64_t* __restrict__ bitmap, double beta, int gyr,
     unsigned long long* __restrict__ work, unsigned int* __restrict__ work_count, unsigned int work_cap,
-    ProbState* __restrict__ states, int32_t* __restrict__ deg, unsigned long long* __restrict__ regions) {
+    ProbState* __restrict__ states, int32_t* __restrict__ deg, unsigned long long* __restrict__ regions,
+    int xcd_remap) {
   const ProbDesc d = descs[blockIdx.y];
   const int n = d.n, W = d.W;
   const int T = W;
   // block = kMfmaRowTiles consecutive row tiles (one per wave) x kMfmaColTiles column tiles; row group
   // fastest, so the blocks in flight share a column group.  Only the blocks that touch the upper triangle
-  // are launched: column group X has min(gyr, 2X + 2) row groups (I0 = 4 Ig <= 8X + 7); blockIdx.x
-  // enumerates them group after group (tim_mfma_grid_blocks is the host-side count).
+  // are launched: column group X has min(gyr, 2X + 2) row groups (I0 = 4 Ig <= 8X + 7); the LOGICAL block
+  // index enumerates them group after group (tim_mfma_grid_blocks is the host-side count).
+  // XCD-aware order: workgroups go to the 8 XCDs round robin in dispatch order, so for one problem the blocks
+  // with the same blockIdx.x % 8 share an XCD (and its L2).  They take CONSECUTIVE logical indices: the four
+  // neighbouring row groups whose transposed words fill one 128-byte line of a bitmap row then run on the same
+  // XCD at about the same time and their 32-byte runs merge in that L2 before they reach HBM; the column
+  // operands of a column group are fetched into one L2 instead of eight.
   int Ig = blockIdx.x, X = 0;
+  if (xcd_remap) {
+    const int nb = gridDim.x, c = blockIdx.x & 7, q = nb >> 3, rem = nb & 7;
+    Ig = c * q + min(c, rem) + (blockIdx.x >> 3);
+  }
   while (Ig >= min(gyr, 2 * X + 2)) {
     Ig -= min(gyr, 2 * X + 2);
     ++X;
   }
   const int I0 = Ig * kMfmaRowTiles, Jbase = X * kMfmaColTiles;
   if (I0 >= T || Jbase >= T || Jbase + kMfmaColTiles - 1 < I0) {  // outside / below the diagonal
-    if (COLD == 1 && (threadIdx.x & 63) == 0)
+    if ((threadIdx.x & 63) == 0)
       regions[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kMfmaRowTiles + (threadIdx.x >> 6)) * kRegionWords] = 0ull;
     return;
   }
@@ -1248,7 +1258,7 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma2_kernel(
       for (int jb = Jbase; jb < Jbase + kMfmaColTiles; jb += kColTilesPerWave)
         if (!(jb + kColTilesPerWave - 1 < I || jb >= T))
           tim_wave_fp64<0>(ps, pd, bm, n, W, I, jb, kc, cbuf[wave]);
-    if (COLD == 1 && lane == 0)
+    if (lane == 0)
       regions[((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kMfmaRowTiles + wave) * kRegionWords] = 0ull;
     return;
   }
@@ -1266,7 +1276,6 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma2_kernel(
   };
   unsigned long long* wbuf = reinterpret_cast<unsigned long long*>(cbuf[wave]);  // private to the wave
   int wcount = 0;  // wave-uniform
-  unsigned int xdummy = 0;
 
   // row operands (A side) of the wave's two 32-row halves, the four MFMAs (three of the u chain, one for w):
   // every load is 1 KB of consecutive memory per wave (lane = (h, c))
@@ -1482,7 +1491,7 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma2_kernel(
   // band") and the padding beyond n (copies of the last point) are dropped.  A 64 x 64 block holding more in-band
   // pairs than the staging buffer (adversarial geometry) flags the problem like a worklist overflow: the host
   // reruns the batch on the FP64 kernel.
-  if (COLD == 1 && rowvalid) {
+  if (rowvalid) {
 #pragma nounroll
     for (int J = max(Jbase, I); J < Jend; ++J) {
       const uint2 xv = lds_xb[wave][J - Jbase][lane];
@@ -1559,7 +1568,7 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma2_kernel(
   // stores at the very end of every wave, where nothing is left to overlap the ~2 us round trip, cost a quarter of
   // the launch (0.95 -> 1.20 ms: profiles/r3j, r3k).  Only a wave with more items (adversarial geometry) sends the
   // rest through the problem's counted segment.
-  if (COLD == 1) {
+  {
     unsigned long long* region = regions + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kMfmaRowTiles + wave) * kRegionWords;
     const int nreg = wcount < kRegionItems ? wcount : kRegionItems;
     if (lane == 0) region[0] = (unsigned long long)nreg;
@@ -1578,7 +1587,6 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma2_kernel(
       }
     }
   }
-  if (COLD == 2 && xdummy == 0xdeadbeefu) bm[0] = 1;
 }
 
 // FP64 resolution of the worklist: one thread per pair, bits rewritten with atomics (a row word
@@ -1740,14 +1748,18 @@ void launch_tim_graph_mfma(hipStream_t s, int phase, const ProbDesc* d_desc, int
   } else if (phase == 1) {
     const int gyr = (T + kMfmaRowTiles - 1) / kMfmaRowTiles;
     const int nblk = tim_mfma_blocks(T);  // blocks touching the upper triangle (see the kernel's decode of blockIdx.x)
+    static const int xcd_remap = [] {
+      const char* e = getenv("TEASER_K1_XCD");  // 0: logical block = blockIdx.x (diagnostics)
+      return e ? atoi(e) : 1;
+    }();
 #define TIM_K1_LAUNCH(V, OCC, PK)                                                                            \
   hipLaunchKernelGGL((tim_graph_mfma_kernel<V, OCC, PK>), dim3(nblk, batch), dim3(256), 0, s, d_desc, d_src, \
                      d_dst, op_src, op_dst, prep, d_bitmap, beta, gyr, work, work_count,                     \
                      (unsigned int)seg_cap, d_state, d_deg)
-#define TIM_K1_LAUNCH2(V, OCC, EARLY, COLD)                                                                                 \
-  hipLaunchKernelGGL((tim_graph_mfma2_kernel<V, OCC, EARLY, COLD>), dim3(nblk, batch), dim3(256), 0, s, d_desc, d_src, d_dst, \
+#define TIM_K1_LAUNCH2(V, OCC, EARLY)                                                                                 \
+  hipLaunchKernelGGL((tim_graph_mfma2_kernel<V, OCC, EARLY>), dim3(nblk, batch), dim3(256), 0, s, d_desc, d_src, d_dst, \
                      reinterpret_cast<const TimOperandTile2*>(d_pk), prep, d_bitmap, beta, gyr, work, work_count, \
-                     (unsigned int)seg_cap, d_state, d_deg, regions)
+                     (unsigned int)seg_cap, d_state, d_deg, regions, xcd_remap)
     switch (variant) {
       case 0: TIM_K1_LAUNCH(0, 3, true); break;
       case 2: TIM_K1_LAUNCH(2, 3, true); break;
@@ -1755,18 +1767,12 @@ void launch_tim_graph_mfma(hipStream_t s, int phase, const ProbDesc* d_desc, int
       case 4: TIM_K1_LAUNCH(1, 3, false); break;
       case 5: TIM_K1_LAUNCH(2, 3, false); break;
       case 6: TIM_K1_LAUNCH(2, 4, false); break;
-      case 7: TIM_K1_LAUNCH2(1, 3, true, 1); break;
-      case 8: TIM_K1_LAUNCH2(2, 3, true, 1); break;
-      case 9: TIM_K1_LAUNCH2(2, 4, false, 1); break;
-      case 10: TIM_K1_LAUNCH2(1, 3, false, 1); break;
-      case 11: TIM_K1_LAUNCH2(2, 3, false, 1); break;
-      case 12: TIM_K1_LAUNCH2(2, 3, true, 3); break;   // timing only: everything but the final flush
-      case 13: TIM_K1_LAUNCH2(2, 3, true, 2); break;   // timing only: full hot path, no push loop
-      case 14: TIM_K1_LAUNCH2(2, 4, false, 0); break;
-      case 15: TIM_K1_LAUNCH2(1, 2, true, 1); break;   // occupancy 2
-      case 16: TIM_K1_LAUNCH2(2, 2, true, 1); break;
+      case 7: TIM_K1_LAUNCH2(1, 3, true); break;
+      case 8: TIM_K1_LAUNCH2(2, 3, true); break;
+      case 9: TIM_K1_LAUNCH2(2, 4, false); break;
+      case 10: TIM_K1_LAUNCH2(1, 3, false); break;
       case 1: TIM_K1_LAUNCH(1, 3, true); break;
-      default: TIM_K1_LAUNCH2(2, 3, false, 1); break;
+      default: TIM_K1_LAUNCH2(2, 3, false); break;  // 11
     }
 #undef TIM_K1_LAUNCH
 #undef TIM_K1_LAUNCH2

@@ -33,11 +33,15 @@ struct Acc {
   double v[kNumAcc];
 };
 
-__device__ __forceinline__ void acc_add(Acc& a, int tag, const double* __restrict__ x,
-                                        const double* __restrict__ r) {
+// measurement behind an endpoint tag: (x, range) from two arrays, or from ONE interleaved array when r == nullptr
+// (the TRIM kernels write (raw, alpha) pairs: one 16-byte gather per endpoint instead of two 8-byte ones)
+__device__ __forceinline__ double2 fetch_xr(int tag, const double* __restrict__ x, const double* __restrict__ r) {
   const int idx = (tag > 0 ? tag : -tag) - 1;
+  if (r) return make_double2(x[idx], r[idx]);
+  return reinterpret_cast<const double2*>(x)[idx];
+}
+__device__ __forceinline__ void acc_add(Acc& a, int tag, double xv, double rv) {
   const double eps = tag > 0 ? 1.0 : -1.0;
-  const double xv = x[idx], rv = r[idx];
   const double w = 1.0 / (rv * rv);  // weights = ranges^-2, registration.cc:45-46
   a.v[0] += eps;
   a.v[1] += eps * w;
@@ -69,12 +73,60 @@ __global__ __launch_bounds__(256) void trim_endpoints_kernel(
     const int64_t k = seg + (j - i - 1);
     const double s = v2 / v1;              // registration.cc:420
     const double a = beta * (1.0 / v1);    // registration.cc:422
-    raw[k] = s;
-    alpha[k] = a;
+    reinterpret_cast<double2*>(raw)[k] = make_double2(s, a);  // interleaved (alpha unused)
     // registration.cc:35-38
     *reinterpret_cast<double2*>(keys + 2 * k) = make_double2(s - a, s + a);
     *reinterpret_cast<int2*>(tags + 2 * k) = make_int2((int)(k + 1), -(int)(k + 1));
   }
+}
+
+// The same for a whole batch of problems (grid (max n - 1, problems)): problem q's TRIMs live at
+// [trim_off, trim_off + M_q) of raw / alpha, its endpoints at twice that, and the tags are GLOBAL
+// (+-(trim_off + k + 1)), so one device-wide sort can carry all the problems at once.
+__global__ __launch_bounds__(256) void trim_endpoints_batch_kernel(
+    const double* __restrict__ src_all, const double* __restrict__ dst_all, const ScaleSeg* __restrict__ segs,
+    double beta, double* __restrict__ raw, double* __restrict__ alpha, double* __restrict__ keys,
+    int32_t* __restrict__ tags) {
+  const ScaleSeg sg = segs[blockIdx.y];
+  const int n = sg.n, i = blockIdx.x;
+  if (i >= n - 1) return;
+  const double* src = src_all + 3 * sg.pt_off;
+  const double* dst = dst_all + 3 * sg.pt_off;
+  const int64_t seg = sg.trim_off + (int64_t)i * n - (int64_t)i * (i + 1) / 2;
+  const double six = src[3 * i], siy = src[3 * i + 1], siz = src[3 * i + 2];
+  const double dix = dst[3 * i], diy = dst[3 * i + 1], diz = dst[3 * i + 2];
+  for (int j = i + 1 + threadIdx.x; j < n; j += 256) {
+    const double ax = src[3 * j] - six, ay = src[3 * j + 1] - siy, az = src[3 * j + 2] - siz;
+    const double bx = dst[3 * j] - dix, by = dst[3 * j + 1] - diy, bz = dst[3 * j + 2] - diz;
+    const double v1 = __builtin_sqrt((ax * ax + ay * ay) + az * az);  // registration.cc:415-418
+    const double v2 = __builtin_sqrt((bx * bx + by * by) + bz * bz);
+    const int64_t k = seg + (j - i - 1);
+    const double sc = v2 / v1;             // registration.cc:420
+    const double a = beta * (1.0 / v1);    // registration.cc:422
+    reinterpret_cast<double2*>(raw)[k] = make_double2(sc, a);  // interleaved (alpha unused)
+    *reinterpret_cast<double2*>(keys + 2 * k) = make_double2(sc - a, sc + a);
+    *reinterpret_cast<int2*>(tags + 2 * k) = make_int2((int)(k + 1), -(int)(k + 1));
+  }
+}
+
+// problem slot of every endpoint after the value sort (binary search of its TRIM index in the segment table):
+// the key of the second, stable, pass that gathers the problems back into contiguous segments
+__global__ __launch_bounds__(256) void scale_slot_kernel(const int32_t* __restrict__ tags, int64_t m,
+                                                         const ScaleSeg* __restrict__ segs, int count,
+                                                         uint32_t* __restrict__ slot) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= m) return;
+  const int tag = tags[e];
+  const int64_t k = (tag > 0 ? tag : -tag) - 1;
+  int lo = 0, hi = count - 1;
+  while (lo < hi) {  // the last segment with trim_off <= k
+    const int mid = (lo + hi + 1) >> 1;
+    if (segs[mid].trim_off <= k)
+      lo = mid;
+    else
+      hi = mid - 1;
+  }
+  slot[e] = (uint32_t)lo;
 }
 
 __global__ __launch_bounds__(256) void tls_endpoints_kernel(const double* __restrict__ x,
@@ -91,13 +143,32 @@ __global__ __launch_bounds__(256) void tls_endpoints_kernel(const double* __rest
 // pass A: totals of every chunk of kSwChunk sorted endpoints.  partials is SoA [kNumAcc][nblk].
 __global__ __launch_bounds__(kSwThreads) void tls_sweep_totals_kernel(
     const int32_t* __restrict__ tags, const double* __restrict__ x, const double* __restrict__ r,
-    int64_t m, int64_t nblk, double* __restrict__ partials) {
+    int64_t m, int64_t nblk, double* __restrict__ partials, double2* __restrict__ sorted_xr,
+    const ScaleSeg* __restrict__ segs) {
   __shared__ double red[kSwThreads / 64][kNumAcc];
+  if (segs) {  // batch: blockIdx.y = problem slot, everything relative to its segment
+    const ScaleSeg sg = segs[blockIdx.y];
+    if ((int64_t)blockIdx.x >= sg.nblk) return;
+    tags += sg.e_off;
+    sorted_xr += sg.e_off;
+    partials += kNumAcc * sg.blk_off;
+    m = sg.m;
+    nblk = sg.nblk;
+  }
   const int64_t base = (int64_t)blockIdx.x * kSwChunk + (int64_t)threadIdx.x * kSwPer;
   Acc a;
   for (int q = 0; q < kNumAcc; ++q) a.v[q] = 0;
+  // the ONLY random gather of the sweep: the measurements are left behind in sorted order for pass C
+  int tg[kSwPer];
+  double2 xr[kSwPer];
+  for (int e = 0; e < kSwPer; ++e) tg[e] = base + e < m ? tags[base + e] : 0;
   for (int e = 0; e < kSwPer; ++e)
-    if (base + e < m) acc_add(a, tags[base + e], x, r);
+    if (tg[e] != 0) xr[e] = fetch_xr(tg[e], x, r);
+  for (int e = 0; e < kSwPer; ++e)
+    if (tg[e] != 0) {
+      sorted_xr[base + e] = xr[e];
+      acc_add(a, tg[e], xr[e].x, xr[e].y);
+    }
   // fixed-shape tree inside the wave, then the waves in order
   for (int q = 0; q < kNumAcc; ++q) {
     double v = a.v[q];
@@ -119,9 +190,16 @@ __global__ __launch_bounds__(kSwThreads) void tls_sweep_totals_kernel(
 // opening ranges (= sum of all ranges, registration.cc:51) -> out[0].
 __global__ __launch_bounds__(1024) void tls_sweep_scan_kernel(double* __restrict__ partials,
                                                               int64_t nblk,
-                                                              double* __restrict__ out) {
+                                                              double* __restrict__ out,
+                                                              const ScaleSeg* __restrict__ segs) {
   __shared__ double tot[kNumAcc][1024];
   const int t = threadIdx.x;
+  if (segs) {  // batch: one workgroup per problem slot
+    const ScaleSeg sg = segs[blockIdx.x];
+    partials += kNumAcc * sg.blk_off;
+    nblk = sg.nblk;
+    out += 2 * blockIdx.x;
+  }
   const int64_t L = (nblk + 1023) / 1024;
   const int64_t b0 = (int64_t)t * L, b1 = b0 + L < nblk ? b0 + L : nblk;
   for (int q = 0; q < kNumAcc; ++q) {
@@ -161,13 +239,28 @@ __device__ __forceinline__ bool best_less(double ca, int64_t pa, double cb, int6
 
 // pass C: per-endpoint cost (registration.cc:58-75) and the chunk's first minimum.
 __global__ __launch_bounds__(kSwThreads) void tls_sweep_cost_kernel(
-    const int32_t* __restrict__ tags, const double* __restrict__ x, const double* __restrict__ r,
+    const int32_t* __restrict__ tags, const double2* __restrict__ sorted_xr,
     int64_t m, int64_t nblk, const double* __restrict__ partials,
     const double* __restrict__ ranges_sum_p, double* __restrict__ best_cost,
-    double* __restrict__ best_hat, int64_t* __restrict__ best_pos, double* __restrict__ first_hat) {
+    double* __restrict__ best_hat, int64_t* __restrict__ best_pos, double* __restrict__ first_hat,
+    const ScaleSeg* __restrict__ segs) {
   __shared__ double wtot[kSwThreads / 64][6];
   __shared__ double bc[kSwThreads / 64], bh[kSwThreads / 64];
   __shared__ int64_t bp[kSwThreads / 64];
+  if (segs) {
+    const ScaleSeg sg = segs[blockIdx.y];
+    if ((int64_t)blockIdx.x >= sg.nblk) return;
+    tags += sg.e_off;
+    sorted_xr += sg.e_off;
+    partials += kNumAcc * sg.blk_off;
+    best_cost += sg.blk_off;
+    best_hat += sg.blk_off;
+    best_pos += sg.blk_off;
+    ranges_sum_p += 2 * blockIdx.y;
+    first_hat += 2 * blockIdx.y;
+    m = sg.m;
+    nblk = sg.nblk;
+  }
   const int64_t base = (int64_t)blockIdx.x * kSwChunk + (int64_t)threadIdx.x * kSwPer;
   int tg[kSwPer];
   double xv[kSwPer], rv[kSwPer];
@@ -178,10 +271,10 @@ __global__ __launch_bounds__(kSwThreads) void tls_sweep_cost_kernel(
     rv[e] = 1;
     if (base + e < m) {
       const int tag = tags[base + e];
-      const int idx = (tag > 0 ? tag : -tag) - 1;
+      const double2 m2 = sorted_xr[base + e];  // (sequential: gathered by pass A)
       tg[e] = tag;
-      xv[e] = x[idx];
-      rv[e] = r[idx];
+      xv[e] = m2.x;
+      rv[e] = m2.y;
       const double eps = tag > 0 ? 1.0 : -1.0, w = 1.0 / (rv[e] * rv[e]);
       loc[0] += eps;
       loc[1] += eps * w;
@@ -264,9 +357,18 @@ __global__ __launch_bounds__(kSwThreads) void tls_sweep_cost_kernel(
 __global__ __launch_bounds__(1024) void tls_sweep_argmin_kernel(
     const double* __restrict__ best_cost, const double* __restrict__ best_hat,
     const int64_t* __restrict__ best_pos, int64_t nblk, const double* __restrict__ first_hat,
-    double* __restrict__ est) {
+    double* __restrict__ est, const ScaleSeg* __restrict__ segs, int64_t est_stride) {
   __shared__ double bc[16], bh[16];
   __shared__ int64_t bp[16];
+  if (segs) {  // batch: one workgroup per problem slot; est = the scale field of problem 0's record
+    const ScaleSeg sg = segs[blockIdx.x];
+    best_cost += sg.blk_off;
+    best_hat += sg.blk_off;
+    best_pos += sg.blk_off;
+    nblk = sg.nblk;
+    first_hat += 2 * blockIdx.x;
+    est = reinterpret_cast<double*>(reinterpret_cast<char*>(est) + (int64_t)sg.prob * est_stride);
+  }
   double c = INFINITY, h = NAN;
   int64_t p = INT64_MAX;
   for (int64_t b = threadIdx.x; b < nblk; b += 1024) {
@@ -394,18 +496,142 @@ hipError_t sort_and_sweep(hipStream_t s, const Work& w, const double* d_x, const
   hipError_t e = rocprim::radix_sort_pairs(w.sort_tmp, tmp, kb, vb, (size_t)m, 0, 64, s);
   if (e != hipSuccess) return e;
   const int32_t* tags = vb.current();
+  // the sorted values are dead (only the order matters): the two key buffers, back to back, take the
+  // measurements in sorted order (2 x 8 -> 16 bytes per endpoint)
+  double2* sorted_xr = reinterpret_cast<double2*>(w.keys[0]);
   hipLaunchKernelGGL(tls_sweep_totals_kernel, dim3((unsigned)w.nblk), dim3(kSwThreads), 0, s, tags,
-                     d_x, d_r, m, w.nblk, w.partials);
+                     d_x, d_r, m, w.nblk, w.partials, sorted_xr, static_cast<const ScaleSeg*>(nullptr));
   hipLaunchKernelGGL(tls_sweep_scan_kernel, dim3(1), dim3(1024), 0, s, w.partials, w.nblk,
-                     w.scalars);
+                     w.scalars, static_cast<const ScaleSeg*>(nullptr));
   hipLaunchKernelGGL(tls_sweep_cost_kernel, dim3((unsigned)w.nblk), dim3(kSwThreads), 0, s, tags,
-                     d_x, d_r, m, w.nblk, w.partials, w.scalars, w.best_cost, w.best_hat,
-                     w.best_pos, w.scalars + 1);
+                     sorted_xr, m, w.nblk, w.partials, w.scalars, w.best_cost, w.best_hat,
+                     w.best_pos, w.scalars + 1, static_cast<const ScaleSeg*>(nullptr));
   hipLaunchKernelGGL(tls_sweep_argmin_kernel, dim3(1), dim3(1024), 0, s, w.best_cost, w.best_hat,
-                     w.best_pos, w.nblk, w.scalars + 1, d_est);
+                     w.best_pos, w.nblk, w.scalars + 1, d_est, static_cast<const ScaleSeg*>(nullptr), (int64_t)0);
   return hipGetLastError();
 }
 }  // namespace
+
+// ---- a batch of problems through ONE value sort ----------------------------------------------------------
+// All the problems' endpoints are generated into one array (global tags), sorted by value in one device-wide
+// stable radix sort, then gathered back into per-problem segments by a second stable pass on the problem
+// slot (ceil(log2 count) bits): LSD order, so inside a segment the endpoints are sorted by value with ties in
+// insertion order -- the order the one-problem path produces.  The three-pass sweep then runs on all segments
+// at once (grid.y = slot), every segment cut into chunks from ITS OWN start, so that each problem's sums are
+// associated exactly as on the one-problem path: the batch is bit-identical to the problems solved one by one.
+void scale_batch_plan(ScaleSeg* segs, int count, int64_t* total_trims, int64_t* total_blocks, int* max_n,
+                      int64_t* max_nblk) {
+  int64_t trims = 0, blocks = 0, mb = 0;
+  int mn = 0;
+  for (int q = 0; q < count; ++q) {
+    ScaleSeg& g = segs[q];
+    const int64_t M = (int64_t)g.n * (g.n - 1) / 2;
+    g.trim_off = trims;
+    g.e_off = 2 * trims;
+    g.m = 2 * M;
+    g.nblk = (g.m + kSwChunk - 1) / kSwChunk;
+    g.blk_off = blocks;
+    trims += M;
+    blocks += g.nblk;
+    mn = g.n > mn ? g.n : mn;
+    mb = g.nblk > mb ? g.nblk : mb;
+  }
+  *total_trims = trims;
+  *total_blocks = blocks;
+  *max_n = mn;
+  *max_nblk = mb;
+}
+
+namespace {
+struct BatchWork {
+  double* keys[2];
+  int32_t* tags[2];
+  double *partials, *best_cost, *best_hat, *scalars;
+  int64_t* best_pos;
+  ScaleSeg* segs;
+  void* sort_tmp;
+  size_t sort_tmp_bytes;
+};
+size_t slot_sort_temp_bytes(int64_t m) {
+  size_t bytes = 0;
+  rocprim::double_buffer<uint32_t> k(nullptr, nullptr);
+  rocprim::double_buffer<int32_t> v(nullptr, nullptr);
+  (void)rocprim::radix_sort_pairs(nullptr, bytes, k, v, (size_t)m, 0, 8, (hipStream_t)0);
+  return bytes;
+}
+BatchWork carve_batch(char* ws, int64_t trims, int64_t blocks, int count, size_t* total) {
+  BatchWork w;
+  const int64_t m = 2 * trims;
+  char* p = ws;
+  auto take = [&](size_t bytes) {
+    char* r = p;
+    p += align_up(bytes);
+    return r;
+  };
+  for (int k = 0; k < 2; ++k) w.keys[k] = reinterpret_cast<double*>(take((size_t)m * 8));
+  for (int k = 0; k < 2; ++k) w.tags[k] = reinterpret_cast<int32_t*>(take((size_t)m * 4));
+  // (the slot keys of the second pass reuse the value keys' storage: the values are dead once sorted)
+  w.partials = reinterpret_cast<double*>(take((size_t)blocks * 8 * kNumAcc));
+  w.best_cost = reinterpret_cast<double*>(take((size_t)blocks * 8));
+  w.best_hat = reinterpret_cast<double*>(take((size_t)blocks * 8));
+  w.best_pos = reinterpret_cast<int64_t*>(take((size_t)blocks * 8));
+  w.scalars = reinterpret_cast<double*>(take((size_t)count * 16));
+  w.segs = reinterpret_cast<ScaleSeg*>(take((size_t)count * sizeof(ScaleSeg)));
+  const size_t a = sort_temp_bytes(m), b = slot_sort_temp_bytes(m);
+  w.sort_tmp_bytes = a > b ? a : b;
+  w.sort_tmp = take(w.sort_tmp_bytes);
+  *total = (size_t)(p - ws);
+  return w;
+}
+}  // namespace
+
+int64_t scale_batch_workspace_bytes(int64_t trims, int64_t blocks, int count) {
+  size_t total = 0;
+  (void)carve_batch(nullptr, trims, blocks, count, &total);
+  return (int64_t)total;
+}
+
+hipError_t launch_tls_scale_batch(hipStream_t s, const double* d_src, const double* d_dst, const ScaleSeg* h_segs,
+                                  int count, int64_t trims, int64_t blocks, int max_n, int64_t max_nblk, double beta,
+                                  double* d_raw, double* d_alpha, char* d_workspace, double* d_scale0,
+                                  int64_t scale_stride) {
+  size_t total = 0;
+  const BatchWork w = carve_batch(d_workspace, trims, blocks, count, &total);
+  const int64_t m = 2 * trims;
+  // (pageable source: the runtime stages it before returning)
+  hipError_t e = hipMemcpyAsync(w.segs, h_segs, (size_t)count * sizeof(ScaleSeg), hipMemcpyHostToDevice, s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(trim_endpoints_batch_kernel, dim3((unsigned)(max_n - 1), (unsigned)count), dim3(256), 0, s, d_src,
+                     d_dst, w.segs, beta, d_raw, d_alpha, w.keys[0], w.tags[0]);
+  rocprim::double_buffer<double> kb(w.keys[0], w.keys[1]);
+  rocprim::double_buffer<int32_t> vb(w.tags[0], w.tags[1]);
+  size_t tmp = w.sort_tmp_bytes;
+  e = rocprim::radix_sort_pairs(w.sort_tmp, tmp, kb, vb, (size_t)m, 0, 64, s);
+  if (e != hipSuccess) return e;
+  int bits = 1;
+  while ((1 << bits) < count) ++bits;
+  uint32_t* slot_in = reinterpret_cast<uint32_t*>(kb.alternate());  // the dead half of the value keys
+  uint32_t* slot_alt = reinterpret_cast<uint32_t*>(kb.current());
+  hipLaunchKernelGGL(scale_slot_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, vb.current(), m, w.segs,
+                     count, slot_in);
+  rocprim::double_buffer<uint32_t> sb(slot_in, slot_alt);
+  rocprim::double_buffer<int32_t> vb2(vb.current(), vb.alternate());
+  tmp = w.sort_tmp_bytes;
+  e = rocprim::radix_sort_pairs(w.sort_tmp, tmp, sb, vb2, (size_t)m, 0, (unsigned)bits, s);
+  if (e != hipSuccess) return e;
+  const int32_t* tags = vb2.current();
+  double2* sorted_xr = reinterpret_cast<double2*>(w.keys[0]);  // (both key buffers are dead by now)
+  hipLaunchKernelGGL(tls_sweep_totals_kernel, dim3((unsigned)max_nblk, (unsigned)count), dim3(kSwThreads), 0, s, tags,
+                     d_raw, static_cast<const double*>(nullptr), (int64_t)0, (int64_t)0, w.partials, sorted_xr, w.segs);
+  hipLaunchKernelGGL(tls_sweep_scan_kernel, dim3((unsigned)count), dim3(1024), 0, s, w.partials, (int64_t)0, w.scalars,
+                     w.segs);
+  hipLaunchKernelGGL(tls_sweep_cost_kernel, dim3((unsigned)max_nblk, (unsigned)count), dim3(kSwThreads), 0, s, tags,
+                     sorted_xr, (int64_t)0, (int64_t)0, w.partials, w.scalars, w.best_cost, w.best_hat, w.best_pos,
+                     w.scalars + 1, w.segs);
+  hipLaunchKernelGGL(tls_sweep_argmin_kernel, dim3((unsigned)count), dim3(1024), 0, s, w.best_cost, w.best_hat,
+                     w.best_pos, (int64_t)0, w.scalars + 1, d_scale0, w.segs, scale_stride);
+  return hipGetLastError();
+}
 
 // Scalar TLS of n measurements x[n] with ranges r[n] (device arrays) -> d_est (+ optional mask).
 hipError_t launch_scalar_tls_large(hipStream_t s, const double* d_x, const double* d_r, int64_t n,
@@ -422,7 +648,7 @@ hipError_t launch_scalar_tls_large(hipStream_t s, const double* d_x, const doubl
 }
 
 // TLS scale estimate of one problem's n points: TRIMs + endpoints fused, then sort + sweep.
-// d_raw / d_alpha: [M] doubles (kept: the sweep gathers from them).
+// d_raw: [M] (raw, alpha) pairs = 16 M bytes (the sweep gathers from it once); d_alpha: unused.
 hipError_t launch_tls_scale_large(hipStream_t s, const double* d_src, const double* d_dst, int n,
                                   double beta, double* d_raw, double* d_alpha, char* d_workspace,
                                   double* d_scale) {
@@ -430,7 +656,7 @@ hipError_t launch_tls_scale_large(hipStream_t s, const double* d_src, const doub
   const Work w = carve(d_workspace, M);
   hipLaunchKernelGGL(trim_endpoints_kernel, dim3(n - 1), dim3(256), 0, s, d_src, d_dst, n, beta,
                      d_raw, d_alpha, w.keys[0], w.tags[0]);
-  return sort_and_sweep(s, w, d_raw, d_alpha, M, d_scale);
+  return sort_and_sweep(s, w, d_raw, nullptr, M, d_scale);  // (raw, alpha) interleaved in d_raw
 }
 
 // Stage entry point solveForScale(v1, v2) on caller-supplied TIMs (registration.h:584, registration.cc

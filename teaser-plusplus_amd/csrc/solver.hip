@@ -160,7 +160,7 @@ struct teaser_hip_solver {
   // stand-alone stages
   DevBuf s_a, s_b, s_c, s_d, s_e;
   // correspondence front-end (FPFH, matcher)
-  DevBuf f_pts, f_counts, f_offsets, f_list, f_normals, f_spfh, f_out, f_meta, f_feat_a, f_feat_b, f_part_d,
+  DevBuf f_pts, f_counts, f_cursor, f_offsets, f_list, f_normals, f_spfh, f_out, f_meta, f_feat_a, f_feat_b, f_part_d,
       f_part_i, f_nn_a, f_nn_b;
 
   PinnedBuf pin_states;  // D2H landing zone of the problem states
@@ -350,6 +350,8 @@ constexpr int kSmallScaledN = 724;  // capability of the single-workgroup sort (
 constexpr int kSingleSmallN = 64;
 constexpr double kLargePathMs = 0.22;  // measured: 64 x n = 724 in 13.7 ms (profiles/r2j)
 constexpr int kMaxScaledN = 46341;
+constexpr int kMidScaledN = 4096;                       // batched radix-sort path: 2 M < 2^24 endpoints per problem
+constexpr int64_t kMidChunkTrims = (int64_t)1 << 27;    // TRIMs per shared sort (2^28 endpoints, ~9 GB of scratch)
 
 // measured model of the single-workgroup path: bitonic sort of P2 >= 2 M endpoints, L (L + 1) / 2 passes
 static double small_path_ms(int n) {
@@ -375,7 +377,7 @@ int32_t scale_stage(teaser_hip_solver* h, int p) {
   }
   const double beta = 2 * h->params.noise_bound * std::sqrt(h->params.cbar2);
   double* d_scale = &(h->d_state.as<ProbState>()[p].scale);
-  HIPCHK(h, h->s_a.ensure((size_t)M * 8));
+  HIPCHK(h, h->s_a.ensure((size_t)M * 16));  // large path: (raw, alpha) interleaved; small path: raw
   HIPCHK(h, h->s_b.ensure((size_t)M * 8));
   if (n > kSingleSmallN) {
     HIPCHK(h, h->s_c.ensure((size_t)scalar_tls_large_workspace_bytes(M)));
@@ -457,11 +459,52 @@ int32_t scale_stage_batch(teaser_hip_solver* h, int batch) {
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(s));  // (sel / off are stack vectors; the next chunk reuses the scratch)
   }
+  std::vector<uint8_t> done((size_t)batch, 0);
+  if (small.size() >= 2)
+    for (size_t k = 0; k < at; ++k) done[(size_t)small[k]] = 1;
+  // The remaining mid-size problems (up to kMidScaledN points: a problem on its own is a string of launch-bound
+  // kernels around a sort of < 2^24 endpoints) share ONE value sort + one gathering pass + one sweep per chunk of
+  // at most kMidChunkTrims TRIMs (kernels_scale.hip); results are bit-identical to the one-problem path.
+  std::vector<ScaleSeg> mid;
+  static const char* evm = getenv("TEASER_SCALE_MID_BATCH");  // diagnostics: 0 = one problem at a time
+  const bool mid_on = !(evm && atoi(evm) == 0) && !(ev && atoi(ev) == 0);
+  for (int b = 0; b < batch && mid_on; ++b) {
+    const ProbDesc& d = h->descs[(size_t)b];
+    if (done[(size_t)b] || d.n < 2 || d.n > kMidScaledN) continue;
+    ScaleSeg g{};
+    g.prob = b;
+    g.n = d.n;
+    g.pt_off = d.pt_off;
+    mid.push_back(g);
+  }
+  size_t mat = 0;
+  while (mid.size() - mat >= 2) {
+    size_t cnt = 0;
+    int64_t trims = 0;
+    while (mat + cnt < mid.size()) {
+      const int64_t M = (int64_t)mid[mat + cnt].n * (mid[mat + cnt].n - 1) / 2;
+      if (cnt > 0 && trims + M > kMidChunkTrims) break;
+      trims += M;
+      ++cnt;
+    }
+    if (cnt < 2) {  // (a problem that fills a chunk on its own takes the one-problem path)
+      ++mat;
+      continue;
+    }
+    int64_t blocks = 0, max_nblk = 0;
+    int max_n = 0;
+    scale_batch_plan(mid.data() + mat, (int)cnt, &trims, &blocks, &max_n, &max_nblk);
+    HIPCHK(h, h->s_a.ensure((size_t)trims * 16));  // (raw, alpha) interleaved
+    HIPCHK(h, h->s_c.ensure((size_t)scale_batch_workspace_bytes(trims, blocks, (int)cnt)));
+    HIPCHK(h, launch_tls_scale_batch(s, h->cur_src, h->cur_dst, mid.data() + mat, (int)cnt, trims, blocks, max_n,
+                                     max_nblk, beta, h->s_a.as<double>(), h->s_b.as<double>(), h->s_c.as<char>(),
+                                     &(h->d_state.as<ProbState>()[0].scale), (int64_t)sizeof(ProbState)));
+    for (size_t k = 0; k < cnt; ++k) done[(size_t)mid[mat + k].prob] = 1;
+    mat += cnt;
+    if (mid.size() - mat >= 1) HIPCHK(h, hipStreamSynchronize(s));  // (the next chunk reuses the scratch)
+  }
   for (int b = 0; b < batch; ++b) {
-    const int n = h->descs[(size_t)b].n;
-    const bool done = n >= 2 && n <= kSmallScaledN && small.size() >= 2 &&
-                      std::find(small.begin(), small.begin() + (std::ptrdiff_t)at, b) != small.begin() + (std::ptrdiff_t)at;
-    if (done) continue;
+    if (done[(size_t)b]) continue;
     const int32_t rc = scale_stage(h, b);
     if (rc != TEASER_HIP_OK) return rc;
   }
@@ -1134,7 +1177,7 @@ void release_handle_resources(teaser_hip_solver* h) {
                     &h->x_src, &h->x_dst, &h->x_bitmap, &h->x_desc, &h->x_state, &h->x_ctrl,
                     &h->x_clique, &h->x_arena, &h->x_probs, &h->x_probs2, &h->x_keys, &h->x_xbits, &h->x_tasks, &h->c_sel, &h->c_colour, &h->c_tent, &h->c_xlist, &h->c_list_a, &h->c_list_b,
                     &h->c_counts, &h->c_bits, &h->c_class,
-                    &h->s_a, &h->s_b, &h->s_c, &h->s_d, &h->s_e, &h->f_pts, &h->f_counts, &h->f_offsets, &h->f_list,
+                    &h->s_a, &h->s_b, &h->s_c, &h->s_d, &h->s_e, &h->f_pts, &h->f_counts, &h->f_cursor, &h->f_offsets, &h->f_list,
                     &h->f_normals, &h->f_spfh, &h->f_out, &h->f_meta, &h->f_feat_a, &h->f_feat_b, &h->f_part_d,
                     &h->f_part_i, &h->f_nn_a, &h->f_nn_b};
   for (DevBuf* b : bufs) b->release();
@@ -1976,6 +2019,7 @@ int32_t feat_neighbours(teaser_hip_solver* h, int n, double radius) {
   hipStream_t s = h->stream;
   const float r2 = (float)(radius * radius);  // pcl::KdTreeFLANN::radiusSearch: static_cast<float>(radius * radius)
   HIPCHK(h, h->f_counts.ensure((size_t)n * 4));
+  HIPCHK(h, h->f_cursor.ensure((size_t)n * 4));
   HIPCHK(h, h->f_offsets.ensure((size_t)(n + 1) * 8));
   HIPCHK(h, h->f_meta.ensure(16));
   launch_feat_radius_count(s, h->f_pts.as<float>(), n, r2, h->f_counts.as<int32_t>());
@@ -1990,7 +2034,7 @@ int32_t feat_neighbours(teaser_hip_solver* h, int n, double radius) {
     return TEASER_HIP_ERR_UNSUPPORTED;
   }
   HIPCHK(h, h->f_list.ensure((size_t)std::max<int64_t>(meta[0], 1) * (size_t)feat_nbr_bytes()));
-  launch_feat_radius_fill_sort(s, h->f_pts.as<float>(), n, r2, h->f_counts.as<int32_t>(),
+  launch_feat_radius_fill_sort(s, h->f_pts.as<float>(), n, r2, h->f_counts.as<int32_t>(), h->f_cursor.as<int32_t>(),
                                h->f_offsets.as<int64_t>(), h->f_list.p);
   HIPCHK(h, hipGetLastError());
   return TEASER_HIP_OK;

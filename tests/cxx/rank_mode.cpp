@@ -1,0 +1,168 @@
+// rank_mode.cpp -- the C ABI's rank mode as a compiled multi-process caller uses it (teaser_hip.h, "Rank mode"):
+// the parent makes the RCCL id, forks WORLD processes (one per GPU; WORLD = argv[1], default the device count),
+// hands each the id through a pipe; every rank solves ITS shard of TOTAL synthetic problems with
+// teaser_hip_solve_batch and all-gathers the solution records; every rank then checks the gathered array against
+// the problems' ground truth and rank 0 against a single-process solve of all problems (bit-identical records).
+// exit codes: 0 ok, 77 no GPU, 1 failure.
+#include <sys/wait.h>
+#include <unistd.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "teaser_hip.h"
+
+namespace {
+constexpr int kTotal = 11;  // (ragged over 2, 3, 4 ranks)
+constexpr int kN = 300;
+
+struct Problem {
+  std::vector<double> src, dst;
+};
+
+// deterministic toy problems: a rotation about z + translation, 40 % of the points replaced by junk
+Problem make_problem(int index) {
+  Problem p;
+  p.src.resize(3 * kN);
+  p.dst.resize(3 * kN);
+  unsigned long long s = 0x9E3779B97F4A7C15ull * (unsigned long long)(index + 1);
+  auto rnd = [&]() {
+    s ^= s << 13;
+    s ^= s >> 7;
+    s ^= s << 17;
+    return (double)(s >> 11) / 9007199254740992.0;
+  };
+  const double th = 0.3 + 0.1 * index, c = std::cos(th), sn = std::sin(th);
+  for (int i = 0; i < kN; ++i) {
+    const double x = rnd() - 0.5, y = rnd() - 0.5, z = rnd() - 0.5;
+    p.src[3 * i] = x, p.src[3 * i + 1] = y, p.src[3 * i + 2] = z;
+    if (i % 5 < 3) {
+      p.dst[3 * i] = c * x - sn * y + 0.1 * index;
+      p.dst[3 * i + 1] = sn * x + c * y - 0.2;
+      p.dst[3 * i + 2] = z + 0.05;
+    } else {
+      p.dst[3 * i] = 4 * rnd() - 2, p.dst[3 * i + 1] = 4 * rnd() - 2, p.dst[3 * i + 2] = 4 * rnd() - 2;
+    }
+  }
+  return p;
+}
+
+int solve_range(teaser_hip_solver* h, int first, int last, std::vector<teaser_solution_c>* out) {
+  std::vector<Problem> probs;
+  for (int b = first; b < last; ++b) probs.push_back(make_problem(b));
+  std::vector<const double*> src, dst;
+  std::vector<int32_t> n;
+  for (auto& p : probs) {
+    src.push_back(p.src.data());
+    dst.push_back(p.dst.data());
+    n.push_back(kN);
+  }
+  out->resize((size_t)(last - first));
+  if (last == first) return 0;
+  return teaser_hip_solve_batch(h, src.data(), dst.data(), n.data(), last - first, out->data());
+}
+
+int run_rank(int rank, int world, int device, const uint8_t* id) {
+  teaser_params_c params;
+  teaser_hip_params_default(&params);
+  params.noise_bound = 0.01;
+  params.estimate_scaling = 0;
+  teaser_hip_solver* h = nullptr;
+  if (teaser_hip_solver_create(&params, device, &h) != TEASER_HIP_OK) return 1;
+  teaser_hip_comm* c = nullptr;
+  int rc = teaser_hip_comm_create(id, rank, world, device, &c);
+  if (rc != TEASER_HIP_OK) {
+    std::fprintf(stderr, "rank %d: comm_create -> %d\n", rank, rc);
+    return 1;
+  }
+  int64_t first = 0, last = 0;
+  teaser_hip_comm_shard(kTotal, rank, world, &first, &last);
+  std::vector<teaser_solution_c> local, all((size_t)kTotal);
+  if (solve_range(h, (int)first, (int)last, &local) != TEASER_HIP_OK) return 1;
+  // a wrong record count is refused before any collective starts
+  if (teaser_hip_comm_gather_solutions(c, local.data(), last - first + 1, kTotal, all.data()) != TEASER_HIP_ERR_BAD_ARG) return 1;
+  rc = teaser_hip_comm_gather_solutions(c, local.data(), last - first, kTotal, all.data());
+  if (rc != TEASER_HIP_OK) {
+    std::fprintf(stderr, "rank %d: gather -> %d (%s)\n", rank, rc, teaser_hip_comm_last_error(c));
+    return 1;
+  }
+  for (int b = 0; b < kTotal; ++b) {
+    const double th = 0.3 + 0.1 * b;
+    const teaser_solution_c& o = all[(size_t)b];
+    if (!o.valid || o.n != kN || std::fabs(o.rotation[0] - std::cos(th)) > 1e-2 ||
+        std::fabs(o.rotation[3] - std::sin(th)) > 1e-2 || std::fabs(o.translation[0] - 0.1 * b) > 2e-2) {
+      std::fprintf(stderr, "rank %d: record %d is wrong\n", rank, b);
+      return 1;
+    }
+  }
+  if (rank == 0) {  // the sharded job == the single-process job, record for record
+    std::vector<teaser_solution_c> ref;
+    if (solve_range(h, 0, kTotal, &ref) != TEASER_HIP_OK) return 1;
+    for (int b = 0; b < kTotal; ++b)
+      if (std::memcmp(&ref[(size_t)b], &all[(size_t)b], sizeof(teaser_solution_c)) != 0) {
+        std::fprintf(stderr, "record %d differs from the single-process solve\n", b);
+        return 1;
+      }
+    std::printf("rank mode: %d ranks, %d problems, records identical to the single-process solve\n", world, kTotal);
+  }
+  teaser_hip_comm_destroy(c);
+  teaser_hip_solver_destroy(h);
+  return 0;
+}
+}  // namespace
+
+int main(int argc, char** argv) {
+  int64_t f = 0, l = 0;
+  // the partition itself (no device needed)
+  if (teaser_hip_comm_shard(11, 0, 4, &f, &l) != TEASER_HIP_OK || f != 0 || l != 3) return 1;
+  if (teaser_hip_comm_shard(11, 3, 4, &f, &l) != TEASER_HIP_OK || f != 9 || l != 11) return 1;
+  if (teaser_hip_comm_shard(2, 3, 4, &f, &l) != TEASER_HIP_OK || f != l) return 1;
+  if (teaser_hip_comm_shard(5, 4, 4, &f, &l) != TEASER_HIP_ERR_BAD_ARG) return 1;
+  // Everything that touches the HIP runtime runs in children: the parent must stay clean to fork the ranks.
+  // The first child counts the devices and makes the RCCL id.
+  struct Hello {
+    int32_t devices;
+    uint8_t id[TEASER_HIP_COMM_ID_BYTES];
+  } hello;
+  int fd[2];
+  if (pipe(fd) != 0) return 1;
+  pid_t maker = fork();
+  if (maker == 0) {
+    Hello mine;
+    std::memset(&mine, 0, sizeof(mine));
+    mine.devices = teaser_hip_device_count();
+    if (mine.devices <= 0) {
+      teaser_hip_comm* c = nullptr;
+      _exit(teaser_hip_comm_create(mine.id, 0, 1, -1, &c) == TEASER_HIP_ERR_NO_DEVICE ? 77 : 1);  // loud, no CPU path
+    }
+    const int rc = teaser_hip_comm_unique_id(mine.id);
+    if (rc == TEASER_HIP_OK && write(fd[1], &mine, sizeof(mine)) != (ssize_t)sizeof(mine)) _exit(1);
+    _exit(rc == TEASER_HIP_OK ? 0 : 1);
+  }
+  int st = 0;
+  waitpid(maker, &st, 0);
+  if (WIFEXITED(st) && WEXITSTATUS(st) == 77) return 77;
+  if (!WIFEXITED(st) || WEXITSTATUS(st) != 0 || read(fd[0], &hello, sizeof(hello)) != (ssize_t)sizeof(hello)) return 1;
+  const int devices = hello.devices;
+  const uint8_t* id = hello.id;
+  const int world = argc > 1 ? std::atoi(argv[1]) : devices;
+  if (world < 1 || world > devices) {  // (RCCL refuses two ranks on one device)
+    std::fprintf(stderr, "world must be 1 .. %d\n", devices);
+    return 1;
+  }
+  std::vector<pid_t> kids;
+  for (int r = 0; r < world; ++r) {
+    pid_t k = fork();
+    if (k == 0) _exit(run_rank(r, world, r, id));
+    kids.push_back(k);
+  }
+  int bad = 0;
+  for (pid_t k : kids) {
+    waitpid(k, &st, 0);
+    bad |= !WIFEXITED(st) || WEXITSTATUS(st) != 0;
+  }
+  return bad ? 1 : 0;
+}

@@ -284,6 +284,34 @@ def test_estimate_scaling_batch_small_problems():
         assert batch[b][4] == ref["max_clique"].tolist() or not ref["clique_unique"]
 
 
+def test_estimate_scaling_batch_mid_size_problems():
+    """estimate_scaling = true, problems of 725 .. 4096 points: ONE value sort for the whole batch, a stable
+    gathering pass by problem, one sweep over all segments (kernels_scale.hip).  Bit-identical to the problems
+    solved one at a time (the sweep chunks are cut from each segment's own start); one against the oracle."""
+    nb = 0.01
+    sizes = [800, 1500, 2000, 900, 1000, 3000, 725]
+    probs = []
+    for i, n in enumerate(sizes):
+        q = tp.synth_problem(700 + i, n, 0.6, nb)
+        probs.append((q["src"], q["dst"] * (0.5 + 0.3 * i)))
+    p = bench_params(estimate_scaling=True, noise_bound=nb * 2.5)
+    s = make_solver(**p)
+    sols = s.solve_batch([q[0] for q in probs], [q[1] for q in probs])
+    batch = [(bool(o.valid), o.scale, o.rotation.copy(), o.translation.copy(), s.getInlierMaxClique(b))
+             for b, o in enumerate(sols)]
+    one = make_solver(**p)
+    for b, q in enumerate(probs):
+        o = one.solve(q[0], q[1])
+        assert bool(o.valid) == batch[b][0]
+        assert o.scale == batch[b][1], sizes[b]
+        assert one.getInlierMaxClique() == batch[b][4], sizes[b]
+        if o.valid:
+            assert (o.rotation == batch[b][2]).all() and (o.translation == batch[b][3]).all()
+    ref = oracle.solve(probs[0][0], probs[0][1], **oracle_params(p))
+    assert abs(batch[0][1] - ref["scale"]) <= 1e-9 * max(1.0, abs(ref["scale"]))
+    assert batch[0][4] == ref["max_clique"].tolist() or not ref["clique_unique"]
+
+
 def test_solve_estimate_scaling_full_size_vs_oracle_fixture():
     """Full-size estimate_scaling = true (N = 10 000: M = 5e7 TRIMs, 1e8 endpoints through the
     radix sort) against the oracle's result committed in tests/golden/scale_golden.json (made by
