@@ -218,7 +218,9 @@ TEASER_HIP_API int32_t teaser_hip_multi_device_count(const teaser_hip_multi* mh)
  *   comm_shard      rank r of `world` owns problems [first, last): contiguous, balanced (the first total % world
  *                   ranks own one more)
  *   comm_unique_id  rank 0 makes the RCCL id (TEASER_HIP_COMM_ID_BYTES bytes) and hands it to the other ranks by
- *                   whatever the job already has (MPI_Bcast, a file, a socket)
+ *                   whatever the job already has (MPI_Bcast, a file, a socket).  The calling process hosts RCCL's
+ *                   bootstrap root: it must stay alive until every rank's comm_create has returned
+ *   comm_last_error(NULL) = why the last failed comm_create of this process failed
  *   comm_create     collective over all ranks; device < 0: the current device
  *   comm_gather_solutions  collective: `local` = this rank's records in shard order (n_local = last - first),
  *                   `all` [total] receives every rank's records in problem order, the same on every rank
@@ -314,6 +316,12 @@ typedef struct teaser_certification_c {
   double best_suboptimality;   /* CertificationResult::best_suboptimality */
 } teaser_certification_c;
 TEASER_HIP_API int32_t teaser_hip_certifier_params_default(teaser_certifier_params_c* p);
+/* The certifier's cold start: the first rocBLAS handle and rocSOLVER call of a process load those libraries'
+ * gfx950 code objects (about 110 s on ROCm 7.2, host-side).  certifier_warmup starts ONE background thread per
+ * process that does this (and a small eigendecomposition + GEMM) and returns at once; teaser_hip_certify joins it.
+ * Call it when the application starts (or right after creating the solver) to take the load off the first
+ * certify().  device < 0: the current device. */
+TEASER_HIP_API int32_t teaser_hip_certifier_warmup(int32_t device);
 TEASER_HIP_API int32_t teaser_hip_certify(teaser_hip_solver* h, const teaser_certifier_params_c* p, const double* R,
                            const double* src, const double* dst, const double* theta, int32_t n,
                            teaser_certification_c* out, double* traj, int32_t traj_cap);

@@ -124,7 +124,7 @@ EXPORTED_SYMBOLS = [
     "teaser_hip_set_pipeline_depth", "teaser_hip_multi_create", "teaser_hip_multi_destroy",
     "teaser_hip_multi_solve_batch", "teaser_hip_multi_route", "teaser_hip_multi_device_count",
     "teaser_hip_solve_for_scale", "teaser_hip_compute_fpfh", "teaser_hip_match_features",
-    "teaser_hip_certifier_params_default", "teaser_hip_certify",
+    "teaser_hip_certifier_params_default", "teaser_hip_certify", "teaser_hip_certifier_warmup",
     "teaser_hip_comm_shard", "teaser_hip_comm_unique_id", "teaser_hip_comm_create", "teaser_hip_comm_destroy",
     "teaser_hip_comm_gather_solutions", "teaser_hip_comm_last_error",
 ]
@@ -731,6 +731,14 @@ class CertificationResult:
                 % (self.is_optimal, self.best_suboptimality))
 
 
+def certifier_warmup(device=-1):
+    """Start loading rocBLAS / rocSOLVER (the certifier's ~110 s cold start) in a background thread; returns at once
+    (teaser_hip_certifier_warmup).  DRSCertifier.certify() waits for it."""
+    rc = lib().teaser_hip_certifier_warmup(C.c_int32(device))
+    if rc != 0:
+        raise RuntimeError("teaser_hip_certifier_warmup: %s" % STATUS_NAMES.get(rc, rc))
+
+
 class DRSCertifier:
     """teaser::DRSCertifier (reference teaser/include/teaser/certification.h:53-239,
     teaser/src/certification.cc:22-190) on the GPU: Douglas-Rachford splitting on the (4 + 4N)-square dual
@@ -835,4 +843,4 @@ from . import batched  # noqa: E402,F401  (sharding + record gather for the mult
 
 __all__ = ["batched", "FPFHEstimation", "Matcher", "MultiDeviceSolver", "RobustRegistrationSolver", "RegistrationSolution", "RotationEstimationAlgorithm",
            "InlierSelectionMode", "InlierGraphFormulation", "TeaserHipError", "synth_problem",
-           "device_count", "build", "lib", "LIB_PATH", "EXPORTED_SYMBOLS"]
+           "device_count", "build", "lib", "LIB_PATH", "EXPORTED_SYMBOLS", "certifier_warmup"]

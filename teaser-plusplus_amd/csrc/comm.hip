@@ -55,6 +55,11 @@ struct teaser_hip_comm {
   std::string err;
 };
 
+namespace {
+std::mutex g_create_mu;
+std::string g_create_err;  // why the last teaser_hip_comm_create of this process failed
+}  // namespace
+
 static_assert(sizeof(ncclUniqueId) == TEASER_HIP_COMM_ID_BYTES, "teaser_hip.h: TEASER_HIP_COMM_ID_BYTES");
 
 extern "C" {
@@ -95,8 +100,14 @@ int32_t teaser_hip_comm_create(const uint8_t* id, int32_t rank, int32_t world, i
   c->device = device;
   ncclUniqueId u;
   std::memcpy(&u, id, sizeof(u));
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-      r.comm_init_rank(&c->comm, world, u, rank) != ncclSuccess) {
+  const hipError_t he = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  const ncclResult_t nr = he == hipSuccess ? r.comm_init_rank(&c->comm, world, u, rank) : ncclSuccess;
+  if (he != hipSuccess || nr != ncclSuccess) {
+    {
+      std::lock_guard<std::mutex> lk(g_create_mu);
+      g_create_err = he != hipSuccess ? std::string("hipStreamCreate: ") + hipGetErrorString(he)
+                                      : std::string("ncclCommInitRank: ") + r.error_string(nr);
+    }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return TEASER_HIP_ERR_HIP;
@@ -116,7 +127,13 @@ int32_t teaser_hip_comm_destroy(teaser_hip_comm* c) {
   return TEASER_HIP_OK;
 }
 
-const char* teaser_hip_comm_last_error(const teaser_hip_comm* c) { return c ? c->err.c_str() : ""; }
+const char* teaser_hip_comm_last_error(const teaser_hip_comm* c) {
+  if (c) return c->err.c_str();
+  std::lock_guard<std::mutex> lk(g_create_mu);  // NULL: the last failed teaser_hip_comm_create of the process
+  static thread_local std::string copy;
+  copy = g_create_err;
+  return copy.c_str();
+}
 
 int32_t teaser_hip_comm_gather_solutions(teaser_hip_comm* c, const teaser_solution_c* local, int64_t n_local,
                                          int64_t total, teaser_solution_c* all) {

@@ -172,6 +172,8 @@ void launch_exact_finish(hipStream_t s, const ProbDesc* d_desc, const ExactProb*
                          const int32_t* d_order_pool, const int32_t* d_clique_pool, int32_t* d_clique,
                          ProbState* d_state);
 // DRS certifier (kernels_certify.hip): 0, or -1 rocSOLVER / rocBLAS not loadable, -2 HIP error, -3 library call failed
+// starts (once per process) a background thread that loads rocBLAS / rocSOLVER and their gfx950 code objects
+void certifier_warmup_async(int device);
 int certify_on_device(hipStream_t s, const double* R, const double* src, const double* dst, const double* theta, int N,
                       double noise_bound, double cbar2, double sub_optimality, double max_iterations,
                       double gamma_tau, int* is_optimal, double* best_suboptimality, std::vector<double>* traj);

@@ -18,13 +18,21 @@
 //     on column-major FP64 matrices that stay in HBM for the whole run (7 n^2 doubles; n = 4004 at N = 1000:
 //     0.9 GB).
 // One host sync per iteration (the gap decides termination, as in the reference).
+#include <dirent.h>
 #include <dlfcn.h>
+#include <link.h>
 
 #include <rocblas/rocblas.h>
 #include <rocsolver/rocsolver.h>
 
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <future>
+#include <mutex>
+#include <string>
 #include <vector>
 
 #include "cert_setup.h"
@@ -244,6 +252,106 @@ __global__ void cert_update_kernel(const double* __restrict__ Maff, const double
 
 }  // namespace
 
+// ---- cold start ---------------------------------------------------------------------------------------------
+// The first rocBLAS handle + the first rocSOLVER call of a process took about 110 s on a fresh box (profiles/r2l).
+// librocsolver.so alone is 931 MB (every gfx target's code objects in one file) and the image pages its files in
+// on demand: the load is page-fault-driven I/O, 4 KB at a time, under the dynamic loader's lock -- which also
+// stalls every other dlopen / import of the process meanwhile.  certifier_warmup_async() takes it off the caller's
+// path: ONE background thread per process (1) READS the library files sequentially (plain read(): fast streaming
+// I/O into the page cache, no lock held), (2) then opens them, creates a handle and runs a small dsyevd (with and
+// without vectors) + dgemm so that the code objects are registered.  certify_on_device() joins it first.
+namespace {
+std::once_flag g_warm_once;
+std::shared_future<void> g_warm_done;
+
+void read_through(const std::string& path) {  // pull a file into the page cache
+  FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f) return;
+  std::vector<char> buf((size_t)8 << 20);
+  while (std::fread(buf.data(), 1, buf.size(), f) == buf.size()) {
+  }
+  std::fclose(f);
+}
+// Where the ROCm libraries live: next to the HIP runtime this process already runs on.
+std::string rocm_lib_dir() {
+  Dl_info info;
+  if (dladdr(reinterpret_cast<void*>(&hipDeviceSynchronize), &info) == 0 || !info.dli_fname) return "/opt/rocm/lib";
+  const std::string path(info.dli_fname);
+  const size_t cut = path.find_last_of('/');
+  return cut == std::string::npos ? std::string("/opt/rocm/lib") : path.substr(0, cut);
+}
+// BEFORE dlopen: measured on a fresh box, dlopen(librocsolver) alone took 117 s (relocation processing faults the
+// 931 MB file in 4 KB at a time, holding the loader lock -- every other dlopen / import of the process waits), a
+// sequential read of the same file 11 s.
+void prefetch_library_files() {
+  const std::string dir = rocm_lib_dir();
+  read_through(dir + "/librocsolver.so.0");
+  read_through(dir + "/librocblas.so.5");
+  // Tensile's per-architecture code objects next to librocblas: <dir>/rocblas/library/*gfx950*
+  const std::string tdir = dir + "/rocblas/library";
+  if (DIR* d = opendir(tdir.c_str())) {
+    while (struct dirent* e = readdir(d))
+      if (std::strstr(e->d_name, "gfx950")) read_through(tdir + "/" + e->d_name);
+    closedir(d);
+  }
+}
+void warmup_body(int device) {
+  const char* dbg = getenv("TEASER_CERT_DEBUG");  // diagnostics: a file the phase times are appended to
+  const auto t0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (!dbg) return;
+    if (FILE* f = std::fopen(dbg, "a")) {
+      std::fprintf(f, "[teaser_hip certifier warm-up] %s at %.2f s\n", what,
+                   std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+      std::fclose(f);
+    }
+  };
+  prefetch_library_files();
+  lap("library files read");
+  CertLibs& L = cert_libs();
+  if (!L.ok) return;
+  lap("libraries opened");
+  if (hipSetDevice(device) != hipSuccess) return;
+  const int n = 132;  // (N = 32: past the libraries' small-size special cases)
+  hipStream_t s = nullptr;
+  rocblas_handle hb = nullptr;
+  double *dA = nullptr, *dB = nullptr, *dC = nullptr, *dD = nullptr, *dE = nullptr;
+  rocblas_int* dInfo = nullptr;
+  std::vector<double> a((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i) {
+    a[(size_t)i * n + i] = 2.0 + i;
+    if (i + 1 < n) a[(size_t)i * n + i + 1] = a[(size_t)(i + 1) * n + i] = -1.0;
+  }
+  const double one = 1.0, zero = 0.0;
+  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess && hipMalloc(&dA, a.size() * 8) == hipSuccess &&
+      hipMalloc(&dB, a.size() * 8) == hipSuccess && hipMalloc(&dC, a.size() * 8) == hipSuccess &&
+      hipMalloc(&dD, (size_t)n * 8) == hipSuccess && hipMalloc(&dE, (size_t)n * 8) == hipSuccess &&
+      hipMalloc(&dInfo, sizeof(rocblas_int)) == hipSuccess && L.create_handle(&hb) == rocblas_status_success &&
+      L.set_stream(hb, s) == rocblas_status_success) {
+    for (int pass = 0; pass < 2; ++pass) {
+      (void)hipMemcpyAsync(dA, a.data(), a.size() * 8, hipMemcpyHostToDevice, s);
+      (void)L.dsyevd(hb, pass == 0 ? rocblas_evect_original : rocblas_evect_none, rocblas_fill_upper, n, dA, n, dD, dE,
+                     dInfo);
+      if (pass == 0)
+        (void)L.dgemm(hb, rocblas_operation_none, rocblas_operation_transpose, n, n, n, &one, dA, n, dA, n, &zero, dC, n);
+    }
+    (void)hipStreamSynchronize(s);
+  }
+  lap("handle + dsyevd + dgemm done");
+  if (hb) (void)L.destroy_handle(hb);
+  for (void* p : {(void*)dA, (void*)dB, (void*)dC, (void*)dD, (void*)dE, (void*)dInfo})
+    if (p) (void)hipFree(p);
+  if (s) (void)hipStreamDestroy(s);
+}
+}  // namespace
+
+void certifier_warmup_async(int device) {
+  std::call_once(g_warm_once, [device] { g_warm_done = std::async(std::launch::async, warmup_body, device).share(); });
+}
+static void certifier_warmup_join() {
+  if (g_warm_done.valid()) g_warm_done.wait();
+}
+
 // src / dst: N points, xyz interleaved (= the 3 x N column-major matrices of the reference); R row-major.
 // Returns 0, or -1 (rocSOLVER / rocBLAS not loadable), -2 (HIP error), -3 (library call failed).
 int certify_on_device(hipStream_t s, const double* R, const double* src, const double* dst, const double* theta, int N,
@@ -253,6 +361,7 @@ int certify_on_device(hipStream_t s, const double* R, const double* src, const d
   *is_optimal = 0;
   *best_suboptimality = INFINITY;
   if (N < 1) return 0;
+  certifier_warmup_join();
   CertLibs& L = cert_libs();
   if (!L.ok) return -1;
   const int n = 4 + 4 * N;

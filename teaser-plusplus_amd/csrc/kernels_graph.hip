@@ -984,10 +984,15 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma_kernel(
 // v_mfma_f32_32x32x16_bf16, w over 13 slots (two-piece operands: w is multiplied by nothing and only needs
 // ~1e-4 relative accuracy) = one more -- four MFMAs per 32 x 32 tile as before.  The points are centred AND scaled
 // per problem by g in (1, sqrt 2] such that 4 (g beta)^2 is a power of two: the factor of w is then an exponent
-// shift of the column operands, exact.  Per pair the VALU does d = fma(u, u, w), one v_alignbit for sign(d) (the
-// edge bit), e = fma(w, K2, |d|) and running min3(e) / max3(w); a tile whose min e <= K0 (a pair inside the error
-// band) or max w >= wtau (a short pair: A <= beta^2) -- about one tile in five -- recomputes its 16 values to
-// find the pairs for the FP64 fix-up list.
+// shift of the column operands, exact.  Per accumulator PAIR the VALU issues eight instructions, no branch:
+// d = fma(u, u, w), -band = fma(w, K2, -K0) (w <= 0), the two band edges d -+ band, and one v_alignbit per edge
+// and value collecting sign(d + band) (the edge bit: certainly an edge) and sign(d - band); the two signs differ
+// <=> the pair lies inside the error band.  K0 is raised to >= 4 beta^4 (mfma2_consts), which puts every short
+// pair (S <= beta: A, B <= beta^2, |d| <= 4 beta^4) inside the band by construction, so the `S <= beta` branch
+// needs no test of its own.  A lane's in-band masks (one 32-bit word per column half tile) are parked in LDS
+// (lds_xb) and harvested BEHIND the column loop, wave-parallel, into the wave's own region of the fix-up worklist
+// (count word + 31 items, plain stores; only an overflowing wave touches the atomic segment list): a returning
+// atomic plus dependent stores at the end of every wave was what bounded the kernel (1.20 -> 0.93 ms).
 //
 // Error budget in the scaled system (u = 2^-24, R = max |scaled centred point|, beta = g beta_0):
 //   eps_u = kEpsU2 u R^2 bounds |u~ - u*|: f32 rounding of the scaled centred coordinates 16 u R^2 (8 per cloud),
@@ -1001,8 +1006,9 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma_kernel(
 //     |d~| > K2 |w~| + K0,  K2 = eta / (1 - 2 eta - 2u),  K0 = (K0' + G) / (1 - 2 eta - 2u) + 2 K2 kappa eps_A
 //     (G: the gap between the reference's rounded double predicate and the exact one, as in the first
 //     formulation), both x 1.001 and rounded outwards;
-//   short pairs: S <= beta implies A <= beta^2 and u <= 0, flagged by w~ >= wtau = -kappa (beta^2 (1 + 8u) +
-//     1.1 eps_A) and u~ <= utau = 1.1 eps_u; they go to the fix-up individually.
+//   short pairs: S <= beta implies A, B <= beta^2, hence u* in [-2 beta^2, 0], w* in [-4 beta^4, 0] and |d*| <= 4 beta^4;
+//     K0 >= short_d (mfma2_consts: that bound plus the error terms) keeps |d~| <= band for all of them: they go to
+//     the fix-up individually, where the reference expression decides.
 // eta > 1/8, beta > R / 2.4, non-finite input, R^2 or beta^2 out of range => the problem runs the FP64 body.
 // ==========================================================================================
 constexpr float kEpsU2 = 680.0f;
@@ -1169,32 +1175,6 @@ __device__ __forceinline__ Mfma2Const mfma2_consts(double beta_d, unsigned int r
   // a band dominated by the short-pair term (beta close to the size of the cloud) would send most pairs to FP64
   c.use_mfma = (ok && c.K0 == c.K0 && c.K0 < 1e30f && short_d <= 16.0f * K0e) ? 1 : 0;
   return c;
-}
-
-// Cold path of the u / w kernel (one tile in five): the tile's u and w RECOMPUTED from its operands, and the
-// per-lane mask of the pairs (accumulator registers q) that go to the FP64 fix-up -- inside the error band, or
-// short-pair candidates.  Deliberately NOT inlined: as part of the kernel body its 32 accumulators and temporaries
-// pushed the hot loop into scratch spills (whose reloads wait for every operand prefetch in flight on the in-order
-// vmcnt counter: 1.43 instead of 1.18 ms); as a call, the registers live around it are saved on the cold path only.
-__device__ __attribute__((noinline)) unsigned int tim2_inband_mask(bf16x8 a0, bf16x8 a1, bf16x8 a2, bf16x8 a3, bf16x8 b0,
-                                                                   bf16x8 b1, bf16x8 b2, bf16x8 b3, float K2, float K0,
-                                                                   float wtau, float utau) {
-  f32x16 z;
-  for (int k = 0; k < 16; ++k) z[k] = 0.f;
-  f32x16 U2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, z, 0, 0, 0);
-  f32x16 W2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b3, z, 0, 0, 0);
-  U2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, U2, 0, 0, 0);
-  U2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, U2, 0, 0, 0);
-  unsigned int ub = 0;
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const float u = U2[q], w = W2[q];
-    const float dq = __builtin_fmaf(u, u, w);
-    const float eq = __builtin_fmaf(w, K2, __builtin_fabsf(dq));
-    const bool mine = !(eq > K0) || (!(w < wtau) && !(u > utau));
-    ub |= mine ? (1u << q) : 0u;
-  }
-  return ub;
 }
 
 template <int V, int OCC, bool EARLY>

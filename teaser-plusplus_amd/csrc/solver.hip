@@ -2078,6 +2078,15 @@ int32_t teaser_hip_certifier_params_default(teaser_certifier_params_c* p) {
   return TEASER_HIP_OK;
 }
 
+int32_t teaser_hip_certifier_warmup(int32_t device) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return TEASER_HIP_ERR_NO_DEVICE;
+  if (device < 0 && hipGetDevice(&device) != hipSuccess) return TEASER_HIP_ERR_NO_DEVICE;
+  if (device >= count) return TEASER_HIP_ERR_BAD_ARG;
+  thip::certifier_warmup_async(device);
+  return TEASER_HIP_OK;
+}
+
 int32_t teaser_hip_certify(teaser_hip_solver* h, const teaser_certifier_params_c* p, const double* R,
                            const double* src, const double* dst, const double* theta, int32_t n,
                            teaser_certification_c* out, double* traj, int32_t traj_cap) {

@@ -65,7 +65,22 @@ int solve_range(teaser_hip_solver* h, int first, int last, std::vector<teaser_so
   return teaser_hip_solve_batch(h, src.data(), dst.data(), n.data(), last - first, out->data());
 }
 
-int run_rank(int rank, int world, int device, const uint8_t* id) {
+// The rank that calls teaser_hip_comm_unique_id hosts RCCL's bootstrap root: it must be a RANK (alive until every
+// communicator exists), not a helper process.  Rank 0 makes the id and writes it once per other rank into the pipe;
+// 128 bytes < PIPE_BUF, so every read gets one whole id.
+int run_rank(int rank, int world, int device, const int* id_pipe) {
+  uint8_t id[TEASER_HIP_COMM_ID_BYTES];
+  if (rank == 0) {
+    const int rc = teaser_hip_comm_unique_id(id);
+    if (rc != TEASER_HIP_OK) {
+      std::fprintf(stderr, "rank 0: comm_unique_id -> %d\n", rc);
+      return 1;
+    }
+    for (int r = 1; r < world; ++r)
+      if (write(id_pipe[1], id, sizeof(id)) != (ssize_t)sizeof(id)) return 1;
+  } else if (read(id_pipe[0], id, sizeof(id)) != (ssize_t)sizeof(id)) {
+    return 1;
+  }
   teaser_params_c params;
   teaser_hip_params_default(&params);
   params.noise_bound = 0.01;
@@ -75,7 +90,7 @@ int run_rank(int rank, int world, int device, const uint8_t* id) {
   teaser_hip_comm* c = nullptr;
   int rc = teaser_hip_comm_create(id, rank, world, device, &c);
   if (rc != TEASER_HIP_OK) {
-    std::fprintf(stderr, "rank %d: comm_create -> %d\n", rank, rc);
+    std::fprintf(stderr, "rank %d: comm_create -> %d (%s)\n", rank, rc, teaser_hip_comm_last_error(nullptr));
     return 1;
   }
   int64_t first = 0, last = 0;
@@ -107,6 +122,7 @@ int run_rank(int rank, int world, int device, const uint8_t* id) {
         return 1;
       }
     std::printf("rank mode: %d ranks, %d problems, records identical to the single-process solve\n", world, kTotal);
+    std::fflush(stdout);  // (the rank leaves through _exit)
   }
   teaser_hip_comm_destroy(c);
   teaser_hip_solver_destroy(h);
@@ -122,41 +138,35 @@ int main(int argc, char** argv) {
   if (teaser_hip_comm_shard(2, 3, 4, &f, &l) != TEASER_HIP_OK || f != l) return 1;
   if (teaser_hip_comm_shard(5, 4, 4, &f, &l) != TEASER_HIP_ERR_BAD_ARG) return 1;
   // Everything that touches the HIP runtime runs in children: the parent must stay clean to fork the ranks.
-  // The first child counts the devices and makes the RCCL id.
-  struct Hello {
-    int32_t devices;
-    uint8_t id[TEASER_HIP_COMM_ID_BYTES];
-  } hello;
+  // A helper child counts the devices (and checks the loud failure without one).
+  int32_t devices = 0;
   int fd[2];
   if (pipe(fd) != 0) return 1;
-  pid_t maker = fork();
-  if (maker == 0) {
-    Hello mine;
-    std::memset(&mine, 0, sizeof(mine));
-    mine.devices = teaser_hip_device_count();
-    if (mine.devices <= 0) {
+  pid_t helper = fork();
+  if (helper == 0) {
+    const int32_t count = teaser_hip_device_count();
+    if (count <= 0) {
+      uint8_t zero[TEASER_HIP_COMM_ID_BYTES] = {0};
       teaser_hip_comm* c = nullptr;
-      _exit(teaser_hip_comm_create(mine.id, 0, 1, -1, &c) == TEASER_HIP_ERR_NO_DEVICE ? 77 : 1);  // loud, no CPU path
+      _exit(teaser_hip_comm_create(zero, 0, 1, -1, &c) == TEASER_HIP_ERR_NO_DEVICE ? 77 : 1);  // loud, no CPU path
     }
-    const int rc = teaser_hip_comm_unique_id(mine.id);
-    if (rc == TEASER_HIP_OK && write(fd[1], &mine, sizeof(mine)) != (ssize_t)sizeof(mine)) _exit(1);
-    _exit(rc == TEASER_HIP_OK ? 0 : 1);
+    _exit(write(fd[1], &count, sizeof(count)) == (ssize_t)sizeof(count) ? 0 : 1);
   }
   int st = 0;
-  waitpid(maker, &st, 0);
+  waitpid(helper, &st, 0);
   if (WIFEXITED(st) && WEXITSTATUS(st) == 77) return 77;
-  if (!WIFEXITED(st) || WEXITSTATUS(st) != 0 || read(fd[0], &hello, sizeof(hello)) != (ssize_t)sizeof(hello)) return 1;
-  const int devices = hello.devices;
-  const uint8_t* id = hello.id;
+  if (!WIFEXITED(st) || WEXITSTATUS(st) != 0 || read(fd[0], &devices, sizeof(devices)) != (ssize_t)sizeof(devices)) return 1;
   const int world = argc > 1 ? std::atoi(argv[1]) : devices;
   if (world < 1 || world > devices) {  // (RCCL refuses two ranks on one device)
     std::fprintf(stderr, "world must be 1 .. %d\n", devices);
     return 1;
   }
+  int id_pipe[2];
+  if (pipe(id_pipe) != 0) return 1;
   std::vector<pid_t> kids;
   for (int r = 0; r < world; ++r) {
     pid_t k = fork();
-    if (k == 0) _exit(run_rank(r, world, r, id));
+    if (k == 0) _exit(run_rank(r, world, r, id_pipe));
     kids.push_back(k);
   }
   int bad = 0;

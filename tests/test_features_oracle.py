@@ -13,8 +13,9 @@ such an evaluation; each of the six evaluations is a listed near-tie (cosines wi
 candidates on the cloud); and with those six decisions FORCED the reference's way (oracle test hook) ALL 13 101
 bins agree with the fixture to 1e-4 (+ half a unit of the fixture's 6-significant-digit print).  The GPU
 kernels are bit-identical to the plain (unforced) restatement (tests/test_gpu_features.py).
-The matcher fixture (matcher-test.cc:46-85) goes through those features: >= 90 % of the reference pairs are
-reproduced."""
+The matcher fixture (matcher-test.cc:46-85) goes through those features: 174 of the 189 reference pairs are
+reproduced and each of the other 15 is shown to be a near-tie of the nearest-neighbour search in one direction
+(test_matcher_case1_fixture)."""
 import numpy as np
 import pytest
 
@@ -107,15 +108,28 @@ def test_matcher_self_matching():
     assert (m[:, 0] == m[:, 1]).all() and len(m) >= 0.9 * len(pts)
 
 
-@pytest.mark.slow
 def test_matcher_case1_fixture():
-    """matcher-test.cc:46-85 (object 1000 points, scene 60 865 points; minutes of brute force on the CPU)."""
+    """matcher-test.cc:46-85 (object 1000 points, scene 60 865 points).  174 of the fixture's 189 pairs are
+    reproduced.  The other 15 are attributed, pair by pair: the cross check needs both nearest-neighbour
+    directions; for each missed pair ONE direction is reproduced exactly and in the other the fixture's partner
+    is a near-tie of the restatement's nearest neighbour (squared descriptor distance within 8 %; 0.2 % .. 7.2 %
+    measured) -- the size of the descriptor differences the near-tie switch decisions of computePairFeatures
+    leave behind (test_fpfh_bunny_fixture_all_bins: a flipped pair moves 100 / (k - 1) between mirror bins of the
+    SPFH of a point, which spreads to the FPFH of its whole neighbourhood)."""
     fo, _ = F.fpfh_features(G["matcher_object"], 0.02, 0.04)
     fs, _ = F.fpfh_features(G["matcher_scene"], 0.02, 0.04)
     m = F.match(fo, fs, crosscheck=True)
     ref = set(map(tuple, G["matcher_matches"].tolist()))
     got = set(map(tuple, m.tolist()))
-    assert len(ref & got) >= 0.9 * len(ref) and abs(len(got) - len(ref)) <= 0.1 * len(ref)
+    assert len(ref & got) >= 174 and abs(len(got) - len(ref)) <= 2
+    worst = 1.0
+    for i, j in sorted(ref - got):
+        di = ((fs - fo[i]) ** 2).sum(1)   # object i against the scene
+        dj = ((fo - fs[j]) ** 2).sum(1)   # scene j against the object
+        ri, rj = di[j] / di.min(), dj[i] / dj.min()
+        assert min(ri, rj) == 1.0 and max(ri, rj) < 1.08, (i, j, ri, rj)
+        worst = max(worst, ri, rj)
+    assert worst > 1.0  # (there ARE missed pairs: the attribution above is not vacuous)
 
 
 def test_match_small_bruteforce_properties():
@@ -129,3 +143,27 @@ def test_match_small_bruteforce_properties():
     assert len(m2) >= len(m) and (np.diff(m2[:, 0]) >= 0).all()
     sw = F.match(b, a, crosscheck=True)   # the larger cloud is searched first; pairs stay (src, dst)
     assert set(map(tuple, sw[:, ::-1].tolist())) == set(map(tuple, m.tolist()))
+
+
+def test_config5_oracle_result_fixture():
+    """BASELINE config 5 end to end on the CPU oracles (features oracle -> registration oracle) against the committed
+    tests/golden/config5_result_golden.json (made by tests/golden/make_config5_result_golden.py): pins both oracles
+    across rebuilds; records that this graph's maximum clique (91 of 626) is not unique."""
+    import hashlib
+    import json
+
+    from oracle import oracle
+    g5 = json.load(open(os.path.join(ROOT, "tests", "golden", "config5_result_golden.json")))
+    C5 = np.load(os.path.join(ROOT, "tests", "golden", "config5_clouds.npz"))
+    A, B, vox = C5["cloud_bin_0"], C5["cloud_bin_4"], float(C5["voxel_size"])
+    fa, _ = F.fpfh_features(A, 2 * vox, 5 * vox)
+    fb, _ = F.fpfh_features(B, 2 * vox, 5 * vox)
+    corr = F.match(fa, fb, crosscheck=True)
+    assert hashlib.sha256(np.ascontiguousarray(corr, dtype=np.int32).tobytes()).hexdigest() == g5["correspondences_sha256"]
+    o = oracle.solve(A[corr[:, 0]].astype(np.float64).T, B[corr[:, 1]].astype(np.float64).T, noise_bound=vox, cbar2=1.0,
+                     estimate_scaling=0, rotation_gnc_factor=1.4, rotation_max_iterations=10000,
+                     rotation_cost_threshold=1e-16)
+    assert o["num_edges"] == g5["num_edges"] and o["max_clique"].tolist() == g5["max_clique"]
+    assert bool(o["clique_unique"]) == g5["clique_unique"] and not g5["clique_unique"]
+    assert np.allclose(np.asarray(o["rotation"]).ravel(), g5["rotation"], atol=1e-12)
+    assert np.allclose(np.asarray(o["translation"]).ravel(), g5["translation"], atol=1e-12)

@@ -77,6 +77,31 @@ def test_matcher_self_matching():
     assert m == [tuple(r) for r in F.match(f, f, crosscheck=True).tolist()]
 
 
+def pose_cross_checks(s, sol, o, src_c, dst_c, nb, kw):
+    """Pose parity when the maximum clique is NOT unique (clique *content* may then differ between two correct
+    solvers): (1) the oracle's estimators on the GPU's clique give the GPU's R, t (1e-4) and inlier lists;
+    (2) both directions: each pose explains the OTHER solver's clique (residuals inside the pairwise-consistency
+    bound for nearly all of its correspondences), the cliques overlap, and the poses agree to well within the
+    noise.  src_c / dst_c: 3 x C correspondence arrays (float64)."""
+    clique = np.array(s.getInlierMaxClique())
+    oc = np.array(o["max_clique"])
+    assert len(clique) == len(oc)
+    sub = oracle.solve(src_c[:, clique], dst_c[:, clique], **kw)
+    assert sub["valid"] and len(sub["max_clique"]) == len(clique)  # (a clique: its own graph is complete)
+    assert np.linalg.norm(sol.rotation - sub["rotation"]) < 1e-4
+    assert np.linalg.norm(sol.translation - sub["translation"]) < 1e-4
+    assert s.getRotationInliers() == [int(v) for v in sub["rotation_inliers"]]
+    assert s.getTranslationInliers() == [int(v) for v in sub["translation_inliers"]]
+    Rg, tg = np.asarray(sol.rotation), np.asarray(sol.translation).ravel()
+    Ro, to = np.asarray(o["rotation"]).reshape(3, 3), np.asarray(o["translation"]).ravel()
+    for R, t, other in ((Rg, tg, oc), (Ro, to, clique)):
+        res = np.linalg.norm(R @ src_c[:, other] + t[:, None] - dst_c[:, other], axis=0)
+        assert (res <= 2 * nb).mean() >= 0.9, float((res <= 2 * nb).mean())
+    assert len(set(clique.tolist()) & set(oc.tolist())) >= 0.8 * len(oc)
+    ang = np.arccos(np.clip((np.trace(Ro.T @ Rg) - 1) / 2, -1, 1))
+    assert ang < np.radians(1.0) and np.linalg.norm(tg - to) < nb
+
+
 def test_front_end_to_registration():
     """examples/teaser_cpp_fpfh/teaser_cpp_fpfh.cc:60-110 end to end on the GPU: a cloud and its transformed,
     noisy copy -> FPFH (0.02, 0.04) -> matcher (cross check) -> solve(cloud, cloud, correspondences); the
@@ -104,6 +129,8 @@ def test_front_end_to_registration():
         assert s.getInlierMaxClique() == o["max_clique"].tolist()
         assert np.linalg.norm(sol.rotation - o["rotation"]) < 1e-4
         assert np.linalg.norm(sol.translation - o["translation"]) < 1e-4
+    pose_cross_checks(s, sol, o, src[c[:, 0]].astype(np.float64).T, dst[c[:, 1]].astype(np.float64).T, 0.001,
+                      dict(p, estimate_scaling=0))
     ang = np.arccos(np.clip((np.trace(T[:, :3].T @ sol.rotation) - 1) / 2, -1, 1))
     assert ang < 0.02 and np.linalg.norm(sol.translation - T[:, 3]) < 0.01
 
@@ -145,8 +172,22 @@ def test_config5_3dmatch_pair():
     _, bm = oracle.inlier_bitmap(A[c[:, 0]].astype(np.float64).T, B[c[:, 1]].astype(np.float64).T, vox, 1.0, False)
     dense = np.unpackbits(bm.view(np.uint8), axis=1, bitorder="little")[:, :len(c)].astype(bool)
     assert dense[np.ix_(clique, clique)].sum() == len(clique) * (len(clique) - 1)  # a clique of the oracle's graph
+    # the committed oracle result (tests/golden/config5_result_golden.json): the maximum clique of this graph is
+    # NOT unique, so content parity cannot be asked of two correct solvers -- pose parity is checked through the
+    # oracle's estimators on the GPU's clique and through both-direction residual checks instead
+    import hashlib
+    import json
+    g5 = json.load(open(os.path.join(ROOT, "tests", "golden", "config5_result_golden.json")))
+    assert g5["correspondences_sha256"] == hashlib.sha256(np.ascontiguousarray(c, dtype=np.int32).tobytes()).hexdigest()
+    assert g5["num_edges"] == o["num_edges"] and g5["clique_size"] == len(clique)
+    assert g5["clique_unique"] == bool(o["clique_unique"]) and g5["max_clique"] == o["max_clique"].tolist()
+    assert np.allclose(np.asarray(g5["rotation"]).reshape(3, 3), o["rotation"], atol=1e-12)
     if o["clique_unique"]:
         assert clique == o["max_clique"].tolist()
+        assert np.linalg.norm(sol.rotation - o["rotation"]) < 1e-4
+        assert np.linalg.norm(sol.translation - o["translation"]) < 1e-4
+    pose_cross_checks(s, sol, o, A[c[:, 0]].astype(np.float64).T, B[c[:, 1]].astype(np.float64).T, vox,
+                      dict(p, estimate_scaling=0))
     from scipy.spatial import cKDTree
     d, _ = cKDTree(B.astype(np.float64)).query(A.astype(np.float64) @ sol.rotation.T + sol.translation)
     assert (d < vox).mean() > 0.4  # the clouds overlap by about half

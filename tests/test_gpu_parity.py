@@ -230,7 +230,11 @@ def test_scalar_tls_large_vs_oracle():
     assert abs(est - oe) < 1e-9 and (mask == om).all()
 
 
-@pytest.mark.parametrize("n,rho,scale,seed", [(725, 0.8, 1.7, 31), (1500, 0.9, 0.6, 32), (2500, 0.9, 2.25, 33)])
+SCALE_DIFF_LOG = []
+
+
+@pytest.mark.parametrize("n,rho,scale,seed", [(725, 0.8, 1.7, 31), (1500, 0.9, 0.6, 32), (2500, 0.9, 2.25, 33),
+                                              (1000, 0.7, 1.0, 34), (2000, 0.85, 3.5, 35), (3000, 0.9, 0.25, 36)])
 def test_solve_estimate_scaling_large_vs_oracle(n, rho, scale, seed):
     """estimate_scaling = true (the Params default) beyond the single-workgroup range
     (registration.cc:410-425 with M = n(n-1)/2 up to 3.1e6 TRIMs here)."""
@@ -246,12 +250,47 @@ def test_solve_estimate_scaling_large_vs_oracle(n, rho, scale, seed):
     assert abs(sol.scale - scale) < 0.05 * scale
     _, ref = oracle.inlier_bitmap(pr["src"], dst, nb, 1.0, True)
     bm = s.getInlierGraphBitmap()
-    # the consensus test |s_k - s_hat| <= alpha_k uses s_hat, which may differ in the last ulps:
-    # allow a handful of boundary pairs, none in practice
-    diff = int(np.unpackbits((bm ^ ref).view(np.uint8)).sum())
-    assert diff <= 2, diff
+    # The consensus test |s_k - s_hat| <= alpha_k uses s_hat.  The sweep's prefix sums are associated
+    # differently from the reference's sequential loop, so s_hat may differ in its last ulps.  Bar: a
+    # bit-identical s_hat must give a bit-identical bitmap; otherwise every differing pair must sit ON the
+    # boundary (| |s_k - s_hat| - alpha_k | within 1e-9 for both estimates), at most two of them.
+    x = bm ^ ref
+    diff = int(np.unpackbits(x.view(np.uint8)).sum())
+    same_scale = np.float64(sol.scale).tobytes() == np.float64(o["scale"]).tobytes()
+    SCALE_DIFF_LOG.append(dict(n=n, scale_bitwise_equal=bool(same_scale), scale_abs_diff=abs(sol.scale - o["scale"]),
+                               bitmap_bits_differing=diff))
+    if same_scale:
+        assert diff == 0, diff
+    else:
+        assert diff <= 2, diff
+        W = x.shape[1]
+        beta = 2 * nb
+        for i, w in zip(*np.nonzero(x)):
+            for b in range(64):
+                if (int(x[i, w]) >> b) & 1:
+                    j = w * 64 + b
+                    va = np.linalg.norm(pr["src"][:, j] - pr["src"][:, i])
+                    vb = np.linalg.norm(dst[:, j] - dst[:, i])
+                    for sh in (sol.scale, o["scale"]):
+                        assert abs(abs(vb / va - sh) - beta / va) <= 1e-9
+        assert W == (n + 63) // 64
     if diff == 0:
         check_solution_parity(s, sol, o)
+
+
+def test_estimate_scaling_bitmap_difference_log():
+    """How often the large-n estimate_scaling bitmap differs from the oracle's: the cases
+    above are summarised into gpurun_out/scale_bitmap_diff.json (copied to profiles/ by the round's scripts)."""
+    import json
+    import os
+
+    from util import ROOT
+    assert len(SCALE_DIFF_LOG) >= 3  # (runs after the parametrised cases, same module, same process)
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    doc = dict(cases=SCALE_DIFF_LOG, cases_with_differing_bits=sum(1 for c in SCALE_DIFF_LOG if c["bitmap_bits_differing"]))
+    json.dump(doc, open(os.path.join(out, "scale_bitmap_diff.json"), "w"), indent=1)
+    assert doc["cases_with_differing_bits"] <= 1
 
 
 def test_estimate_scaling_batch_small_problems():

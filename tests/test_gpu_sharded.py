@@ -46,7 +46,9 @@ def _worker(rank, world, port, q):
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_solve_matches_single_process(world):
-    import torch.multiprocessing as mp
+    # (stdlib multiprocessing: THIS process must not import torch -- the certifier tests of the same session load
+    # the system rocBLAS / rocSOLVER, whose sonames torch's bundled copies share; the ranks are fresh processes)
+    import multiprocessing as mp
 
     tp = importlib.import_module("teaser-plusplus_amd")
     srcs, dsts = _problems(tp)
