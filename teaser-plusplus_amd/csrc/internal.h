@@ -54,7 +54,7 @@ struct ProbState {
   int32_t tls_arrive;    // translation stage: axis workgroups of this problem that have finished
   int32_t heu_closed;    // heuristic: 1 once a start's clique is proven maximum by the degree count
   int32_t next_start;    // heuristic: next start of the problem's queue (host: workgroups per problem)
-  int32_t pad1;
+  int32_t scale_overflow;  // 1: the scale stage's float-key sort met a run it could not fix (host reruns with the 64-bit sort)
   int32_t start_vertex[kMaxStarts];
   int32_t start_size[kMaxStarts];
   unsigned long long deg_sum;  // sum of degrees = 2 * edges
@@ -210,8 +210,10 @@ void launch_scalar_tls(hipStream_t s, const double* d_x, const double* d_r, int3
 
 // scalar TLS over many measurements: device radix sort + blocked sweep (kernels_scale.hip)
 int64_t scalar_tls_large_workspace_bytes(int64_t n);
+// d_overflow: nullptr = 64-bit sort; else the float-key path (4 radix passes + exact order restored inside runs of
+// equal float keys), *d_overflow (zeroed by the caller) set when a run was too long: repeat with nullptr
 hipError_t launch_scalar_tls_large(hipStream_t s, const double* d_x, const double* d_r, int64_t n,
-                                   char* d_workspace, double* d_est, uint8_t* d_mask);
+                                   char* d_workspace, double* d_est, uint8_t* d_mask, int32_t* d_overflow);
 // one problem of a batched scale stage (kernels_scale.hip, "a batch of problems through ONE value sort")
 struct ScaleSeg {
   int64_t e_off, m;        // first endpoint, endpoints (2 M)
@@ -227,10 +229,10 @@ int64_t scale_batch_workspace_bytes(int64_t trims, int64_t blocks, int count);
 hipError_t launch_tls_scale_batch(hipStream_t s, const double* d_src, const double* d_dst, const ScaleSeg* h_segs,
                                   int count, int64_t trims, int64_t blocks, int max_n, int64_t max_nblk, double beta,
                                   double* d_raw, double* d_alpha, char* d_workspace, double* d_scale0,
-                                  int64_t scale_stride);
+                                  int64_t scale_stride, int32_t* d_overflow0 /* same stride; nullptr: 64-bit sort */);
 hipError_t launch_tls_scale_large(hipStream_t s, const double* d_src, const double* d_dst, int n,
                                   double beta, double* d_raw, double* d_alpha, char* d_workspace,
-                                  double* d_scale);
+                                  double* d_scale, int32_t* d_overflow);
 
 // correspondence front-end (kernels_features.hip): radius neighbour lists (count -> scan -> fill + sort by
 // (distance, index)), PCL-style normals, SPFH + FPFH, exact L2 1-NN

@@ -365,7 +365,7 @@ static double small_path_ms(int n) {
   return 8.6 * ((double)P2 * L * (L + 1) / 2) / (65536.0 * 136.0) + 0.05;
 }
 
-int32_t scale_stage(teaser_hip_solver* h, int p) {
+int32_t scale_stage(teaser_hip_solver* h, int p, bool sort64) {
   hipStream_t s = h->stream;
   const ProbDesc d = h->descs[(size_t)p];
   const int n = d.n;
@@ -383,7 +383,7 @@ int32_t scale_stage(teaser_hip_solver* h, int p) {
     HIPCHK(h, h->s_c.ensure((size_t)scalar_tls_large_workspace_bytes(M)));
     HIPCHK(h, launch_tls_scale_large(s, h->cur_src + 3 * d.pt_off, h->cur_dst + 3 * d.pt_off, n, beta,
                                      h->s_a.as<double>(), h->s_b.as<double>(), h->s_c.as<char>(),
-                                     d_scale));
+                                     d_scale, sort64 ? nullptr : &(h->d_state.as<ProbState>()[p].scale_overflow)));
     return TEASER_HIP_OK;
   }
   int64_t P2 = 2;
@@ -400,7 +400,7 @@ int32_t scale_stage(teaser_hip_solver* h, int p) {
 // per chunk -- all their TRIMs, all their scalar TLS problems -- instead of two launches per problem one after
 // the other; chunks bound the scratch (TRIM arrays + sort scratch) to ~8 GB.  Larger problems keep the
 // device-wide radix sort path, one problem at a time (each saturates the GPU on its own).
-int32_t scale_stage_batch(teaser_hip_solver* h, int batch) {
+int32_t scale_stage_batch(teaser_hip_solver* h, int batch, bool sort64) {
   hipStream_t s = h->stream;
   const double beta = 2 * h->params.noise_bound * std::sqrt(h->params.cbar2);
   // candidates for the shared launches, smallest first; the largest ones are dropped while one such workgroup
@@ -498,14 +498,15 @@ int32_t scale_stage_batch(teaser_hip_solver* h, int batch) {
     HIPCHK(h, h->s_c.ensure((size_t)scale_batch_workspace_bytes(trims, blocks, (int)cnt)));
     HIPCHK(h, launch_tls_scale_batch(s, h->cur_src, h->cur_dst, mid.data() + mat, (int)cnt, trims, blocks, max_n,
                                      max_nblk, beta, h->s_a.as<double>(), h->s_b.as<double>(), h->s_c.as<char>(),
-                                     &(h->d_state.as<ProbState>()[0].scale), (int64_t)sizeof(ProbState)));
+                                     &(h->d_state.as<ProbState>()[0].scale), (int64_t)sizeof(ProbState),
+                                     sort64 ? nullptr : &(h->d_state.as<ProbState>()[0].scale_overflow)));
     for (size_t k = 0; k < cnt; ++k) done[(size_t)mid[mat + k].prob] = 1;
     mat += cnt;
     if (mid.size() - mat >= 1) HIPCHK(h, hipStreamSynchronize(s));  // (the next chunk reuses the scratch)
   }
   for (int b = 0; b < batch; ++b) {
     if (done[(size_t)b]) continue;
-    const int32_t rc = scale_stage(h, b);
+    const int32_t rc = scale_stage(h, b, sort64);
     if (rc != TEASER_HIP_OK) return rc;
   }
   return TEASER_HIP_OK;
@@ -874,7 +875,7 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
 
   if (P.estimate_scaling) {
     StageScope sc(h, ST_TIM);
-    int32_t rc = scale_stage_batch(h, batch);
+    int32_t rc = scale_stage_batch(h, batch, fp64_k1);  // (a rerun also takes the 64-bit sort)
     if (rc != TEASER_HIP_OK) return rc;
   }
   if (need_graph) {
@@ -968,8 +969,8 @@ int32_t solve_packed_finish(teaser_hip_solver* h, teaser_solution_c* out, bool* 
   memcpy(h->states.data(), h->pin_states.p, sizeof(ProbState) * (size_t)batch);
   *k1_overflow = false;
   for (int b = 0; b < batch; ++b)
-    if (h->states[(size_t)b].k1_overflow) *k1_overflow = true;
-  if (*k1_overflow) return TEASER_HIP_OK;  // the caller reruns the batch with the FP64 K1
+    if (h->states[(size_t)b].k1_overflow || h->states[(size_t)b].scale_overflow) *k1_overflow = true;
+  if (*k1_overflow) return TEASER_HIP_OK;  // the caller reruns the batch with the FP64 K1 / the 64-bit scale sort
   for (int b = 0; b < batch; ++b) h->heu_size[(size_t)b] = h->states[(size_t)b].lb;
   if (h->pend.need_graph && h->pend.mode == TEASER_INLIER_PMC_EXACT) {
     bool changed = false;
@@ -1750,16 +1751,26 @@ int32_t teaser_hip_scalar_tls(teaser_hip_solver* h, const double* x, const doubl
   HIPCHK(h, h->s_e.ensure((size_t)n + 16));
   HIPCHK(h, hipMemcpyAsync(h->s_a.p, x, (size_t)n * 8, hipMemcpyHostToDevice, s));
   HIPCHK(h, hipMemcpyAsync(h->s_b.p, ranges, (size_t)n * 8, hipMemcpyHostToDevice, s));
-  if (large)
-    HIPCHK(h, launch_scalar_tls_large(s, h->s_a.as<double>(), h->s_b.as<double>(), n, h->s_c.as<char>(),
-                                      h->s_d.as<double>(), h->s_e.as<uint8_t>()));
-  else
-    launch_scalar_tls(s, h->s_a.as<double>(), h->s_b.as<double>(), n, h->s_c.as<char>(),
-                      h->s_d.as<double>(), h->s_e.as<uint8_t>());
-  HIPCHK(h, hipGetLastError());
-  HIPCHK(h, hipMemcpyAsync(estimate, h->s_d.p, 8, hipMemcpyDeviceToHost, s));
-  if (inlier_mask) HIPCHK(h, hipMemcpyAsync(inlier_mask, h->s_e.p, (size_t)n, hipMemcpyDeviceToHost, s));
-  HIPCHK(h, hipStreamSynchronize(s));
+  // large: float-key sort first; a run of equal float keys too long to fix (flag at s_d + 8) repeats the call
+  // with the 64-bit sort
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    int32_t* d_flag = reinterpret_cast<int32_t*>(h->s_d.as<char>() + 8);
+    if (large) {
+      HIPCHK(h, hipMemsetAsync(d_flag, 0, 4, s));
+      HIPCHK(h, launch_scalar_tls_large(s, h->s_a.as<double>(), h->s_b.as<double>(), n, h->s_c.as<char>(),
+                                        h->s_d.as<double>(), h->s_e.as<uint8_t>(), attempt == 0 ? d_flag : nullptr));
+    } else {
+      launch_scalar_tls(s, h->s_a.as<double>(), h->s_b.as<double>(), n, h->s_c.as<char>(),
+                        h->s_d.as<double>(), h->s_e.as<uint8_t>());
+    }
+    HIPCHK(h, hipGetLastError());
+    int32_t flag = 0;
+    HIPCHK(h, hipMemcpyAsync(estimate, h->s_d.p, 8, hipMemcpyDeviceToHost, s));
+    if (large) HIPCHK(h, hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, s));
+    if (inlier_mask) HIPCHK(h, hipMemcpyAsync(inlier_mask, h->s_e.p, (size_t)n, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    if (!flag) break;
+  }
   return TEASER_HIP_OK;
 }
 
@@ -1791,12 +1802,21 @@ int32_t teaser_hip_solve_for_scale(teaser_hip_solver* h, const double* v1, const
     HIPCHK(h, h->s_c.ensure(large ? (size_t)scalar_tls_large_workspace_bytes(m) : (size_t)P2 * 12 + 64));
     launch_tim_scale_terms(s, h->s_a.as<double>(), h->s_b.as<double>(), m, beta, 1, h->x_src.as<double>(),
                            h->x_dst.as<double>(), nullptr);
-    if (large)
-      HIPCHK(h, launch_scalar_tls_large(s, h->x_src.as<double>(), h->x_dst.as<double>(), m, h->s_c.as<char>(),
-                                        h->s_d.as<double>(), h->s_e.as<uint8_t>()));
-    else
-      launch_scalar_tls(s, h->x_src.as<double>(), h->x_dst.as<double>(), (int32_t)m, h->s_c.as<char>(),
-                        h->s_d.as<double>(), h->s_e.as<uint8_t>());
+    for (int attempt = 0; attempt < 2; ++attempt) {  // (as teaser_hip_scalar_tls)
+      int32_t* d_flag = reinterpret_cast<int32_t*>(h->s_d.as<char>() + 8);
+      int32_t flag = 0;
+      if (large) {
+        HIPCHK(h, hipMemsetAsync(d_flag, 0, 4, s));
+        HIPCHK(h, launch_scalar_tls_large(s, h->x_src.as<double>(), h->x_dst.as<double>(), m, h->s_c.as<char>(),
+                                          h->s_d.as<double>(), h->s_e.as<uint8_t>(), attempt == 0 ? d_flag : nullptr));
+        HIPCHK(h, hipMemcpyAsync(&flag, d_flag, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipStreamSynchronize(s));
+      } else {
+        launch_scalar_tls(s, h->x_src.as<double>(), h->x_dst.as<double>(), (int32_t)m, h->s_c.as<char>(),
+                          h->s_d.as<double>(), h->s_e.as<uint8_t>());
+      }
+      if (!flag) break;
+    }
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(scale, h->s_d.p, 8, hipMemcpyDeviceToHost, s));
   } else {

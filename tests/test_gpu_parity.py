@@ -230,6 +230,59 @@ def test_scalar_tls_large_vs_oracle():
     assert abs(est - oe) < 1e-9 and (mask == om).all()
 
 
+def test_scale_float_key_sort_matches_the_64_bit_sort():
+    """The scale stage sorts FLOAT-rounded endpoint keys (4 radix passes over 8-byte items) and restores the exact
+    FP64 order inside runs of equal float keys (tls_order_fix_kernel); runs too long to fix fall back to the 64-bit
+    sort.  Both paths must produce the SAME order, hence bit-identical estimates (the sums then associate
+    identically): random data, clusters of doubles that collide as floats (in-run reordering does the work), exact
+    duplicates (ties keep insertion order), and whole solves, single and batched (TEASER_SCALE_SORT64 flips the
+    path inside this process)."""
+    import os
+    rng = np.random.default_rng(14)
+    s = make_solver()
+
+    def both(fn):
+        os.environ.pop("TEASER_SCALE_SORT64", None)
+        a = fn()
+        os.environ["TEASER_SCALE_SORT64"] = "1"
+        try:
+            b = fn()
+        finally:
+            os.environ.pop("TEASER_SCALE_SORT64", None)
+        return a, b
+
+    n = 400000
+    cases = []
+    cases.append((np.concatenate([rng.normal(1.3, 0.004, size=n // 10), rng.uniform(0.2, 4.0, size=n - n // 10)]),
+                  rng.uniform(0.005, 0.05, size=n)))
+    # clusters of 24 values 1e-9 apart (one float at this magnitude spans 6e-8 .. 2.4e-7), shuffled; equal ranges
+    # inside a cluster so that the endpoint keys collide as floats too
+    base = np.repeat(rng.uniform(0.5, 3.0, size=n // 24 + 1), 24)[:n]
+    x = base + 1e-9 * (rng.permutation(n) % 24)
+    rr = np.repeat(rng.uniform(0.01, 0.05, size=n // 24 + 1), 24)[:n]
+    cases.append((x, rr))
+    # exact duplicates in runs of 8 (ties: insertion order) mixed with near-duplicates
+    x2 = np.repeat(rng.uniform(0.5, 3.0, size=n // 8 + 1), 8)[:n]
+    x2[::3] += 3e-10
+    cases.append((x2, np.repeat(rng.uniform(0.01, 0.05, size=n // 8 + 1), 8)[:n]))
+    for x, r in cases:
+        (ea, ma), (eb, mb) = both(lambda: s.scalarTLS(x, r))
+        assert np.float64(ea).tobytes() == np.float64(eb).tobytes()
+        assert (ma == mb).all()
+        oe, om = oracle.scalar_tls(x, r)
+        assert abs(ea - oe) < 1e-9 and (ma == om).all()
+    # whole solves: one large problem, one mid-size batch
+    p = bench_params(estimate_scaling=True, noise_bound=0.02)
+    pr = tp.synth_problem(4242, 3000, 0.8, 0.01)
+    sv = make_solver(**p)
+    a, b = both(lambda: sv.solve(pr["src"], pr["dst"] * 1.5).scale)
+    assert np.float64(a).tobytes() == np.float64(b).tobytes() and abs(a - 1.5) < 0.05
+    probs = [tp.synth_problem(4300 + i, m, 0.7, 0.01) for i, m in enumerate([900, 1500, 800, 2000])]
+    srcs, dsts = [q["src"] for q in probs], [q["dst"] * (1.0 + 0.2 * i) for i, q in enumerate(probs)]
+    a, b = both(lambda: [o.scale for o in sv.solve_batch(srcs, dsts)])
+    assert [np.float64(v).tobytes() for v in a] == [np.float64(v).tobytes() for v in b]
+
+
 SCALE_DIFF_LOG = []
 
 
