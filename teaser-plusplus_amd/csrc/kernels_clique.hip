@@ -96,6 +96,69 @@ __device__ int colour_sort(const uint64_t* __restrict__ bitmap, int W, const uin
   return m;
 }
 
+// The same colouring for graphs of up to 256 vertices (W <= 4 words: real descriptor graphs such as BASELINE config 5
+// after the bounds have thinned them), entirely in wave-UNIFORM registers.  The generic version spreads a bit set
+// over the lanes, one word each, and pays a ballot + shuffle + LDS round trip + barrier per coloured vertex -- with
+// three words, 61 idle lanes and ~0.4 us per vertex (58 us per search node at config 5, whose tree is a thin spine
+// of ~90 dependent levels: the search's wall time IS the per-node cost).  Here Q and Qc are W scalars, the highest
+// set bit is a scalar instruction, and the only memory access per vertex is its adjacency row (a broadcast load made
+// uniform with readfirstlane).  Same order, same classes, same output as the generic version.
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+template <int WN>
+__device__ int colour_sort_small(const uint64_t* __restrict__ bitmap, const uint64_t* P, int pcount, int need,
+                                 int32_t* order, int32_t* colour) {
+  const int lane = threadIdx.x;
+  uint64_t Q[WN], Qc[WN];
+#pragma unroll
+  for (int w = 0; w < WN; ++w) Q[w] = uniform64(P[w]);
+  int remaining = pcount, k = 0, m = 0;
+  while (remaining > 0) {
+    if (k + remaining <= need) break;
+    ++k;
+#pragma unroll
+    for (int w = 0; w < WN; ++w) Qc[w] = Q[w];
+    while (true) {
+      int u = -1;
+#pragma unroll
+      for (int w = WN - 1; w >= 0; --w)
+        if (u < 0 && Qc[w] != 0ull) u = w * 64 + 63 - __builtin_clzll(Qc[w]);
+      if (u < 0) break;
+      const uint64_t* ru = bitmap + (int64_t)u * WN;
+#pragma unroll
+      for (int w = 0; w < WN; ++w) {
+        Qc[w] &= ~uniform64(ru[w]);
+        if (w == (u >> 6)) {
+          Qc[w] &= ~(1ull << (u & 63));
+          Q[w] &= ~(1ull << (u & 63));
+        }
+      }
+      --remaining;
+      if (k > need) {
+        if (lane == 0) {
+          order[m] = u;
+          colour[m] = k;
+        }
+        ++m;
+      }
+    }
+  }
+  __syncthreads();
+  return m;
+}
+__device__ __forceinline__ int colour_sort_any(const uint64_t* __restrict__ bitmap, int W, const uint64_t* P, int pcount,
+                                               int need, uint64_t* Q, uint64_t* Qc, int32_t* order, int32_t* colour) {
+  switch (W) {
+    case 1: return colour_sort_small<1>(bitmap, P, pcount, need, order, colour);
+    case 2: return colour_sort_small<2>(bitmap, P, pcount, need, order, colour);
+    case 3: return colour_sort_small<3>(bitmap, P, pcount, need, order, colour);
+    case 4: return colour_sort_small<4>(bitmap, P, pcount, need, order, colour);
+    default: return colour_sort(bitmap, W, P, pcount, need, Q, Qc, order, colour);
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // The search, in three launches over ALL open problems of a batch (no host round trip in between):
 //   phase 1  one wave per root (waves of a problem pull its roots from a counter): level-0 colouring, every
@@ -109,21 +172,22 @@ __device__ int colour_sort(const uint64_t* __restrict__ bitmap, int W, const uin
 // incumbent has overtaken is dropped when it is pulled -- the same pruning the sequential order does.
 // A full queue is not an error: the emitting wave searches that child itself.
 // ------------------------------------------------------------------------------------------
-struct ExactTask {   // 32-byte header of a task slot; the candidate bit set (W2 words) follows
+constexpr int kTaskPrefix = 8;  // deepest task: a clique prefix of this many vertices
+struct ExactTask {   // 48-byte header of a task slot; the candidate bit set (W2 words) follows
   int32_t q;         // problem index in the launch
-  int32_t csize;     // clique prefix length (<= 4)
+  int32_t csize;     // clique prefix length (<= kTaskPrefix)
   int32_t cnt;       // |P|
   int32_t cb;        // a clique through this node has at most this many vertices (parent's colour bound)
-  int32_t C[4];      // the prefix (compact vertex indices)
+  int32_t C[kTaskPrefix];  // the prefix (compact vertex indices)
 };
 
+// Queue k holds the tasks of depth k + 1 (written by the pass that expands depth k, read by the next one); queues
+// alternate between the two halves of the task pool (queue k - 1 is dead once queue k has been written).
 struct ExactQueues {
-  char* pool1;
-  char* pool2;
-  int32_t* counters;  // [0] queue-1 count, [1] queue-2 count, [2] queue-1 head, [3] queue-2 head
-  int32_t cap1, cap2;
-  int32_t slot_bytes;  // 32 + 8 * max W2, multiple of 32
-  int32_t pad;
+  char* pool[2];
+  int32_t* counters;  // [2 k] queue k: tasks written, [2 k + 1] queue k: next task to take
+  int32_t cap;        // slots per half
+  int32_t slot_bytes;  // header + 8 * max W2, multiple of 32
 };
 
 struct WaveCtx {
@@ -138,13 +202,26 @@ struct WaveCtx {
   int64_t deadline;
   long long t_start;
   unsigned int steps;
+  char* lds_stack;       // wave-private LDS for the small (deep, hot) levels of the sequential search
+  int lds_stack_bytes;
 };
 
 // Sequential branch and bound below the node whose candidate set P (pc vertices) sits in the level record at
 // cx.stack0 and whose clique prefix is cx.C[0 .. csize).  Returns 0, or 1 arena overflow / 2 time limit.
+// Level records live on TWO stacks: the per-wave HBM arena, and a small wave-private LDS stack for the records that
+// are small -- the deep levels, where the search spends its time: a node of the sequential search is a chain of
+// dependent accesses to its level's header, colour list and candidate set (pop test, branch vertex, child set,
+// child header), each an L2 round trip when the record lives in the arena.  Levels are created and destroyed in
+// LIFO order overall, hence in LIFO order on each of the two stacks: a record's offset says where it lives
+// (>= kLdsLevelTag: LDS) and popping it resets that stack's top to its own offset.
+constexpr int64_t kLdsLevelTag = (int64_t)1 << 40;
+constexpr int kLdsLevelMax = 768;  // bytes: records up to this size go to the LDS stack while it has room
+
 __device__ int dfs_subtree(WaveCtx& cx, int32_t* __restrict__ best_clique, int csize, int pc) {
   const int lane = threadIdx.x, W = cx.W;
   char* arena = cx.arena;
+  char* lds = cx.lds_stack;
+  auto at = [&](int64_t o) -> char* { return o >= kLdsLevelTag ? lds + (o - kLdsLevelTag) : arena + o; };
   int32_t* C = cx.C;
   int32_t* best_size = &cx.pb->ctrl[0];
   int32_t* recorded_size = &cx.pb->ctrl[1];
@@ -154,12 +231,14 @@ __device__ int dfs_subtree(WaveCtx& cx, int32_t* __restrict__ best_clique, int c
   int best = __hip_atomic_load(best_size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int64_t lvl_bytes = hdr_b + p_b + 2 * align16((int64_t)pc * 4);
   if (off + lvl_bytes > cx.arena_bytes) return 1;
+  int64_t htop = off + lvl_bytes;  // top of the HBM stack
+  int ltop = 0;                    // top of the LDS stack
   LevelHdr* L = reinterpret_cast<LevelHdr*>(arena + off);
   uint64_t* P = reinterpret_cast<uint64_t*>(arena + off + hdr_b);
   int32_t* order = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(P) + p_b);
   int32_t* colour = order + (align16((int64_t)pc * 4) / 4);
   __syncthreads();
-  const int m = colour_sort(cx.bmrows, W, P, pc, best - csize, cx.Q, cx.Qc, order, colour);
+  const int m = colour_sort_any(cx.bmrows, W, P, pc, best - csize, cx.Q, cx.Qc, order, colour);
   if (lane == 0) {
     L->pcount = pc;
     L->m = m;
@@ -172,16 +251,21 @@ __device__ int dfs_subtree(WaveCtx& cx, int32_t* __restrict__ best_clique, int c
   while (depth >= 0) {
     // the time limit also holds INSIDE a subtree (checked every 256 steps)
     if ((++cx.steps & 255u) == 0u && cx.deadline > 0 && wall_clock64() - cx.t_start > cx.deadline) return 2;
-    L = reinterpret_cast<LevelHdr*>(arena + off);
-    P = reinterpret_cast<uint64_t*>(arena + off + hdr_b);
+    L = reinterpret_cast<LevelHdr*>(at(off));
+    P = reinterpret_cast<uint64_t*>(at(off) + hdr_b);
     const int lpc = L->pcount;
     order = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(P) + p_b);
     colour = order + (align16((int64_t)lpc * 4) / 4);
     const int idx = L->idx;
-    best = __hip_atomic_load(best_size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((cx.steps & 15u) == 0u)  // (the incumbent of the other waves: every 16th node is often enough)
+      best = __hip_atomic_load(best_size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     bool pop = idx < 0;
     if (!pop && colour[idx] <= best - csize) pop = true;
     if (pop) {
+      if (off >= kLdsLevelTag)
+        ltop = (int)(off - kLdsLevelTag);
+      else
+        htop = off;
       off = L->prev_off;
       --depth;
       --csize;
@@ -191,11 +275,14 @@ __device__ int dfs_subtree(WaveCtx& cx, int32_t* __restrict__ best_clique, int c
     const int u = order[idx];
     __syncthreads();
     if (lane == 0) L->idx = idx - 1;
-    // child candidate set NP = P & N(u), built in place at the next arena slot
-    const int64_t noff = off + L->bytes;
-    if (noff + hdr_b + p_b > cx.arena_bytes) return 1;
-    LevelHdr* NL = reinterpret_cast<LevelHdr*>(arena + noff);
-    uint64_t* NP = reinterpret_cast<uint64_t*>(arena + noff + hdr_b);
+    // child candidate set NP = P & N(u), built in place at the top of the stack its record will live on
+    // (|NP| <= |P| - 1 bounds the record's size before it is known)
+    const int64_t nbytes_max = hdr_b + p_b + 2 * align16((int64_t)lpc * 4);
+    const bool in_lds = nbytes_max <= kLdsLevelMax && ltop + nbytes_max <= cx.lds_stack_bytes;
+    const int64_t noff = in_lds ? kLdsLevelTag + ltop : htop;
+    if (!in_lds && noff + hdr_b + p_b > cx.arena_bytes) return 1;
+    LevelHdr* NL = reinterpret_cast<LevelHdr*>(at(noff));
+    uint64_t* NP = reinterpret_cast<uint64_t*>(at(noff) + hdr_b);
     const uint64_t* ru = cx.bmrows + (int64_t)u * W;
     int cnt = 0;
     for (int w = lane; w < W; w += 64) {
@@ -211,7 +298,9 @@ __device__ int dfs_subtree(WaveCtx& cx, int32_t* __restrict__ best_clique, int c
     __syncthreads();
     if (cnt == 0) {
       const int size = csize + 1;
+      if (size > best) best = max(best, __hip_atomic_load(best_size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
       if (size > best) {
+        best = size;
         if (lane == 0) {
           atomicMax(best_size, size);
           while (atomicCAS(lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(2);
@@ -229,11 +318,11 @@ __device__ int dfs_subtree(WaveCtx& cx, int32_t* __restrict__ best_clique, int c
       }
     } else if (csize + 1 + cnt > best) {
       const int64_t nbytes = hdr_b + p_b + 2 * align16((int64_t)cnt * 4);
-      if (noff + nbytes > cx.arena_bytes) return 1;
+      if (!in_lds && noff + nbytes > cx.arena_bytes) return 1;
       int32_t* norder = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(NP) + p_b);
       int32_t* ncolour = norder + (align16((int64_t)cnt * 4) / 4);
       ++csize;
-      const int nm = colour_sort(cx.bmrows, W, NP, cnt, best - csize, cx.Q, cx.Qc, norder, ncolour);
+      const int nm = colour_sort_any(cx.bmrows, W, NP, cnt, best - csize, cx.Q, cx.Qc, norder, ncolour);
       if (lane == 0) {
         NL->pcount = cnt;
         NL->m = nm;
@@ -242,6 +331,10 @@ __device__ int dfs_subtree(WaveCtx& cx, int32_t* __restrict__ best_clique, int c
         NL->bytes = nbytes;
       }
       __syncthreads();
+      if (in_lds)
+        ltop += (int)nbytes;
+      else
+        htop += nbytes;
       off = noff;
       ++depth;
     }
@@ -269,7 +362,7 @@ __device__ int expand_node(WaveCtx& cx, int32_t* __restrict__ best_clique, int q
   int32_t* colour = order + (align16((int64_t)pc * 4) / 4);
   uint64_t* NP = reinterpret_cast<uint64_t*>(arena + noff + hdr_b);
   __syncthreads();
-  const int m = colour_sort(cx.bmrows, W, P, pc, best - csize, cx.Q, cx.Qc, order, colour);
+  const int m = colour_sort_any(cx.bmrows, W, P, pc, best - csize, cx.Q, cx.Qc, order, colour);
   __syncthreads();
   for (int idx = m - 1; idx >= 0; --idx) {
     best = __hip_atomic_load(best_size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -313,7 +406,7 @@ __device__ int expand_node(WaveCtx& cx, int32_t* __restrict__ best_clique, int q
     }
     if (csize + 1 + cnt <= best) continue;
     int slot = cap;
-    if (csize + 1 <= 4) {
+    if (csize + 1 <= kTaskPrefix) {
       if (lane == 0) slot = atomicAdd(pool_count, 1);
       slot = __builtin_amdgcn_readfirstlane(slot);
     }
@@ -333,7 +426,7 @@ __device__ int expand_node(WaveCtx& cx, int32_t* __restrict__ best_clique, int q
       // queue full (or the prefix does not fit a task): search this child here and now
       if (lane == 0) {
         C[csize] = u;
-        if (slot >= cap && csize + 1 <= 4) atomicSub(pool_count, 1);  // give the ticket back (count stays <= cap + waves)
+        if (slot >= cap && csize + 1 <= kTaskPrefix) atomicSub(pool_count, 1);  // give the ticket back (count stays <= cap + waves)
       }
       __syncthreads();
       const int64_t save = cx.stack0;
@@ -372,13 +465,16 @@ __global__ __launch_bounds__(64) void exact_clique_kernel(ExactProb* __restrict_
                                                           const uint64_t* __restrict__ bitmap_pool,
                                                           char* __restrict__ arena_pool, int64_t arena_bytes,
                                                           int max_W2, int32_t* __restrict__ clique_pool,
-                                                          ExactQueues qs, int64_t deadline_ticks) {
+                                                          ExactQueues qs, int64_t deadline_ticks, int lds_stack_off,
+                                                          int lds_stack_bytes, int in_level) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x;
   WaveCtx cx;
   cx.Q = reinterpret_cast<uint64_t*>(smem);
   cx.Qc = cx.Q + ((max_W2 + 1) & ~1);
   uint64_t* lds_bm = cx.Qc + ((max_W2 + 1) & ~1);
+  cx.lds_stack = smem + lds_stack_off;
+  cx.lds_stack_bytes = lds_stack_bytes;
   cx.deadline = deadline_ticks;
   cx.t_start = wall_clock64();
   cx.steps = 0;
@@ -435,13 +531,14 @@ __global__ __launch_bounds__(64) void exact_clique_kernel(ExactProb* __restrict_
       if (lane == 0) cx.C[0] = v;
       __syncthreads();
       ++cx.steps;
-      status_rc = expand_node(cx, best_clique, q, 1, pc, qs.pool1, qs.counters + 0, qs.cap1, qs.slot_bytes);
+      status_rc = expand_node(cx, best_clique, q, 1, pc, qs.pool[0], qs.counters + 0, qs.cap, qs.slot_bytes);
       if (status_rc) break;
     }
   } else {
-    const char* pool_in = PHASE == 2 ? qs.pool1 : qs.pool2;
-    const int n_in = min(PHASE == 2 ? qs.counters[0] : qs.counters[1], PHASE == 2 ? qs.cap1 : qs.cap2);
-    int32_t* head = qs.counters + (PHASE == 2 ? 2 : 3);
+    // PHASE 2: queue in_level -> queue in_level + 1 (one more level of every task); PHASE 3: queue in_level -> search
+    const char* pool_in = qs.pool[in_level & 1];
+    const int n_in = min(qs.counters[2 * in_level], qs.cap);
+    int32_t* head = qs.counters + 2 * in_level + 1;
     int cur_q = -1;
     while (true) {
       int i = 0;
@@ -480,7 +577,8 @@ __global__ __launch_bounds__(64) void exact_clique_kernel(ExactProb* __restrict_
       ++cx.steps;
       int rc;
       if (PHASE == 2)
-        rc = expand_node(cx, best_clique, q, csize, cnt, qs.pool2, qs.counters + 1, qs.cap2, qs.slot_bytes);
+        rc = expand_node(cx, best_clique, q, csize, cnt, qs.pool[(in_level + 1) & 1], qs.counters + 2 * (in_level + 1), qs.cap,
+                         qs.slot_bytes);
       else
         rc = dfs_subtree(cx, best_clique, csize, cnt);
       if (rc && lane == 0) atomicMax(&pb->ctrl[4], rc);
@@ -497,7 +595,15 @@ void launch_exact_clique(hipStream_t s, ExactProb* d_probs, int nprob, int total
                          int64_t arena_bytes, int arena_waves, int32_t* d_clique_pool, char* d_task_pool,
                          int64_t task_pool_bytes, int32_t* d_counters /* 4, zeroed here */, int64_t deadline_ticks) {
   if (nprob <= 0 || total_waves <= 0) return;
-  const size_t lds = (size_t)2 * ((max_W2 + 1) & ~1) * 8 + (size_t)max_lds_bitmap_bytes;
+  // LDS of a (one-wave) workgroup: Q / Qc, the compact adjacency when it fits, and the wave's stack of small level
+  // records (dfs_subtree) -- as long as the total leaves several workgroups per CU
+  const size_t lds_base = (((size_t)2 * ((max_W2 + 1) & ~1) * 8 + (size_t)max_lds_bitmap_bytes) + 15) & ~(size_t)15;
+  static const int stack_env = [] {
+    const char* e = getenv("TEASER_K4_LDS_STACK");  // bytes; 0 = every level record in the HBM arena
+    return e ? atoi(e) : 8192;
+  }();
+  const int lds_stack_bytes = (lds_base + (size_t)stack_env <= 40 * 1024) ? (stack_env & ~15) : 0;
+  const size_t lds = lds_base + (size_t)lds_stack_bytes;
   static DynLdsOptIn optin1, optin2, optin3;
   if (lds > 48 * 1024) {
     optin1.ensure(reinterpret_cast<const void*>(exact_clique_kernel<1>), (int)lds);
@@ -507,20 +613,29 @@ void launch_exact_clique(hipStream_t s, ExactProb* d_probs, int nprob, int total
   ExactQueues qs;
   qs.slot_bytes = (int32_t)((sizeof(ExactTask) + 8 * (size_t)max_W2 + 31) & ~(size_t)31);
   const int64_t slots = task_pool_bytes / qs.slot_bytes;
-  qs.cap1 = (int32_t)std::min<int64_t>(slots / 4, 1 << 22);
-  qs.cap2 = (int32_t)std::min<int64_t>(slots - qs.cap1, 1 << 24);
-  qs.pool1 = d_task_pool;
-  qs.pool2 = d_task_pool + (int64_t)qs.cap1 * qs.slot_bytes;
+  qs.cap = (int32_t)std::min<int64_t>(slots / 2, 1 << 23);
+  qs.pool[0] = d_task_pool;
+  qs.pool[1] = d_task_pool + (int64_t)qs.cap * qs.slot_bytes;
   qs.counters = d_counters;
-  qs.pad = 0;
-  (void)hipMemsetAsync(d_counters, 0, 4 * sizeof(int32_t), s);
+  // expansion passes between the roots and the sequential search: every pass turns each task into its children
+  // (breadth first; the colouring of a node is done once, by whichever pass reaches it), so that a heavy subtree is
+  // cut into many small ones -- the search's wall time is its longest task
+  static const int passes = [] {
+    const char* e = getenv("TEASER_K4_EXPAND");
+    const int v = e ? atoi(e) : kExactExpandPasses;
+    return v < 0 ? 0 : (v > kTaskPrefix - 1 ? kTaskPrefix - 1 : v);
+  }();
+  (void)hipMemsetAsync(d_counters, 0, (size_t)kExactCounterInts * sizeof(int32_t), s);
   const int w1 = std::min(total_waves, arena_waves);
   hipLaunchKernelGGL(exact_clique_kernel<1>, dim3(w1), dim3(64), lds, s, d_probs, nprob, d_bitmap_pool, d_arena_pool,
-                     arena_bytes, max_W2, d_clique_pool, qs, deadline_ticks);
-  hipLaunchKernelGGL(exact_clique_kernel<2>, dim3(arena_waves), dim3(64), lds, s, d_probs, nprob, d_bitmap_pool,
-                     d_arena_pool, arena_bytes, max_W2, d_clique_pool, qs, deadline_ticks);
+                     arena_bytes, max_W2, d_clique_pool, qs, deadline_ticks, (int)lds_base, lds_stack_bytes, 0);
+  for (int l = 0; l < passes; ++l)
+    hipLaunchKernelGGL(exact_clique_kernel<2>, dim3(arena_waves), dim3(64), lds, s, d_probs, nprob, d_bitmap_pool,
+                       d_arena_pool, arena_bytes, max_W2, d_clique_pool, qs, deadline_ticks, (int)lds_base, lds_stack_bytes,
+                       l);
   hipLaunchKernelGGL(exact_clique_kernel<3>, dim3(arena_waves), dim3(64), lds, s, d_probs, nprob, d_bitmap_pool,
-                     d_arena_pool, arena_bytes, max_W2, d_clique_pool, qs, deadline_ticks);
+                     d_arena_pool, arena_bytes, max_W2, d_clique_pool, qs, deadline_ticks, (int)lds_base, lds_stack_bytes,
+                     passes);
 }
 
 // ------------------------------------------------------------------------------------------

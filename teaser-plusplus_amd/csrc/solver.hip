@@ -186,6 +186,7 @@ struct teaser_hip_solver {
   int depth = 2;                           // lanes (TEASER_HIP_DEPTH / teaser_hip_set_pipeline_depth)
   int next_lane = 0, last_lane = -1;
   bool stagger_k1 = true;                  // TEASER_HIP_STAGGER=0 lets the K1 kernels of the lanes co-run
+  int stagger_point = 1;                   // where k1_done is recorded: 1 behind K1, 2 behind the greedy kernel, 3 behind the peel
   // Alternative schedule, TEASER_HIP_K1_STREAM=1 (off by default): the K1 phase (header upload,
   // pre-pass, K1, fix-up) of EVERY lane on ONE low-priority stream owned by the parent, the
   // latency-bound tail of each lane on the lane's own HIGH-priority stream.  Measured on one MI355X
@@ -666,7 +667,7 @@ int32_t close_clique_bounds(teaser_hip_solver* h, int batch, int64_t total_n, bo
     HIPCHK(h, h->x_arena.ensure((size_t)arena_waves * (size_t)arena_bytes));
     const int64_t task_bytes = std::min<int64_t>((int64_t)1 << 30, std::max<int64_t>((int64_t)64 << 20, (int64_t)(64 + 8 * max_W2) * 65536));
     HIPCHK(h, h->x_tasks.ensure((size_t)task_bytes));
-    HIPCHK(h, h->x_ctrl.ensure(64));
+    HIPCHK(h, h->x_ctrl.ensure(kExactCounterInts * sizeof(int32_t)));
     HIPCHK(h, hipMemcpyAsync(h->x_probs2.p, run.data(), sizeof(ExactProb) * run.size(), hipMemcpyHostToDevice, s));
     if (!built) {
       launch_exact_build(s, dd, h->x_probs2.as<ExactProb>(), (int)run.size(), max_W, max_n2, h->d_bitmap.as<uint64_t>(),
@@ -683,6 +684,12 @@ int32_t close_clique_bounds(teaser_hip_solver* h, int batch, int64_t total_n, bo
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(run.data(), h->x_probs2.p, sizeof(ExactProb) * run.size(), hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
+    if (dbg) {  // diagnostics only: the task queues of this launch
+      int32_t qc[kExactCounterInts] = {0};
+      (void)hipMemcpy(qc, h->x_ctrl.p, sizeof(qc), hipMemcpyDeviceToHost);
+      fprintf(stderr, "[teaser_hip] exact search: %zu problems, %d root waves, %d persistent waves; tasks per depth: %d %d %d %d "
+              "%d %d\n", run.size(), total_waves, arena_waves, qc[0], qc[2], qc[4], qc[6], qc[8], qc[10]);
+    }
     std::vector<ExactProb> again;
     for (ExactProb& e : run) {
       ProbState& st = h->states[(size_t)e.prob];
@@ -899,7 +906,7 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
                                 h->d_work.p, cap, h->d_bitmap.as<uint64_t>(), ds, h->d_deg.as<int32_t>(),
                                 P.noise_bound, P.cbar2);
         }
-        if (phase == 1 && h->k1_done && s1 == s) {
+        if (phase == 1 && h->k1_done && s1 == s && h->stagger_point == 1) {
           HIPCHK(h, hipEventRecord(h->k1_done, s));
           h->k1_recorded = true;
         }
@@ -922,6 +929,10 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
       StageScope sc(h, ST_HEU);
       launch_heuristic(s, dd, batch, max_W, h->d_bitmap.as<uint64_t>(), h->d_deg.as<int32_t>(), ds,
                        h->d_start_cliques.as<int32_t>(), total_n, nullptr, h->d_clique.as<int32_t>());
+      if (mfma_k1 && h->k1_done && h->stagger_point == 2) {
+        HIPCHK(h, hipEventRecord(h->k1_done, s));
+        h->k1_recorded = true;
+      }
       launch_select_best(s, dd, batch, max_W, h->d_deg.as<int32_t>(), ds,
                          h->d_start_cliques.as<int32_t>(), total_n, h->d_clique.as<int32_t>(),
                          h->d_alive_a.as<uint64_t>(), mode == TEASER_INLIER_PMC_EXACT ? 1 : 0);
@@ -943,6 +954,10 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
       launch_peel_rounds(s, dd, batch, max_W, h->d_bitmap.as<uint64_t>(), ds,
                          h->d_alive_a.as<uint64_t>(), h->d_alive_b.as<uint64_t>(),
                          h->d_next_count.as<int32_t>(), kPeelRounds);
+    }
+    if (mfma_k1 && h->k1_done && h->stagger_point == 3) {
+      HIPCHK(h, hipEventRecord(h->k1_done, s));
+      h->k1_recorded = true;
     }
     h->have_graph = true;
   } else {
@@ -1119,6 +1134,7 @@ int32_t make_lane(teaser_hip_solver* h, teaser_hip_solver** out) {
   teaser_hip_solver* lane = new teaser_hip_solver();
   lane->device = h->device;
   lane->params = h->params;
+  lane->stagger_point = h->stagger_point;
   lane->is_lane = true;
   memset(&lane->prof, 0, sizeof(lane->prof));
   int prio_least = 0, prio_greatest = 0;
@@ -1488,7 +1504,10 @@ int32_t teaser_hip_solver_create(const teaser_params_c* params, int32_t device,
     const int v = atoi(e);
     if (v >= 1 && v <= 16) h->depth = v;
   }
-  if (const char* e = getenv("TEASER_HIP_STAGGER")) h->stagger_k1 = atoi(e) != 0;
+  if (const char* e = getenv("TEASER_HIP_STAGGER")) {
+    h->stagger_k1 = atoi(e) != 0;
+    if (atoi(e) >= 1 && atoi(e) <= 3) h->stagger_point = atoi(e);
+  }
   if (const char* e = getenv("TEASER_HIP_K1_STREAM")) h->shared_k1_stream = atoi(e) != 0;
   if (const char* e = getenv("TEASER_HIP_TAIL_CUS")) h->tail_cus = std::max(0, atoi(e));
   if (const char* e = getenv("TEASER_HIP_TAIL_CU_BLOCK")) h->tail_cu_block = atoi(e) != 0;
