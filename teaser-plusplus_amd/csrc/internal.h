@@ -151,10 +151,10 @@ struct ExactProb {
 };
 constexpr int64_t kExactLdsBitmapBytes = 128 * 1024;  // compact adjacency up to 128 KB is staged in LDS
 constexpr int kExactBuildCap = 8192;  // compact vertices the device-side ordering handles (beyond: host path)
-constexpr int kExactXCap = 512;
+constexpr int kExactXCap = 512;       // |X| up to which only X and its neighbourhood enter the compact problem
 constexpr int kExactExpandPasses = 1;   // task depth = passes + 1; more passes (TEASER_K4_EXPAND) cut bushy trees finer -- the
                                         // descriptor graphs measured here have thin, deep trees (branching ~1.1) and gain nothing
-constexpr int kExactCounterInts = 16;   // 2 ints per task queue       // |X| up to which only X and its neighbourhood enter the compact problem
+constexpr int kExactCounterInts = 16;   // 2 ints per task queue
 // step 1 (one workgroup per open problem): root filter, candidate set, sizes -> ExactProb.{n2, n_roots, ...}
 void launch_exact_count(hipStream_t s, const ProbDesc* d_desc, ExactProb* d_probs, int nprob, int max_W,
                         const uint64_t* d_bitmap, const uint64_t* d_alive, const int32_t* d_deg,
