@@ -121,7 +121,8 @@ def roofline_object(k1_ms, k1_launches, k1_bytes, k1_pairs, k1_aux_ms, traffic, 
     mfma_tf = rate(K1_MFMA_FLOPS_PER_PAIR * pairs_per_launch) / 1e12
     hbm_gbs = rate(bytes_per_launch) / 1e9
     return {
-        "kernel": "tim_graph_mfma_kernel (K1: squared TIM norms on the matrix cores + prune + adjacency bitmap)",
+        "kernel": "tim_graph_mfma2_kernel (K1: TIM-norm predicate terms u, w on the matrix cores + prune + adjacency "
+                  "bitmap)",
         "bound": "mfma", "achieved": fp64_tf, "peak": FP64_PEAK_TF, "unit": "TFLOP/s",
         "frac": fp64_tf / FP64_PEAK_TF, "traffic": traffic,
         "avg_launch_ms": 1e3 * k1_avg_s, "launches": k1_launches,
@@ -132,8 +133,8 @@ def roofline_object(k1_ms, k1_launches, k1_bytes, k1_pairs, k1_aux_ms, traffic, 
                 "the kernel alone; peak = dense FP64 peak (matrix = vector = 78.6 TFLOP/s): an algorithm-equivalent "
                 "rate.  The kernel issues NO FP64: it decides the same predicate with an exact bf16-split MFMA + f32 "
                 "VALU filter and an FP64 fix-up (bitmap bit-identical), so the pipes it really loads are "
-                "`executed_mfma` (bf16 matrix pipe) and `issue` (VALU instruction issue, its actual bound: "
-                "DESIGN.md 3).  With --depth > 1 the kernel shares the GPU with the latency-bound tail kernels of "
+                "`executed_mfma` (bf16 matrix pipe) and `issue` (SQ counters: VALU busy 74 %, matrix pipe 22 % of the "
+                "SIMD time; DESIGN.md 3).  With --depth > 1 the kernel shares the GPU with the latency-bound tail kernels of "
                 "the previous batch, which is included in its time",
         "executed_mfma": {"achieved": mfma_tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                           "frac": mfma_tf / MFMA_BF16_PEAK_TF,
@@ -163,8 +164,9 @@ def _latest_profile_json(name, pred):
 
 def k1_traffic(batch, n):
     """HBM bytes per K1 launch from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE are
-    collected in SEPARATE runs of this same command, profiles/<round>/pmc_traffic.json, with the
-    gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md); null when no pass matches this shape."""
+    collected in SEPARATE runs -- of this command in rounds 1-2, of the K1 probe on the same batch shape
+    (scripts/probe/k1_probe 64 10000, the same kernel launch) in round 3: profiles/<round>/pmc_traffic.json, with
+    the gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md); null when no pass matches this shape."""
     hit = _latest_profile_json("pmc_traffic.json", lambda k: "tim_graph_mfma" in k["kernel"] and
                                k.get("batch") == batch and k.get("n") == n)
     return (hit[0]["hbm_bytes_per_launch"], hit[1]) if hit else (None, None)

@@ -241,6 +241,9 @@ hipError_t launch_tls_scale_large(hipStream_t s, const double* d_src, const doub
 // (distance, index)), PCL-style normals, SPFH + FPFH, exact L2 1-NN
 int64_t feat_nbr_bytes();
 int feat_sort_capacity();
+// lists with more than feat_sort_capacity() entries (skipped by the LDS sort): rank sort through d_scratch (list-sized)
+void launch_feat_sort_long(hipStream_t s, int n, const int32_t* d_counts, const int64_t* d_offsets, void* d_list,
+                           void* d_scratch);
 void launch_feat_radius_count(hipStream_t s, const float* d_pts, int n, float r2, int32_t* d_counts);
 void launch_feat_scan(hipStream_t s, const int32_t* d_counts, int n, int64_t* d_offsets /* n + 1 */,
                       int64_t* d_total_max /* 2 */);

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void feat_sort_kernel(const int64_t* __restric
   __shared__ Nbr buf[kFeatSortCap];
   const int q = blockIdx.x;
   const int k = counts[q];
-  if (k <= 1) return;
+  if (k <= 1 || k > kFeatSortCap) return;  // (longer lists: feat_sort_long_kernel)
   Nbr* mine = list + offsets[q];
   int P2 = 2;
   while (P2 < k) P2 <<= 1;
@@ -199,6 +199,29 @@ __global__ __launch_bounds__(256) void feat_sort_kernel(const int64_t* __restric
       __syncthreads();
     }
   for (int i = threadIdx.x; i < k; i += 256) mine[i] = buf[i];
+}
+
+// Lists longer than the LDS sort holds (a radius that catches more than kFeatSortCap neighbours: dense clouds, large
+// radii -- rare at the reference's settings, where a point has a few hundred): rank sort through a scratch copy, one
+// workgroup per such list, O(k^2) comparisons.  (d2, idx) is a total order, so the result is the one the LDS sort
+// gives; feat_sort_kernel skips these lists.
+__global__ __launch_bounds__(256) void feat_sort_long_kernel(const int64_t* __restrict__ offsets,
+                                                             const int32_t* __restrict__ counts, Nbr* __restrict__ list,
+                                                             Nbr* __restrict__ scratch) {
+  const int q = blockIdx.x;
+  const int k = counts[q];
+  if (k <= kFeatSortCap) return;
+  Nbr* mine = list + offsets[q];
+  Nbr* out = scratch + offsets[q];
+  for (int i = threadIdx.x; i < k; i += 256) {
+    const Nbr a = mine[i];
+    int rank = 0;
+    for (int j = 0; j < k; ++j) rank += nbr_less(mine[j], a) ? 1 : 0;
+    out[rank] = a;
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int i = threadIdx.x; i < k; i += 256) mine[i] = out[i];
 }
 
 // ---- normals: pcl::NormalEstimation::computeFeature ----------------------------------------------
@@ -579,6 +602,12 @@ void launch_feat_radius_fill_sort(hipStream_t s, const float* d_pts, int n, floa
   hipLaunchKernelGGL(feat_sort_kernel, dim3(n), dim3(256), 0, s, d_offsets, d_counts, reinterpret_cast<Nbr*>(d_list));
 }
 int feat_sort_capacity() { return kFeatSortCap; }
+void launch_feat_sort_long(hipStream_t s, int n, const int32_t* d_counts, const int64_t* d_offsets, void* d_list,
+                           void* d_scratch) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(feat_sort_long_kernel, dim3(n), dim3(256), 0, s, d_offsets, d_counts, reinterpret_cast<Nbr*>(d_list),
+                     reinterpret_cast<Nbr*>(d_scratch));
+}
 void launch_feat_normals(hipStream_t s, const float* d_pts, int n, const int64_t* d_offsets, const int32_t* d_counts,
                          const void* d_list, float* d_normals) {
   if (n <= 0) return;

@@ -160,7 +160,7 @@ struct teaser_hip_solver {
   // stand-alone stages
   DevBuf s_a, s_b, s_c, s_d, s_e;
   // correspondence front-end (FPFH, matcher)
-  DevBuf f_pts, f_counts, f_cursor, f_offsets, f_list, f_normals, f_spfh, f_out, f_meta, f_feat_a, f_feat_b, f_part_d,
+  DevBuf f_pts, f_counts, f_cursor, f_offsets, f_list, f_list2, f_normals, f_spfh, f_out, f_meta, f_feat_a, f_feat_b, f_part_d,
       f_part_i, f_nn_a, f_nn_b;
 
   PinnedBuf pin_states;  // D2H landing zone of the problem states
@@ -1194,7 +1194,7 @@ void release_handle_resources(teaser_hip_solver* h) {
                     &h->x_src, &h->x_dst, &h->x_bitmap, &h->x_desc, &h->x_state, &h->x_ctrl,
                     &h->x_clique, &h->x_arena, &h->x_probs, &h->x_probs2, &h->x_keys, &h->x_xbits, &h->x_tasks, &h->c_sel, &h->c_colour, &h->c_tent, &h->c_xlist, &h->c_list_a, &h->c_list_b,
                     &h->c_counts, &h->c_bits, &h->c_class,
-                    &h->s_a, &h->s_b, &h->s_c, &h->s_d, &h->s_e, &h->f_pts, &h->f_counts, &h->f_cursor, &h->f_offsets, &h->f_list,
+                    &h->s_a, &h->s_b, &h->s_c, &h->s_d, &h->s_e, &h->f_pts, &h->f_counts, &h->f_cursor, &h->f_offsets, &h->f_list, &h->f_list2,
                     &h->f_normals, &h->f_spfh, &h->f_out, &h->f_meta, &h->f_feat_a, &h->f_feat_b, &h->f_part_d,
                     &h->f_part_i, &h->f_nn_a, &h->f_nn_b};
   for (DevBuf* b : bufs) b->release();
@@ -2067,14 +2067,13 @@ int32_t feat_neighbours(teaser_hip_solver* h, int n, double radius) {
   int64_t meta[2] = {0, 0};
   HIPCHK(h, hipMemcpyAsync(meta, h->f_meta.p, 16, hipMemcpyDeviceToHost, s));
   HIPCHK(h, hipStreamSynchronize(s));
-  if (meta[1] > feat_sort_capacity()) {
-    h->err = "FPFH: a point has " + std::to_string(meta[1]) + " neighbours inside the search radius (limit " +
-             std::to_string(feat_sort_capacity()) + "): use a smaller radius or a down-sampled cloud";
-    return TEASER_HIP_ERR_UNSUPPORTED;
-  }
   HIPCHK(h, h->f_list.ensure((size_t)std::max<int64_t>(meta[0], 1) * (size_t)feat_nbr_bytes()));
   launch_feat_radius_fill_sort(s, h->f_pts.as<float>(), n, r2, h->f_counts.as<int32_t>(), h->f_cursor.as<int32_t>(),
                                h->f_offsets.as<int64_t>(), h->f_list.p);
+  if (meta[1] > feat_sort_capacity()) {  // some list is longer than the LDS sort holds: those take the rank sort
+    HIPCHK(h, h->f_list2.ensure((size_t)std::max<int64_t>(meta[0], 1) * (size_t)feat_nbr_bytes()));
+    launch_feat_sort_long(s, n, h->f_counts.as<int32_t>(), h->f_offsets.as<int64_t>(), h->f_list.p, h->f_list2.p);
+  }
   HIPCHK(h, hipGetLastError());
   return TEASER_HIP_OK;
 }

@@ -17,7 +17,7 @@ def pytest_configure(config):
 def pytest_collection_modifyitems(config, items):
     # the certifier tests go LAST: the warm-up thread started below (rocBLAS / rocSOLVER code objects, ~110 s of
     # host-side loading) then runs behind the rest of the GPU suite instead of in front of it
-    items.sort(key=lambda it: 1 if "test_gpu_certifier" in it.nodeid else 0)
+    items.sort(key=lambda it: 1 if "certifier" in it.nodeid and "gpu" in it.keywords else 0)
     if any("test_gpu_certifier" in it.nodeid and "gpu" in it.keywords for it in items) and \
             "not gpu" not in (config.getoption("-m") or ""):
         try:

@@ -39,7 +39,7 @@ def test_fpfh_other_clouds_bit_exact_vs_oracle(key, rn, rf):
 
 
 def test_fpfh_sparse_points_and_limits():
-    """Isolated points (< 3 neighbours -> NaN normal, as PCL) and a neighbourhood beyond the sort capacity."""
+    """Isolated points (< 3 neighbours -> NaN normal, as PCL)."""
     rng = np.random.default_rng(5)
     pts = np.concatenate([rng.uniform(0, 0.2, size=(300, 3)), [[5, 5, 5], [9, 9, 9]]]).astype(np.float32)
     est = tp.FPFHEstimation()
@@ -47,9 +47,8 @@ def test_fpfh_sparse_points_and_limits():
     fo, no = F.fpfh_features(pts, 0.03, 0.05)
     assert np.isnan(est.getNormals()[-1]).all() and np.array_equal(est.getNormals(), no, equal_nan=True)
     assert np.array_equal(f, fo, equal_nan=True)
-    dense = rng.uniform(0, 0.01, size=(5000, 3)).astype(np.float32)
-    with pytest.raises(tp.TeaserHipError):
-        est.computeFPFHFeatures(dense, 0.03, 0.05)  # 5000 neighbours per point: refused, loudly
+    # (a neighbourhood beyond the LDS sort's 4096 entries, refused in round 2, now takes the rank sort:
+    # test_fpfh_more_than_4096_neighbours)
 
 
 def test_matcher_vs_oracle_and_fixture():
@@ -193,3 +192,16 @@ def test_config5_3dmatch_pair():
     assert (d < vox).mean() > 0.4  # the clouds overlap by about half
     print("config5: %d + %d points, %d correspondences, clique %d; front-end %.2f ms, solve %.2f ms"
           % (len(A), len(B), len(corr), len(clique), 1e3 * (t1 - t0), 1e3 * (t3 - t2)))
+
+
+def test_fpfh_more_than_4096_neighbours():
+    """A radius that catches more neighbours than the LDS sort holds (4096): those lists take the rank sort
+    (feat_sort_long_kernel).  5 000 points in a ball, FPFH radius = the ball: every list has all 5 000 points.
+    Bit-identical to the features oracle, like every other case (PCL has no cap; round 2 refused this input)."""
+    rng = np.random.default_rng(5)
+    pts = rng.normal(size=(5000, 3))
+    pts = (pts / np.linalg.norm(pts, axis=1, keepdims=True) * rng.uniform(0, 0.5, size=(5000, 1)) ** (1 / 3)).astype(np.float32)
+    est = tp.FPFHEstimation()
+    f = est.computeFPFHFeatures(pts, 0.2, 1.1)   # normals from ~ 300 neighbours, FPFH from all 5 000
+    fo, no = F.fpfh_features(pts, 0.2, 1.1)
+    assert np.array_equal(f, fo) and np.array_equal(est.getNormals(), no)
