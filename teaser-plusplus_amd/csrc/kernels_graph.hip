@@ -2183,8 +2183,9 @@ template <int kGreedyThreads>
 __global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
     const ProbDesc* __restrict__ descs, const uint64_t* __restrict__ bitmap,
     const int32_t* __restrict__ deg, ProbState* __restrict__ states,
-    int32_t* __restrict__ start_cliques, int64_t total_n) {
+    int32_t* __restrict__ start_cliques, int64_t total_n, long long* __restrict__ trace) {
   TAIL_WAVE_PRIO();
+  if (trace && threadIdx.x == 0) trace[2 * (blockIdx.y * gridDim.x + blockIdx.x)] = wall_clock64();
   constexpr int kGreedyWaves = kGreedyThreads / 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int next_s;
@@ -2194,6 +2195,8 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
   int sidx = blockIdx.x;
   while (sidx < kMaxStarts) {
     const int csize = greedy_one_start<kGreedyThreads>(descs, bitmap, deg, states, start_cliques, total_n, smem, sidx);
+    if (trace && threadIdx.x == 0 && sidx == (int)blockIdx.x)
+      trace[(size_t)40 * 2 * 4096 + 2 * (blockIdx.y * gridDim.x + blockIdx.x)] = wall_clock64();
     if (gridDim.x >= kMaxStarts) break;  // every start has its own workgroup: nothing left to skip
     // closure test: the peel at threshold csize, in LDS (the start's P / U bitsets are free again)
     const int W = d.W, tid = threadIdx.x;
@@ -2249,6 +2252,8 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
       if (c2 == cnt) break;  // fixpoint above csize: not closed
       cnt = c2;
     }
+    if (trace && threadIdx.x == 0 && sidx == (int)blockIdx.x)
+      trace[(size_t)40 * 2 * 4096 + 2 * (blockIdx.y * gridDim.x + blockIdx.x) + 1] = wall_clock64();
     if (threadIdx.x == 0) {
       int nx = kMaxStarts;
       if (cnt <= csize) {
@@ -2262,6 +2267,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
     sidx = next_s;
     __syncthreads();
   }
+  if (trace && threadIdx.x == 0) trace[2 * (blockIdx.y * gridDim.x + blockIdx.x) + 1] = wall_clock64();
 }
 
 // Per problem: choose the best start (largest clique, ties to the lowest start), emit it SORTED
@@ -2397,15 +2403,66 @@ void launch_heuristic(hipStream_t s, const ProbDesc* d_desc, int batch, int max_
   // TEASER_GREEDY_THREADS=256|512 forces one (diagnostics).
   const char* ev = getenv("TEASER_GREEDY_THREADS");
   const bool wide = ev ? atoi(ev) == 512 : batch <= 16;
+  // diagnostics (TEASER_HEU_TRACE=<file>): per-workgroup start / end clocks (100 MHz) of launches 20 .. 59, dumped once
+  static const char* trace_path = getenv("TEASER_HEU_TRACE");
+  static long long* d_trace = nullptr;
+  static int launch_no = 0;
+  constexpr int kTraceFirst = 20, kTraceCount = 40;
+  long long* trace = nullptr;
+  const int wgs = nblk * batch;
+  if (trace_path) {
+    if (!d_trace) {
+      (void)hipMalloc(&d_trace, (size_t)2 * kTraceCount * 2 * 4096 * sizeof(long long));
+      (void)hipMemset(d_trace, 0, (size_t)2 * kTraceCount * 2 * 4096 * sizeof(long long));
+    }
+    if (wgs <= 4096 && launch_no >= kTraceFirst && launch_no < kTraceFirst + kTraceCount)
+      trace = d_trace + (size_t)(launch_no - kTraceFirst) * 2 * 4096;
+    if (launch_no == kTraceFirst + kTraceCount + 4) {
+      (void)hipDeviceSynchronize();
+      std::vector<long long> h((size_t)2 * kTraceCount * 2 * 4096);
+      (void)hipMemcpy(h.data(), d_trace, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+      if (FILE* f = fopen(trace_path, "w")) {
+        for (int l = 0; l < kTraceCount; ++l) {
+          long long t0 = -1, last_start = 0, last_end = 0, sum_dur = 0, max_dur = 0, sum_a = 0, sum_b = 0;
+          int cnt = 0;
+          for (int g = 0; g < 4096; ++g) {
+            const long long a = h[((size_t)l * 4096 + g) * 2], b = h[((size_t)l * 4096 + g) * 2 + 1];
+            if (a == 0 || b == 0) continue;
+            if (t0 < 0 || a < t0) t0 = a;
+            ++cnt;
+          }
+          for (int g = 0; g < 4096; ++g) {
+            const long long a = h[((size_t)l * 4096 + g) * 2], b = h[((size_t)l * 4096 + g) * 2 + 1];
+            if (a == 0 || b == 0) continue;
+            last_start = std::max(last_start, a - t0);
+            last_end = std::max(last_end, b - t0);
+            sum_dur += b - a;
+            max_dur = std::max(max_dur, b - a);
+            const long long m1 = h[(size_t)kTraceCount * 2 * 4096 + ((size_t)l * 4096 + g) * 2];
+            const long long m2 = h[(size_t)kTraceCount * 2 * 4096 + ((size_t)l * 4096 + g) * 2 + 1];
+            if (m1) sum_a += m1 - a;
+            if (m1 && m2) sum_b += m2 - m1;
+          }
+          if (cnt)
+            fprintf(f, "launch %d: %d workgroups; last start +%.1f us, last end +%.1f us; workgroup duration mean %.1f us, max %.1f us; "
+                    "first start mean %.1f us, first closure test mean %.1f us\n",
+                    l + kTraceFirst, cnt, last_start * 0.01, last_end * 0.01, sum_dur * 0.01 / cnt, max_dur * 0.01,
+                    sum_a * 0.01 / cnt, sum_b * 0.01 / cnt);
+        }
+        fclose(f);
+      }
+    }
+    ++launch_no;
+  }
   static DynLdsOptIn optin256, optin512;  // beyond the 64 KB default dynamic-LDS limit once W >= ~300
   if (wide) {
     if (lds > 48 * 1024) optin512.ensure(reinterpret_cast<const void*>(greedy_clique_kernel<512>), (int)lds);
     hipLaunchKernelGGL(greedy_clique_kernel<512>, dim3(nblk, batch), dim3(512), lds, s, d_desc, d_bitmap,
-                       d_deg, d_state, d_start_cliques, total_n);
+                       d_deg, d_state, d_start_cliques, total_n, trace);
   } else {
     if (lds > 48 * 1024) optin256.ensure(reinterpret_cast<const void*>(greedy_clique_kernel<256>), (int)lds);
     hipLaunchKernelGGL(greedy_clique_kernel<256>, dim3(nblk, batch), dim3(256), lds, s, d_desc, d_bitmap,
-                       d_deg, d_state, d_start_cliques, total_n);
+                       d_deg, d_state, d_start_cliques, total_n, trace);
   }
 }
 
