@@ -2169,6 +2169,64 @@ __device__ __forceinline__ int greedy_one_start(
   return csize;
 }
 
+// One round of the closure test (greedy_clique_kernel): keep the alive vertices with >= csize alive neighbours.
+// NOT inlined: its 16 loads in flight per lane would add to the greedy kernel's register peak (167 VGPRs: more
+// than 208 and a greedy wave no longer fits where ONE K1 wave has retired).
+template <int kGreedyThreads>
+__device__ __attribute__((noinline)) void closure_round(const uint64_t* __restrict__ bm, int W, const uint64_t* Pa,
+                                                        uint64_t* Pb, const int* alist, int cnt, int csize, int tid) {
+      // One round = the bitmap rows of every alive vertex (~640 x 1.25 KB at N = 10 k, cold in HBM) against the alive
+  // bitset.  What bounds it is memory-level parallelism, not bytes: one thread per row, and then 16 lanes per row
+  // with one row per group, both left a single memory latency per pass exposed (158 us per round, half of this
+  // workgroup's time: profiles/r3d/heu_trace_*.txt).  Here a group of 16 lanes owns kRowsPerGroup rows at a time
+  // and issues kChunk loads of each before it consumes any: 20 loads in flight per lane (more would push the kernel past
+  // the 208 VGPRs one retiring K1 wave leaves free on a SIMD), 64 rows per workgroup
+  // pass.
+  constexpr int kLanesPerRow = 16, kRowsPerGroup = 4, kChunk = 5;
+  constexpr int kRowsPerPass = kGreedyThreads / kLanesPerRow * kRowsPerGroup;
+  const int gid = tid / kLanesPerRow, sub = tid % kLanesPerRow;
+#pragma unroll 1
+  for (int k0 = 0; k0 < cnt; k0 += kRowsPerPass) {
+    int v[kRowsPerGroup], c[kRowsPerGroup];
+    const uint64_t* row[kRowsPerGroup];
+#pragma unroll
+    for (int r = 0; r < kRowsPerGroup; ++r) {
+      const int k = k0 + gid * kRowsPerGroup + r;
+      v[r] = k < cnt ? alist[k] : -1;
+      row[r] = bm + (int64_t)(v[r] < 0 ? 0 : v[r]) * W;
+      c[r] = 0;
+    }
+#pragma unroll 1
+    for (int x0 = 0; x0 < W; x0 += kLanesPerRow * kChunk) {
+      uint64_t buf[kRowsPerGroup][kChunk];
+#pragma unroll
+      for (int r = 0; r < kRowsPerGroup; ++r)
+#pragma unroll
+        for (int u = 0; u < kChunk; ++u) {
+          const int x = x0 + u * kLanesPerRow + sub;
+          buf[r][u] = (x < W && v[r] >= 0) ? row[r][x] : 0ull;
+        }
+#pragma unroll
+      for (int u = 0; u < kChunk; ++u) {
+        const int x = x0 + u * kLanesPerRow + sub;
+        const uint64_t pa = x < W ? Pa[x] : 0ull;
+#pragma unroll
+        for (int r = 0; r < kRowsPerGroup; ++r) c[r] += __popcll(buf[r][u] & pa);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < kRowsPerGroup; ++r) {
+      int cc = c[r];
+      cc += __shfl_xor(cc, 8, 64);
+      cc += __shfl_xor(cc, 4, 64);
+      cc += __shfl_xor(cc, 2, 64);
+      cc += __shfl_xor(cc, 1, 64);
+      if (v[r] >= 0 && sub == 0 && cc >= csize)
+        atomicOr(reinterpret_cast<unsigned long long*>(&Pb[v[r] >> 6]), 1ull << (v[r] & 63));
+    }
+  }
+}
+
 // Grid (B, batch): B workgroups per problem share the kMaxStarts starts.  Workgroup x begins with start x;
 // further starts come from the problem's queue (ProbState.next_start, initialised to B by the host) until it
 // is empty or the problem is CLOSED: a start whose clique of size c leaves at most c vertices in the peel at
@@ -2183,9 +2241,8 @@ template <int kGreedyThreads>
 __global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
     const ProbDesc* __restrict__ descs, const uint64_t* __restrict__ bitmap,
     const int32_t* __restrict__ deg, ProbState* __restrict__ states,
-    int32_t* __restrict__ start_cliques, int64_t total_n, long long* __restrict__ trace) {
+    int32_t* __restrict__ start_cliques, int64_t total_n) {
   TAIL_WAVE_PRIO();
-  if (trace && threadIdx.x == 0) trace[2 * (blockIdx.y * gridDim.x + blockIdx.x)] = wall_clock64();
   constexpr int kGreedyWaves = kGreedyThreads / 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int next_s;
@@ -2195,8 +2252,6 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
   int sidx = blockIdx.x;
   while (sidx < kMaxStarts) {
     const int csize = greedy_one_start<kGreedyThreads>(descs, bitmap, deg, states, start_cliques, total_n, smem, sidx);
-    if (trace && threadIdx.x == 0 && sidx == (int)blockIdx.x)
-      trace[(size_t)40 * 2 * 4096 + 2 * (blockIdx.y * gridDim.x + blockIdx.x)] = wall_clock64();
     if (gridDim.x >= kMaxStarts) break;  // every start has its own workgroup: nothing left to skip
     // closure test: the peel at threshold csize, in LDS (the start's P / U bitsets are free again)
     const int W = d.W, tid = threadIdx.x;
@@ -2205,18 +2260,20 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
     const uint64_t* bm = bitmap + d.bm_off;
     int cnt = 0;
     __syncthreads();
-    for (int w = tid; w < W; w += kGreedyThreads) {
-      uint64_t bits = 0;
-      const int vmax = min(64, d.n - w * 64);
-      for (int b = 0; b < vmax; ++b) bits |= (uint64_t)(deg[d.pt_off + w * 64 + b] >= csize ? 1 : 0) << b;
-      Pa[w] = bits;
-      cnt += __popcll(bits);
+    // alive = { deg >= csize }: a wave builds a word with ONE coalesced load + ballot (a thread per word read its 64
+    // degrees one by one, 64 different cache lines per wave-level load: ~100 us of this test's 177)
+    for (int w = tid >> 6; w < W; w += kGreedyWaves) {
+      const int v = w * 64 + (tid & 63);
+      const uint64_t bits = __ballot(v < d.n && deg[d.pt_off + v] >= csize);
+      if ((tid & 63) == 0) {
+        Pa[w] = bits;
+        cnt += __popcll(bits);
+      }
     }
     cnt = blockN_sum_i<kGreedyWaves>(cnt, red_c);  // (barriers inside: Pa is visible after)
-    // Only worth trying when the survivors are few.  One THREAD per alive vertex (index list in the LDS region
-    // of the start's compact matrix): each lane walks its own bitmap row word by word against the alive
-    // bitset -- 64 rows in flight per wave, every 128-byte line fetched once and reused 16 times from L1 --
-    // instead of one wave per row (a dependent round trip to L2 per row: 0.7 ms beside K1 in the benchmark).
+    // Only worth trying when the survivors are few.  The alive vertices are listed (index list in the LDS region of
+    // the start's compact matrix) and their bitmap rows counted against the alive bitset, several rows in flight per
+    // wave (one wave per row was a dependent round trip to L2 per row: 0.7 ms beside K1 in the benchmark).
     constexpr int kClosureCap = 4096;
     int* alist = reinterpret_cast<int*>(Pb + ((W + 1) & ~1));  // the A region: >= kCap * kCapStride * 8 bytes
     for (int round = 0; round < 8 && cnt > csize && cnt <= 2 * csize + 256 && cnt <= kClosureCap; ++round) {
@@ -2234,13 +2291,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
         }
       }
       __syncthreads();
-      for (int k = tid; k < cnt; k += kGreedyThreads) {
-        const int v = alist[k];
-        const uint64_t* row = bm + (int64_t)v * W;
-        int c = 0;
-        for (int x = 0; x < W; ++x) c += __popcll(row[x] & Pa[x]);
-        if (c >= csize) atomicOr(reinterpret_cast<unsigned long long*>(&Pb[v >> 6]), 1ull << (v & 63));
-      }
+      closure_round<kGreedyThreads>(bm, W, Pa, Pb, alist, cnt, csize, tid);
       __syncthreads();
       int c2 = 0;
       for (int w = tid; w < W; w += kGreedyThreads) {
@@ -2252,8 +2303,6 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
       if (c2 == cnt) break;  // fixpoint above csize: not closed
       cnt = c2;
     }
-    if (trace && threadIdx.x == 0 && sidx == (int)blockIdx.x)
-      trace[(size_t)40 * 2 * 4096 + 2 * (blockIdx.y * gridDim.x + blockIdx.x) + 1] = wall_clock64();
     if (threadIdx.x == 0) {
       int nx = kMaxStarts;
       if (cnt <= csize) {
@@ -2267,7 +2316,6 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
     sidx = next_s;
     __syncthreads();
   }
-  if (trace && threadIdx.x == 0) trace[2 * (blockIdx.y * gridDim.x + blockIdx.x) + 1] = wall_clock64();
 }
 
 // Per problem: choose the best start (largest clique, ties to the lowest start), emit it SORTED
@@ -2403,66 +2451,15 @@ void launch_heuristic(hipStream_t s, const ProbDesc* d_desc, int batch, int max_
   // TEASER_GREEDY_THREADS=256|512 forces one (diagnostics).
   const char* ev = getenv("TEASER_GREEDY_THREADS");
   const bool wide = ev ? atoi(ev) == 512 : batch <= 16;
-  // diagnostics (TEASER_HEU_TRACE=<file>): per-workgroup start / end clocks (100 MHz) of launches 20 .. 59, dumped once
-  static const char* trace_path = getenv("TEASER_HEU_TRACE");
-  static long long* d_trace = nullptr;
-  static int launch_no = 0;
-  constexpr int kTraceFirst = 20, kTraceCount = 40;
-  long long* trace = nullptr;
-  const int wgs = nblk * batch;
-  if (trace_path) {
-    if (!d_trace) {
-      (void)hipMalloc(&d_trace, (size_t)2 * kTraceCount * 2 * 4096 * sizeof(long long));
-      (void)hipMemset(d_trace, 0, (size_t)2 * kTraceCount * 2 * 4096 * sizeof(long long));
-    }
-    if (wgs <= 4096 && launch_no >= kTraceFirst && launch_no < kTraceFirst + kTraceCount)
-      trace = d_trace + (size_t)(launch_no - kTraceFirst) * 2 * 4096;
-    if (launch_no == kTraceFirst + kTraceCount + 4) {
-      (void)hipDeviceSynchronize();
-      std::vector<long long> h((size_t)2 * kTraceCount * 2 * 4096);
-      (void)hipMemcpy(h.data(), d_trace, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
-      if (FILE* f = fopen(trace_path, "w")) {
-        for (int l = 0; l < kTraceCount; ++l) {
-          long long t0 = -1, last_start = 0, last_end = 0, sum_dur = 0, max_dur = 0, sum_a = 0, sum_b = 0;
-          int cnt = 0;
-          for (int g = 0; g < 4096; ++g) {
-            const long long a = h[((size_t)l * 4096 + g) * 2], b = h[((size_t)l * 4096 + g) * 2 + 1];
-            if (a == 0 || b == 0) continue;
-            if (t0 < 0 || a < t0) t0 = a;
-            ++cnt;
-          }
-          for (int g = 0; g < 4096; ++g) {
-            const long long a = h[((size_t)l * 4096 + g) * 2], b = h[((size_t)l * 4096 + g) * 2 + 1];
-            if (a == 0 || b == 0) continue;
-            last_start = std::max(last_start, a - t0);
-            last_end = std::max(last_end, b - t0);
-            sum_dur += b - a;
-            max_dur = std::max(max_dur, b - a);
-            const long long m1 = h[(size_t)kTraceCount * 2 * 4096 + ((size_t)l * 4096 + g) * 2];
-            const long long m2 = h[(size_t)kTraceCount * 2 * 4096 + ((size_t)l * 4096 + g) * 2 + 1];
-            if (m1) sum_a += m1 - a;
-            if (m1 && m2) sum_b += m2 - m1;
-          }
-          if (cnt)
-            fprintf(f, "launch %d: %d workgroups; last start +%.1f us, last end +%.1f us; workgroup duration mean %.1f us, max %.1f us; "
-                    "first start mean %.1f us, first closure test mean %.1f us\n",
-                    l + kTraceFirst, cnt, last_start * 0.01, last_end * 0.01, sum_dur * 0.01 / cnt, max_dur * 0.01,
-                    sum_a * 0.01 / cnt, sum_b * 0.01 / cnt);
-        }
-        fclose(f);
-      }
-    }
-    ++launch_no;
-  }
   static DynLdsOptIn optin256, optin512;  // beyond the 64 KB default dynamic-LDS limit once W >= ~300
   if (wide) {
     if (lds > 48 * 1024) optin512.ensure(reinterpret_cast<const void*>(greedy_clique_kernel<512>), (int)lds);
     hipLaunchKernelGGL(greedy_clique_kernel<512>, dim3(nblk, batch), dim3(512), lds, s, d_desc, d_bitmap,
-                       d_deg, d_state, d_start_cliques, total_n, trace);
+                       d_deg, d_state, d_start_cliques, total_n);
   } else {
     if (lds > 48 * 1024) optin256.ensure(reinterpret_cast<const void*>(greedy_clique_kernel<256>), (int)lds);
     hipLaunchKernelGGL(greedy_clique_kernel<256>, dim3(nblk, batch), dim3(256), lds, s, d_desc, d_bitmap,
-                       d_deg, d_state, d_start_cliques, total_n, trace);
+                       d_deg, d_state, d_start_cliques, total_n);
   }
 }
 
