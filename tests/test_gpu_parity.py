@@ -283,6 +283,36 @@ def test_scale_float_key_sort_matches_the_64_bit_sort():
     assert [np.float64(v).tobytes() for v in a] == [np.float64(v).tobytes() for v in b]
 
 
+def test_estimate_scaling_degenerate_ties_fall_back_to_the_64_bit_sort():
+    """A lattice cloud and its exact double: every TRIM has the same raw scale (2.0) and the ranges take a few dozen
+    distinct values, so the endpoint keys form runs of tens of thousands of EQUAL float keys -- far beyond what the
+    order-fix kernel repairs in place.  The stage must notice (scale_overflow), the solve must repeat itself with the
+    64-bit sort, and the result must be the one the 64-bit path gives directly (and the oracle's)."""
+    import os
+    g = np.arange(12, dtype=np.float64)
+    src = np.stack(np.meshgrid(g, g, g, indexing="ij"), axis=0).reshape(3, -1) * 0.1   # 1728 points
+    dst = 2.0 * src
+    p = bench_params(estimate_scaling=True, noise_bound=0.01)
+    s = make_solver(**p)
+    os.environ.pop("TEASER_SCALE_SORT64", None)
+    a = s.solve(src, dst)
+    os.environ["TEASER_SCALE_SORT64"] = "1"
+    try:
+        b = s.solve(src, dst)
+    finally:
+        os.environ.pop("TEASER_SCALE_SORT64", None)
+    assert a.valid and b.valid
+    assert np.float64(a.scale).tobytes() == np.float64(b.scale).tobytes()
+    assert abs(a.scale - 2.0) < 1e-9
+    o = oracle.solve(src, dst, **oracle_params(p))
+    assert abs(a.scale - o["scale"]) <= 1e-9
+    # the same inside a batch (mid-size path: composite keys), next to an ordinary problem
+    pr = tp.synth_problem(4711, 1500, 0.7, 0.01)
+    sols = s.solve_batch([src, pr["src"]], [dst, pr["dst"] * 1.25])
+    assert np.float64(sols[0].scale).tobytes() == np.float64(a.scale).tobytes()
+    assert abs(sols[1].scale - 1.25) < 0.05
+
+
 SCALE_DIFF_LOG = []
 
 
