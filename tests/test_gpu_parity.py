@@ -956,6 +956,23 @@ def test_inlier_selection_modes():
         s.solve(pr["src"], pr["dst"])
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_reference_no_max_clique_and_clique_finder_modes(seed):
+    """The reference's own NoMaxClique / CliqueFinderModes tests (registration-test.cc:469-680; inputs restated in
+    tests/reference_cases.py) through the HIP path: the reference's thresholds, and parity with the oracle."""
+    from reference_cases import PARAMS, T_REF, angular_error, case
+    src, tgt, outliers = case(seed)
+    runs = [dict(PARAMS, use_max_clique=False)] + [dict(PARAMS, inlier_selection_mode=m) for m in (0, 1, 2, 3)]
+    for kw in runs:
+        s = make_solver(**kw)
+        sol = s.solve(src, tgt)
+        assert sol.valid
+        assert angular_error(T_REF[:, :3], sol.rotation) <= 0.2
+        assert np.linalg.norm(T_REF[:, 3] - sol.translation) <= 0.1
+        o = oracle.solve(src, tgt, **oracle_params(dict(kw, use_max_clique=int(kw.get("use_max_clique", True)))))
+        check_solution_parity(s, sol, o)
+
+
 # ---------------------------------------------------------------------------------------------
 # FGR / QUATRO rotation estimators (registration.cc:206-408)
 # ---------------------------------------------------------------------------------------------

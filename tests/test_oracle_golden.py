@@ -340,3 +340,22 @@ def test_config_fixture_is_what_the_oracle_returns():
         _, bm = oracle.inlier_bitmap(pr["src"], pr["dst"], 0.01, 1.0, False)
         assert hashlib.sha256(np.ascontiguousarray(bm).tobytes()).hexdigest() == fx["bitmap_sha256"]
     assert fx_all["config3"]["n"] == 50000 and fx_all["config3"]["clique_unique"]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_reference_no_max_clique_and_clique_finder_modes(seed):
+    """registration-test.cc:469-533 (use_max_clique = false) and :535-680 (PMC_EXACT, PMC_HEU, KCORE_HEU, NONE) on the
+    reference's own scenario (tests/reference_cases.py), at the reference's thresholds: rotation within 0.2 rad,
+    translation within 0.1."""
+    from reference_cases import PARAMS, T_REF, angular_error, case
+    src, tgt, outliers = case(seed)
+    runs = [dict(PARAMS, use_max_clique=0)] + [dict(PARAMS, inlier_selection_mode=m) for m in (0, 1, 2, 3)]
+    for kw in runs:
+        o = oracle.solve(src, tgt, **dict(kw, estimate_scaling=0))
+        assert o["valid"]
+        assert angular_error(T_REF[:, :3], np.asarray(o["rotation"]).reshape(3, 3)) <= 0.2
+        assert np.linalg.norm(T_REF[:, 3] - np.asarray(o["translation"]).ravel()) <= 0.1
+        if kw.get("use_max_clique", 1) == 0 or kw.get("inlier_selection_mode") == 3:
+            assert len(o["max_clique"]) == src.shape[1]     # no inlier selection: every correspondence goes on
+        elif kw.get("inlier_selection_mode") in (0, 1):
+            assert o["max_clique"].tolist() == np.flatnonzero(~outliers).tolist()
