@@ -184,24 +184,54 @@ def k1_issue():
     return dict(keep, source=src) if keep else None
 
 
-def cpu_baseline(tp, n, outlier_ratio, nb, seed, max_solves, budget_s, problems=None, extra_kw=None):
-    """Oracle (kind = port: the reference needs Eigen3 + pmc, absent here) on a bounded sample of the
-    same workload, all host cores, built gcc -O3 -fopenmp without -march=native (the reference's
-    default flags, CMakeLists.txt:27).  Two forms, SURVEY.md 8(d): (i) STREAMING -- no TIM storage,
-    adjacency bitmap: the faster one, reported as `value`; (ii) REFERENCE-FAITHFUL -- materialises both
-    3 x M TIM matrices, index maps, norm vectors and the bool mask and builds the vector-of-vectors graph
-    with the duplicate-edge scan, as registration.cc:512-551, 427-443, 614-619 do."""
-    from oracle import oracle
+def host_cpu_info():
+    """What the host really gives this process: os.cpu_count() is the machine, the scheduler affinity mask and the
+    cgroup CPU quota are the lease (a 256-thread OpenMP team on a quota of a few cores runs like one slow core)."""
+    info = {"os_cpu_count": os.cpu_count() or 1}
+    try:
+        info["sched_affinity"] = len(os.sched_getaffinity(0))
+    except Exception:
+        info["sched_affinity"] = info["os_cpu_count"]
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                info["cgroup_cpu_max"] = " ".join(txt)
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                info["cgroup_cpu_max"] = "%d %d" % (q, per)
+                if q > 0:
+                    quota = q / per
+            break
+        except Exception:
+            continue
+    eff = min(info["os_cpu_count"], info["sched_affinity"])
+    if quota:
+        eff = max(1, min(eff, int(quota + 0.5)))
+    info["effective_cores"] = eff
+    return info
 
-    cores = os.cpu_count() or 1
-    kw = dict(noise_bound=nb, cbar2=1.0, estimate_scaling=0, rotation_gnc_factor=1.4,
-              rotation_max_iterations=100, rotation_cost_threshold=0.005, max_clique_num_threads=cores)
-    kw.update(extra_kw or {})
+
+def _cpu_worker(spec_path):
+    """`bench.py --cpu-worker spec.json` (a subprocess of cpu_baseline, with OMP_NUM_THREADS / OMP_PROC_BIND in its
+    environment): times the oracle on the spec's sample and prints one JSON line."""
+    from oracle import oracle
+    spec = json.load(open(spec_path))
+    tp = importlib.import_module("teaser-plusplus_amd")
+    problems = None
+    if spec.get("problems_npz"):
+        z = np.load(spec["problems_npz"])
+        problems = [(z["s%d" % i], z["d%d" % i]) for i in range(int(z["count"]))]
+    kw = spec["kw"]
 
     def problem(i):
         if problems is not None:
             return problems[i % len(problems)]
-        pr = tp.synth_problem(seed + 100000 + i, n, outlier_ratio, nb)
+        pr = tp.synth_problem(spec["seed"] + 100000 + i, spec["n"], spec["rho"], spec["nb"])
         return pr["src"], pr["dst"]
 
     def run(materialise, count, budget):
@@ -218,24 +248,89 @@ def cpu_baseline(tp, n, outlier_ratio, nb, seed, max_solves, budget_s, problems=
         return times
 
     run(False, 1, 0.0)  # warm-up (OpenMP pool, page faults)
-    ts = run(False, max_solves, budget_s)
+    out = {"stream": run(False, spec["max_solves"], spec["budget_s"])}
+    if spec.get("materialise"):
+        out["mat"] = run(True, 2, min(spec["budget_s"], 8.0))
+    print(json.dumps(out))
+
+
+_CPU_STATE = {}
+
+
+def cpu_baseline(tp, n, outlier_ratio, nb, seed, max_solves, budget_s, problems=None, extra_kw=None):
+    """Oracle (kind = port: the reference needs Eigen3 + pmc, absent here) on a bounded sample of the
+    same workload, built gcc -O3 -fopenmp without -march=native (the reference's default flags,
+    CMakeLists.txt:27).  Two forms, SURVEY.md 8(d): (i) STREAMING -- no TIM storage, adjacency bitmap: the faster one,
+    reported as `value`; (ii) REFERENCE-FAITHFUL -- materialises both 3 x M TIM matrices, index maps, norm vectors and
+    the bool mask and builds the vector-of-vectors graph with the duplicate-edge scan, as registration.cc:512-551,
+    427-443, 614-619 do.  Threads: every measurement runs in its own subprocess with OMP_NUM_THREADS = k and
+    OMP_PROC_BIND = close; the first call sweeps k over powers of two up to the machine's thread count and prints the
+    whole sweep (`thread_sweep`), `value` is the best k's rate and `cores` that k; later calls reuse the best k."""
+    import subprocess
+    import tempfile
+
+    info = _CPU_STATE.setdefault("info", host_cpu_info())
+    kw = dict(noise_bound=nb, cbar2=1.0, estimate_scaling=0, rotation_gnc_factor=1.4,
+              rotation_max_iterations=100, rotation_cost_threshold=0.005)
+    kw.update(extra_kw or {})
+    pairs = n * (n - 1) // 2
+    tmpdir = tempfile.mkdtemp(prefix="teaser_cpu_")
+    spec = dict(n=n, rho=outlier_ratio, nb=nb, seed=seed, max_solves=max_solves, budget_s=budget_s, kw=kw)
+    if problems is not None:
+        arrs = {"count": len(problems)}
+        for i, (s_, d_) in enumerate(problems):
+            arrs["s%d" % i], arrs["d%d" % i] = s_, d_
+        spec["problems_npz"] = os.path.join(tmpdir, "problems.npz")
+        np.savez(spec["problems_npz"], **arrs)
+
+    def measure(threads, solves, budget, materialise):
+        sp = dict(spec, max_solves=solves, budget_s=budget, materialise=materialise)
+        sp["kw"] = dict(kw, max_clique_num_threads=threads)
+        path = os.path.join(tmpdir, "spec_%d.json" % threads)
+        json.dump(sp, open(path, "w"))
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), OMP_PROC_BIND="close", OMP_PLACES="cores")
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", path], env=env,
+                           capture_output=True, text=True, timeout=600)
+        if r.returncode != 0:
+            raise RuntimeError("cpu worker failed: " + r.stderr[-400:])
+        return json.loads(r.stdout.strip().splitlines()[-1])
+
+    sweep = None
+    if "best_threads" not in _CPU_STATE:
+        cand = [k for k in (1, 8, 16, 32, 64, 128, 256, 512) if k <= info["os_cpu_count"]]
+        if info["effective_cores"] not in cand:
+            cand.append(info["effective_cores"])
+        sweep = {}
+        for k in sorted(set(cand)):
+            ts = measure(k, 3, 4.0, False)["stream"]
+            sweep[str(k)] = round(1e3 * float(np.median(ts)), 2)
+        _CPU_STATE["best_threads"] = int(min(sweep, key=lambda k: sweep[k]))
+    threads = _CPU_STATE["best_threads"]
+    res = measure(threads, max_solves, budget_s, pairs * 81 < 24e9)
+    ts = res["stream"]
     med = float(np.median(ts))
     what = ("N=%d, %.0f%% outliers" % (n, 100 * outlier_ratio)) if problems is None else \
         "%d-%d correspondences (real descriptors)" % (min(p[0].shape[1] for p in problems),
                                                       max(p[0].shape[1] for p in problems))
-    out = {"value": 1.0 / med, "unit": "registrations/s", "cores": cores, "kind": "port",
+    out = {"value": 1.0 / med, "unit": "registrations/s", "cores": threads, "kind": "port", "host": info,
            "sample": "%d solves of this workload (%s), median %.1f ms each, streaming oracle (no TIM storage), "
-                     "gcc -O3 -fopenmp without -march=native, OMP threads = %d" % (len(ts), what, 1e3 * med, cores)}
-    pairs = n * (n - 1) // 2
-    if pairs * 81 < 24e9:  # the materialised form needs ~81 B per pair of host memory
-        tm = run(True, 2, min(budget_s, 8.0))
-        mm = float(np.median(tm))
+                     "gcc -O3 -fopenmp without -march=native, OMP_NUM_THREADS = %d (the best of the sweep), "
+                     "OMP_PROC_BIND = close" % (len(ts), what, 1e3 * med, threads)}
+    if sweep is not None:
+        out["thread_sweep"] = {"ms_per_solve_by_threads": sweep,
+                               "note": "median of 3 solves per thread count, one subprocess each; the host reports "
+                                       "%d hardware threads, affinity %d, cgroup cpu.max %r" %
+                                       (info["os_cpu_count"], info["sched_affinity"], info.get("cgroup_cpu_max"))}
+    if "mat" in res:
+        mm = float(np.median(res["mat"]))
         out["reference_faithful"] = {
             "value": 1.0 / mm, "unit": "registrations/s",
             "sample": "%d solves, median %.1f ms each, TIMs materialised (~%.2f GB), serial mask and "
-                      "vector-of-vectors graph build as the reference" % (len(tm), 1e3 * mm, pairs * 81 / 1e9)}
+                      "vector-of-vectors graph build as the reference" % (len(res["mat"]), 1e3 * mm, pairs * 81 / 1e9)}
     else:
         out["reference_faithful"] = {"value": None, "sample": "infeasible: ~%.0f GB of TIM storage" % (pairs * 81 / 1e9)}
+    import shutil
+    shutil.rmtree(tmpdir, ignore_errors=True)
     return out
 
 
@@ -489,6 +584,8 @@ def synth_workload(tp, args, rank, tag, B, n, rho, n_batches, cpu_solves, cpu_bu
 
 
 def main():
+    if len(sys.argv) >= 3 and sys.argv[1] == "--cpu-worker":
+        return _cpu_worker(sys.argv[2])
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:
         relaunch_as_ranks(args)  # does not return

@@ -1,0 +1,109 @@
+#!/bin/bash
+# ONE parameterised GPU-box script (run through gpurun):   bash scripts/gpu.sh <tag> <task> [<task> ...]
+# Every task runs under its own `timeout`; outputs go to gpurun_out/<tag>/ (merged back by gpurun).
+#   smoke            __graft_entry__.smoke()
+#   k1probe          K1 alone: variants -1 / 11..15 on 64 x 10 k (HIP events, bitmap hashes must agree)
+#   k1tests          the K1 / bitmap parity tests only
+#   tests:<expr>     pytest -m gpu -k <expr>
+#   suite            the whole GPU suite as the driver runs it
+#   bench            python bench.py (the default command)      benchq: headline only, no CPU baseline
+#   benchprof        the headline command under rocprofv3 --kernel-trace --stats (--no-latency)
+#   k1pmc            K1 probe under rocprofv3: kernel trace, SQ counter sets, FETCH_SIZE, WRITE_SIZE (separate runs)
+#   cliquepmc        LDS / VMEM counters of the clique-stage kernels on config 5 (single + batched) and config 3
+#   c3prof, c5prof   rocprofv3 --kernel-trace --stats of one config-3 / config-5 run
+#   stages           per-stage HIP-event times (scripts/profile_stages.py [+ big])
+#   scale            estimate_scaling = true at N = 10 k (scripts/profile_scale.py)
+#   pipe             k1_probe pipe mode (depths / schedules)
+TAG=${1:-x}; shift
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/$TAG
+export TMPDIR=/tmp
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
+R=$GRAFT_REPO_ROOT
+P=$R/scripts/probe/k1_probe
+SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"
+SQ2="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA SQ_WAVES"
+LDS1="SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU"
+LDS2="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_WAVES SQ_BUSY_CYCLES"
+CLIQUE_KERNELS="exact_clique_kernel,colour_assign_kernel,colour_resolve_kernel,colour_round_kernel,colour_persistent_kernel,greedy_clique_kernel,peel_round_kernel,tail_fused_kernel"
+
+prof() {  # prof <dir> <rocprofv3 args...> -- <cmd...>: rocprofv3 from /tmp, csv output into $OUT/<dir>
+  local d=$1; shift
+  (cd /tmp && timeout 300 rocprofv3 "$@") > $OUT/$d.log 2>&1; echo "$d rc=$?"
+}
+for task in "$@"; do
+  echo "=== $task"
+  case $task in
+    smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
+    k1probe) timeout 200 $P 64 10000 10 k1 > $OUT/probe_k1.jsonl 2> $OUT/probe_k1.err; echo "rc=$?"; cat $OUT/probe_k1.jsonl; tail -3 $OUT/probe_k1.err ;;
+    k1probe4) timeout 200 $P 128 5000 10 k1 0.9 > $OUT/probe_k1_128x5k.jsonl 2>/dev/null; cat $OUT/probe_k1_128x5k.jsonl ;;
+    pipe) timeout 300 $P 64 10000 30 pipe > $OUT/probe_pipe.jsonl 2>/dev/null; cat $OUT/probe_pipe.jsonl ;;
+    k1tests) timeout 600 python -m pytest tests -m gpu -q -x -k "k1 or config2 or config3 or config4 or fixture" > $OUT/k1tests.txt 2>&1; echo "rc=$?"; tail -5 $OUT/k1tests.txt ;;
+    tests:*) timeout 900 python -m pytest tests -m gpu -q -x -k "${task#tests:}" > $OUT/tests_sel.txt 2>&1; echo "rc=$?"; tail -8 $OUT/tests_sel.txt ;;
+    suite) SECONDS=0; TEASER_CERT_DEBUG=$OUT/cert_warmup.txt timeout 1500 python -m pytest tests/ -x -q -m gpu --durations=12 > $OUT/gpu_tests.txt 2>&1; echo "suite rc=$? in ${SECONDS}s"; tail -22 $OUT/gpu_tests.txt ;;
+    bench) timeout 1200 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "rc=$?"; cut -c1-700 $OUT/bench.json; tail -3 $OUT/bench.err ;;
+    benchq) timeout 400 python bench.py --configs '' --no-cpu-baseline > $OUT/benchq.json 2> $OUT/benchq.err; echo "rc=$?"; cut -c1-500 $OUT/benchq.json; tail -3 $OUT/benchq.err ;;
+    bench4) timeout 600 python bench.py --configs 4 --no-cpu-baseline > $OUT/bench4.json 2> $OUT/bench4.err; echo "rc=$?"; python - <<PY
+import json
+d=json.loads(open("$OUT/bench4.json").read().strip().splitlines()[-1])
+print("top", round(d["value"]), d["ms_per_step"], d["config"].get("host_resident",{}))
+c=d["configs"]["config4"]; print("c4", round(c["value"]), c["ms_per_step"], c.get("host_resident"), c["stage_ms"])
+PY
+      ;;
+    benchprof)
+      prof bench_prof --kernel-trace --stats --output-format csv -d $OUT/bench_prof -o t -- python $R/bench.py --configs '' --no-cpu-baseline --no-latency --no-host-resident
+      grep '^{' $OUT/bench_prof.log | tail -1 > $OUT/bench_under_rocprof.json
+      cp $(find $OUT/bench_prof -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv; head -14 $OUT/bench_kernel_stats.csv | cut -c1-150 ;;
+    k1pmc)
+      K="$P 64 10000 5 one"
+      prof kt --kernel-trace --output-format csv -d $OUT/kt -o t -- $K
+      prof sq1 --pmc $SQ1 --output-format csv -d $OUT/sq1 -o t -- $K
+      prof sq2 --pmc $SQ2 --output-format csv -d $OUT/sq2 -o t -- $K
+      prof fetch --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o t -- $K
+      prof write --pmc WRITE_SIZE --output-format csv -d $OUT/write -o t -- $K
+      python scripts/summarize_pmc.py $(find $OUT/fetch -name "*counter_collection.csv") $(find $OUT/write -name "*counter_collection.csv") $OUT/pmc_traffic.json 64 10000 | grep -i "tim_graph"
+      python scripts/summarize_k1.py $OUT/k1_sq_counters.json 64 10000 $(find $OUT/kt -name "*kernel_trace.csv") $(find $OUT/sq1 -name "*counter_collection.csv") $(find $OUT/sq2 -name "*counter_collection.csv") | cut -c1-700 ;;
+    cliquepmc)
+      i=0
+      for set in "$LDS1" "$LDS2"; do
+        i=$((i+1))
+        prof c5_lds$i --pmc $set --output-format csv -d $OUT/c5_lds$i -o t -- python $R/scripts/profile_config5.py
+        prof c5b_lds$i --pmc $set --output-format csv -d $OUT/c5b_lds$i -o t -- python $R/scripts/profile_config5.py batch
+        prof c3_lds$i --pmc $set --output-format csv -d $OUT/c3_lds$i -o t -- python $R/scripts/profile_stages.py big
+      done
+      for w in c5 c5b c3; do
+        python scripts/summarize_counters.py $OUT/clique_lds_counters.json $w $CLIQUE_KERNELS $(find $OUT/${w}_lds1 $OUT/${w}_lds2 -name "*counter_collection.csv") | cut -c1-400
+      done ;;
+    c3prof)
+      prof c3_prof --kernel-trace --stats --output-format csv -d $OUT/c3_prof -o t -- python $R/scripts/profile_stages.py big
+      grep '^{' $OUT/c3_prof.log > $OUT/config3_stages.jsonl; cat $OUT/config3_stages.jsonl | cut -c1-500
+      cp $(find $OUT/c3_prof -name "*kernel_stats.csv" | head -1) $OUT/config3_kernel_stats.csv; head -16 $OUT/config3_kernel_stats.csv | cut -c1-150 ;;
+    c5prof)
+      prof c5_prof --kernel-trace --stats --output-format csv -d $OUT/c5_prof -o t -- python $R/scripts/profile_config5.py batch
+      grep '^{' $OUT/c5_prof.log > $OUT/config5.jsonl; cat $OUT/config5.jsonl | cut -c1-600
+      cp $(find $OUT/c5_prof -name "*kernel_stats.csv" | head -1) $OUT/config5_kernel_stats.csv; head -14 $OUT/config5_kernel_stats.csv | cut -c1-150 ;;
+    c5) timeout 300 python scripts/profile_config5.py batch > $OUT/config5_run.jsonl 2> $OUT/config5_run.err; echo "rc=$?"; cut -c1-600 $OUT/config5_run.jsonl; grep -i "k4\|exact" $OUT/config5_run.err | tail -5 ;;
+    stages) timeout 300 python scripts/profile_stages.py > $OUT/stages.log 2>&1; timeout 200 python scripts/profile_stages.py big >> $OUT/stages.log 2>&1; grep '^{' $OUT/stages.log > $OUT/stages.jsonl; cut -c1-420 $OUT/stages.jsonl ;;
+    scale) timeout 400 python scripts/profile_scale.py > $OUT/scale.jsonl 2> $OUT/scale.err; echo "rc=$?"; cut -c1-400 $OUT/scale.jsonl ;;
+    k1occ)  # K1 alone at 1 / 2 / 3 workgroups per CU (unused dynamic LDS limits the occupancy)
+      for v in 20 23; do for pad in 0 30000 60000; do
+        TEASER_K1_VARIANT=$v TEASER_K1_LDS_PAD=$pad timeout 60 $P 64 10000 5 one 2>/dev/null | sed "s/^{/{\"lds_pad\":$pad,\"v\":$v,/" | cut -c1-140
+      done; done | tee $OUT/k1_occupancy.jsonl ;;
+    valurate) timeout 300 $R/scripts/probe/valu_rate 2.0 > $OUT/valu_rate.jsonl 2>&1; echo "rc=$?"; python - <<PY
+import json
+rows=[json.loads(l) for l in open("$OUT/valu_rate.jsonl") if l.startswith("{") and "inst" in l]
+print("%-32s %7s %7s %7s | %7s %7s %7s  (cycles per instruction per SIMD at 2.0 GHz: indep / dep / indep+mfma at 1 and 3 waves)" % ("inst","1w","1w dep","1w+mf","3w","3w dep","3w+mf"))
+names=[]
+for r in rows:
+    if r["inst"] not in names: names.append(r["inst"])
+for n in names:
+    g={(r["waves_per_simd"],r["dependent"],r["with_mfma"]):r for r in rows if r["inst"]==n}
+    f=lambda w,d,m: g[(w,d,m)]["cycles_per_inst_per_simd"] if (w,d,m) in g else float("nan")
+    print("%-32s %7.2f %7.2f %7.2f | %7.2f %7.2f %7.2f" % (n,f(1,0,0),f(1,1,0),f(1,0,1),f(3,0,0),f(3,1,0),f(3,0,1)))
+PY
+      ;;
+    timeline)
+      prof tl --kernel-trace --output-format csv -d $OUT/tl -o t -- python $R/bench.py --configs '' --no-cpu-baseline --no-latency --no-host-resident --steps 12
+      python scripts/trace_timeline.py $(find $OUT/tl -name "*kernel_trace.csv" | head -1) > $OUT/timeline.txt 2>&1; tail -60 $OUT/timeline.txt | cut -c1-200 ;;
+    *) echo "unknown task $task" ;;
+  esac
+done

@@ -45,3 +45,27 @@ print(json.dumps(dict(config=5, points=[len(A), len(B)], correspondences=len(cor
                       heuristic=raw.heuristic_size, exact_run=raw.clique_exact_run, edges=raw.num_edges,
                       front_end_ms=round(1e3 * (t1 - t0), 3), solve_wall_ms=round(1e3 * float(np.median(walls)), 3),
                       **med)))
+
+if len(sys.argv) > 1 and sys.argv[1] == "batch":
+    # the bench's batched config-5 step: 64 perturbed copies of the pair, each with its own FPFH correspondences
+    import argparse
+    import bench
+    solver, wl = bench.config5_workload(tp, argparse.Namespace(seed=20250523, noise_bound=vox), 0, 64, 1)
+    src, dst = wl["pool"][0]
+    offs, szs = wl["offsets"][0], wl["sizes"][0]
+    srcs = [np.ascontiguousarray(src[o:o + m].T) for o, m in zip(offs, szs)]
+    dsts = [np.ascontiguousarray(dst[o:o + m].T) for o, m in zip(offs, szs)]
+    solver.solve_batch(srcs, dsts)
+    solver.set_profiling(True)
+    walls, profs = [], []
+    for _ in range(5):
+        t2 = time.perf_counter()
+        out = solver.solve_batch(srcs, dsts)
+        walls.append(time.perf_counter() - t2)
+        profs.append(solver.get_profile())
+    med = {k: round(float(np.median([q[k] for q in profs])), 4) for k in profs[0]}
+    cl = [int(solver.raw_solution(b).clique_size) for b in range(len(srcs))]
+    ex = [int(solver.raw_solution(b).clique_exact_run) for b in range(len(srcs))]
+    print(json.dumps(dict(config="5 batched", problems=len(srcs), sizes=[int(szs.min()), int(szs.max())],
+                          clique_min_max=[min(cl), max(cl)], exact_runs=sum(ex),
+                          step_wall_ms=round(1e3 * float(np.median(walls)), 3), **med)))

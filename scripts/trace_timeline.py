@@ -11,7 +11,7 @@ def short(n):
 ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), int(r["Stream_Id"])) for r in rows]
 ev.sort()
 t0 = ev[0][0]
-k1 = [e for e in ev if e[2] == "tim_graph_mfma_kernel"]
+k1 = [e for e in ev if e[2].startswith("tim_graph_mfma")]
 print("K1 launches", len(k1))
 per = [(k1[i + 1][0] - k1[i][0]) / 1e3 for i in range(len(k1) - 1)]
 print("K1 start-to-start us:", " ".join("%.0f" % p for p in per))

@@ -621,7 +621,9 @@ constexpr int kMfmaRowTiles = 4;
 constexpr int kMfmaColTiles = 8;
 
 constexpr int kWorkBuf = 64 * 6;  // per-wave LDS staging (the FP64 path's column buffer): 384 items
-constexpr int kRegionWords = 32;  // u / w kernel: every wave owns a region of the worklist: a count word + 31 items
+// u / w kernels: every wave owns a region of the worklist: a count word + 63 items (the constant band of the third
+// formulation flags ~23 lane-tiles per wave at the bench geometry; 31 slots sent 4 % of the waves through the atomic)
+constexpr int kRegionWords = 64;
 constexpr int kRegionItems = kRegionWords - 1;
 
 // item = prob << 32 | row << 16 | col  (n <= 65536).  The worklist is cut into one segment of `cap` items per
@@ -1569,6 +1571,583 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma2_kernel(
   }
 }
 
+// ==========================================================================================
+// K1, third formulation ("min |d|"): the u / w algebra and operands of the second one, with the error band taken
+// off the per-pair path.  Per accumulator value the VALU now issues 2.5 instructions instead of 6:
+//   d = fma(u, u, w)                         (the provisional edge bit is sign(d), collected by one v_alignbit)
+//   m = min3(m, |d_0|, |d_1|)                (one v_min3_f32 per two values: the smallest |d| of the lane's 16 pairs
+//                                             of a 32 x 32 tile)
+// and ONE compare per lane and tile decides whether any of those 16 pairs could lie inside the error band
+// (m <= C).  Such a lane-tile is a GROUP item for the FP64 fix-up: (problem, column, 16 rows 4h + (q & 3) + 8 (q >> 2)
+// of a 32-row half tile); tim_fixup_group_kernel evaluates the reference expression for all 16 pairs and flips the
+// bits (and degrees) that differ from the provisional ones.  Nothing is parked in LDS: the lane's group flags of
+// the whole block row (8 column tiles x 4 half tiles = 32 bits) live in one register.
+//
+// The band is a CONSTANT per problem (WBAND = false) or the second formulation's K2 |w| + K0 (WBAND = true, one
+// more fma per value).  Constant band, in the scaled system of the second formulation (eps_u, eps_w = kappa eps_A
+// as there; u~ = u* + e_u, w~ = w* + e_w, d~ = fl(u~^2 + w~)):  |w*| <= kappa (2R)^2 = (4 beta R)^2 =: Wm.
+//   (A) |u*| <= U0 := 4 beta R (1 + 1e-3) + 2 eps_u:  |u~^2 + w~ - d*| <= 2 U0 eps_u + eps_u^2 + eps_w =: E, so
+//       |d~| > C >= (E + G) / (1 - 4u) implies sign(d~) = sign(d*) and |d*| > G (the gap between the reference's
+//       rounded double predicate and the exact one);
+//   (B) |u*| >  U0:  d* >= U0^2 - Wm > 0 (not an edge), and u~^2 + w~ >= (U0 - eps_u)^2 - Wm - eps_w > 0 as well
+//       (eps_w = 5200 u beta^2 R^2 << 2e-3 Wm): the provisional bit is right whatever |d~| is.
+//   Short pairs (S <= beta, the one region where the sign of d misleads) have |d~| <= short_d <= C: always a group.
+// Self pairs (u = -beta^2, w = 0, d = beta^4 <= C) would flag every lane of a diagonal tile: the diagonal column tile
+// of a wave runs a second copy of the loop body that leaves them out of the minimum.
+// ==========================================================================================
+struct Mfma3Const {
+  float K2, K0, C;
+  int use_mfma;
+};
+__device__ __forceinline__ Mfma3Const mfma3_consts(double beta_d, unsigned int r2_bits) {
+  const Mfma2Const c2 = mfma2_consts(beta_d, r2_bits);
+  Mfma3Const c;
+  c.K2 = c2.K2;
+  c.K0 = c2.K0;
+  double g;
+  int kexp;
+  tim2_scale(beta_d, &g, &kexp);
+  const float u = 5.9604644775390625e-8f;  // 2^-24
+  const float up = 1.000001f;
+  const float beta = (float)(beta_d * g) * up;
+  const float kappa = (float)pow2_d(kexp);
+  const float R2 = __uint_as_float(r2_bits) * up;
+  const float R = __builtin_sqrtf(R2) * up;
+  const float b2 = 0.25f * kappa;
+  const float eps_u = kEpsU2 * u * R2 * up;
+  const float eps_w = kappa * (kEpsA2 * u * R2 * up) * up;
+  const float U0 = (4.0f * beta * R * 1.001f + 2.0f * eps_u) * up;
+  const float G = (1.3e-13f * beta * R2 * R + 8e-15f * b2 * R2) * up;
+  const float E = (2.0f * U0 * eps_u + eps_u * eps_u + eps_w + G) * up;
+  const float C0 = E / (1.0f - 4.0f * u) * 1.001f * up;
+  const float short_d = (4.0f * b2 * b2 * (1.0f + 16.0f * u) + 4.0f * b2 * eps_u + eps_u * eps_u + eps_w) * 1.001f * up;
+  c.C = (C0 > short_d ? C0 : short_d) * 1.00001f;
+  // (same admission as the second formulation; a band dominated by the short-pair term would flag most lane-tiles)
+  c.use_mfma = (c2.use_mfma && c.C == c.C && c.C < 1e30f && short_d <= 16.0f * C0) ? 1 : 0;
+  return c;
+}
+
+constexpr unsigned long long kGroupItem = 1ull << 63;  // worklist item: 16 rows of one column (tim_fixup_group_kernel)
+
+// BAND: 0 = constant band C; 1 = K2 |w| + K0 per value (one more fma per value); 2 = K2 max|w| + K0 with the
+// largest |w| of the lane-tile's 16 values (one more v_min3 per two values).
+// PIPE: software-pipelined schedule.  The wave works on QUARTER tiles (32 x 32) with two accumulator sets: while the
+// matrix pipe runs the four MFMAs of quarter k + 1, the vector ALU runs the epilogue of quarter k -- interleaved
+// inside the one wave (sched_group_barrier: one MFMA, then a share of the epilogue), across the column tiles of the
+// loop as well.  The flat schedule (PIPE = false: 8 MFMAs, then both epilogues) relies on the other two waves of the
+// SIMD to fill the matrix pipe's shadow, and the counters say they do not: VALU 60 % + MFMA 25 % busy, hardly
+// overlapping (profiles/r4a).
+template <int BAND, bool PIPE, int OCC, int DEFER>
+__global__ __launch_bounds__(256, OCC) void tim_graph_mfma3_kernel(
+    const ProbDesc* __restrict__ descs, const double* __restrict__ src,
+    const double* __restrict__ dst, const TimOperandTile2* __restrict__ ops, const TimPrep* __restrict__ prep,
+    uint64_t* __restrict__ bitmap, double beta, int gyr,
+    unsigned long long* __restrict__ work, unsigned int* __restrict__ work_count, unsigned int work_cap,
+    ProbState* __restrict__ states, int32_t* __restrict__ deg, unsigned long long* __restrict__ regions,
+    int xcd_remap) {
+  const ProbDesc d = descs[blockIdx.y];
+  const int n = d.n, W = d.W;
+  const int T = W;
+  // block decode: as tim_graph_mfma2_kernel (triangular grid, XCD-aware order)
+  int Ig = blockIdx.x, X = 0;
+  if (xcd_remap) {
+    const int nb = gridDim.x, c = blockIdx.x & 7, q = nb >> 3, rem = nb & 7;
+    Ig = c * q + min(c, rem) + (blockIdx.x >> 3);
+  }
+  while (Ig >= min(gyr, 2 * X + 2)) {
+    Ig -= min(gyr, 2 * X + 2);
+    ++X;
+  }
+  const int I0 = Ig * kMfmaRowTiles, Jbase = X * kMfmaColTiles;
+  unsigned long long* const region =
+      regions + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kMfmaRowTiles + (threadIdx.x >> 6)) * kRegionWords;
+  if (I0 >= T || Jbase >= T || Jbase + kMfmaColTiles - 1 < I0) {  // outside / below the diagonal
+    if ((threadIdx.x & 63) == 0) region[0] = 0ull;
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int I = I0 + wave;
+
+  const double* __restrict__ ps = src + 3 * d.pt_off;
+  const double* __restrict__ pd = dst + 3 * d.pt_off;
+  uint64_t* __restrict__ bm = bitmap + d.bm_off;
+  // ONE LDS array (18 KB per workgroup): the wave's own words of all its column tiles, staged so that every global
+  // store covers whole 64-byte runs.  The FP64 body's column buffer and the group-item staging of the harvest reuse
+  // the wave's slice (neither is live together with the own words).
+  __shared__ __attribute__((aligned(16))) uint64_t lds_own[kMfmaRowTiles][64][kMfmaColTiles + 1];  // +1: conflict-free
+  static_assert(sizeof(lds_own[0]) >= sizeof(double) * 64 * 6 && sizeof(lds_own[0]) >= 8 * kWorkBuf, "aliased buffers");
+  // DEFER = 1: the transposed words of the whole block row are parked here ([column tile][row][wave]: the four
+  // waves' words of a bitmap row are 32 contiguous bytes) and written behind the loop, so that the loop's only
+  // vector-memory operations are the operand loads.  (DEFER = 0 stores them per column tile: a 64-line scattered
+  // store + a degree atomic per wave and tile, and since gfx9 counts loads and stores on ONE in-order vmcnt, every
+  // other operand wait of the loop also waited for their acknowledgement.  DEFER = 2: timing build, they are dropped.)
+  __shared__ __attribute__((aligned(16))) uint64_t lds_tr[DEFER == 1 ? kMfmaColTiles : 1][64][kMfmaRowTiles];
+  const Mfma3Const mc = mfma3_consts(beta, prep[blockIdx.y].r2_bits);
+  if (!__builtin_amdgcn_readfirstlane(mc.use_mfma)) {  // per problem: uniform over the block
+    EdgeConst kc;
+    kc.beta = beta;
+    kc.beta2 = beta * beta;
+    kc.m2beta2 = -2.0 * kc.beta2;
+    kc.beta4 = kc.beta2 * kc.beta2;
+    kc.s_hat = 1.0;
+    if (I < T)
+      for (int jb = Jbase; jb < Jbase + kMfmaColTiles; jb += kColTilesPerWave)
+        if (!(jb + kColTilesPerWave - 1 < I || jb >= T))
+          tim_wave_fp64<0>(ps, pd, bm, n, W, I, jb, kc, reinterpret_cast<double*>(&lds_own[wave][0][0]));
+    if (lane == 0) region[0] = 0ull;
+    return;
+  }
+  const TimOperandTile2* __restrict__ qt = ops + d.w_off;
+  const int h = lane >> 5, c = lane & 31;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t q_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)qt, 0, (int)((unsigned int)T * (unsigned int)sizeof(TimOperandTile2)), 0x00020000);
+  auto load_op = [&](int tile, int side, int g, int m) -> uint4 {  // side 0 = a (rows), 1 = b; m = MFMA 0..3
+    const int soff = tile * (int)sizeof(TimOperandTile2) + side * (int)sizeof(TimOperandTile2) / 2 + (g * 4 + m) * 1024;
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(q_rsrc, lane * 16, soff, 0);
+    return make_uint4(v.x, v.y, v.z, v.w);
+  };
+  bf16x8 ar[2][4];
+  {
+    const int It = min(I, T - 1);
+    for (int rt = 0; rt < 2; ++rt)
+      for (int m = 0; m < 4; ++m) ar[rt][m] = __builtin_bit_cast(bf16x8, load_op(It, 0, rt, m));
+  }
+  const bool rowvalid = I < T;
+  const uint64_t rowmask = !rowvalid ? 0ull : (n - I * 64 >= 64) ? ~0ull : ((1ull << (n - I * 64)) - 1ull);
+  const int Jfirst = max(Jbase, I), Jend = min(Jbase + kMfmaColTiles, T);
+  uint4 bX[4], bY[4];  // column operands: X = the tile's first 32 columns (ct 0), Y = the other 32 (PIPE only)
+  {
+    const int Jf = min(Jfirst, T - 1);
+    for (int m = 0; m < 4; ++m) bX[m] = load_op(Jf, 1, 0, m);
+    if (PIPE)
+      for (int m = 0; m < 4; ++m) bY[m] = load_op(Jf, 1, 1, m);
+  }
+  const __amdgpu_buffer_rsrc_t deg_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(deg + d.pt_off), 0, (int)((unsigned int)n * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t bm_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)bm, 0, (int)((unsigned int)n * (unsigned int)W * 8u), 0x00020000);
+  int degacc = 0;
+  // What column tile Jp leaves in global memory besides the own words: the wave's transposed words (lane = row
+  // Jp * 64 + lane, word I) and the degree contributions of their bits -- always ONE buffer store + ONE no-return
+  // buffer atomic per lane (nothing to do => out-of-range offset, dropped by the hardware), issued at the end of
+  // iteration Jp behind the operand loads already in flight, so that the compiler's vmcnt bookkeeping is exact (the
+  // same two dummies are issued before the loop: both edges into it agree).
+  auto flush_tr = [&](int Jp, uint64_t w_own, bool have) {
+    const int cnt = have ? __builtin_popcountll(w_own) : 0;
+    const u32x2 dw = {(unsigned int)w_own, (unsigned int)(w_own >> 32)};
+    unsigned int off = (have && Jp * 64 + lane < n)
+                           ? ((unsigned int)(Jp * 64 + lane) * (unsigned int)W + (unsigned int)I) * 8u
+                           : kOobOffset;
+    __builtin_amdgcn_raw_buffer_store_b64(dw, bm_rsrc, off, 0, 0);
+    unsigned int aoff = cnt ? (unsigned int)(Jp * 64 + lane) * 4u : kOobOffset;
+    __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(cnt, deg_rsrc, aoff, 0, 0);
+  };
+  // the value of a diagonal 32 x 32 tile (ct == rt) that is this lane's self pair: row 4h + (q & 3) + 8 (q >> 2) == c
+  const int cq = c - 4 * h;
+  const int selfq = (cq >= 0 && (cq & 4) == 0) ? ((cq & 3) | ((cq >> 3) << 2)) : -1;
+  unsigned int flags = 0;  // one bit per (active column tile, ct, rt) in issue order, youngest in bit 0
+  const float thr = BAND == 0 ? mc.C : mc.K0;
+  const float k2 = mc.K2;
+
+  struct Acc {
+    f32x16 U, W;
+  };
+  // the four MFMAs of one 32 x 32 quarter tile: u = B - A - beta^2 over 48 K slots (three chained), w = -4 beta^2 A
+  // over 16 (one); w sits between the first two links of the chain
+  auto mf = [&](Acc& a, const bf16x8(&arow)[4], const uint4(&b)[4]) {
+    f32x16 z;
+    for (int k = 0; k < 16; ++k) z[k] = 0.f;
+    a.U = __builtin_amdgcn_mfma_f32_32x32x16_bf16(arow[0], __builtin_bit_cast(bf16x8, b[0]), z, 0, 0, 0);
+    a.W = __builtin_amdgcn_mfma_f32_32x32x16_bf16(arow[3], __builtin_bit_cast(bf16x8, b[3]), z, 0, 0, 0);
+    a.U = __builtin_amdgcn_mfma_f32_32x32x16_bf16(arow[1], __builtin_bit_cast(bf16x8, b[1]), a.U, 0, 0, 0);
+    a.U = __builtin_amdgcn_mfma_f32_32x32x16_bf16(arow[2], __builtin_bit_cast(bf16x8, b[2]), a.U, 0, 0, 0);
+  };
+  // epilogue of one quarter tile: the lane's 16 provisional column bits (sign of d = u^2 + w) and the group flag
+  auto epi = [&](const Acc& a, bool self_tile) -> unsigned int {
+    unsigned int colbits = 0;
+    float m = INFINITY, wm = 0.f;
+#pragma unroll
+    for (int qp = 7; qp >= 0; --qp) {  // descending q: bit q of the word = register q
+      const f32x2 u2 = {a.U[2 * qp], a.U[2 * qp + 1]}, w2 = {a.W[2 * qp], a.W[2 * qp + 1]};
+      const f32x2 d2 = __builtin_elementwise_fma(u2, u2, w2);
+      float v0, v1;
+      if (BAND == 1) {  // |d| - K2 |w|  (w <= 0)
+        v0 = __builtin_fmaf(w2.x, k2, __builtin_fabsf(d2.x));
+        v1 = __builtin_fmaf(w2.y, k2, __builtin_fabsf(d2.y));
+      } else {
+        v0 = __builtin_fabsf(d2.x);
+        v1 = __builtin_fabsf(d2.y);
+      }
+      if (self_tile) {
+        v0 = (selfq == 2 * qp) ? INFINITY : v0;
+        v1 = (selfq == 2 * qp + 1) ? INFINITY : v1;
+      }
+      m = __builtin_fminf(__builtin_fminf(m, v0), v1);
+      if (BAND == 2) wm = __builtin_fminf(__builtin_fminf(wm, w2.x), w2.y);  // most negative w = largest |w|
+      colbits = __builtin_amdgcn_alignbit(colbits, __float_as_uint(d2.y), 31);
+      colbits = __builtin_amdgcn_alignbit(colbits, __float_as_uint(d2.x), 31);
+    }
+    const float t = BAND == 2 ? __builtin_fmaf(wm, -k2, thr) : thr;
+    flags = (flags << 1) | ((m > t) ? 0u : 1u);
+    return colbits;
+  };
+  // stage j = 16 of the bit transposes: after v_permlane16_swap(x, x) the first result holds {own, partner} and the
+  // second {partner, own} in the {even, odd} rows of 16 lanes; one byte permute builds the stage's output
+  const unsigned int sel16 = (lane & 16) ? 0x03020706u : 0x01000504u;
+  // a column tile's four quarter words -> transposed words (lower triangle) and own words (LDS), degrees
+  auto finish_tile = [&](const int J, const bool diag, const unsigned int (&tr)[2][2]) {
+    const int j0 = J * 64;
+    // lane (c, h) holds rows 4h + (q&3) + 8(q>>2) of column (ct, c); after the half swap lanes 0-31 hold column
+    // (0, c) and lanes 32-63 column (1, c) = column `lane`
+    unsigned int tw[2], ow[2];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      unsigned int s0 = spread_nibbles(tr[0][rt]) << (4 * h);
+      unsigned int s1 = spread_nibbles(tr[1][rt]) << (4 * h);
+      const auto r = __builtin_amdgcn_permlane32_swap(s0, s1, false, false);
+      tw[rt] = r[0] | r[1];
+      // row-major words = the 32 x 32 bit transpose of the column words inside each half: 5 butterfly stages over
+      // lane distance j = 16 .. 1 (the lower lane of a pair keeps x & m and takes (partner << j) & ~m, the upper one
+      // keeps x & ~m and takes (partner >> j) & m).  The partner's word comes through the VALU's own cross-lane
+      // paths -- v_permlane16_swap + one byte permute for j = 16, DPP moves for 8 (row_ror:8), 4 (row_half_mirror,
+      // then the quads reversed), 2 and 1 (quad_perm) -- not through ds_swizzle: ten LDS round trips per column tile
+      // in a dependent chain were the part of the epilogue no schedule could hide.
+      unsigned int x;
+      {
+        const auto sw = __builtin_amdgcn_permlane16_swap(tw[rt], tw[rt], false, false);
+        x = __builtin_amdgcn_perm(sw[0], sw[1], sel16);
+      }
+#pragma unroll
+      for (int st = 1; st < 5; ++st) {
+        const int j = 16 >> st;
+        unsigned int p;
+        switch (st) {
+          case 1: p = __builtin_amdgcn_update_dpp(0u, x, 0x128, 0xf, 0xf, false); break;  // row_ror:8
+          case 2:
+            p = __builtin_amdgcn_update_dpp(0u, x, 0x141, 0xf, 0xf, false);   // row_half_mirror: lane ^ 7
+            p = __builtin_amdgcn_update_dpp(0u, p, 0x1b, 0xf, 0xf, false);    // quad_perm [3,2,1,0]: lane ^ 3
+            break;
+          case 3: p = __builtin_amdgcn_update_dpp(0u, x, 0x4e, 0xf, 0xf, false); break;   // quad_perm [2,3,0,1]
+          default: p = __builtin_amdgcn_update_dpp(0u, x, 0xb1, 0xf, 0xf, false); break;  // quad_perm [1,0,3,2]
+        }
+        const bool up = (lane & j) != 0;
+        const unsigned int shifted = __builtin_amdgcn_alignbit(p, p, up ? j : 32 - j);
+        const unsigned int km[5] = {0x0000FFFFu, 0x00FF00FFu, 0x0F0F0F0Fu, 0x33333333u, 0x55555555u};
+        const unsigned int keep = up ? ~km[st] : km[st];
+        x = ((x ^ shifted) & keep) ^ shifted;  // v_bfi_b32 keep, x, shifted
+      }
+      ow[rt] = x;  // lane (r, half ct): the 32 column bits (ct) of row 32 rt + r
+    }
+    const auto ro = __builtin_amdgcn_permlane32_swap(ow[0], ow[1], false, false);
+    uint64_t ownw = ((uint64_t)ro[1] << 32) | ro[0];
+    const uint64_t trw = ((uint64_t)tw[1] << 32) | tw[0];
+    const uint64_t colmask = (n - j0 >= 64) ? ~0ull : ((1ull << (n - j0)) - 1ull);
+    ownw &= colmask;
+    if (diag) ownw &= ~(1ull << lane);
+    lds_own[wave][lane][J - Jbase] = ownw;
+    degacc += __builtin_popcountll(ownw);
+    // rows beyond n hold no bits (clamped: the padding repeats the last point); the diagonal tile has no transposed copy
+    const uint64_t trw_out = (!diag && j0 + lane < n) ? (trw & rowmask) : 0ull;
+    if (DEFER == 0) flush_tr(J, trw_out, !diag);
+    if (DEFER == 1) lds_tr[J - Jbase][lane][wave] = trw_out;
+  };
+
+  // flat schedule: per 32-column half the 8 MFMAs of both row halves (chains interleaved by hand), then the epilogues
+  auto body_flat = [&](const int J, auto diag_tag) {
+    constexpr bool DIAG = decltype(diag_tag)::value;
+    unsigned int tr[2][2];  // [ct][rt]: this lane's 16 column bits
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const bf16x8 b0 = __builtin_bit_cast(bf16x8, bX[0]), b1 = __builtin_bit_cast(bf16x8, bX[1]);
+      const bf16x8 b2 = __builtin_bit_cast(bf16x8, bX[2]), b3 = __builtin_bit_cast(bf16x8, bX[3]);
+      const int Jn = (ct == 0 || J + 1 >= Jend) ? J : J + 1, gn = ct ^ 1;
+      f32x16 z;
+      for (int k = 0; k < 16; ++k) z[k] = 0.f;
+      Acc acc[2];
+      acc[0].U = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[0][0], b0, z, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[1].U = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[1][0], b0, z, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0].U = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[0][1], b1, acc[0].U, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[1].U = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[1][1], b1, acc[1].U, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0].U = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[0][2], b2, acc[0].U, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[1].U = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[1][2], b2, acc[1].U, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0].W = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[0][3], b3, z, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[1].W = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[1][3], b3, z, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      for (int m = 0; m < 4; ++m) bX[m] = load_op(Jn, 1, gn, m);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) tr[ct][rt] = epi(acc[rt], DIAG && ct == rt);
+    }
+    finish_tile(J, DIAG, tr);
+  };
+
+  // pipelined schedule.  Invariant at the top of an iteration: accA holds the MFMA results of quarter (ct 0, rt 0)
+  // of column tile J, bX / bY the column operands of J.  Phase k runs the MFMAs of quarter k + 1 beside the epilogue
+  // of quarter k; the last phase starts the next column tile (its operands were fetched two phases earlier).
+  Acc accA, accB;
+  // schedule of one phase: 4 x (1 MFMA, a share of the VALU work)
+#define TIM_K1_INTERLEAVE(N)                                                              \
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                      \
+  __builtin_amdgcn_sched_group_barrier(0x002, N, 0);                                      \
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                      \
+  __builtin_amdgcn_sched_group_barrier(0x002, N, 0);                                      \
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                      \
+  __builtin_amdgcn_sched_group_barrier(0x002, N, 0);                                      \
+  __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                      \
+  __builtin_amdgcn_sched_group_barrier(0x002, N, 0)
+  constexpr int kEpiShare = BAND == 1 ? 13 : BAND == 2 ? 11 : 9;
+  auto body_pipe = [&](const int J, auto diag_tag) {
+    constexpr bool DIAG = decltype(diag_tag)::value;
+    const int Jn = min(J + 1, Jend - 1);  // (the last iteration starts a quarter nobody reads)
+    unsigned int tr[2][2];
+    mf(accB, ar[1], bX);                  // (ct 0, rt 1)
+    tr[0][0] = epi(accA, DIAG);
+    TIM_K1_INTERLEAVE(kEpiShare);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int m = 0; m < 4; ++m) bX[m] = load_op(Jn, 1, 0, m);  // X is free: next tile's first half, used in phase 3
+    mf(accA, ar[0], bY);                  // (ct 1, rt 0)
+    tr[0][1] = epi(accB, false);
+    __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+    TIM_K1_INTERLEAVE(kEpiShare);
+    __builtin_amdgcn_sched_barrier(0);
+    mf(accB, ar[1], bY);                  // (ct 1, rt 1)
+    tr[1][0] = epi(accA, false);
+    TIM_K1_INTERLEAVE(kEpiShare);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int m = 0; m < 4; ++m) bY[m] = load_op(Jn, 1, 1, m);  // Y is free: next tile's second half, used in phase 1
+    mf(accA, ar[0], bX);                  // next tile's (ct 0, rt 0)
+    tr[1][1] = epi(accB, DIAG);
+    finish_tile(J, DIAG, tr);
+    __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+    TIM_K1_INTERLEAVE(kEpiShare + 16);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+#undef TIM_K1_INTERLEAVE
+  if (DEFER == 0) {
+    __builtin_amdgcn_sched_barrier(0);
+    flush_tr(Jbase - 1, 0ull, false);  // the two dummies (see above)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  if (rowvalid && Jfirst < Jend) {
+    int J = Jfirst;
+    if (PIPE) {
+      mf(accA, ar[0], bX);
+      __builtin_amdgcn_sched_barrier(0);
+      if (J == I) {
+        body_pipe(J, std::true_type());
+        ++J;
+      }
+#pragma nounroll
+      for (; J < Jend; ++J) body_pipe(J, std::false_type());
+    } else {
+      if (J == I) {
+        body_flat(J, std::true_type());
+        ++J;
+      }
+#pragma nounroll
+      for (; J < Jend; ++J) body_flat(J, std::false_type());
+    }
+  }
+  const int nact = rowvalid ? max(Jend - Jfirst, 0) : 0;
+  if (DEFER == 1) {
+    // transposed words of the block: thread -> (column tile, row): the four waves' words I0 .. I0 + 3 of bitmap row
+    // j (32 contiguous bytes; a word exists where its row tile lies strictly below the column tile), and ONE degree
+    // atomic per row for their bits
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < (kMfmaColTiles * 64) / 256; ++it) {
+      const int idx = it * 256 + (int)threadIdx.x, Jr = idx >> 6, r = idx & 63, J = Jbase + Jr, j = J * 64 + r;
+      const uint4 lo = *reinterpret_cast<const uint4*>(&lds_tr[Jr][r][0]);
+      const uint4 hi = *reinterpret_cast<const uint4*>(&lds_tr[Jr][r][2]);
+      const bool rowok = J < Jend && j < n;
+      bool ok[4];
+      for (int k = 0; k < 4; ++k) ok[k] = rowok && I0 + k < T && I0 + k < J;
+      const unsigned int w32[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+      int cnt = 0;
+      for (int k = 0; k < 4; ++k) cnt += ok[k] ? __builtin_popcount(w32[2 * k]) + __builtin_popcount(w32[2 * k + 1]) : 0;
+      const unsigned int base = ((unsigned int)j * (unsigned int)W + (unsigned int)I0) * 8u;
+      if (ok[3]) {  // (ok[3] implies the other three)
+        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo.x, lo.y, lo.z, lo.w}, bm_rsrc, base, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{hi.x, hi.y, hi.z, hi.w}, bm_rsrc, base + 16u, 0, 0);
+      } else {
+        for (int k = 0; k < 3; ++k)
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{w32[2 * k], w32[2 * k + 1]}, bm_rsrc,
+                                                ok[k] ? base + 8u * k : kOobOffset, 0, 0);
+      }
+      __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(cnt, deg_rsrc, cnt ? (unsigned int)j * 4u : kOobOffset, 0, 0);
+    }
+  }
+  // own words: lanes 8r..8r+7 store the (up to) 8 consecutive words of one row
+  if (rowvalid) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int r = it * 8 + (lane >> 3), k = lane & 7, J = Jbase + k;
+      if (J >= I && J < Jend && I * 64 + r < n) bm[(int64_t)(I * 64 + r) * W + J] = lds_own[wave][r][k];
+    }
+    __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(degacc, deg_rsrc, (unsigned int)(I * 64 + lane) * 4u, 0, 0);
+  }
+  // ---- group items of the flagged lane-tiles: one pass over the wave's active column tiles, behind the hot loop;
+  // staged in the wave's LDS slice (the own words are on their way), then the wave's OWN region of the worklist
+  // (plain stores, no atomic); only a wave with more items sends the rest through the problem's counted segment.
+  unsigned long long* wbuf = reinterpret_cast<unsigned long long*>(&lds_own[wave][0][0]);  // private to the wave
+  int wcount = 0;  // wave-uniform
+  if (__builtin_amdgcn_ballot_w64(flags != 0u) != 0ull) {
+#pragma nounroll
+    for (int a = 0; a < nact; ++a) {
+      unsigned int nib = (flags >> (4 * (nact - 1 - a))) & 15u;  // bit 3: (ct 0, rt 0), 2: (0, 1), 1: (1, 0), 0: (1, 1)
+      if (__builtin_amdgcn_ballot_w64(nib != 0u) == 0ull) continue;
+      const int J = Jfirst + a, j0 = J * 64;
+      if (j0 + c >= n) nib &= 3u;        // columns beyond n: copies of the last point
+      if (j0 + 32 + c >= n) nib &= 12u;
+      if (I * 64 + 4 * h >= n) nib &= 5u;       // half tiles whose 16 rows all lie beyond n
+      if (I * 64 + 32 + 4 * h >= n) nib &= 10u;
+      const int mine = __builtin_popcount(nib);
+      int total = 0, base = 0;
+      uint64_t left = __builtin_amdgcn_ballot_w64(mine != 0);
+#pragma nounroll
+      while (left) {
+        const int l = __builtin_ctzll(left);
+        left &= left - 1ull;
+        base = (lane == l) ? total : base;
+        total += __builtin_amdgcn_readlane(mine, l);
+      }
+      if (total == 0) continue;
+      if (wcount + total > kWorkBuf)
+        wcount = flush_work(wbuf, wcount, work, work_count, work_cap, states + blockIdx.y, lane);
+      int kk = wcount + base;
+      const unsigned long long hi = kGroupItem | ((unsigned long long)blockIdx.y << 32);
+#pragma nounroll
+      while (nib) {
+        const int pos = 31 - __builtin_clz(nib);
+        nib &= ~(1u << pos);
+        const int ct = (pos >> 1) ^ 1, rt = (pos & 1) ^ 1;
+        const unsigned int rowp = (unsigned int)(I * 64 + 32 * rt + 4 * h);
+        const unsigned int colp = (unsigned int)(j0 + 32 * ct + c);
+        wbuf[kk++] = hi | ((unsigned long long)rowp << 16) | (unsigned long long)colp;
+      }
+      wcount += total;
+    }
+  }
+  {
+    const int nreg = wcount < kRegionItems ? wcount : kRegionItems;
+    if (lane == 0) region[0] = (unsigned long long)nreg;
+    if (lane < nreg) region[1 + lane] = wbuf[lane];
+    if (wcount > kRegionItems) {
+      const int extra = wcount - kRegionItems;
+      unsigned int base = 0;
+      if (lane == 0) base = atomicAdd(work_count + blockIdx.y, (unsigned int)extra);
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (base + (unsigned int)extra > work_cap) {
+        if (lane == 0) states[blockIdx.y].k1_overflow = 1;
+      } else {
+        unsigned long long* seg = work + (size_t)blockIdx.y * work_cap;
+#pragma nounroll
+        for (int k2i = lane; k2i < extra; k2i += 64) seg[base + k2i] = wbuf[kRegionItems + k2i];
+      }
+    }
+  }
+}
+
+// FP64 resolution of the third formulation's GROUP items: 16 lanes per item, lane q owns the pair
+// (row0 + (q & 3) + 8 (q >> 2), col).  The bitmap holds the filter's provisional bit sign(d~); a pair whose reference
+// predicate disagrees flips its bit(s) with one atomicXor each (row-major copy; transposed copy outside diagonal
+// blocks) and the two degrees follow.  Every bit is owned by exactly one lane of one item, so the plain read of the
+// provisional bit races with nothing.  A WAVE takes a whole region with one load (lane 0: the count word, lane k:
+// item k) and resolves four items per step, every load of a step issued before the first use (two memory round
+// trips per region, not three per item: this kernel sits on its batch's serial chain, beside the next batch's K1).
+// 15 of a group's 16 pairs are far from the boundary: the FP64 fast path (FMA, no sqrt, its own 2e-12 guard band:
+// tim_edge_fast) decides them, the reference expression itself only inside that band.
+// Overflow: as tim_fixup_kernel (bitmaps cleared, problem flagged, host reruns the batch on FP64).
+__global__ __launch_bounds__(256) void tim_fixup_group_kernel(const ProbDesc* __restrict__ descs, int batch,
+                                                              const double* __restrict__ src,
+                                                              const double* __restrict__ dst,
+                                                              uint64_t* __restrict__ bitmap, double beta,
+                                                              const unsigned long long* __restrict__ work,
+                                                              const unsigned int* __restrict__ work_count,
+                                                              unsigned int cap, ProbState* __restrict__ states,
+                                                              int32_t* __restrict__ deg,
+                                                              const unsigned long long* __restrict__ regions,
+                                                              unsigned int regions_per_problem) {
+  TAIL_WAVE_PRIO();
+  const int prob = blockIdx.y;
+  const unsigned int total = work_count[prob];
+  const ProbDesc d = descs[prob];
+  const int n = d.n, W = d.W;
+  if (total > cap) {
+    const int64_t words = (int64_t)n * W;
+    uint64_t* bm = bitmap + d.bm_off;
+    for (int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x; w < words; w += (int64_t)gridDim.x * 256) bm[w] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) states[prob].k1_overflow = 1;
+    return;
+  }
+  const double* ps = src + 3 * d.pt_off;
+  const double* pd = dst + 3 * d.pt_off;
+  unsigned int* bm32 = reinterpret_cast<unsigned int*>(bitmap + d.bm_off);
+  int32_t* dg = deg + d.pt_off;
+  EdgeConst kc;
+  kc.beta = beta;
+  kc.beta2 = beta * beta;
+  kc.m2beta2 = -2.0 * kc.beta2;
+  kc.beta4 = kc.beta2 * kc.beta2;
+  kc.s_hat = 1.0;
+  const int lane = threadIdx.x & 63, q = lane & 15, sub = lane >> 4;
+  const int rq = (q & 3) + 8 * (q >> 2);
+  auto resolve = [&](unsigned long long it, bool valid) {
+    int r = (int)((it >> 16) & 0xffff) + rq, col = (int)(it & 0xffff);
+    valid = valid && r < n && col < n && r != col;
+    r = valid ? r : 0;
+    col = valid ? col : 0;
+    // every load up front: the two points and the word that holds the provisional bit
+    const double sx = ps[3 * r], sy = ps[3 * r + 1], sz = ps[3 * r + 2];
+    const double dx = pd[3 * r], dy = pd[3 * r + 1], dz = pd[3 * r + 2];
+    const double cx = ps[3 * col], cy = ps[3 * col + 1], cz = ps[3 * col + 2];
+    const double ex = pd[3 * col], ey = pd[3 * col + 1], ez = pd[3 * col + 2];
+    unsigned int* wp = bm32 + 2 * ((int64_t)r * W + (col >> 6)) + ((col >> 5) & 1);
+    const unsigned int word = *wp;
+    const double ax = cx - sx, ay = cy - sy, az = cz - sz, bx = ex - dx, by = ey - dy, bz = ez - dz;
+    bool unc, shortp;
+    bool e = tim_edge_fast(ax, ay, az, bx, by, bz, kc, &unc, &shortp);
+    e |= shortp;
+    if (unc) e = tim_edge_exact(ax, ay, az, bx, by, bz, beta);
+    const unsigned int bit = 1u << (col & 31);
+    if (!valid || ((word & bit) != 0u) == e) return;
+    atomicXor(wp, bit);
+    atomicAdd(dg + r, e ? 1 : -1);
+    if ((r >> 6) != (col >> 6)) {  // the transposed copy
+      atomicXor(bm32 + 2 * ((int64_t)col * W + (r >> 6)) + ((r >> 5) & 1), 1u << (r & 31));
+      atomicAdd(dg + col, e ? 1 : -1);
+    }
+  };
+  const unsigned long long* reg = regions + (size_t)prob * regions_per_problem * kRegionWords;
+  const unsigned int wv = blockIdx.x * 4 + (threadIdx.x >> 6), nwv = gridDim.x * 4;
+  static_assert(kRegionWords == 64, "one region = one 64-lane load");
+  for (unsigned int rg = wv; rg < regions_per_problem; rg += nwv) {
+    const unsigned long long mine = reg[(size_t)rg * kRegionWords + lane];
+    const int cnt = (int)__builtin_amdgcn_readfirstlane((unsigned int)mine);
+#pragma nounroll
+    for (int base = 1; base <= cnt; base += 4) {
+      const int k = base + sub;
+      const unsigned int lo = (unsigned int)__shfl((int)(unsigned int)mine, k & 63, 64);
+      const unsigned int hi = (unsigned int)__shfl((int)(unsigned int)(mine >> 32), k & 63, 64);
+      resolve(((unsigned long long)hi << 32) | lo, k <= cnt);
+    }
+  }
+  const unsigned long long* seg = work + (size_t)prob * cap;
+  const unsigned int ngrp = gridDim.x * 16;
+  for (unsigned int w = (blockIdx.x * 256 + threadIdx.x) >> 4; w < total; w += ngrp) resolve(seg[w], true);
+}
+
 // FP64 resolution of the worklist: one thread per pair, bits rewritten with atomics (a row word
 // can receive several patches).  Diagonal blocks evaluate (r, c) and (c, r) as separate pairs, each
 // patching only its own bit; elsewhere one pair patches both the row-major and the transposed bit.
@@ -1670,23 +2249,26 @@ static int tim_mfma_blocks(int T) {
   return nblk;
 }
 
-// worklist capacity in 8-byte words: one counted segment per problem, each 1/64 of the pairs of the LARGEST problem
-// (>= 2^16 items; typical use is ~1e-4 of the pairs), followed by the per-wave regions of the u / w kernel
-// (kRegionWords per wave of every block, sized for the largest problem).  Returns the total.
+// Worklist capacity in 8-byte words: per problem one counted segment (the overflow of the waves' own regions) of
+// the batch's pairs / 256 / batch items, at least 2^16 -- a uniform stride sized from the batch's TOTAL, so that a
+// mixed batch does not pay the largest problem's share for every member (typical use: ~1e-3 of the pairs as group
+// items, most of them in the regions) -- followed by the per-wave regions (kRegionWords per wave of every block of
+// the launch grid, i.e. shaped by the largest problem).  A segment that overflows flags its problem and the host
+// reruns the batch on the FP64 kernel.  Returns the total.
 static int64_t tim_region_words(int max_n) {
   return (int64_t)tim_mfma_blocks((max_n + 63) / 64) * kMfmaRowTiles * kRegionWords;
 }
 int64_t tim_work_items(const int32_t* n, int batch) {
-  int64_t mx = 0;
+  int64_t pairs = 0;
   int max_n = 0;
   for (int b = 0; b < batch; ++b) {
-    mx = std::max<int64_t>(mx, (int64_t)n[b] * (n[b] - 1) / 2);
+    pairs += (int64_t)n[b] * (n[b] - 1) / 2;
     max_n = std::max(max_n, n[b]);
   }
-  int64_t seg = mx / 64;
-  if (seg < (1 << 16)) seg = 1 << 16;
+  const int64_t nb = std::max(batch, 1);
+  int64_t seg = std::max<int64_t>(pairs / 256 / nb, 1 << 16);
   if (seg > 0x7fffffffll) seg = 0x7fffffffll;
-  return (seg + tim_region_words(max_n)) * std::max(batch, 1);
+  return (seg + tim_region_words(max_n)) * nb;
 }
 
 // phase 0 pre-pass (bbox, centred bf16 operands, R^2, degrees zeroed), 1 the matrix-core kernel (bitmap
@@ -1713,8 +2295,9 @@ void launch_tim_graph_mfma(hipStream_t s, int phase, const ProbDesc* d_desc, int
   // scheduling variant / formulation of the kernel (diagnostics; read per launch so that a probe can switch):
   // 0..6 the first formulation (A, B from the matrix pipe), 7 / 8 the u / w formulation (staged / unstaged stores)
   const char* ev = getenv("TEASER_K1_VARIANT");
-  const int variant = ev ? atoi(ev) : 11;
-  const bool form2 = variant >= 7;
+  const int variant = ev ? atoi(ev) : 21;
+  const bool form2 = variant >= 7;   // operand layout of the u / w algebra
+  const bool form3 = variant >= 12;  // min |d| epilogue, group items
   if (phase == 0) {
     // prep (and the worklist counter behind it) arrive zeroed: part of the solve's header upload
     hipLaunchKernelGGL(tim_prep_bbox_kernel, dim3((max_n + 1023) / 1024, batch), dim3(256), 0, s, d_desc,
@@ -1740,7 +2323,29 @@ void launch_tim_graph_mfma(hipStream_t s, int phase, const ProbDesc* d_desc, int
   hipLaunchKernelGGL((tim_graph_mfma2_kernel<V, OCC, EARLY>), dim3(nblk, batch), dim3(256), 0, s, d_desc, d_src, d_dst, \
                      reinterpret_cast<const TimOperandTile2*>(d_pk), prep, d_bitmap, beta, gyr, work, work_count, \
                      (unsigned int)seg_cap, d_state, d_deg, regions, xcd_remap)
+    // diagnostics: TEASER_K1_LDS_PAD = bytes of unused dynamic LDS per workgroup (occupancy experiments)
+    static const int lds_pad = [] {
+      const char* e = getenv("TEASER_K1_LDS_PAD");
+      return e ? atoi(e) : 0;
+    }();
+#define TIM_K1_LAUNCH3(BAND, PIPE, OCC, DEFER)                                                                          \
+  hipLaunchKernelGGL((tim_graph_mfma3_kernel<BAND, PIPE, OCC, DEFER>), dim3(nblk, batch), dim3(256), lds_pad, s, d_desc, d_src, d_dst, \
+                     reinterpret_cast<const TimOperandTile2*>(d_pk), prep, d_bitmap, beta, gyr, work, work_count, \
+                     (unsigned int)seg_cap, d_state, d_deg, regions, xcd_remap)
     switch (variant) {
+      case 12: TIM_K1_LAUNCH3(0, false, 3, 0); break;
+      case 13: TIM_K1_LAUNCH3(1, false, 3, 0); break;
+      case 14: TIM_K1_LAUNCH3(2, false, 3, 0); break;
+      case 15: TIM_K1_LAUNCH3(0, true, 3, 0); break;
+      case 18: TIM_K1_LAUNCH3(0, true, 2, 0); break;
+      case 20: TIM_K1_LAUNCH3(0, false, 3, 1); break;
+      case 21: TIM_K1_LAUNCH3(1, false, 3, 1); break;
+      case 22: TIM_K1_LAUNCH3(2, false, 3, 1); break;
+      case 23: TIM_K1_LAUNCH3(0, true, 3, 1); break;
+      case 24: TIM_K1_LAUNCH3(0, true, 2, 1); break;
+      case 25: TIM_K1_LAUNCH3(2, true, 2, 1); break;
+      case 30: TIM_K1_LAUNCH3(1, false, 3, 2); break;  // timing build: transposed words dropped (wrong bitmaps)
+      case 11: TIM_K1_LAUNCH2(2, 3, false); break;
       case 0: TIM_K1_LAUNCH(0, 3, true); break;
       case 2: TIM_K1_LAUNCH(2, 3, true); break;
       case 3: TIM_K1_LAUNCH(2, 4, true); break;
@@ -1752,15 +2357,22 @@ void launch_tim_graph_mfma(hipStream_t s, int phase, const ProbDesc* d_desc, int
       case 9: TIM_K1_LAUNCH2(2, 4, false); break;
       case 10: TIM_K1_LAUNCH2(1, 3, false); break;
       case 1: TIM_K1_LAUNCH(1, 3, true); break;
-      default: TIM_K1_LAUNCH2(2, 3, false); break;  // 11
+      default: TIM_K1_LAUNCH3(1, false, 3, 1); break;  // 21
     }
 #undef TIM_K1_LAUNCH
 #undef TIM_K1_LAUNCH2
+#undef TIM_K1_LAUNCH3
   } else {
     // problems whose geometry the filter cannot handle ran the FP64 body inside K1 (no degree atomics
     // there): their degrees come from the row-popcount pass, which skips every other problem
     hipLaunchKernelGGL(degree_kernel, dim3(batch >= 64 ? 8 : 64, batch), dim3(256), 0, s, d_desc, d_bitmap, d_deg,
-                       prep, beta, form2 ? 1 : 0);
+                       prep, beta, form3 ? 2 : form2 ? 1 : 0);
+    if (form3)  // a wave per region of the largest problem (up to 2048 workgroups per problem)
+      hipLaunchKernelGGL(tim_fixup_group_kernel,
+                         dim3((unsigned)std::max<int64_t>(4, std::min<int64_t>(2048, (reg_words / kRegionWords + 3) / 4)), batch),
+                         dim3(256), 0, s, d_desc, batch, d_src, d_dst, d_bitmap, beta, work, work_count,
+                         (unsigned int)seg_cap, d_state, d_deg, regions, (unsigned int)(reg_words / kRegionWords));
+    else
     hipLaunchKernelGGL(tim_fixup_kernel, dim3(std::max(4, std::min(512, 1024 / std::max(batch, 1))), batch), dim3(256), 0, s, d_desc, batch, d_src, d_dst, d_bitmap,
                        beta, work, work_count, (unsigned int)seg_cap, d_state, d_deg,
                        form2 ? regions : static_cast<const unsigned long long*>(nullptr),
@@ -1786,8 +2398,9 @@ __global__ __launch_bounds__(256) void degree_kernel(const ProbDesc* __restrict_
                                                      const TimPrep* __restrict__ prep, double beta, int form2) {
   // prep != null: only the problems that ran the FP64 body inside the matrix-core K1 (the others got
   // their degrees from K1's atomics); that launch uses a small grid (gridDim.x row groups per problem)
-  if (prep && (form2 ? mfma2_consts(beta, prep[blockIdx.y].r2_bits).use_mfma
-                     : mfma_consts(beta, prep[blockIdx.y].r2_bits).use_mfma))
+  if (prep && (form2 == 2   ? mfma3_consts(beta, prep[blockIdx.y].r2_bits).use_mfma
+               : form2 == 1 ? mfma2_consts(beta, prep[blockIdx.y].r2_bits).use_mfma
+                            : mfma_consts(beta, prep[blockIdx.y].r2_bits).use_mfma))
     return;
   const ProbDesc d = descs[blockIdx.y];
   const int lane = threadIdx.x & 63;

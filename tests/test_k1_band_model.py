@@ -308,3 +308,114 @@ def test_band2_short_pairs_are_never_trusted():
         assert not trusted[short].any()
         ref = reference_edge(src, dst, i, j, beta)
         assert (np.signbit((d - nb).astype(np.float32))[trusted] == ref[trusted]).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# third formulation (tim_graph_mfma3_kernel): same operands and accumulation, CONSTANT band C per problem; the
+# provisional bit is sign(d~), a pair is trusted iff |d~| > C (in the kernel: iff the minimum of |d~| over the 16
+# pairs of its lane-tile exceeds C -- a subset of this condition)
+# ---------------------------------------------------------------------------------------------
+def consts3(beta, r2max):
+    f = np.float32
+    g, kexp = scale2(beta)
+    up = f(1.000001)
+    b = f(beta * g) * up
+    kappa = f(2.0 ** kexp)
+    R2 = f(r2max) * up
+    R = np.sqrt(R2) * up
+    b2 = f(0.25) * kappa
+    eps_u = K_EPS_U2 * U * R2 * up
+    eps_w = kappa * (K_EPS_A2 * U * R2 * up) * up
+    U0 = (f(4) * b * R * f(1.001) + f(2) * eps_u) * up
+    G = (f(1.3e-13) * b * R2 * R + f(8e-15) * b2 * R2) * up
+    E = (f(2) * U0 * eps_u + eps_u * eps_u + eps_w + G) * up
+    C0 = E / (f(1) - f(4) * U) * f(1.001) * up
+    short_d = (f(4) * b2 * b2 * (f(1) + f(16) * U) + f(4) * b2 * eps_u + eps_u * eps_u + eps_w) * f(1.001) * up
+    return dict(C=max(C0, short_d) * f(1.00001), C0=C0, short_d=short_d)
+
+
+def check3(src, dst, beta, rng, npairs, pairs=None):
+    n = len(src)
+    A, B, r2, g, kexp = operands2(src, dst, beta)
+    C = consts3(beta, r2)["C"]
+    if pairs is None:
+        i = rng.integers(0, n, size=npairs)
+        j = rng.integers(0, n, size=npairs)
+    else:
+        i, j = pairs
+    keep = i != j
+    i, j = i[keep], j[keep]
+    ref = reference_edge(src, dst, i, j, beta)
+    fma = lambda x, y, z: (np.asarray(x, np.float64) * np.asarray(y, np.float64) + np.asarray(z, np.float64)).astype(np.float32)
+    trusted_total = 0
+    for order_u, order_w in ((list(range(48)), list(range(48, 64))),
+                             (list(range(47, -1, -1)), list(range(63, 47, -1))),
+                             (list(rng.permutation(48)), list(48 + rng.permutation(16)))):
+        u = accumulate(A[i], B[j], order_u)
+        w = accumulate(A[i], B[j], order_w)
+        d = fma(u, u, w)
+        trusted = np.abs(d) > C
+        assert (np.signbit(d)[trusted] == ref[trusted]).all(), "min |d| filter trusted a wrong sign"
+        trusted_total += int(trusted.sum())
+    return trusted_total / (3.0 * len(i)), ref, (i, j)
+
+
+def test_band3_random_and_adversarial():
+    rng = np.random.default_rng(2027)
+    n = 3000
+    src = rng.uniform(size=(n, 3))
+    Rm = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+    dst = src @ Rm.T + rng.uniform(-1, 1, size=3)
+    out = rng.uniform(size=n) < 0.95
+    dst[out] = rng.uniform(-1, 1, size=(int(out.sum()), 3))
+    dst[~out] += rng.uniform(-0.0057, 0.0057, size=(int((~out).sum()), 3))
+    frac, _, _ = check3(src, dst, 0.02, rng, 1_000_000)
+    assert frac > 0.999  # constant band: ~2.4 x the pairs of the w-dependent band, still < 1e-3 of all pairs
+    for scale, beta in ((1.0, 0.02), (300.0, 0.1), (0.05, 2e-4)):
+        n = 1500
+        src = rng.uniform(-1, 1, size=(n, 3)) * scale
+        Rm = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+        dst = src @ Rm.T
+        off = rng.choice([0.0, 1.0, -1.0], size=n) * beta * (
+            1 + rng.choice([0, 1e-15, 1e-12, 1e-9, 1e-7, 1e-6, 1e-5, 1e-4, 1e-3], size=n))
+        d = dst / np.linalg.norm(dst, axis=1, keepdims=True)
+        dst = dst + d * (off * rng.uniform(0.3, 1.0, size=n))[:, None]
+        check3(src, dst, beta, rng, 600_000)
+    # large offsets are absorbed by the centring; far pairs (|u*| > U0, case B of the derivation) dominate here
+    src = rng.uniform(size=(1000, 3)) + np.array([1e4, -2e4, 3e4])
+    dst = src @ Rm.T + 50.0
+    check3(src, dst, 0.02, rng, 300_000)
+    # clouds of very different extent (|u*| far beyond U0 for most pairs)
+    src = rng.uniform(-1, 1, size=(1500, 3))
+    dst = rng.uniform(-1, 1, size=(1500, 3)) * 0.05
+    check3(src, dst, 0.02, rng, 300_000)
+    check3(dst, src, 0.02, rng, 300_000)
+
+
+def test_band3_short_pairs_are_never_trusted():
+    rng = np.random.default_rng(8)
+    for scale, beta in ((1.0, 0.02), (1.0, 0.2), (10.0, 0.05), (0.05, 2e-4)):
+        n = 1200
+        centres = rng.uniform(-1, 1, size=(40, 3)) * scale
+        which = rng.integers(0, 40, size=n)
+        src = centres[which] + rng.uniform(-1, 1, size=(n, 3)) * beta * rng.choice([0.05, 0.3, 0.6], size=(n, 1))
+        Rm = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+        dst = src @ Rm.T + rng.uniform(-1, 1, size=(n, 3)) * beta * rng.choice([0.0, 0.05, 0.3], size=(n, 1))
+        A, B, r2, g, kexp = operands2(src, dst, beta)
+        C = consts3(beta, r2)["C"]
+        i = rng.integers(0, n, size=400_000)
+        j = rng.integers(0, n, size=400_000)
+        keep = (i != j) & (which[i] == which[j])
+        i, j = i[keep], j[keep]
+        a = np.linalg.norm(src[j] - src[i], axis=1)
+        b = np.linalg.norm(dst[j] - dst[i], axis=1)
+        short = a + b <= beta * (1 + 1e-9)
+        assert short.sum() > 1000
+        fma = lambda x, y, z: (np.asarray(x, np.float64) * np.asarray(y, np.float64) + np.asarray(z, np.float64)).astype(np.float32)
+        u = accumulate(A[i], B[j], list(range(48)))
+        w = accumulate(A[i], B[j], list(range(48, 64)))
+        d = fma(u, u, w)
+        trusted = np.abs(d) > C
+        assert not trusted[short].any()
+        ref = reference_edge(src, dst, i, j, beta)
+        assert (np.signbit(d)[trusted] == ref[trusted]).all()
