@@ -28,7 +28,7 @@ CLIQUE_KERNELS="exact_clique_kernel,colour_assign_kernel,colour_resolve_kernel,c
 
 prof() {  # prof <dir> <rocprofv3 args...> -- <cmd...>: rocprofv3 from /tmp, csv output into $OUT/<dir>
   local d=$1; shift
-  (cd /tmp && timeout 300 rocprofv3 "$@") > $OUT/$d.log 2>&1; echo "$d rc=$?"
+  (cd /tmp && timeout ${PROF_TIMEOUT:-300} rocprofv3 "$@") > $OUT/$d.log 2>&1; echo "$d rc=$?"
 }
 for task in "$@"; do
   echo "=== $task"
@@ -50,7 +50,7 @@ c=d["configs"]["config4"]; print("c4", round(c["value"]), c["ms_per_step"], c.ge
 PY
       ;;
     benchprof)
-      prof bench_prof --kernel-trace --stats --output-format csv -d $OUT/bench_prof -o t -- python $R/bench.py --configs '' --no-cpu-baseline --no-latency --no-host-resident
+      PROF_TIMEOUT=600 prof bench_prof --kernel-trace --stats --output-format csv -d $OUT/bench_prof -o t -- python $R/bench.py --configs '' --no-cpu-baseline --no-latency --no-host-resident
       grep '^{' $OUT/bench_prof.log | tail -1 > $OUT/bench_under_rocprof.json
       cp $(find $OUT/bench_prof -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv; head -14 $OUT/bench_kernel_stats.csv | cut -c1-150 ;;
     k1pmc)
@@ -88,6 +88,9 @@ PY
       for v in 20 23; do for pad in 0 30000 60000; do
         TEASER_K1_VARIANT=$v TEASER_K1_LDS_PAD=$pad timeout 60 $P 64 10000 5 one 2>/dev/null | sed "s/^{/{\"lds_pad\":$pad,\"v\":$v,/" | cut -c1-140
       done; done | tee $OUT/k1_occupancy.jsonl ;;
+    pcsample)  # stochastic PC sampling of K1 alone (beta feature: short timeout, nothing else in the call depends on it)
+      (cd /tmp && TEASER_K1_VARIANT=${K1V:-20} timeout 120 rocprofv3 --pc-sampling-beta-enabled --pc-sampling-unit ${PCS_UNIT:-time} --pc-sampling-method ${PCS_METHOD:-host_trap} --pc-sampling-interval ${PCS_INT:-1} --output-format csv json -d $OUT/pcs -o t -- $P 64 10000 3 one) > $OUT/pcs.log 2>&1; echo "pcs rc=$?"; tail -5 $OUT/pcs.log | cut -c1-300; ls -la $OUT/pcs 2>/dev/null | head ;;
+    k1trace) for v in 40 42; do TEASER_K1_VARIANT=$v timeout 60 $P 64 10000 3 one 2>&1 | grep -i "K1 cycles\|k1_ms" | cut -c1-330 | tail -2; done | tee $OUT/k1_phase_trace.txt ;;
     valurate) timeout 300 $R/scripts/probe/valu_rate 2.0 > $OUT/valu_rate.jsonl 2>&1; echo "rc=$?"; python - <<PY
 import json
 rows=[json.loads(l) for l in open("$OUT/valu_rate.jsonl") if l.startswith("{") and "inst" in l]
@@ -102,7 +105,7 @@ for n in names:
 PY
       ;;
     timeline)
-      prof tl --kernel-trace --output-format csv -d $OUT/tl -o t -- python $R/bench.py --configs '' --no-cpu-baseline --no-latency --no-host-resident --steps 12
+      PROF_TIMEOUT=600 prof tl --kernel-trace --output-format csv -d $OUT/tl -o t -- python $R/bench.py --configs '' --no-cpu-baseline --no-latency --no-host-resident --steps 16 --warmup 2 --pool 6
       python scripts/trace_timeline.py $(find $OUT/tl -name "*kernel_trace.csv" | head -1) > $OUT/timeline.txt 2>&1; tail -60 $OUT/timeline.txt | cut -c1-200 ;;
     *) echo "unknown task $task" ;;
   esac

@@ -90,7 +90,7 @@ int main(int argc, char** argv) {
   std::vector<uint64_t> bm((size_t)n * W);
 
   if (mode == "k1" || mode == "one") {
-    const char* variants_all[] = {"-1", "11", "13", "15", "18", "20", "21", "22", "23", "24", "25", "30"};
+    const char* variants_all[] = {"-1", "11", "12", "20", "21", "22", "23", "27"};
     std::vector<std::string> vs;
     if (mode == "one")
       vs.push_back(getenv("TEASER_K1_VARIANT") ? getenv("TEASER_K1_VARIANT") : "");  // "": the library's default

@@ -1627,6 +1627,7 @@ __device__ __forceinline__ Mfma3Const mfma3_consts(double beta_d, unsigned int r
   return c;
 }
 
+__device__ unsigned long long g_k1_trace[8];  // TRACE builds: cycles per phase summed over the sampled waves, [7] = iterations
 constexpr unsigned long long kGroupItem = 1ull << 63;  // worklist item: 16 rows of one column (tim_fixup_group_kernel)
 
 // BAND: 0 = constant band C; 1 = K2 |w| + K0 per value (one more fma per value); 2 = K2 max|w| + K0 with the
@@ -1637,7 +1638,7 @@ constexpr unsigned long long kGroupItem = 1ull << 63;  // worklist item: 16 rows
 // loop as well.  The flat schedule (PIPE = false: 8 MFMAs, then both epilogues) relies on the other two waves of the
 // SIMD to fill the matrix pipe's shadow, and the counters say they do not: VALU 60 % + MFMA 25 % busy, hardly
 // overlapping (profiles/r4a).
-template <int BAND, bool PIPE, int OCC, int DEFER>
+template <int BAND, bool PIPE, int OCC, int DEFER, int CHUNKS, bool TRACE = false>
 __global__ __launch_bounds__(256, OCC) void tim_graph_mfma3_kernel(
     const ProbDesc* __restrict__ descs, const double* __restrict__ src,
     const double* __restrict__ dst, const TimOperandTile2* __restrict__ ops, const TimPrep* __restrict__ prep,
@@ -1645,6 +1646,7 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma3_kernel(
     unsigned long long* __restrict__ work, unsigned int* __restrict__ work_count, unsigned int work_cap,
     ProbState* __restrict__ states, int32_t* __restrict__ deg, unsigned long long* __restrict__ regions,
     int xcd_remap) {
+  const unsigned long long t_entry = TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
   const ProbDesc d = descs[blockIdx.y];
   const int n = d.n, W = d.W;
   const int T = W;
@@ -1654,15 +1656,21 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma3_kernel(
     const int nb = gridDim.x, c = blockIdx.x & 7, q = nb >> 3, rem = nb & 7;
     Ig = c * q + min(c, rem) + (blockIdx.x >> 3);
   }
-  while (Ig >= min(gyr, 2 * X + 2)) {
-    Ig -= min(gyr, 2 * X + 2);
+  // a block = 4 row tiles x CHUNKS chunks of kMfmaColTiles column tiles, walked chunk after chunk by the same four
+  // waves: a wave's set-up (descriptors, band constants, row operands: three dependent memory round trips) and its
+  // wind-down (the last stores' acknowledgement) took 40 % of its lifetime when it lived for 8 column tiles only
+  // (s_memtime trace, profiles/r4f); column group X has min(gyr, 2 CHUNKS (X + 1)) row groups
+  constexpr int kBlockColTiles = kMfmaColTiles * CHUNKS;
+  while (Ig >= min(gyr, 2 * CHUNKS * (X + 1))) {
+    Ig -= min(gyr, 2 * CHUNKS * (X + 1));
     ++X;
   }
-  const int I0 = Ig * kMfmaRowTiles, Jbase = X * kMfmaColTiles;
-  unsigned long long* const region =
-      regions + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kMfmaRowTiles + (threadIdx.x >> 6)) * kRegionWords;
-  if (I0 >= T || Jbase >= T || Jbase + kMfmaColTiles - 1 < I0) {  // outside / below the diagonal
-    if ((threadIdx.x & 63) == 0) region[0] = 0ull;
+  const int I0 = Ig * kMfmaRowTiles, Jbase = X * kBlockColTiles;
+  // the wave's region of chunk c: regions_of_wave + c * kRegionWords
+  unsigned long long* const regions_of_wave =
+      regions + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * kMfmaRowTiles + (threadIdx.x >> 6)) * CHUNKS * kRegionWords;
+  if (I0 >= T || Jbase >= T || Jbase + kBlockColTiles - 1 < I0) {  // outside / below the diagonal
+    if ((threadIdx.x & 63) < CHUNKS) regions_of_wave[(threadIdx.x & 63) * kRegionWords] = 0ull;
     return;
   }
   const int lane = threadIdx.x & 63;
@@ -1683,21 +1691,7 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma3_kernel(
   // store + a degree atomic per wave and tile, and since gfx9 counts loads and stores on ONE in-order vmcnt, every
   // other operand wait of the loop also waited for their acknowledgement.  DEFER = 2: timing build, they are dropped.)
   __shared__ __attribute__((aligned(16))) uint64_t lds_tr[DEFER == 1 ? kMfmaColTiles : 1][64][kMfmaRowTiles];
-  const Mfma3Const mc = mfma3_consts(beta, prep[blockIdx.y].r2_bits);
-  if (!__builtin_amdgcn_readfirstlane(mc.use_mfma)) {  // per problem: uniform over the block
-    EdgeConst kc;
-    kc.beta = beta;
-    kc.beta2 = beta * beta;
-    kc.m2beta2 = -2.0 * kc.beta2;
-    kc.beta4 = kc.beta2 * kc.beta2;
-    kc.s_hat = 1.0;
-    if (I < T)
-      for (int jb = Jbase; jb < Jbase + kMfmaColTiles; jb += kColTilesPerWave)
-        if (!(jb + kColTilesPerWave - 1 < I || jb >= T))
-          tim_wave_fp64<0>(ps, pd, bm, n, W, I, jb, kc, reinterpret_cast<double*>(&lds_own[wave][0][0]));
-    if (lane == 0) region[0] = 0ull;
-    return;
-  }
+  // (the operand loads are issued before the band constants are worked out: they are harmless on the FP64 route)
   const TimOperandTile2* __restrict__ qt = ops + d.w_off;
   const int h = lane >> 5, c = lane & 31;
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -1716,13 +1710,28 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma3_kernel(
   }
   const bool rowvalid = I < T;
   const uint64_t rowmask = !rowvalid ? 0ull : (n - I * 64 >= 64) ? ~0ull : ((1ull << (n - I * 64)) - 1ull);
-  const int Jfirst = max(Jbase, I), Jend = min(Jbase + kMfmaColTiles, T);
+  const int Jfirst = max(Jbase, I), Jend = min(Jbase + kBlockColTiles, T);  // the wave's column tiles, all chunks
   uint4 bX[4], bY[4];  // column operands: X = the tile's first 32 columns (ct 0), Y = the other 32 (PIPE only)
   {
     const int Jf = min(Jfirst, T - 1);
     for (int m = 0; m < 4; ++m) bX[m] = load_op(Jf, 1, 0, m);
     if (PIPE)
       for (int m = 0; m < 4; ++m) bY[m] = load_op(Jf, 1, 1, m);
+  }
+  const Mfma3Const mc = mfma3_consts(beta, prep[blockIdx.y].r2_bits);
+  if (!__builtin_amdgcn_readfirstlane(mc.use_mfma)) {  // per problem: uniform over the block
+    EdgeConst kc;
+    kc.beta = beta;
+    kc.beta2 = beta * beta;
+    kc.m2beta2 = -2.0 * kc.beta2;
+    kc.beta4 = kc.beta2 * kc.beta2;
+    kc.s_hat = 1.0;
+    if (I < T)
+      for (int jb = Jbase; jb < Jbase + kBlockColTiles; jb += kColTilesPerWave)
+        if (!(jb + kColTilesPerWave - 1 < I || jb >= T))
+          tim_wave_fp64<0>(ps, pd, bm, n, W, I, jb, kc, reinterpret_cast<double*>(&lds_own[wave][0][0]));
+    if (lane < CHUNKS) regions_of_wave[lane * kRegionWords] = 0ull;
+    return;
   }
   const __amdgpu_buffer_rsrc_t deg_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(deg + d.pt_off), 0, (int)((unsigned int)n * 4u), 0x00020000);
@@ -1846,18 +1855,27 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma3_kernel(
     const uint64_t colmask = (n - j0 >= 64) ? ~0ull : ((1ull << (n - j0)) - 1ull);
     ownw &= colmask;
     if (diag) ownw &= ~(1ull << lane);
-    lds_own[wave][lane][J - Jbase] = ownw;
+    lds_own[wave][lane][(J - Jbase) & (kMfmaColTiles - 1)] = ownw;
     degacc += __builtin_popcountll(ownw);
     // rows beyond n hold no bits (clamped: the padding repeats the last point); the diagonal tile has no transposed copy
     const uint64_t trw_out = (!diag && j0 + lane < n) ? (trw & rowmask) : 0ull;
     if (DEFER == 0) flush_tr(J, trw_out, !diag);
-    if (DEFER == 1) lds_tr[J - Jbase][lane][wave] = trw_out;
+    if (DEFER == 1) lds_tr[(J - Jbase) & (kMfmaColTiles - 1)][lane][wave] = trw_out;
   };
 
   // flat schedule: per 32-column half the 8 MFMAs of both row halves (chains interleaved by hand), then the epilogues
+  unsigned long long tph[6] = {0, 0, 0, 0, 0, 0};
+  auto tick = [&]() -> unsigned long long {
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+  };
   auto body_flat = [&](const int J, auto diag_tag) {
     constexpr bool DIAG = decltype(diag_tag)::value;
     unsigned int tr[2][2];  // [ct][rt]: this lane's 16 column bits
+    unsigned long long tprev = 0;
+    if (TRACE) tprev = tick();
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
       const bf16x8 b0 = __builtin_bit_cast(bf16x8, bX[0]), b1 = __builtin_bit_cast(bf16x8, bX[1]);
@@ -1884,10 +1902,27 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma3_kernel(
       __builtin_amdgcn_sched_barrier(0);
       for (int m = 0; m < 4; ++m) bX[m] = load_op(Jn, 1, gn, m);
       __builtin_amdgcn_sched_barrier(0);
+      if (TRACE) {  // phase 0 / 2: the 8 MFMAs issued (incl. the operand wait in front of them)
+        const unsigned long long t = tick();
+        tph[2 * ct] += t - tprev;
+        tprev = t;
+      }
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) tr[ct][rt] = epi(acc[rt], DIAG && ct == rt);
+      if (TRACE) {  // phase 1 / 3: both epilogues (incl. the wait for the MFMA results)
+        asm volatile("" ::"v"(tr[ct][0]), "v"(tr[ct][1]), "v"(flags));
+        const unsigned long long t = tick();
+        tph[2 * ct + 1] += t - tprev;
+        tprev = t;
+      }
     }
     finish_tile(J, DIAG, tr);
+    if (TRACE) {  // phase 4: transposes + LDS
+      asm volatile("" ::"v"(degacc));
+      const unsigned long long t = tick();
+      tph[4] += t - tprev;
+      tph[5] += 1;
+    }
   };
 
   // pipelined schedule.  Invariant at the top of an iteration: accA holds the MFMA results of quarter (ct 0, rt 0)
@@ -1938,124 +1973,176 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma3_kernel(
     flush_tr(Jbase - 1, 0ull, false);  // the two dummies (see above)
     __builtin_amdgcn_sched_barrier(0);
   }
-  if (rowvalid && Jfirst < Jend) {
-    int J = Jfirst;
-    if (PIPE) {
-      mf(accA, ar[0], bX);
-      __builtin_amdgcn_sched_barrier(0);
-      if (J == I) {
-        body_pipe(J, std::true_type());
-        ++J;
-      }
-#pragma nounroll
-      for (; J < Jend; ++J) body_pipe(J, std::false_type());
-    } else {
-      if (J == I) {
-        body_flat(J, std::true_type());
-        ++J;
-      }
-#pragma nounroll
-      for (; J < Jend; ++J) body_flat(J, std::false_type());
-    }
-  }
-  const int nact = rowvalid ? max(Jend - Jfirst, 0) : 0;
-  if (DEFER == 1) {
-    // transposed words of the block: thread -> (column tile, row): the four waves' words I0 .. I0 + 3 of bitmap row
-    // j (32 contiguous bytes; a word exists where its row tile lies strictly below the column tile), and ONE degree
-    // atomic per row for their bits
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < (kMfmaColTiles * 64) / 256; ++it) {
-      const int idx = it * 256 + (int)threadIdx.x, Jr = idx >> 6, r = idx & 63, J = Jbase + Jr, j = J * 64 + r;
-      const uint4 lo = *reinterpret_cast<const uint4*>(&lds_tr[Jr][r][0]);
-      const uint4 hi = *reinterpret_cast<const uint4*>(&lds_tr[Jr][r][2]);
-      const bool rowok = J < Jend && j < n;
-      bool ok[4];
-      for (int k = 0; k < 4; ++k) ok[k] = rowok && I0 + k < T && I0 + k < J;
-      const unsigned int w32[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-      int cnt = 0;
-      for (int k = 0; k < 4; ++k) cnt += ok[k] ? __builtin_popcount(w32[2 * k]) + __builtin_popcount(w32[2 * k + 1]) : 0;
-      const unsigned int base = ((unsigned int)j * (unsigned int)W + (unsigned int)I0) * 8u;
-      if (ok[3]) {  // (ok[3] implies the other three)
-        typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo.x, lo.y, lo.z, lo.w}, bm_rsrc, base, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{hi.x, hi.y, hi.z, hi.w}, bm_rsrc, base + 16u, 0, 0);
-      } else {
-        for (int k = 0; k < 3; ++k)
-          __builtin_amdgcn_raw_buffer_store_b64(u32x2{w32[2 * k], w32[2 * k + 1]}, bm_rsrc,
-                                                ok[k] ? base + 8u * k : kOobOffset, 0, 0);
-      }
-      __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(cnt, deg_rsrc, cnt ? (unsigned int)j * 4u : kOobOffset, 0, 0);
-    }
-  }
-  // own words: lanes 8r..8r+7 store the (up to) 8 consecutive words of one row
-  if (rowvalid) {
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int r = it * 8 + (lane >> 3), k = lane & 7, J = Jbase + k;
-      if (J >= I && J < Jend && I * 64 + r < n) bm[(int64_t)(I * 64 + r) * W + J] = lds_own[wave][r][k];
-    }
-    __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(degacc, deg_rsrc, (unsigned int)(I * 64 + lane) * 4u, 0, 0);
-  }
-  // ---- group items of the flagged lane-tiles: one pass over the wave's active column tiles, behind the hot loop;
-  // staged in the wave's LDS slice (the own words are on their way), then the wave's OWN region of the worklist
-  // (plain stores, no atomic); only a wave with more items sends the rest through the problem's counted segment.
   unsigned long long* wbuf = reinterpret_cast<unsigned long long*>(&lds_own[wave][0][0]);  // private to the wave
-  int wcount = 0;  // wave-uniform
-  if (__builtin_amdgcn_ballot_w64(flags != 0u) != 0ull) {
+  bool primed = false;  // PIPE: accA holds the first quarter of the next column tile
+  unsigned long long t_loop = 0, t_flush = 0;
 #pragma nounroll
-    for (int a = 0; a < nact; ++a) {
-      unsigned int nib = (flags >> (4 * (nact - 1 - a))) & 15u;  // bit 3: (ct 0, rt 0), 2: (0, 1), 1: (1, 0), 0: (1, 1)
-      if (__builtin_amdgcn_ballot_w64(nib != 0u) == 0ull) continue;
-      const int J = Jfirst + a, j0 = J * 64;
-      if (j0 + c >= n) nib &= 3u;        // columns beyond n: copies of the last point
-      if (j0 + 32 + c >= n) nib &= 12u;
-      if (I * 64 + 4 * h >= n) nib &= 5u;       // half tiles whose 16 rows all lie beyond n
-      if (I * 64 + 32 + 4 * h >= n) nib &= 10u;
-      const int mine = __builtin_popcount(nib);
-      int total = 0, base = 0;
-      uint64_t left = __builtin_amdgcn_ballot_w64(mine != 0);
-#pragma nounroll
-      while (left) {
-        const int l = __builtin_ctzll(left);
-        left &= left - 1ull;
-        base = (lane == l) ? total : base;
-        total += __builtin_amdgcn_readlane(mine, l);
-      }
-      if (total == 0) continue;
-      if (wcount + total > kWorkBuf)
-        wcount = flush_work(wbuf, wcount, work, work_count, work_cap, states + blockIdx.y, lane);
-      int kk = wcount + base;
-      const unsigned long long hi = kGroupItem | ((unsigned long long)blockIdx.y << 32);
-#pragma nounroll
-      while (nib) {
-        const int pos = 31 - __builtin_clz(nib);
-        nib &= ~(1u << pos);
-        const int ct = (pos >> 1) ^ 1, rt = (pos & 1) ^ 1;
-        const unsigned int rowp = (unsigned int)(I * 64 + 32 * rt + 4 * h);
-        const unsigned int colp = (unsigned int)(j0 + 32 * ct + c);
-        wbuf[kk++] = hi | ((unsigned long long)rowp << 16) | (unsigned long long)colp;
-      }
-      wcount += total;
+  for (int chunk = 0; chunk < CHUNKS; ++chunk) {
+    const int Jc0 = Jbase + chunk * kMfmaColTiles, Jc1 = min(Jc0 + kMfmaColTiles, Jend);
+    if (Jc0 >= Jend) {  // (block-uniform) beyond the problem: no region to resolve
+      if (lane == 0) regions_of_wave[chunk * kRegionWords] = 0ull;
+      continue;
     }
-  }
-  {
-    const int nreg = wcount < kRegionItems ? wcount : kRegionItems;
-    if (lane == 0) region[0] = (unsigned long long)nreg;
-    if (lane < nreg) region[1 + lane] = wbuf[lane];
-    if (wcount > kRegionItems) {
-      const int extra = wcount - kRegionItems;
-      unsigned int base = 0;
-      if (lane == 0) base = atomicAdd(work_count + blockIdx.y, (unsigned int)extra);
-      base = __builtin_amdgcn_readfirstlane(base);
-      if (base + (unsigned int)extra > work_cap) {
-        if (lane == 0) states[blockIdx.y].k1_overflow = 1;
+    const int Ja = rowvalid ? max(Jc0, Jfirst) : Jc1;  // this wave's first column tile of the chunk
+    unsigned long long t0 = 0;
+    if (TRACE) t0 = tick();
+    if (Ja < Jc1) {
+      int J = Ja;
+      if (PIPE) {
+        if (!primed) {
+          mf(accA, ar[0], bX);
+          __builtin_amdgcn_sched_barrier(0);
+          primed = true;
+        }
+        if (J == I) {
+          body_pipe(J, std::true_type());
+          ++J;
+        }
+#pragma nounroll
+        for (; J < Jc1; ++J) body_pipe(J, std::false_type());
       } else {
-        unsigned long long* seg = work + (size_t)blockIdx.y * work_cap;
+        if (J == I) {
+          body_flat(J, std::true_type());
+          ++J;
+        }
 #pragma nounroll
-        for (int k2i = lane; k2i < extra; k2i += 64) seg[base + k2i] = wbuf[kRegionItems + k2i];
+        for (; J < Jc1; ++J) body_flat(J, std::false_type());
       }
     }
+    unsigned long long t1 = 0;
+    if (TRACE) {
+      t1 = tick();
+      t_loop += t1 - t0;
+    }
+    const int nact = max(Jc1 - Ja, 0);
+    if (DEFER == 1) {
+      // transposed words of the chunk: thread -> (column tile, row): the four waves' words I0 .. I0 + 3 of bitmap
+      // row j (32 contiguous bytes; a word exists where its row tile lies strictly below the column tile), and ONE
+      // degree atomic per row for their bits.  (Block-uniform control flow up to here: every wave meets the barriers.)
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < (kMfmaColTiles * 64) / 256; ++it) {
+        const int idx = it * 256 + (int)threadIdx.x, Jr = idx >> 6, r = idx & 63, J = Jc0 + Jr, j = J * 64 + r;
+        const uint4 lo = *reinterpret_cast<const uint4*>(&lds_tr[Jr][r][0]);
+        const uint4 hi = *reinterpret_cast<const uint4*>(&lds_tr[Jr][r][2]);
+        const bool rowok = J < Jc1 && j < n;
+        const unsigned int base = ((unsigned int)j * (unsigned int)W + (unsigned int)I0) * 8u;
+        if (Jc0 > I0 + 3 && I0 + 3 < T) {  // (block-uniform) the chunk lies strictly right of all four row tiles
+          const int cnt = (__builtin_popcount(lo.x) + __builtin_popcount(lo.y)) + (__builtin_popcount(lo.z) + __builtin_popcount(lo.w)) +
+                          (__builtin_popcount(hi.x) + __builtin_popcount(hi.y)) + (__builtin_popcount(hi.z) + __builtin_popcount(hi.w));
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo.x, lo.y, lo.z, lo.w}, bm_rsrc, rowok ? base : kOobOffset, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{hi.x, hi.y, hi.z, hi.w}, bm_rsrc, rowok ? base + 16u : kOobOffset, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(cnt, deg_rsrc, (rowok && cnt) ? (unsigned int)j * 4u : kOobOffset, 0, 0);
+          continue;
+        }
+        bool ok[4];
+        for (int k = 0; k < 4; ++k) ok[k] = rowok && I0 + k < T && I0 + k < J;
+        const unsigned int w32[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        int cnt = 0;
+        for (int k = 0; k < 4; ++k) cnt += ok[k] ? __builtin_popcount(w32[2 * k]) + __builtin_popcount(w32[2 * k + 1]) : 0;
+        if (ok[3]) {  // (ok[3] implies the other three)
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{lo.x, lo.y, lo.z, lo.w}, bm_rsrc, base, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(u32x4{hi.x, hi.y, hi.z, hi.w}, bm_rsrc, base + 16u, 0, 0);
+        } else {
+          for (int k = 0; k < 3; ++k)
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{w32[2 * k], w32[2 * k + 1]}, bm_rsrc,
+                                                  ok[k] ? base + 8u * k : kOobOffset, 0, 0);
+        }
+        __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(cnt, deg_rsrc, cnt ? (unsigned int)j * 4u : kOobOffset, 0, 0);
+      }
+      if (CHUNKS > 1) __syncthreads();  // (the next chunk rewrites lds_tr)
+    }
+    // own words of the chunk: lanes 8r..8r+7 store the (up to) 8 consecutive words of one row
+    if (nact > 0) {
+      const int kk = lane & 7, J = Jc0 + kk;
+      const bool colok = J >= Ja && J < Jc1;
+      const unsigned int off0 = ((unsigned int)(I * 64 + (lane >> 3)) * (unsigned int)W + (unsigned int)J) * 8u;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int r = it * 8 + (lane >> 3);
+        const uint64_t w = lds_own[wave][r][kk];
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{(unsigned int)w, (unsigned int)(w >> 32)}, bm_rsrc,
+                                              (colok && I * 64 + r < n) ? off0 + (unsigned int)it * 64u * (unsigned int)W : kOobOffset,
+                                              0, 0);
+      }
+    }
+    // ---- group items of the chunk's flagged lane-tiles: one pass over the wave's active column tiles, staged in the
+    // wave's LDS slice (the own words are on their way), then the wave's OWN region of the worklist (plain stores, no
+    // atomic); only a wave with more items sends the rest through the problem's counted segment.
+    int wcount = 0;  // wave-uniform
+    {
+      // flags: 4 bits per active column tile, the OLDEST tile in the highest nibble; bit 3: (ct 0, rt 0), 2: (0, 1),
+      // 1: (1, 0), 0: (1, 1).  Lane-tiles beyond n (padding: copies of the last point) are dropped: rows only in the
+      // problem's last row tile, columns only in its last column tile.
+      unsigned int vf = flags;
+      if (I * 64 + 4 * h >= n) vf &= ~0xAAAAAAAAu;       // rt 0
+      if (I * 64 + 32 + 4 * h >= n) vf &= ~0x55555555u;  // rt 1
+      if (T - 1 >= Ja && T - 1 < Jc1 && (n & 63)) {
+        const int sh = 4 * (Jc1 - T);  // (= nact - 1 - (T - 1 - Ja))
+        if ((T - 1) * 64 + c >= n) vf &= ~(0xCu << sh);
+        if ((T - 1) * 64 + 32 + c >= n) vf &= ~(0x3u << sh);
+      }
+      if (__builtin_amdgcn_ballot_w64(vf != 0u) != 0ull) {
+        // exclusive prefix of the lanes' item counts, bit by bit through v_mbcnt (no cross-lane dependency chain)
+        const int mine = __builtin_popcount(vf);
+        int base = 0, total = 0;
+#pragma unroll
+        for (int bit = 0; bit < 6; ++bit) {
+          const uint64_t m = __builtin_amdgcn_ballot_w64(((mine >> bit) & 1) != 0);
+          base += (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u)) << bit;
+          total += __builtin_popcountll(m) << bit;
+        }
+        if (total > kWorkBuf) {  // adversarial geometry: the host reruns the batch on the FP64 kernel
+          if (lane == 0) states[blockIdx.y].k1_overflow = 1;
+        } else {
+          int kk = base;
+          const unsigned long long hi = kGroupItem | ((unsigned long long)blockIdx.y << 32);
+#pragma nounroll
+          while (vf) {
+            const int pos = 31 - __builtin_clz(vf);
+            vf &= ~(1u << pos);
+            const int J = Ja + (nact - 1 - (pos >> 2));
+            const int ct = ((pos >> 1) & 1) ^ 1, rt = (pos & 1) ^ 1;
+            const unsigned int rowp = (unsigned int)(I * 64 + 32 * rt + 4 * h);
+            const unsigned int colp = (unsigned int)(J * 64 + 32 * ct + c);
+            wbuf[kk++] = hi | ((unsigned long long)rowp << 16) | (unsigned long long)colp;
+          }
+          wcount = total;
+        }
+      }
+    }
+    flags = 0;
+    {
+      unsigned long long* region = regions_of_wave + chunk * kRegionWords;
+      const int nreg = wcount < kRegionItems ? wcount : kRegionItems;
+      if (lane == 0) region[0] = (unsigned long long)nreg;
+      if (lane < nreg) region[1 + lane] = wbuf[lane];
+      if (wcount > kRegionItems) {
+        const int extra = wcount - kRegionItems;
+        unsigned int base = 0;
+        if (lane == 0) base = atomicAdd(work_count + blockIdx.y, (unsigned int)extra);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (base + (unsigned int)extra > work_cap) {
+          if (lane == 0) states[blockIdx.y].k1_overflow = 1;
+        } else {
+          unsigned long long* seg = work + (size_t)blockIdx.y * work_cap;
+#pragma nounroll
+          for (int k2i = lane; k2i < extra; k2i += 64) seg[base + k2i] = wbuf[kRegionItems + k2i];
+        }
+      }
+    }
+    if (TRACE) t_flush += tick() - t1;
+  }
+  if (rowvalid)
+    __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(degacc, deg_rsrc, (unsigned int)(I * 64 + lane) * 4u, 0, 0);
+  if (TRACE && lane == 0 && wave == 1 && (blockIdx.x & 15) == 3 && tph[5] > 0) {
+    const unsigned long long t_a = tick();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t_exit = tick();
+    for (int k = 0; k < 5; ++k) atomicAdd(&g_k1_trace[k], tph[k]);
+    atomicAdd(&g_k1_trace[7], tph[5]);
+    atomicAdd(&g_k1_trace[5], t_exit - t_entry - t_loop - t_flush - (t_exit - t_a));  // set-up (everything outside loop / flush / drain)
+    atomicAdd(&g_k1_trace[6], t_flush + (t_exit - t_a));                             // chunk flushes + final store drain
   }
 }
 
@@ -2241,13 +2328,17 @@ __global__ void degree_kernel(const ProbDesc* __restrict__ descs, const uint64_t
 
 int64_t tim_operand_bytes(int64_t total_tiles) { return 2 * total_tiles * (int64_t)sizeof(TimOperandTile); }
 
-// blocks of the matrix-core kernels for a problem of T 64-point tiles: those touching the upper triangle
-static int tim_mfma_blocks(int T) {
-  const int gxc = (T + kMfmaColTiles - 1) / kMfmaColTiles, gyr = (T + kMfmaRowTiles - 1) / kMfmaRowTiles;
+// blocks of the matrix-core kernels for a problem of T 64-point tiles: those touching the upper triangle; a block
+// covers 4 row tiles x `chunks` chunks of kMfmaColTiles column tiles
+static int tim_mfma_blocks(int T, int chunks = 1) {
+  const int ct = kMfmaColTiles * chunks;
+  const int gxc = (T + ct - 1) / ct, gyr = (T + kMfmaRowTiles - 1) / kMfmaRowTiles;
   int nblk = 0;
-  for (int X = 0; X < gxc; ++X) nblk += std::min(gyr, 2 * X + 2);
+  for (int X = 0; X < gxc; ++X) nblk += std::min(gyr, 2 * chunks * (X + 1));
   return nblk;
 }
+// per-wave regions of one problem for a launch geometry (third formulation: one region per wave and chunk)
+static int64_t tim_regions_per_problem(int T, int chunks) { return (int64_t)tim_mfma_blocks(T, chunks) * kMfmaRowTiles * chunks; }
 
 // Worklist capacity in 8-byte words: per problem one counted segment (the overflow of the waves' own regions) of
 // the batch's pairs / 256 / batch items, at least 2^16 -- a uniform stride sized from the batch's TOTAL, so that a
@@ -2255,8 +2346,11 @@ static int tim_mfma_blocks(int T) {
 // items, most of them in the regions) -- followed by the per-wave regions (kRegionWords per wave of every block of
 // the launch grid, i.e. shaped by the largest problem).  A segment that overflows flags its problem and the host
 // reruns the batch on the FP64 kernel.  Returns the total.
-static int64_t tim_region_words(int max_n) {
-  return (int64_t)tim_mfma_blocks((max_n + 63) / 64) * kMfmaRowTiles * kRegionWords;
+static int64_t tim_region_words(int max_n) {  // (the largest of the launch geometries a variant may pick)
+  const int T = (max_n + 63) / 64;
+  int64_t r = 0;
+  for (int ch : {1, 2, 4}) r = std::max(r, tim_regions_per_problem(T, ch));
+  return r * kRegionWords;
 }
 int64_t tim_work_items(const int32_t* n, int batch) {
   int64_t pairs = 0;
@@ -2270,6 +2364,9 @@ int64_t tim_work_items(const int32_t* n, int batch) {
   if (seg > 0x7fffffffll) seg = 0x7fffffffll;
   return (seg + tim_region_words(max_n)) * nb;
 }
+
+// third formulation: column chunks per block of a TEASER_K1_VARIANT (kernel template parameter CHUNKS)
+static int tim_variant_chunks(int variant) { return (variant == 27 || variant == 42) ? 4 : 1; }
 
 // phase 0 pre-pass (bbox, centred bf16 operands, R^2, degrees zeroed), 1 the matrix-core kernel (bitmap
 // + degrees), 2 FP64 fix-up of the worklist (+ overflow clear).  Three calls so that the profiling span
@@ -2295,9 +2392,11 @@ void launch_tim_graph_mfma(hipStream_t s, int phase, const ProbDesc* d_desc, int
   // scheduling variant / formulation of the kernel (diagnostics; read per launch so that a probe can switch):
   // 0..6 the first formulation (A, B from the matrix pipe), 7 / 8 the u / w formulation (staged / unstaged stores)
   const char* ev = getenv("TEASER_K1_VARIANT");
-  const int variant = ev ? atoi(ev) : 21;
+  const int variant = ev ? atoi(ev) : 20;
   const bool form2 = variant >= 7;   // operand layout of the u / w algebra
   const bool form3 = variant >= 12;  // min |d| epilogue, group items
+  const int chunks = form3 ? tim_variant_chunks(variant) : 1;
+  const int64_t regs_per_problem = tim_regions_per_problem(T, chunks);  // (reg_words is the arena's stride: the largest geometry)
   if (phase == 0) {
     // prep (and the worklist counter behind it) arrive zeroed: part of the solve's header upload
     hipLaunchKernelGGL(tim_prep_bbox_kernel, dim3((max_n + 1023) / 1024, batch), dim3(256), 0, s, d_desc,
@@ -2328,23 +2427,31 @@ void launch_tim_graph_mfma(hipStream_t s, int phase, const ProbDesc* d_desc, int
       const char* e = getenv("TEASER_K1_LDS_PAD");
       return e ? atoi(e) : 0;
     }();
-#define TIM_K1_LAUNCH3(BAND, PIPE, OCC, DEFER)                                                                          \
-  hipLaunchKernelGGL((tim_graph_mfma3_kernel<BAND, PIPE, OCC, DEFER>), dim3(nblk, batch), dim3(256), lds_pad, s, d_desc, d_src, d_dst, \
+#define TIM_K1_LAUNCH3(BAND, PIPE, OCC, DEFER, CHUNKS, ...)                                                             \
+  hipLaunchKernelGGL((tim_graph_mfma3_kernel<BAND, PIPE, OCC, DEFER, CHUNKS, ##__VA_ARGS__>),                           \
+                     dim3(tim_mfma_blocks(T, CHUNKS), batch), dim3(256), lds_pad, s, d_desc, d_src, d_dst,             \
                      reinterpret_cast<const TimOperandTile2*>(d_pk), prep, d_bitmap, beta, gyr, work, work_count, \
                      (unsigned int)seg_cap, d_state, d_deg, regions, xcd_remap)
     switch (variant) {
-      case 12: TIM_K1_LAUNCH3(0, false, 3, 0); break;
-      case 13: TIM_K1_LAUNCH3(1, false, 3, 0); break;
-      case 14: TIM_K1_LAUNCH3(2, false, 3, 0); break;
-      case 15: TIM_K1_LAUNCH3(0, true, 3, 0); break;
-      case 18: TIM_K1_LAUNCH3(0, true, 2, 0); break;
-      case 20: TIM_K1_LAUNCH3(0, false, 3, 1); break;
-      case 21: TIM_K1_LAUNCH3(1, false, 3, 1); break;
-      case 22: TIM_K1_LAUNCH3(2, false, 3, 1); break;
-      case 23: TIM_K1_LAUNCH3(0, true, 3, 1); break;
-      case 24: TIM_K1_LAUNCH3(0, true, 2, 1); break;
-      case 25: TIM_K1_LAUNCH3(2, true, 2, 1); break;
-      case 30: TIM_K1_LAUNCH3(1, false, 3, 2); break;  // timing build: transposed words dropped (wrong bitmaps)
+      case 12: TIM_K1_LAUNCH3(0, false, 3, 0, 1); break;  // transposed words stored per column tile
+      case 13: TIM_K1_LAUNCH3(1, false, 3, 0, 1); break;
+      case 21: TIM_K1_LAUNCH3(1, false, 3, 1, 1); break;  // band K2 |w| + K0 per value
+      case 22: TIM_K1_LAUNCH3(2, false, 3, 1, 1); break;  // band K2 max |w| + K0 per lane-tile
+      case 23: TIM_K1_LAUNCH3(0, true, 3, 1, 1); break;   // pipelined schedule
+      case 27: TIM_K1_LAUNCH3(0, false, 3, 1, 4); break;  // 32 column tiles per block (4 chunks)
+      case 30: TIM_K1_LAUNCH3(1, false, 3, 2, 1); break;  // timing build: transposed words dropped (wrong bitmaps)
+      case 40: case 42: {  // diagnostics: per-phase s_memtime totals of sampled waves (1 / 4 chunks)
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_k1_trace), z, sizeof(z), 0, hipMemcpyHostToDevice, s);
+        if (variant == 40) { TIM_K1_LAUNCH3(0, false, 3, 1, 1, true); }
+        if (variant == 42) { TIM_K1_LAUNCH3(0, false, 3, 1, 4, true); }
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpyFromSymbol(z, HIP_SYMBOL(g_k1_trace), sizeof(z));
+        fprintf(stderr, "[teaser_hip] K1 cycles per column tile (sampled waves, %llu tiles): mfma0 %.0f epi0 %.0f mfma1 %.0f epi1 %.0f finish %.0f | set-up %.0f, chunk flushes + store drain %.0f\n",
+                z[7], (double)z[0] / z[7], (double)z[1] / z[7], (double)z[2] / z[7], (double)z[3] / z[7], (double)z[4] / z[7],
+                (double)z[5] / z[7], (double)z[6] / z[7]);
+        break;
+      }
       case 11: TIM_K1_LAUNCH2(2, 3, false); break;
       case 0: TIM_K1_LAUNCH(0, 3, true); break;
       case 2: TIM_K1_LAUNCH(2, 3, true); break;
@@ -2357,7 +2464,7 @@ void launch_tim_graph_mfma(hipStream_t s, int phase, const ProbDesc* d_desc, int
       case 9: TIM_K1_LAUNCH2(2, 4, false); break;
       case 10: TIM_K1_LAUNCH2(1, 3, false); break;
       case 1: TIM_K1_LAUNCH(1, 3, true); break;
-      default: TIM_K1_LAUNCH3(1, false, 3, 1); break;  // 21
+      default: TIM_K1_LAUNCH3(0, false, 3, 1, 1); break;  // 20: constant band, flat schedule, transposed words parked in LDS
     }
 #undef TIM_K1_LAUNCH
 #undef TIM_K1_LAUNCH2
@@ -2369,14 +2476,14 @@ void launch_tim_graph_mfma(hipStream_t s, int phase, const ProbDesc* d_desc, int
                        prep, beta, form3 ? 2 : form2 ? 1 : 0);
     if (form3)  // a wave per region of the largest problem (up to 2048 workgroups per problem)
       hipLaunchKernelGGL(tim_fixup_group_kernel,
-                         dim3((unsigned)std::max<int64_t>(4, std::min<int64_t>(2048, (reg_words / kRegionWords + 3) / 4)), batch),
+                         dim3((unsigned)std::max<int64_t>(4, std::min<int64_t>(2048, (regs_per_problem + 3) / 4)), batch),
                          dim3(256), 0, s, d_desc, batch, d_src, d_dst, d_bitmap, beta, work, work_count,
-                         (unsigned int)seg_cap, d_state, d_deg, regions, (unsigned int)(reg_words / kRegionWords));
+                         (unsigned int)seg_cap, d_state, d_deg, regions, (unsigned int)regs_per_problem);
     else
     hipLaunchKernelGGL(tim_fixup_kernel, dim3(std::max(4, std::min(512, 1024 / std::max(batch, 1))), batch), dim3(256), 0, s, d_desc, batch, d_src, d_dst, d_bitmap,
                        beta, work, work_count, (unsigned int)seg_cap, d_state, d_deg,
                        form2 ? regions : static_cast<const unsigned long long*>(nullptr),
-                       (unsigned int)(reg_words / kRegionWords));
+                       (unsigned int)regs_per_problem);
     static const bool dbg = getenv("TEASER_K1_DEBUG") != nullptr;
     if (dbg) {  // diagnostics only: pairs sent to the FP64 fix-up
       std::vector<unsigned int> cnt((size_t)batch);

@@ -1243,12 +1243,13 @@ def test_multi_device_fan_out():
 def test_k1_scheduling_variants_bit_identical(monkeypatch):
     """TEASER_K1_VARIANT: 0..6 are instruction schedules of the first matrix-core formulation of K1 (A, B from the
     matrix pipe; 3, 6: 128-VGPR builds; 4..6: plain instead of packed f32 epilogue), 7..11 of the second one
-    (u / w; 11 = round 3's default), 12..15 of the third one (min |d| epilogue with group fix-up items: 12 = the
-    default, constant band; 13: w-dependent band; 14: 128-VGPR build; 15: plain instead of packed fma), -1 forces the
-    all-FP64 kernel; all bitmaps are identical (and equal the oracle's)."""
+    (u / w; 11 = round 3's default), 12.. of the third one (min |d| epilogue with group fix-up items: 20 = the default --
+    constant band, transposed words parked in LDS; 12 / 13: stored per column tile; 21 / 22: w-dependent bands; 23:
+    pipelined schedule; 27: 32 column tiles per block), -1 forces the all-FP64 kernel; all bitmaps are identical (and
+    equal the oracle's)."""
     pr = tp.synth_problem(61, 4500, 0.9, 0.01)
     _, ref = oracle.inlier_bitmap(pr["src"], pr["dst"], 0.01, 1.0, False)
-    for v in ("-1", "0", "1", "2", "3", "4", "5", "6", "7", "8", "9", "10", "11", "12", "13", "14", "15"):
+    for v in ("-1", "0", "1", "2", "3", "4", "5", "6", "7", "8", "9", "10", "11", "12", "13", "20", "21", "22", "23", "27"):
         monkeypatch.setenv("TEASER_K1_VARIANT", v)
         s = make_solver(**bench_params())
         s.solve(pr["src"], pr["dst"])
