@@ -42,6 +42,24 @@ for task in "$@"; do
     suite) SECONDS=0; TEASER_CERT_DEBUG=$OUT/cert_warmup.txt timeout 1500 python -m pytest tests/ -x -q -m gpu --durations=12 > $OUT/gpu_tests.txt 2>&1; echo "suite rc=$? in ${SECONDS}s"; tail -22 $OUT/gpu_tests.txt ;;
     bench) timeout 1200 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "rc=$?"; cut -c1-700 $OUT/bench.json; tail -3 $OUT/bench.err ;;
     benchq) timeout 400 python bench.py --configs '' --no-cpu-baseline > $OUT/benchq.json 2> $OUT/benchq.err; echo "rc=$?"; cut -c1-500 $OUT/benchq.json; tail -3 $OUT/benchq.err ;;
+    benchv)  # headline only, per K1 variant in $K1VS
+      for v in ${K1VS:-20 21 22}; do TEASER_K1_VARIANT=$v timeout 300 python bench.py --configs '' --no-cpu-baseline --no-latency --no-host-resident --steps 40 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
+print('variant $v: %.0f reg/s, %.4f ms/step, K1 %.4f ms, aux %.4f ms' % (d['value'], d['ms_per_step'], r['avg_launch_ms'], r['aux_ms_per_launch']))"; done | tee $OUT/bench_variants.txt ;;
+    benchenv)  # headline only, one run per environment setting in $ENVS (semicolon-separated "A=1 B=2" groups)
+      IFS=";" read -ra GRPS <<< "${ENVS}"
+      for g in "${GRPS[@]}"; do env $g timeout 300 python bench.py $BENCH_EXTRA --configs '' --no-cpu-baseline --no-latency --no-host-resident --steps 40 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
+print('$g: %.0f reg/s, %.4f ms/step, K1 %.4f ms, aux %.4f ms' % (d['value'], d['ms_per_step'], r['avg_launch_ms'], r['aux_ms_per_launch']))"; done | tee $OUT/bench_env.txt ;;
+    stagesenv)  # per-stage times of the two batched bench shapes, one run per environment setting in $ENVS
+      IFS=";" read -ra GRPS <<< "${ENVS}"
+      for g in "${GRPS[@]}"; do echo "# $g"; env $g timeout 200 python scripts/profile_stages.py batch 2>/dev/null | python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('  n=%d x %d: heuristic %.4f peel %.4f rotation %.4f tim %.4f aux %.4f total %.4f wall %.4f' % (d['n'], d['batch'], d['heuristic_ms'], d['peel_ms'], d['rotation_ms'], d['tim_graph_ms'], d.get('tim_aux_ms',0), d['total_ms'], d['wall_ms']))"; done | tee $OUT/stages_env.txt ;;
     bench4) timeout 600 python bench.py --configs 4 --no-cpu-baseline > $OUT/bench4.json 2> $OUT/bench4.err; echo "rc=$?"; python - <<PY
 import json
 d=json.loads(open("$OUT/bench4.json").read().strip().splitlines()[-1])

@@ -47,5 +47,7 @@ if __name__ == "__main__":
     cfgs = [(1889, 0.6, 1), (5000, 0.9, 1), (10000, 0.95, 1), (10000, 0.95, 16), (5000, 0.9, 128)]
     if len(sys.argv) > 1 and sys.argv[1] == "big":
         cfgs = [(50000, 0.99, 1)]
+    if len(sys.argv) > 1 and sys.argv[1] == "batch":
+        cfgs = [(10000, 0.95, 64), (5000, 0.9, 128)]
     for n, rho, b in cfgs:
         run(n, rho, b, reps=3 if n >= 50000 else 5)

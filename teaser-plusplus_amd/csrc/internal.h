@@ -207,6 +207,11 @@ void launch_tls_translation(hipStream_t s, const ProbDesc* d_desc, int batch, co
                             const double* d_dst, const int32_t* d_clique, ProbState* d_state,
                             EstParams ep, char* d_scratch, int64_t scratch_stride,
                             int32_t* d_trans_inliers);
+// rotation + translation + inlier lists + state hand-over of every problem in ONE launch (one workgroup per problem)
+void launch_estimate_fused(hipStream_t s, const ProbDesc* d_desc, int batch, const double* d_src, const double* d_dst,
+                           const int32_t* d_clique, ProbState* d_state, EstParams ep, double* d_weights,
+                           int32_t* d_rot_inliers, const int64_t* d_tim_off, char* d_tls_scratch, int64_t tls_stride,
+                           int32_t* d_trans_inliers, void* host_states /* page-locked mirror, or null */);
 // generic scalar TLS on device arrays (one workgroup)
 void launch_scalar_tls(hipStream_t s, const double* d_x, const double* d_r, int32_t n,
                        char* d_scratch, double* d_est, uint8_t* d_mask);

@@ -9,6 +9,8 @@
 //       TLSTranslationSolver::solveForTranslation, reference registration.cc:445-471.
 #include <math.h>
 
+#include <type_traits>
+
 #include "internal.h"
 
 namespace thip {
@@ -52,7 +54,10 @@ __device__ void svd_rot3(const double* H, double* R) {
           beta += B[3 * r + q] * B[3 * r + q];
           gamma += B[3 * r + p] * B[3 * r + q];
         }
-        if (gamma == 0.0 || fabs(gamma) <= 1e-17 * sqrt(alpha * beta)) continue;
+        // converged pair: the columns are orthogonal to working precision.  (The threshold used to be 1e-17, below
+        // the rounding noise of gamma itself (~1e-16 sqrt(alpha beta)): most calls then ran all 60 sweeps -- ~50 us
+        // of one thread's FP64 divisions and square roots per GNC iteration, the larger part of the rotation stage.)
+        if (gamma == 0.0 || fabs(gamma) <= 1e-15 * sqrt(alpha * beta)) continue;
         rotated = true;
         const double zeta = (beta - alpha) / (2.0 * gamma);
         const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
@@ -865,6 +870,482 @@ void launch_tls_translation(hipStream_t s, const ProbDesc* d_desc, int batch, co
   hipLaunchKernelGGL(tls_translation_kernel, dim3(3, batch), dim3(256), kTlsGroupLds, s, d_desc,
                      d_src, d_dst, d_clique, d_state, ep, d_scratch, scratch_stride,
                      d_trans_inliers);
+}
+
+// ------------------------------------------------------------------------------------------
+// Fused estimators: ONE workgroup per problem runs the rotation stage, the translation stage, both inlier lists and
+// the hand-over of the problem's state record to the host -- one launch instead of three (gnc_tls_kernel,
+// tls_translation_kernel, state_push_kernel) on the serial chain of a batch.
+//   FAST route (GNC-TLS, CHAIN TIMs, clique of at most kFuseMaxK vertices -- every BASELINE config):
+//   * the clique's points are gathered ONCE (LDS); every thread keeps its <= 2 TIMs and weights in registers, so a
+//     GNC iteration touches no memory besides the block reductions.  Sums are formed in exactly the order of
+//     gnc_tls_block (thread-strided partials, xor-shuffle tree, (s0 + s1) + (s2 + s3)) and every thread runs the
+//     same 3x3 SVD on the reduced H, so R, cost, iterations and weights are BIT-IDENTICAL to gnc_tls_kernel;
+//   * translation (registration.cc:445-471): the three axes run on three waves in parallel.  All ranges are equal
+//     (beta), so the scalar TLS of registration.cc:21-88 needs no endpoint sort with payloads: the values are sorted
+//     in registers (bitonic network over the wave, no workgroup barrier), the consensus set after the e-th endpoint
+//     is a contiguous WINDOW [lo, hi) of the sorted values (hi = openings so far, lo = closings so far), its sums
+//     come from prefix sums, and each lane finds the merged position of its endpoints by two binary searches.
+//     First minimum in endpoint order, NaN never wins -- as :77-78.  Endpoint ties (an opening and a closing of
+//     exactly equal value) are unpinned in the reference (std::sort); here the opening goes first.  Window sums
+//     associate differently from the sequential sweep (~1e-16 relative).
+//   GENERAL route (FGR / QUATRO / COMPLETE TIMs / larger cliques): the block functions of the separate kernels,
+//   the three axes one after the other.
+// ------------------------------------------------------------------------------------------
+constexpr int kFuseMaxK = 512;
+constexpr int kFuseE = kFuseMaxK / 64;  // sorted values per lane
+constexpr int kFuseLdsFast = 3 * (4 * kFuseMaxK + 8) * 8;
+constexpr int kFuseLds = kFuseLdsFast > kTlsGroupLds ? kFuseLdsFast : kTlsGroupLds;
+
+__device__ __forceinline__ double shfl_xor_d(double v, int m) { return __shfl_xor(v, m, 64); }
+
+// ascending bitonic sort of 64 * kFuseE doubles held by one wave, blocked layout (element lane * E + r)
+__device__ __forceinline__ void wave_sort_blocked(double (&v)[kFuseE], int lane) {
+  constexpr int E = kFuseE, N = 64 * E;
+#pragma nounroll
+  for (int k = 2; k <= N; k <<= 1) {
+#pragma nounroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j >= E) {  // partner in another lane, same register
+        const int m = j / E;
+        const bool upper = (lane & m) != 0;
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+          const int idx = lane * E + r;
+          const bool asc = (idx & k) == 0;
+          const double o = shfl_xor_d(v[r], m);
+          const double lo = v[r] < o ? v[r] : o, hi = v[r] < o ? o : v[r];
+          v[r] = (asc != upper) ? lo : hi;  // the lower index of the pair keeps the smaller value when ascending
+        }
+      } else {  // partner in this lane: register r ^ j  (j = 1, 2, 4)
+        auto inlane = [&](auto jc) {
+          constexpr int JJ = decltype(jc)::value;
+#pragma unroll
+          for (int r = 0; r < E; ++r) {
+            if ((r & JJ) == 0) {
+              const int idx = lane * E + r;
+              const bool asc = (idx & k) == 0;
+              const double a = v[r], b = v[r | JJ];
+              const double lo = a < b ? a : b, hi = a < b ? b : a;
+              v[r] = asc ? lo : hi;
+              v[r | JJ] = asc ? hi : lo;
+            }
+          }
+        };
+        if (j == 1) inlane(std::integral_constant<int, 1>());
+        if (j == 2) inlane(std::integral_constant<int, 2>());
+        if (j == 4) inlane(std::integral_constant<int, 4>());
+      }
+    }
+  }
+}
+static_assert(kFuseE == 8, "wave_sort_blocked handles in-lane distances 1, 2, 4");
+
+// ordered list of { j < count * 256 : flag(j) } for elements j = q * 256 + tid held as per-thread flags fl[q]
+template <int Q>
+__device__ __forceinline__ int block_compact_flags(const bool (&fl)[Q], int32_t* out, int* tab /* LDS Q * 4 + 1 */) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint64_t bal[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    bal[q] = __builtin_amdgcn_ballot_w64(fl[q]);
+    if (lane == 0) tab[q * 4 + wave] = __builtin_popcountll(bal[q]);
+  }
+  __syncthreads();
+  int total = 0;
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    int base = total;
+    for (int w = 0; w < 4; ++w) {
+      const int cnt = tab[q * 4 + w];
+      base += (w < wave) ? cnt : 0;
+      total += cnt;
+    }
+    if (fl[q]) {
+      const int pos = base + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(bal[q] >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo((unsigned int)bal[q], 0u));
+      out[pos] = q * 256 + tid;
+    }
+  }
+  __syncthreads();
+  return total;
+}
+
+__global__ __launch_bounds__(256) void estimate_fused_kernel(
+    const ProbDesc* __restrict__ descs, const double* __restrict__ src, const double* __restrict__ dst,
+    const int32_t* __restrict__ clique, ProbState* __restrict__ states, EstParams ep,
+    double* __restrict__ weights, int32_t* __restrict__ rot_inliers, const int64_t* __restrict__ tim_off,
+    char* __restrict__ tls_glob, int64_t tls_stride, int32_t* __restrict__ trans_inliers,
+    uint2* __restrict__ host_states /* page-locked mirror of `states`, or null */) {
+  TAIL_WAVE_PRIO();
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ double sh[64];
+  __shared__ int scan[257];
+  const int prob = blockIdx.x;
+  const ProbDesc d = descs[prob];
+  ProbState* st = states + prob;
+  const int K = st->clique_size;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const double* psrc = src + 3 * d.pt_off;
+  const double* pdst = dst + 3 * d.pt_off;
+  const int32_t* cq = clique + d.pt_off;
+  const double scale = st->scale;
+  if (K <= 1) {  // registration.cc:643-647: invalid, rotation / translation untouched
+    if (tid == 0) {
+      st->n_rot = 0;
+      st->gnc_iters = 0;
+      st->n_trans = 0;
+    }
+  } else if (ep.algorithm == TEASER_ROT_GNC_TLS && ep.tim_graph == 0 && K <= kFuseMaxK) {
+    // ---------------- fast route ----------------
+    double* Pl = reinterpret_cast<double*>(smem);  // [K][6]: src xyz, dst xyz of the clique's vertices
+    double* sH = sh;        // [4][9]
+    double* sS = sh + 45;   // 4
+    constexpr int Q = kFuseMaxK / 256;
+    double px[Q][6];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int j = q * 256 + tid;
+      if (j < K) {
+        const int64_t v = cq[j];
+        for (int r = 0; r < 3; ++r) {
+          px[q][r] = psrc[3 * v + r];
+          px[q][3 + r] = pdst[3 * v + r];
+        }
+        for (int r = 0; r < 6; ++r) Pl[6 * j + r] = px[q][r];
+      }
+    }
+    __syncthreads();
+    // CHAIN TIMs (registration.cc:657-680, :697): TIM j = vertex (j + 1) % K minus vertex j
+    const double inv_scale = 1 / scale;
+    double tx[Q][3], ty[Q][3], w[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int j = q * 256 + tid;
+      w[q] = 1.0;
+      if (j < K) {
+        const int b = (j + 1 == K) ? 0 : j + 1;
+        for (int r = 0; r < 3; ++r) {
+          tx[q][r] = Pl[6 * b + r] - px[q][r];
+          ty[q][r] = (Pl[6 * b + 3 + r] - px[q][3 + r]) * inv_scale;
+        }
+      } else {
+        for (int r = 0; r < 3; ++r) tx[q][r] = ty[q][r] = 0;
+      }
+    }
+    const double nb_rot = ep.noise_bound * (2 / scale);  // registration.cc:702-704
+    double noise_bound_sq = nb_rot * nb_rot;             // :793-796
+    if (noise_bound_sq < 1e-16) noise_bound_sq = 1e-2;
+    double mu = 1, prev_cost = INFINITY, cost = INFINITY;
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    int iters = 0;
+    for (int64_t it = 0; it < ep.max_iterations; ++it) {
+      ++iters;
+      double hh[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        if (q * 256 + tid < K) {
+          for (int r = 0; r < 3; ++r) {
+            const double xw = tx[q][r] * w[q];
+            hh[3 * r] += xw * ty[q][0];
+            hh[3 * r + 1] += xw * ty[q][1];
+            hh[3 * r + 2] += xw * ty[q][2];
+          }
+        }
+      }
+      for (int k = 0; k < 9; ++k) {
+        const double v = wave_sum_d(hh[k]);
+        if (lane == 0) sH[wave * 9 + k] = v;
+      }
+      __syncthreads();
+      {
+        double H[9];
+        for (int k = 0; k < 9; ++k) H[k] = (sH[k] + sH[9 + k]) + (sH[18 + k] + sH[27 + k]);
+        svd_rot3(H, R);  // registration.cc:809 -- every thread, same input, same result
+      }
+      double r2[Q];
+#pragma unroll
+      for (int q = 0; q < Q; ++q) r2[q] = residual_sq(R, tx[q], ty[q]);
+      if (it == 0) {  // registration.cc:814-825
+        double mx = -INFINITY;
+#pragma unroll
+        for (int q = 0; q < Q; ++q)
+          if (q * 256 + tid < K) mx = r2[q] > mx ? r2[q] : mx;
+        mx = wave_max_d(mx);
+        if (lane == 0) sS[wave] = mx;
+        __syncthreads();
+        const double m01 = sS[0] > sS[1] ? sS[0] : sS[1];
+        const double m23 = sS[2] > sS[3] ? sS[2] : sS[3];
+        const double max_residual = m01 > m23 ? m01 : m23;
+        mu = 1 / (2 * max_residual / noise_bound_sq - 1);
+        __syncthreads();
+        if (mu <= 0) break;
+      }
+      const double th1 = (mu + 1) / mu * noise_bound_sq;  // registration.cc:828-829
+      const double th2 = mu / (mu + 1) * noise_bound_sq;
+      double c = 0;
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        if (q * 256 + tid < K) {  // registration.cc:831-844
+          c += w[q] * r2[q];
+          double nw;
+          if (r2[q] >= th1) {
+            nw = 0;
+          } else if (r2[q] <= th2) {
+            nw = 1;
+          } else {
+            nw = sqrt(noise_bound_sq * mu * (mu + 1) / r2[q]) - mu;
+          }
+          w[q] = nw;
+        }
+      }
+      c = wave_sum_d(c);
+      __syncthreads();  // (sH / sS of this iteration have been read by everybody)
+      if (lane == 0) sS[wave] = c;
+      __syncthreads();
+      cost = (sS[0] + sS[1]) + (sS[2] + sS[3]);
+      const double cost_diff = fabs(cost - prev_cost);  // registration.cc:847-858
+      mu = mu * ep.gnc_factor;
+      prev_cost = cost;
+      if (cost_diff < ep.cost_threshold) break;
+    }
+    __syncthreads();
+    // rotation inliers (registration.cc:861-865, :712-716) + the weights for the getters
+    {
+      double* wg = weights + tim_off[prob];
+      bool fl[Q];
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+        const int j = q * 256 + tid;
+        fl[q] = j < K && w[q] >= 0.5;
+        if (j < K) wg[j] = w[q];
+      }
+      const int cnt = block_compact_flags<Q>(fl, rot_inliers + tim_off[prob], scan);
+      if (tid == 0) {
+        for (int k = 0; k < 9; ++k) st->R[k] = R[k];
+        st->gnc_cost = cost;
+        st->gnc_iters = iters;
+        st->n_rot = cnt;
+      }
+    }
+    // ---- translation: raw = dst - (scale R) src per clique vertex (registration.cc:726, :455)
+    double* Xl = reinterpret_cast<double*>(smem);           // [3][kFuseMaxK]   (Pl is dead: the TIMs are in registers)
+    double* Sx = Xl + 3 * kFuseMaxK;                        // [3][kFuseMaxK]   sorted
+    double* S1 = Sx + 3 * kFuseMaxK;                        // [3][kFuseMaxK + 4] exclusive prefix of x
+    double* S2 = S1 + 3 * (kFuseMaxK + 4);                  // [3][kFuseMaxK + 4] exclusive prefix of x^2
+    double xa[Q][3];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const int j = q * 256 + tid;
+      for (int a = 0; a < 3; ++a) {
+        const double r0 = scale * R[3 * a], r1 = scale * R[3 * a + 1], r2v = scale * R[3 * a + 2];
+        const double acc = r0 * px[q][0] + r1 * px[q][1] + r2v * px[q][2];
+        xa[q][a] = px[q][3 + a] - acc;
+        if (j < K) Xl[a * kFuseMaxK + j] = xa[q][a];
+      }
+    }
+    __syncthreads();
+    const double beta = ep.noise_bound * sqrt(ep.cbar2);  // registration.cc:459 (not doubled)
+    double* est3 = sh + 50;                                 // [3]
+    if (wave < 3) {
+      const int a = wave;
+      const double* X = Xl + a * kFuseMaxK;
+      double* sx = Sx + a * kFuseMaxK;
+      double* p1 = S1 + a * (kFuseMaxK + 4);
+      double* p2 = S2 + a * (kFuseMaxK + 4);
+      double v[kFuseE];
+#pragma unroll
+      for (int r = 0; r < kFuseE; ++r) {
+        const int i = lane * kFuseE + r;
+        v[r] = i < K ? X[i] : INFINITY;
+      }
+      wave_sort_blocked(v, lane);
+      // exclusive prefix sums over the sorted order: lane-local, then across the lanes
+      double l1 = 0, l2 = 0;
+#pragma unroll
+      for (int r = 0; r < kFuseE; ++r) {
+        const int i = lane * kFuseE + r;
+        sx[i] = v[r];
+        if (i < K) {
+          l1 += v[r];
+          l2 += v[r] * v[r];
+        }
+      }
+      double i1 = l1, i2 = l2;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const double t1 = __shfl_up(i1, o, 64), t2 = __shfl_up(i2, o, 64);
+        if (lane >= o) {
+          i1 += t1;
+          i2 += t2;
+        }
+      }
+      double e1 = i1 - l1, e2 = i2 - l2;  // exclusive
+#pragma unroll
+      for (int r = 0; r < kFuseE; ++r) {
+        const int i = lane * kFuseE + r;
+        if (i <= K) {
+          p1[i] = e1;
+          p2[i] = e2;
+        }
+        if (i < K) {
+          e1 += v[r];
+          e2 += v[r] * v[r];
+        }
+      }
+      if (lane == 63 && K == 64 * kFuseE) {
+        p1[K] = e1;
+        p2[K] = e2;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // every endpoint: its position in the merged order, the window after it, the cost (registration.cc:58-75)
+      double bcost = INFINITY, bhat = NAN;
+      int bpos = 0x7fffffff;
+      auto consider = [&](int lo, int hi, int pos) {
+        const double card = (double)(hi - lo);
+        const double s1 = p1[hi] - p1[lo], s2 = p2[hi] - p2[lo];
+        const double x_hat = s1 / card;  // (weights 1 / beta^2 cancel)
+        const double residual = card * x_hat * x_hat + s2 - 2 * s1 * x_hat;
+        const double c = residual + beta * (double)(K - (hi - lo));
+        if (c < bcost || (c == bcost && pos < bpos)) {  // first minimum; NaN (empty window) never wins
+          bcost = c;
+          bhat = x_hat;
+          bpos = pos;
+        }
+      };
+#pragma unroll
+      for (int r = 0; r < kFuseE; ++r) {
+        const int i = lane * kFuseE + r;
+        if (i < K) {
+          const double av = v[r] - beta, bv = v[r] + beta;
+          // closings strictly before this opening: #{ j : x_j + beta < av }
+          int lo = 0, n1 = K;
+          while (n1 > 0) {
+            const int half = n1 >> 1;
+            if (sx[lo + half] + beta < av) {
+              lo += half + 1;
+              n1 -= half + 1;
+            } else {
+              n1 = half;
+            }
+          }
+          consider(lo, i + 1, i + lo);
+          // openings up to this closing (ties: the opening first): #{ j : x_j - beta <= bv }
+          int hi = 0;
+          n1 = K;
+          while (n1 > 0) {
+            const int half = n1 >> 1;
+            if (sx[hi + half] - beta <= bv) {
+              hi += half + 1;
+              n1 -= half + 1;
+            } else {
+              n1 = half;
+            }
+          }
+          consider(i + 1, hi, i + hi);
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const double oc = __shfl_xor(bcost, o, 64), oh = __shfl_xor(bhat, o, 64);
+        const int op = __shfl_xor(bpos, o, 64);
+        if (oc < bcost || (oc == bcost && op < bpos)) {
+          bcost = oc;
+          bhat = oh;
+          bpos = op;
+        }
+      }
+      if (!(bcost < INFINITY)) bhat = p1[1] - p1[0];  // no finite cost anywhere: the first endpoint's x_hat
+      if (lane == 0) est3[a] = bhat;
+    }
+    __syncthreads();
+    {
+      const double e0 = est3[0], e1 = est3[1], e2 = est3[2];
+      bool fl[Q];
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {  // registration.cc:86 per axis, :463-470 AND, :731 findNonzero
+        const int j = q * 256 + tid;
+        fl[q] = j < K && fabs(xa[q][0] - e0) <= beta && fabs(xa[q][1] - e1) <= beta && fabs(xa[q][2] - e2) <= beta;
+      }
+      const int cnt = block_compact_flags<Q>(fl, trans_inliers + d.pt_off, scan);
+      if (tid == 0) {
+        st->t[0] = e0;
+        st->t[1] = e1;
+        st->t[2] = e2;
+        st->n_trans = cnt;
+      }
+    }
+  } else {
+    // ---------------- general route: the block functions of the separate kernels ----------------
+    TimSource ts;
+    ts.ps = psrc;
+    ts.pd = pdst;
+    ts.c = cq;
+    ts.K = K;
+    ts.mode = ep.tim_graph;
+    ts.inv_scale = 1 / scale;
+    const int64_t KT = ep.tim_graph == 0 ? (int64_t)K : (int64_t)K * (K - 1) / 2;
+    double* wg = weights + tim_off[prob];
+    const double nb = ep.noise_bound * (2 / scale);  // registration.cc:702-704
+    rotation_block(ep.algorithm, ts, KT, nb, ep, wg, st->R, &st->gnc_cost, &st->gnc_iters, sh);
+    const int alg = ep.algorithm;
+    const int cnt = block_compact(KT, [&](int64_t j) { return rotation_inlier(alg, wg[j]); },
+                                  rot_inliers + tim_off[prob], scan);
+    if (tid == 0) st->n_rot = cnt;
+    __threadfence_block();
+    __syncthreads();
+    char* ps = tls_glob + (int64_t)prob * tls_stride;  // layout as tls_translation_kernel
+    const int64_t Kp = (K + 1) & ~1;
+    int P2 = 2;
+    while (P2 < 2 * K) P2 <<= 1;
+    const double beta = ep.noise_bound * sqrt(ep.cbar2);
+    for (int g = 0; g < 3; ++g) {
+      double* X = reinterpret_cast<double*>(ps) + g * Kp;
+      uint8_t* mask = reinterpret_cast<uint8_t*>(ps + 3 * Kp * 8) + (int64_t)g * Kp;
+      char* glob_ep = ps + 3 * Kp * 8 + 3 * Kp + 16 + (int64_t)g * ((int64_t)P2 * 12 + 16);
+      glob_ep = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(glob_ep) + 15) & ~(uintptr_t)15);
+      const double r0 = scale * st->R[3 * g], r1 = scale * st->R[3 * g + 1], r2 = scale * st->R[3 * g + 2];
+      for (int j = tid; j < K; j += 256) {
+        const int64_t v = cq[j];
+        X[j] = pdst[3 * v + g] - (r0 * psrc[3 * v] + r1 * psrc[3 * v + 1] + r2 * psrc[3 * v + 2]);
+      }
+      __syncthreads();
+      TlsScratch sc = tls_scratch(smem, glob_ep, K);
+      const double est = scalar_tls_group(X, nullptr, beta, K, sc, tid);
+      for (int j = tid; j < K; j += 256) mask[j] = fabs(X[j] - est) <= beta ? 1 : 0;
+      if (tid == 0) st->t[g] = est;
+      __syncthreads();
+    }
+    const uint8_t* m0 = reinterpret_cast<uint8_t*>(ps + 3 * Kp * 8);
+    const uint8_t* m1 = m0 + Kp;
+    const uint8_t* m2 = m1 + Kp;
+    const int cnt2 = block_compact(K, [&](int64_t j) { return (m0[j] & m1[j] & m2[j]) != 0; },
+                                   trans_inliers + d.pt_off, scan);
+    if (tid == 0) st->n_trans = cnt2;
+  }
+  // ---- the problem's state record goes to the host mirror (what state_push_kernel did for the whole batch)
+  if (host_states) {
+    // (the record was written by this workgroup's threads through the L1 of this CU: release, meet, acquire at
+    // agent scope -- the acquire drops the CU's possibly stale lines -- before other threads read it back)
+    __threadfence();
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    constexpr int n8 = (int)(sizeof(ProbState) / 8);
+    const uint2* from = reinterpret_cast<const uint2*>(st);
+    uint2* to = host_states + (size_t)prob * n8;
+    if (tid < n8) to[tid] = from[tid];
+  }
+}
+
+void launch_estimate_fused(hipStream_t s, const ProbDesc* d_desc, int batch, const double* d_src, const double* d_dst,
+                           const int32_t* d_clique, ProbState* d_state, EstParams ep, double* d_weights,
+                           int32_t* d_rot_inliers, const int64_t* d_tim_off, char* d_tls_scratch, int64_t tls_stride,
+                           int32_t* d_trans_inliers, void* host_states) {
+  if (batch <= 0) return;
+  hipLaunchKernelGGL(estimate_fused_kernel, dim3(batch), dim3(256), kFuseLds, s, d_desc, d_src, d_dst, d_clique,
+                     d_state, ep, d_weights, d_rot_inliers, d_tim_off, d_tls_scratch, tls_stride, d_trans_inliers,
+                     reinterpret_cast<uint2*>(host_states));
 }
 
 // Stand-alone scalar TLS on device arrays x[n], r[n] (one group).

@@ -732,6 +732,20 @@ int32_t enqueue_estimators(teaser_hip_solver* h) {
   const ProbDesc* dd = h->d_desc.as<ProbDesc>();
   ProbState* ds = h->d_state.as<ProbState>();
   const EstParams ep = est_params(h->params);
+  // TEASER_HIP_FUSED_EST=0: the three separate launches (rotation, translation, state push) instead of the fused one
+  const char* fe = getenv("TEASER_HIP_FUSED_EST");  // (read per call: the A/B test switches it)
+  const bool fused = !(fe && atoi(fe) == 0);
+  static_assert(sizeof(ProbState) % 8 == 0, "ProbState is moved in 8-byte pieces");
+  HIPCHK(h, h->pin_states.ensure(sizeof(ProbState) * (size_t)batch));
+  if (fused) {
+    StageScope sc(h, ST_ROT);  // (rotation_ms then covers rotation + translation + the state hand-over)
+    launch_estimate_fused(s, dd, batch, h->pend.d_src, h->pend.d_dst, h->d_clique.as<int32_t>(), ds, ep,
+                          h->d_weights.as<double>(), h->d_rot_inl.as<int32_t>(), h->d_tim_off.as<int64_t>(),
+                          h->d_tls_scratch.as<char>(), h->pend.tls_stride, h->d_trans_inl.as<int32_t>(),
+                          h->pin_states.p);
+    HIPCHK(h, hipGetLastError());
+    return TEASER_HIP_OK;
+  }
   {
     StageScope sc(h, ST_ROT);
     launch_gnc_tls(s, dd, batch, h->pend.d_src, h->pend.d_dst, h->d_clique.as<int32_t>(), ds, ep,
@@ -745,8 +759,6 @@ int32_t enqueue_estimators(teaser_hip_solver* h) {
   HIPCHK(h, hipGetLastError());
   {
     StageScope sc(h, ST_D2H);
-    static_assert(sizeof(ProbState) % 8 == 0, "ProbState is moved in 8-byte pieces");
-    HIPCHK(h, h->pin_states.ensure(sizeof(ProbState) * (size_t)batch));
     const int n8 = (int)(sizeof(ProbState) * (size_t)batch / 8);
     hipLaunchKernelGGL(state_push_kernel, dim3((unsigned)std::min(8, (n8 + 255) / 256)), dim3(256), 0, s,
                        h->d_state.as<uint2>(), reinterpret_cast<uint2*>(h->pin_states.p), n8);

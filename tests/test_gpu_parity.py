@@ -1254,3 +1254,48 @@ def test_k1_scheduling_variants_bit_identical(monkeypatch):
         s = make_solver(**bench_params())
         s.solve(pr["src"], pr["dst"])
         assert (s.getInlierGraphBitmap() == ref).all(), v
+
+
+def test_fused_estimators_match_the_separate_kernels(monkeypatch):
+    """estimate_fused_kernel (rotation + translation + inlier lists + state hand-over in one launch) against the three
+    separate launches (TEASER_HIP_FUSED_EST=0): the GNC-TLS arithmetic is ordered identically, so R, the GNC cost, the
+    iteration count and the rotation inliers are bit-identical; the translation comes from the window form of the scalar
+    TLS (sorted values + prefix sums instead of the endpoint sweep): same estimate to ~1e-15, same inlier list.  Cliques of
+    2 .. 512 vertices take the fast route, larger ones (and FGR / QUATRO / COMPLETE) the general route inside the kernel."""
+    cases = [(300, 0.5, 31), (1200, 0.7, 32), (2500, 0.9, 33), (640, 0.1, 34), (9, 0.4, 35), (64, 0.0, 36), (513, 0.0, 37)]
+    probs = [tp.synth_problem(9000 + seed, n, rho, 0.01) for n, rho, seed in cases]
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("TEASER_HIP_FUSED_EST", mode)
+        s = make_solver(**bench_params())
+        out = []
+        for pr in probs:
+            sol = s.solve(pr["src"], pr["dst"])
+            raw = s.raw_solution()
+            out.append((sol.rotation.copy(), sol.translation.copy(), s.getRotationInliers(), s.getTranslationInliers(),
+                        raw.gnc_cost, raw.gnc_iterations, s.getInlierMaxClique()))
+        sols = s.solve_batch([p["src"] for p in probs], [p["dst"] for p in probs])
+        out.append([(o.rotation.copy(), o.translation.copy()) for o in sols])
+        res[mode] = out
+    for k in range(len(probs)):
+        a, b = res["0"][k], res["1"][k]
+        assert a[6] == b[6]
+        assert (a[0] == b[0]).all(), cases[k]
+        assert a[2] == b[2] and a[4] == b[4] and a[5] == b[5]
+        assert np.abs(a[1] - b[1]).max() <= 1e-13 * max(1.0, np.abs(a[1]).max()), (cases[k], a[1], b[1])
+        assert a[3] == b[3]
+        # batched = single, within a route
+        for mode in ("0", "1"):
+            assert (res[mode][-1][k][0] == res[mode][k][0]).all() and (res[mode][-1][k][1] == res[mode][k][1]).all()
+    # FGR, QUATRO and COMPLETE TIMs: the general route
+    for kw in (dict(rotation_estimation_algorithm=tp.RotationEstimationAlgorithm.FGR),
+               dict(rotation_estimation_algorithm=tp.RotationEstimationAlgorithm.QUATRO),
+               dict(rotation_tim_graph=tp.InlierGraphFormulation.COMPLETE)):
+        got = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("TEASER_HIP_FUSED_EST", mode)
+            s = make_solver(**bench_params(**kw))
+            sol = s.solve(probs[0]["src"], probs[0]["dst"])
+            got[mode] = (sol.rotation.copy(), sol.translation.copy(), s.getRotationInliers(), s.getTranslationInliers())
+        assert (got["0"][0] == got["1"][0]).all() and (got["0"][1] == got["1"][1]).all()
+        assert got["0"][2] == got["1"][2] and got["0"][3] == got["1"][3]
