@@ -3153,8 +3153,9 @@ int heuristic_blocks_per_problem(int batch) {
   static const char* ev = getenv("TEASER_HEU_BLOCKS");  // diagnostics
   if (ev && atoi(ev) >= 1 && atoi(ev) <= kMaxStarts) return atoi(ev);
   // about 128 workgroups in flight: every start in parallel for small batches (lowest latency, the GPU is
-  // otherwise idle), two workgroups per problem from 64 problems on (they run beside the next batch's K1 and
-  // each has to wait for a slot a retiring K1 workgroup frees: 2 measured 6 % faster than 4, 4 % faster than 16)
+  // otherwise idle), ONE workgroup per problem from 64 problems on (they run beside the next batch's K1, whose
+  // time they inflate: 1 measured 3-5 % faster than 2, 2 6 % faster than 4; profiles/r4l, r4m)
+  if (batch >= 64) return 1;
   return std::max(2, std::min(kMaxStarts, 128 / std::max(batch, 1)));
 }
 
