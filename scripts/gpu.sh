@@ -60,6 +60,9 @@ import json,sys
 for l in sys.stdin:
     if l.startswith('{'):
         d=json.loads(l); print('  n=%d x %d: heuristic %.4f peel %.4f rotation %.4f tim %.4f aux %.4f total %.4f wall %.4f' % (d['n'], d['batch'], d['heuristic_ms'], d['peel_ms'], d['rotation_ms'], d['tim_graph_ms'], d.get('tim_aux_ms',0), d['total_ms'], d['wall_ms']))"; done | tee $OUT/stages_env.txt ;;
+    c5env)  # config 5 (single + batched) per environment setting in $ENVS
+      IFS=";" read -ra GRPS <<< "${ENVS}"
+      for g in "${GRPS[@]}"; do echo "# $g"; env $g timeout 200 python scripts/profile_config5.py batch 2>/dev/null | python scripts/pick.py config,exact_ms,heuristic_ms,colour_ms,rotation_ms,total_ms; done | tee $OUT/config5_env.txt ;;
     bench4) timeout 600 python bench.py --configs 4 --no-cpu-baseline > $OUT/bench4.json 2> $OUT/bench4.err; echo "rc=$?"; python - <<PY
 import json
 d=json.loads(open("$OUT/bench4.json").read().strip().splitlines()[-1])

@@ -314,6 +314,7 @@ class RobustRegistrationSolver:
             pass
 
     def _check(self, rc):
+        self.last_status = int(rc)  # (5 = TIME_LIMIT is not an error: see STATUS_NAMES)
         if rc not in (0, 5):  # TIME_LIMIT still returns the incumbent (graph.cc:44)
             raise TeaserHipError(rc, self._lib.teaser_hip_last_error(self._h).decode())
 

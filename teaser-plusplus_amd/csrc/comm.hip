@@ -7,7 +7,6 @@
 // librccl is dlopen'ed on first use, so the library loads (and every other entry works) without it.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 
 #include <cstring>
 #include <mutex>
@@ -15,6 +14,25 @@
 #include <vector>
 
 #include "teaser_hip.h"
+
+// The five RCCL entry points used here, declared locally (their C ABI is NCCL's and stable): the library builds on a
+// ROCm install without the RCCL development headers, and the calls resolve at run time through dlopen / dlsym.
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct {
+  char internal[128];  // NCCL_UNIQUE_ID_BYTES
+} ncclUniqueId;
+typedef int ncclResult_t;    // ncclSuccess = 0
+typedef int ncclDataType_t;  // ncclUint8 = 1
+ncclResult_t ncclGetUniqueId(ncclUniqueId* id);
+ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int rank);
+ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t datatype,
+                           ncclComm_t comm, hipStream_t stream);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+const char* ncclGetErrorString(ncclResult_t result);
+}
+constexpr ncclResult_t ncclSuccess = 0;
+constexpr ncclDataType_t ncclUint8 = 1;
 
 namespace {
 struct Rccl {
@@ -140,12 +158,15 @@ int32_t teaser_hip_comm_gather_solutions(teaser_hip_comm* c, const teaser_soluti
   if (!c || total < 0 || n_local < 0 || (n_local > 0 && !local) || (total > 0 && !all)) return TEASER_HIP_ERR_BAD_ARG;
   int64_t first = 0, last = 0;
   (void)teaser_hip_comm_shard(total, c->rank, c->world, &first, &last);
-  if (n_local != last - first) {
+  // A rank whose record count is wrong still TAKES PART in the collective (with a zeroed block) and reports
+  // BAD_ARG afterwards: returning early would leave its peers waiting inside ncclAllGather for ever.
+  const bool bad_count = n_local != last - first;
+  if (bad_count) {
     c->err = "teaser_hip_comm_gather_solutions: this rank's shard of " + std::to_string(total) + " problems holds " +
              std::to_string(last - first) + " records, not " + std::to_string(n_local);
-    return TEASER_HIP_ERR_BAD_ARG;
+    n_local = 0;
   }
-  if (total == 0) return TEASER_HIP_OK;
+  if (total == 0) return bad_count ? TEASER_HIP_ERR_BAD_ARG : TEASER_HIP_OK;
   if (hipSetDevice(c->device) != hipSuccess) return TEASER_HIP_ERR_HIP;
   // shards are ragged by at most one record: every rank sends a block of the largest shard's size
   const int64_t cap = (total + c->world - 1) / c->world;
@@ -190,7 +211,7 @@ int32_t teaser_hip_comm_gather_solutions(teaser_hip_comm* c, const teaser_soluti
     (void)teaser_hip_comm_shard(total, r, c->world, &f, &l);
     if (l > f) std::memcpy(all + f, got.data() + (size_t)r * (size_t)cap, (size_t)(l - f) * sizeof(teaser_solution_c));
   }
-  return TEASER_HIP_OK;
+  return bad_count ? TEASER_HIP_ERR_BAD_ARG : TEASER_HIP_OK;
 }
 
 }  // extern "C"

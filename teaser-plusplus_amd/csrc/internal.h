@@ -118,7 +118,7 @@ void launch_degrees(hipStream_t s, const ProbDesc* d_desc, int batch, int max_n,
                     const uint64_t* d_bitmap, int32_t* d_deg, ProbState* d_state);
 // greedy multi-start clique heuristic (each workgroup picks its own start vertex; the problem states
 // must arrive zeroed); writes per-start cliques, then the per-problem best
-int heuristic_blocks_per_problem(int batch);
+int heuristic_blocks_per_problem(int batch, int max_W);
 void launch_heuristic(hipStream_t s, const ProbDesc* d_desc, int batch, int max_W,
                       const uint64_t* d_bitmap, const int32_t* d_deg, ProbState* d_state,
                       int32_t* d_start_cliques /* [kMaxStarts][sum n] */, int64_t total_n,
@@ -150,11 +150,10 @@ struct ExactProb {
                          // (0 ok / 1 arena overflow / 2 time limit), [5] raw |X|, [6] kept |X|, [7] spare
 };
 constexpr int64_t kExactLdsBitmapBytes = 128 * 1024;  // compact adjacency up to 128 KB is staged in LDS
-constexpr int kExactBuildCap = 8192;  // compact vertices the device-side ordering handles (beyond: host path)
 constexpr int kExactXCap = 512;       // |X| up to which only X and its neighbourhood enter the compact problem
 constexpr int kExactExpandPasses = 1;   // task depth = passes + 1; more passes (TEASER_K4_EXPAND) cut bushy trees finer -- the
                                         // descriptor graphs measured here have thin, deep trees (branching ~1.1) and gain nothing
-constexpr int kExactCounterInts = 16;   // 2 ints per task queue
+constexpr int kExactCounterInts = 96;   // 2 ints per task queue (8 queues), then the donation queue / termination counters
 // step 1 (one workgroup per open problem): root filter, candidate set, sizes -> ExactProb.{n2, n_roots, ...}
 void launch_exact_count(hipStream_t s, const ProbDesc* d_desc, ExactProb* d_probs, int nprob, int max_W,
                         const uint64_t* d_bitmap, const uint64_t* d_alive, const int32_t* d_deg,

@@ -30,8 +30,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <future>
+#include <algorithm>
+#include <atomic>
+#include <climits>
 #include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -262,13 +265,15 @@ __global__ void cert_update_kernel(const double* __restrict__ Maff, const double
 // without vectors) + dgemm so that the code objects are registered.  certify_on_device() joins it first.
 namespace {
 std::once_flag g_warm_once;
-std::shared_future<void> g_warm_done;
+std::mutex g_warm_mu;              // guards the join
+std::thread g_warm_thread;         // (a plain thread + an atexit hook: a std::async future parked in a static would be
+std::atomic<bool> g_warm_stop{false};  // joined by a static destructor, i.e. AFTER the HIP runtime began to unload)
 
-void read_through(const std::string& path) {  // pull a file into the page cache
+void read_through(const std::string& path) {  // pull a file into the page cache (gives up when the process is exiting)
   FILE* f = std::fopen(path.c_str(), "rb");
   if (!f) return;
   std::vector<char> buf((size_t)8 << 20);
-  while (std::fread(buf.data(), 1, buf.size(), f) == buf.size()) {
+  while (!g_warm_stop.load(std::memory_order_relaxed) && std::fread(buf.data(), 1, buf.size(), f) == buf.size()) {
   }
   std::fclose(f);
 }
@@ -285,8 +290,21 @@ std::string rocm_lib_dir() {
 // sequential read of the same file 11 s.
 void prefetch_library_files() {
   const std::string dir = rocm_lib_dir();
-  read_through(dir + "/librocsolver.so.0");
-  read_through(dir + "/librocblas.so.5");
+  // librocsolver.so.<major> / librocblas.so.<major>: whatever major version this ROCm ships (one file each: the
+  // versioned names are links to the same file, read once)
+  if (DIR* d = opendir(dir.c_str())) {
+    std::vector<std::string> seen;
+    while (struct dirent* e = readdir(d)) {
+      const std::string name(e->d_name);
+      if (name.rfind("librocsolver.so.", 0) != 0 && name.rfind("librocblas.so.", 0) != 0) continue;
+      char real[4096];
+      if (!realpath((dir + "/" + name).c_str(), real)) continue;
+      if (std::find(seen.begin(), seen.end(), std::string(real)) != seen.end()) continue;
+      seen.push_back(real);
+    }
+    closedir(d);
+    for (const std::string& f : seen) read_through(f);
+  }
   // Tensile's per-architecture code objects next to librocblas: <dir>/rocblas/library/*gfx950*
   const std::string tdir = dir + "/rocblas/library";
   if (DIR* d = opendir(tdir.c_str())) {
@@ -308,6 +326,7 @@ void warmup_body(int device) {
   };
   prefetch_library_files();
   lap("library files read");
+  if (g_warm_stop.load()) return;  // the process is exiting: do not start loading libraries now
   CertLibs& L = cert_libs();
   if (!L.ok) return;
   lap("libraries opened");
@@ -345,11 +364,20 @@ void warmup_body(int device) {
 }
 }  // namespace
 
-void certifier_warmup_async(int device) {
-  std::call_once(g_warm_once, [device] { g_warm_done = std::async(std::launch::async, warmup_body, device).share(); });
-}
 static void certifier_warmup_join() {
-  if (g_warm_done.valid()) g_warm_done.wait();
+  std::lock_guard<std::mutex> lk(g_warm_mu);
+  if (g_warm_thread.joinable()) g_warm_thread.join();
+}
+void certifier_warmup_async(int device) {
+  std::call_once(g_warm_once, [device] {
+    g_warm_thread = std::thread(warmup_body, device);
+    // registered AFTER the HIP runtime's own exit handlers, hence run BEFORE them: the thread is stopped (file
+    // prefetch) or waited for (library load, seconds once the files are cached) while HIP is still alive
+    std::atexit([] {
+      g_warm_stop.store(true);
+      certifier_warmup_join();
+    });
+  });
 }
 
 // src / dst: N points, xyz interleaved (= the 3 x N column-major matrices of the reference); R row-major.

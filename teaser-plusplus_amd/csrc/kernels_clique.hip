@@ -188,7 +188,26 @@ struct ExactQueues {
   int32_t* counters;  // [2 k] queue k: tasks written, [2 k + 1] queue k: next task to take
   int32_t cap;        // slots per half
   int32_t slot_bytes;  // header + 8 * max W2, multiple of 32
+  // donation queue of the sequential phase (see dfs_subtree): slots of dslot_bytes = task header | candidate set
+  // (max W2 words) | clique prefix beyond the header's kTaskPrefix entries (up to dprefix vertices in all)
+  char* dpool;
+  int32_t* dready;    // [dcap] slot published (release store by the donor once the slot is written)
+  int32_t dcap, dslot_bytes, dprefix;
+  int32_t donate_after;  // nodes a wave searches on its own before it first gives work away
+  int32_t max_hungry;    // pollers the launch keeps; further idle waves leave at once
 };
+// counters[] of the donation queue / termination (behind the phase queues' 2 x 8)
+// (one 64-byte line each: thousands of idle waves poll them)
+constexpr int kCntDCount = 32;   // slots reserved
+constexpr int kCntDHead = 48;    // next slot to take
+constexpr int kCntActive = 64;   // waves holding (or about to take) a task
+constexpr int kCntHungry = 80;   // waves polling for work
+static_assert(kExactCounterInts >= 96, "counters of the donation queue");
+constexpr int kDonateLevels = 256;   // depth up to which a wave remembers its level records (LDS, 8 bytes each)
+constexpr unsigned int kDonateEvery = 32;  // search nodes between two looks at the hungry counter
+constexpr unsigned int kDonateAfter = 64; // nodes a wave searches on its own before it first gives work away
+constexpr int kMaxHungry = 64;       // pollers the launch keeps; further idle waves leave at once (nobody needs them:
+                                     // a donation is a handful of tasks, and a poller that finds none stays)
 
 struct WaveCtx {
   ExactProb* pb;
@@ -204,6 +223,10 @@ struct WaveCtx {
   unsigned int steps;
   char* lds_stack;       // wave-private LDS for the small (deep, hot) levels of the sequential search
   int lds_stack_bytes;
+  const ExactQueues* dq;  // donation queue (null: none)
+  int64_t* lvl;           // LDS [kDonateLevels]: offset of the level record at every depth of the running subtree
+  int q;                  // problem index in the launch (tasks carry it)
+  int max_W2;             // the launch's slot geometry
 };
 
 // Sequential branch and bound below the node whose candidate set P (pc vertices) sits in the level record at
@@ -215,7 +238,98 @@ struct WaveCtx {
 // LIFO order overall, hence in LIFO order on each of the two stacks: a record's offset says where it lives
 // (>= kLdsLevelTag: LDS) and popping it resets that stack's top to its own offset.
 constexpr int64_t kLdsLevelTag = (int64_t)1 << 40;
-constexpr int kLdsLevelMax = 768;  // bytes: records up to this size go to the LDS stack while it has room
+constexpr int kLdsLevelMax = 2048;  // bytes: records up to this size go to the LDS stack while it has room
+
+// Best clique of a problem: incumbent size by atomicMax, the vertices under the problem's lock.
+__device__ __forceinline__ void record_clique(ExactProb* pb, int32_t* __restrict__ best_clique, const int32_t* C, int size) {
+  int32_t* best_size = &pb->ctrl[0];
+  int32_t* recorded_size = &pb->ctrl[1];
+  int32_t* lock = &pb->ctrl[2];
+  atomicMax(best_size, size);
+  while (atomicCAS(lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(2);
+  __threadfence();
+  const int rec = __hip_atomic_load(recorded_size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (size > rec) {
+    for (int k = 0; k < size; ++k) __hip_atomic_store(best_clique + k, C[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(recorded_size, size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __threadfence();
+  atomicExch(lock, 0);
+}
+
+// DYNAMIC LOAD BALANCE of the sequential phase.  Static task depths leave the wall time of a batch at its heaviest
+// subtree (config 5 x 64: 169 k nodes of evenly spread work would be 0.4 ms, the phase took 19 ms).  A wave that has
+// been searching for a while looks at the launch's `hungry` counter every kDonateEvery nodes; if other waves have
+// nothing to do, it gives away the SHALLOWEST level of its stack that still has untried branches: every such branch
+// (prefix + branch vertex, candidate set P & N(u), the level's colour bound) becomes a task of the donation queue,
+// the level is marked exhausted, and the donor goes on with the path it is on.  Idle waves poll that queue; the
+// phase ends when no wave holds a task and both queues are drained.  Shallow levels first: their subtrees are the
+// largest, and deeper levels may be given away at later looks.  Exactly the branches the donor would have tried are
+// tried by somebody, against the same shared incumbent: the result is a maximum clique either way.
+__device__ __attribute__((noinline)) int donate_level(WaveCtx& cx, int64_t off_d, int csize_d, int best) {
+  const int lane = threadIdx.x, W = cx.W;
+  const ExactQueues& Q = *cx.dq;
+  char* arena = cx.arena;
+  char* lds = cx.lds_stack;
+  char* rec = off_d >= kLdsLevelTag ? lds + (off_d - kLdsLevelTag) : arena + off_d;
+  const int64_t hdr_b = align16(sizeof(LevelHdr)), p_b = align16((int64_t)W * 8);
+  LevelHdr* L = reinterpret_cast<LevelHdr*>(rec);
+  uint64_t* P = reinterpret_cast<uint64_t*>(rec + hdr_b);
+  const int lpc = L->pcount;
+  const int32_t* order = reinterpret_cast<const int32_t*>(reinterpret_cast<char*>(P) + p_b);
+  const int32_t* colour = order + (align16((int64_t)lpc * 4) / 4);
+  int idx = L->idx, given = 0;
+  __syncthreads();
+  for (; idx >= 0; --idx) {
+    const int col = colour[idx];
+    if (col <= best - csize_d) {  // colours are listed in non-decreasing order: nothing below can improve
+      idx = -1;
+      break;
+    }
+    const int u = order[idx];
+    const uint64_t* ru = cx.bmrows + (int64_t)u * W;
+    // the queue's state is ONE 64-bit word, slots reserved << 32 | next slot to take (pollers read it with one load)
+    unsigned long long* qword = reinterpret_cast<unsigned long long*>(&Q.counters[kCntDCount]);
+    int slot = 0;
+    if (lane == 0) slot = (int)(atomicAdd(qword, 1ull << 32) >> 32);
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    if (slot >= Q.dcap) {  // queue full (the reservation stays: slots beyond dcap are never taken): keep this branch
+      break;               // and the ones below it
+    }
+    ExactTask* t = reinterpret_cast<ExactTask*>(Q.dpool + (int64_t)slot * Q.dslot_bytes);
+    uint64_t* tp = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(t) + sizeof(ExactTask));
+    int32_t* tail = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(t) + sizeof(ExactTask) + 8 * (int64_t)cx.max_W2);
+    int cnt = 0;
+    for (int w = lane; w < W; w += 64) {
+      const uint64_t x = P[w] & ru[w];
+      tp[w] = x;
+      cnt += __popcll(x);
+    }
+    cnt = wsum(cnt);
+    __syncthreads();
+    if (lane == 0) P[u >> 6] &= ~(1ull << (u & 63));
+    for (int k = lane; k < csize_d; k += 64) {
+      if (k < kTaskPrefix) t->C[k] = cx.C[k];
+      else tail[k - kTaskPrefix] = cx.C[k];
+    }
+    if (lane == 0) {
+      if (csize_d < kTaskPrefix) t->C[csize_d] = u;
+      else tail[csize_d - kTaskPrefix] = u;
+      t->q = cx.q;
+      t->csize = csize_d + 1;
+      // (a child without candidates is a clique of csize_d + 1: the taker records it if it beats the incumbent)
+      t->cnt = cnt;
+      t->cb = csize_d + col;
+    }
+    __threadfence();
+    __syncthreads();
+    if (lane == 0) __hip_atomic_store(&Q.dready[slot], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    ++given;
+  }
+  if (lane == 0) L->idx = idx;
+  __syncthreads();
+  return given;
+}
 
 __device__ int dfs_subtree(WaveCtx& cx, int32_t* __restrict__ best_clique, int csize, int pc) {
   const int lane = threadIdx.x, W = cx.W;
@@ -248,9 +362,27 @@ __device__ int dfs_subtree(WaveCtx& cx, int32_t* __restrict__ best_clique, int c
   }
   __syncthreads();
   int depth = 0;
+  int donate_depth = 0;  // levels below it have been given away (or had nothing left to give)
+  const unsigned int steps0 = cx.steps;
+  if (cx.dq && lane == 0) cx.lvl[0] = off;
   while (depth >= 0) {
     // the time limit also holds INSIDE a subtree (checked every 256 steps)
     if ((++cx.steps & 255u) == 0u && cx.deadline > 0 && wall_clock64() - cx.t_start > cx.deadline) return 2;
+    if (cx.dq && (cx.steps & (kDonateEvery - 1)) == 0u && cx.steps - steps0 >= (unsigned int)cx.dq->donate_after && donate_depth <= depth &&
+        donate_depth < kDonateLevels &&
+        __hip_atomic_load(&cx.dq->counters[kCntHungry], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) {
+      // the shallowest level that still has a branch worth trying (the current level included: its untried branches
+      // are as good as any; the one being expanded is past idx); levels found empty are not looked at again
+      best = __hip_atomic_load(best_size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int given = 0;
+      while (given == 0 && donate_depth <= depth && donate_depth < kDonateLevels) {
+        const int csize_d = csize - (depth - donate_depth);
+        if (csize_d + 1 > cx.dq->dprefix) break;
+        __syncthreads();
+        given = donate_level(cx, cx.lvl[donate_depth], csize_d, best);
+        ++donate_depth;
+      }
+    }
     L = reinterpret_cast<LevelHdr*>(at(off));
     P = reinterpret_cast<uint64_t*>(at(off) + hdr_b);
     const int lpc = L->pcount;
@@ -337,6 +469,7 @@ __device__ int dfs_subtree(WaveCtx& cx, int32_t* __restrict__ best_clique, int c
         htop += nbytes;
       off = noff;
       ++depth;
+      if (cx.dq && depth < kDonateLevels && lane == 0) cx.lvl[depth] = off;
     }
   }
   return 0;
@@ -475,6 +608,11 @@ __global__ __launch_bounds__(64) void exact_clique_kernel(ExactProb* __restrict_
   uint64_t* lds_bm = cx.Qc + ((max_W2 + 1) & ~1);
   cx.lds_stack = smem + lds_stack_off;
   cx.lds_stack_bytes = lds_stack_bytes;
+  const ExactQueues qs_copy = qs;  // (a local copy: the wave context points at it)
+  cx.dq = (PHASE == 3 && qs.dcap > 0) ? &qs_copy : nullptr;
+  cx.lvl = reinterpret_cast<int64_t*>(smem + lds_stack_off + lds_stack_bytes);  // (allocated only with a donation queue)
+  cx.q = -1;
+  cx.max_W2 = max_W2;
   cx.deadline = deadline_ticks;
   cx.t_start = wall_clock64();
   cx.steps = 0;
@@ -540,12 +678,82 @@ __global__ __launch_bounds__(64) void exact_clique_kernel(ExactProb* __restrict_
     const int n_in = min(qs.counters[2 * in_level], qs.cap);
     int32_t* head = qs.counters + 2 * in_level + 1;
     int cur_q = -1;
+    const bool donating = PHASE == 3 && qs.dcap > 0;
+    int32_t* active = qs.counters + kCntActive;
+    int32_t* hungry = qs.counters + kCntHungry;
+    bool primary_done = false, am_hungry = false, holding = false;
     while (true) {
-      int i = 0;
-      if (lane == 0) i = atomicAdd(head, 1);
-      i = __builtin_amdgcn_readfirstlane(i);
-      if (i >= n_in) break;
-      const ExactTask* t = reinterpret_cast<const ExactTask*>(pool_in + (int64_t)i * qs.slot_bytes);
+      // ---- next task: the phase's own queue first, then (sequential phase) what busy waves have given away
+      if (holding) {  // the previous task is finished
+        if (donating && lane == 0) atomicSub(active, 1);
+        holding = false;
+      }
+      const ExactTask* t = nullptr;
+      const int32_t* tail = nullptr;
+      if (!primary_done) {
+        int i = 0;
+        if (lane == 0) {
+          if (donating) atomicAdd(active, 1);
+          i = atomicAdd(head, 1);
+        }
+        i = __builtin_amdgcn_readfirstlane(i);
+        if (i < n_in) {
+          t = reinterpret_cast<const ExactTask*>(pool_in + (int64_t)i * qs.slot_bytes);
+          holding = true;
+        } else {
+          primary_done = true;
+          if (donating && lane == 0) atomicSub(active, 1);
+          if (!donating) break;
+        }
+      }
+      if (!t) {
+        if (!donating) break;
+        // poll: active is read BEFORE the queue -- a wave can only give work away while it is counted active, so
+        // "nobody active" seen first and "queue drained" seen after it means nothing can arrive any more
+        int slot = -1, done = 0;
+        if (lane == 0) {
+          unsigned long long* qword = reinterpret_cast<unsigned long long*>(&qs.counters[kCntDCount]);
+          const int a = __hip_atomic_load(active, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long w = __hip_atomic_load(qword, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+          const int cnt_d = min((int)(w >> 32), qs.dcap), hd = (int)(w & 0xffffffffull);
+          if (hd < cnt_d) {
+            atomicAdd(active, 1);
+            if (atomicCAS(qword, w, w + 1ull) == w) {
+              slot = hd;
+              while (__hip_atomic_load(&qs.dready[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0)
+                __builtin_amdgcn_s_sleep(1);
+            } else {
+              atomicSub(active, 1);
+            }
+          } else if (a == 0) {
+            done = 1;
+          }
+        }
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        done = __builtin_amdgcn_readfirstlane(done);
+        if (done) break;
+        if (slot < 0) {
+          if (!am_hungry) {
+            int hn = 0;
+            if (lane == 0) hn = atomicAdd(hungry, 1);
+            hn = __builtin_amdgcn_readfirstlane(hn);
+            if (hn >= qs.max_hungry) {  // enough pollers already
+              if (lane == 0) atomicSub(hungry, 1);
+              break;
+            }
+            am_hungry = true;
+          }
+          __builtin_amdgcn_s_sleep(127);  // ~4 us between two looks: pollers must not crowd the L2 channel of the word
+          continue;
+        }
+        t = reinterpret_cast<const ExactTask*>(qs.dpool + (int64_t)slot * qs.dslot_bytes);
+        tail = reinterpret_cast<const int32_t*>(reinterpret_cast<const char*>(t) + sizeof(ExactTask) + 8 * (int64_t)max_W2);
+        holding = true;
+      }
+      if (am_hungry) {
+        if (lane == 0) atomicSub(hungry, 1);
+        am_hungry = false;
+      }
       const int q = t->q, csize = t->csize, cnt = t->cnt, cb = t->cb;
       ExactProb* tpb = probs + q;
       const int best = __hip_atomic_load(&tpb->ctrl[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -561,6 +769,7 @@ __global__ __launch_bounds__(64) void exact_clique_kernel(ExactProb* __restrict_
         pb = tpb;
         stage_problem(cx, pb, bitmap_pool, arena_wave, arena_bytes, lds_bm);
         cur_q = q;
+        cx.q = q;
       }
       const int W = cx.W;
       if (cx.stack0 + hdr_b + align16((int64_t)W * 8) > arena_bytes) {
@@ -571,10 +780,23 @@ __global__ __launch_bounds__(64) void exact_clique_kernel(ExactProb* __restrict_
       const uint64_t* tp = reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(t) + sizeof(ExactTask));
       __syncthreads();
       for (int w = lane; w < W; w += 64) P[w] = tp[w];
-      if (lane < csize) cx.C[lane] = t->C[lane];
+      {  // (prefix beyond the header's entries: donated tasks only)
+        const int32_t* ext = tail ? tail : t->C;
+        for (int k = lane; k < csize; k += 64) {
+          int v;
+          if (k < kTaskPrefix) v = t->C[k];
+          else v = ext[k - kTaskPrefix];
+          cx.C[k] = v;
+        }
+      }
       __syncthreads();
       int32_t* best_clique = clique_pool + pb->clique_off;
       ++cx.steps;
+      if (cnt == 0) {  // (a donated leaf: the clique is the prefix itself)
+        if (csize > best && lane == 0) record_clique(pb, best_clique, cx.C, csize);
+        __syncthreads();
+        continue;
+      }
       int rc;
       if (PHASE == 2)
         rc = expand_node(cx, best_clique, q, csize, cnt, qs.pool[(in_level + 1) & 1], qs.counters + 2 * (in_level + 1), qs.cap,
@@ -600,17 +822,38 @@ void launch_exact_clique(hipStream_t s, ExactProb* d_probs, int nprob, int total
   const size_t lds_base = (((size_t)2 * ((max_W2 + 1) & ~1) * 8 + (size_t)max_lds_bitmap_bytes) + 15) & ~(size_t)15;
   static const int stack_env = [] {
     const char* e = getenv("TEASER_K4_LDS_STACK");  // bytes; 0 = every level record in the HBM arena
-    return e ? atoi(e) : 8192;
+    return e ? atoi(e) : 16384;
   }();
-  const int lds_stack_bytes = (lds_base + (size_t)stack_env <= 40 * 1024) ? (stack_env & ~15) : 0;
-  const size_t lds = lds_base + (size_t)lds_stack_bytes;
+  const int lds_stack_bytes = (lds_base + (size_t)stack_env <= 56 * 1024) ? (stack_env & ~15) : 0;
+  // donation queue of the sequential phase, carved from the END of the task pool: dcap slots of header | candidate
+  // set | clique prefix, then the slots' ready flags.  TEASER_K4_DONATE=0: static tasks only (diagnostics).
+  static const bool donate_env = [] {
+    const char* e = getenv("TEASER_K4_DONATE");
+    return !(e && atoi(e) == 0);
+  }();
+  ExactQueues qs;
+  qs.dprefix = std::min(64 * max_W2, 512);
+  qs.dslot_bytes = (int32_t)((sizeof(ExactTask) + 8 * (size_t)max_W2 + 4 * (size_t)qs.dprefix + 31) & ~(size_t)31);
+  qs.dcap = donate_env ? 32768 : 0;
+  static const int after_env = [] { const char* e = getenv("TEASER_K4_DONATE_AFTER"); return e ? atoi(e) : (int)kDonateAfter; }();
+  static const int hungry_env = [] { const char* e = getenv("TEASER_K4_HUNGRY"); return e ? atoi(e) : kMaxHungry; }();
+  qs.donate_after = after_env;
+  qs.max_hungry = hungry_env;
+  int64_t donate_bytes = (int64_t)qs.dcap * (qs.dslot_bytes + 4);
+  if (donate_bytes * 2 > task_pool_bytes) {  // (the host sizes the pool for it; a caller with a small pool gets none)
+    qs.dcap = 0;
+    donate_bytes = 0;
+  }
+  task_pool_bytes -= donate_bytes;
+  qs.dpool = d_task_pool + task_pool_bytes;
+  qs.dready = reinterpret_cast<int32_t*>(qs.dpool + (int64_t)qs.dcap * qs.dslot_bytes);
+  const size_t lds = lds_base + (size_t)lds_stack_bytes + (qs.dcap > 0 ? (size_t)kDonateLevels * 8 : 0);
   static DynLdsOptIn optin1, optin2, optin3;
   if (lds > 48 * 1024) {
     optin1.ensure(reinterpret_cast<const void*>(exact_clique_kernel<1>), (int)lds);
     optin2.ensure(reinterpret_cast<const void*>(exact_clique_kernel<2>), (int)lds);
     optin3.ensure(reinterpret_cast<const void*>(exact_clique_kernel<3>), (int)lds);
   }
-  ExactQueues qs;
   qs.slot_bytes = (int32_t)((sizeof(ExactTask) + 8 * (size_t)max_W2 + 31) & ~(size_t)31);
   const int64_t slots = task_pool_bytes / qs.slot_bytes;
   qs.cap = (int32_t)std::min<int64_t>(slots / 2, 1 << 23);
@@ -626,6 +869,7 @@ void launch_exact_clique(hipStream_t s, ExactProb* d_probs, int nprob, int total
     return v < 0 ? 0 : (v > kTaskPrefix - 1 ? kTaskPrefix - 1 : v);
   }();
   (void)hipMemsetAsync(d_counters, 0, (size_t)kExactCounterInts * sizeof(int32_t), s);
+  if (qs.dcap > 0) (void)hipMemsetAsync(qs.dready, 0, (size_t)qs.dcap * sizeof(int32_t), s);
   const int w1 = std::min(total_waves, arena_waves);
   hipLaunchKernelGGL(exact_clique_kernel<1>, dim3(w1), dim3(64), lds, s, d_probs, nprob, d_bitmap_pool, d_arena_pool,
                      arena_bytes, max_W2, d_clique_pool, qs, deadline_ticks, (int)lds_base, lds_stack_bytes, 0);

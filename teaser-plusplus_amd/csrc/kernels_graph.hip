@@ -3149,13 +3149,15 @@ size_t greedy_lds_bytes(int max_W) {
 }
 
 // workgroups per problem of the heuristic (the host initialises ProbState.next_start with it)
-int heuristic_blocks_per_problem(int batch) {
+int heuristic_blocks_per_problem(int batch, int max_W) {
   static const char* ev = getenv("TEASER_HEU_BLOCKS");  // diagnostics
   if (ev && atoi(ev) >= 1 && atoi(ev) <= kMaxStarts) return atoi(ev);
   // about 128 workgroups in flight: every start in parallel for small batches (lowest latency, the GPU is
   // otherwise idle), ONE workgroup per problem from 64 problems on (they run beside the next batch's K1, whose
   // time they inflate: 1 measured 3-5 % faster than 2, 2 6 % faster than 4; profiles/r4l, r4m)
-  if (batch >= 64) return 1;
+  // (small graphs -- descriptor correspondences, a few hundred vertices -- are seldom closed by their first start:
+  // four workgroups share the 16 starts there, config 5 x 64: 3.2 -> 0.9 ms of heuristic stage)
+  if (batch >= 64) return max_W >= 32 ? 1 : 4;
   return std::max(2, std::min(kMaxStarts, 128 / std::max(batch, 1)));
 }
 
@@ -3164,7 +3166,7 @@ void launch_heuristic(hipStream_t s, const ProbDesc* d_desc, int batch, int max_
                       int32_t* d_start_cliques, int64_t total_n, int32_t* d_cand,
                       int32_t* d_clique) {
   if (batch <= 0) return;
-  const int nblk = heuristic_blocks_per_problem(batch);
+  const int nblk = heuristic_blocks_per_problem(batch, max_W);
   const size_t lds = greedy_lds_bytes(max_W);
   // Small batches (<= 16 problems = at most one workgroup per CU) run 512-thread workgroups: nothing
   // competes for the CUs and the gather loops finish sooner (N = 1889: 0.51 vs 0.90 ms).  Larger batches

@@ -232,7 +232,10 @@ struct teaser_hip_solver {
     std::vector<int64_t> off;
     std::vector<int32_t> n;
   } staged;
-  std::vector<int> ticket_lane;            // ticket -> lane index, -1 staged, -2 free (depth + 1 tickets)
+  int32_t staged_rc = TEASER_HIP_OK;       // why the staged batch could not be enqueued (ticket_lane = -3)
+  std::string staged_err;
+  std::vector<int> ticket_lane;            // ticket -> lane index, -1 staged, -2 free, -3 failed on leaving the
+                                           // staging slot (depth + 1 tickets)
 };
 
 // several devices, one process: one handle (and one host thread per solve call) per device
@@ -626,8 +629,11 @@ int32_t close_clique_bounds(teaser_hip_solver* h, int batch, int64_t total_n, bo
   HIPCHK(h, h->x_bitmap.ensure(8 * (size_t)o_bm));
   HIPCHK(h, h->x_clique.ensure(4 * (size_t)o_cl));
   HIPCHK(h, h->x_probs2.ensure(sizeof(ExactProb) * open.size()));
+  // max_clique_time_limit (graph.cc:44) covers the WHOLE exact stage of this call: every launch (three or more per
+  // attempt, retries after an arena overflow) gets what is left of it, measured on the host clock from here
   const double lim = h->params.max_clique_time_limit;
-  const int64_t deadline = (lim > 0 && lim < 1e7) ? (int64_t)(lim * 1e8) : 0;  // 100 MHz counter
+  const bool limited = lim > 0 && lim < 1e7;
+  const auto t_stage = std::chrono::steady_clock::now();
   static const bool dbg = getenv("TEASER_K4_DEBUG") != nullptr;
   bool built = false;
   std::vector<ExactProb> run = open;
@@ -665,7 +671,10 @@ int32_t close_clique_bounds(teaser_hip_solver* h, int batch, int64_t total_n, bo
       }
     }
     HIPCHK(h, h->x_arena.ensure((size_t)arena_waves * (size_t)arena_bytes));
-    const int64_t task_bytes = std::min<int64_t>((int64_t)1 << 30, std::max<int64_t>((int64_t)64 << 20, (int64_t)(64 + 8 * max_W2) * 65536));
+    // task queues of the expansion phases + the donation queue of the sequential phase (32768 slots of header |
+    // candidate set | clique prefix of up to min(64 W2, 512) vertices, + flags: launch_exact_clique)
+    const int64_t donate_bytes = (int64_t)32768 * (48 + 8 * max_W2 + 4 * std::min(64 * max_W2, 512) + 32 + 4);
+    const int64_t task_bytes = std::min<int64_t>((int64_t)1 << 30, std::max<int64_t>((int64_t)64 << 20, (int64_t)(64 + 8 * max_W2) * 65536)) + donate_bytes;
     HIPCHK(h, h->x_tasks.ensure((size_t)task_bytes));
     HIPCHK(h, h->x_ctrl.ensure(kExactCounterInts * sizeof(int32_t)));
     HIPCHK(h, hipMemcpyAsync(h->x_probs2.p, run.data(), sizeof(ExactProb) * run.size(), hipMemcpyHostToDevice, s));
@@ -676,6 +685,15 @@ int32_t close_clique_bounds(teaser_hip_solver* h, int batch, int64_t total_n, bo
       built = true;
     }
     const auto t0 = std::chrono::steady_clock::now();
+    int64_t deadline = 0;  // device ticks (100 MHz) this launch may still spend; 0 = unlimited
+    if (limited) {
+      const double left = lim - std::chrono::duration<double>(t0 - t_stage).count();
+      if (left <= 0) {
+        for (const ExactProb& e : run) h->prob_status[(size_t)e.prob] = TEASER_HIP_ERR_TIME_LIMIT;
+        break;
+      }
+      deadline = std::max<int64_t>(1, (int64_t)(left * 1e8));
+    }
     launch_exact_clique(s, h->x_probs2.as<ExactProb>(), (int)run.size(), total_waves, max_W2, max_lds,
                         h->x_bitmap.as<uint64_t>(), h->x_arena.as<char>(), arena_bytes, arena_waves,
                         h->x_clique.as<int32_t>(), h->x_tasks.as<char>(), task_bytes, h->x_ctrl.as<int32_t>(), deadline);
@@ -688,7 +706,8 @@ int32_t close_clique_bounds(teaser_hip_solver* h, int batch, int64_t total_n, bo
       int32_t qc[kExactCounterInts] = {0};
       (void)hipMemcpy(qc, h->x_ctrl.p, sizeof(qc), hipMemcpyDeviceToHost);
       fprintf(stderr, "[teaser_hip] exact search: %zu problems, %d root waves, %d persistent waves; tasks per depth: %d %d %d %d "
-              "%d %d\n", run.size(), total_waves, arena_waves, qc[0], qc[2], qc[4], qc[6], qc[8], qc[10]);
+              "%d %d; given away %d (taken %d)\n", run.size(), total_waves, arena_waves, qc[0], qc[2], qc[4], qc[6], qc[8], qc[10],
+              qc[33], qc[32]);
     }
     std::vector<ExactProb> again;
     for (ExactProb& e : run) {
@@ -790,6 +809,12 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
   h->colour_x.assign((size_t)batch, -1);
   int64_t bm = 0, wo = 0, tims = 0, maxpt = 0;
   int max_n = 0;
+  int heu_blocks = 1;
+  {
+    int mx = 0;
+    for (int b = 0; b < batch; ++b) mx = std::max(mx, n[b]);
+    heu_blocks = heuristic_blocks_per_problem(batch, (mx + 63) / 64);
+  }
   for (int b = 0; b < batch; ++b) {
     if (n[b] < 0) return TEASER_HIP_ERR_BAD_ARG;
     ProbDesc& d = h->descs[(size_t)b];
@@ -811,7 +836,7 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
     st.scale = 1.0;
     st.R[0] = st.R[4] = st.R[8] = 1.0;
     st.gnc_cost = INFINITY;
-    st.next_start = heuristic_blocks_per_problem(batch);  // (the heuristic's start queue begins behind its workgroups)
+    st.next_start = heu_blocks;  // (the heuristic's start queue begins behind its workgroups)
     for (int k = 0; k < kMaxStarts; ++k) st.start_vertex[k] = -1;
   }
   if (tims > ((int64_t)1 << 31)) {
@@ -1326,15 +1351,29 @@ int32_t enqueue_on_lane(teaser_hip_solver* h, int idx, int32_t ticket, const dou
   return TEASER_HIP_OK;
 }
 
-// a staged host batch moves to the lane whose turn it is as soon as that lane is free
+// A staged host batch moves to a lane as soon as ONE is free: the lane whose turn it is if possible, else the first
+// free one (tickets may be waited for in any order: with depth 2, after submit t0, t1, t2 (staged) and wait(t1), lane
+// 1 is free while it is lane 0's turn).  If the enqueue fails, the failure belongs to the STAGED ticket: it is kept
+// (ticket_lane = -3) and reported by that ticket's own wait(), not by the unrelated call that triggered the flush.
 int32_t flush_staged(teaser_hip_solver* h) {
   if (!h->staged.active) return TEASER_HIP_OK;
-  const int idx = h->next_lane;
-  if (h->lanes[(size_t)idx]->job.busy) return TEASER_HIP_OK;
+  int idx = -1;
+  for (int k = 0; k < h->depth && idx < 0; ++k) {
+    const int cand = (h->next_lane + k) % h->depth;
+    if (!h->lanes[(size_t)cand]->job.busy) idx = cand;
+  }
+  if (idx < 0) return TEASER_HIP_OK;
   h->staged.active = false;
+  const int32_t ticket = h->staged.ticket;
   const teaser_hip_solver::InSet& is = h->in_sets[(size_t)h->staged.in_set];
-  return enqueue_on_lane(h, idx, h->staged.ticket, is.src.as<double>(), is.dst.as<double>(), h->staged.off.data(),
-                         h->staged.n.data(), (int)h->staged.n.size(), h->staged.in_set);
+  const int32_t rc = enqueue_on_lane(h, idx, ticket, is.src.as<double>(), is.dst.as<double>(), h->staged.off.data(),
+                                     h->staged.n.data(), (int)h->staged.n.size(), h->staged.in_set);
+  if (rc != TEASER_HIP_OK) {
+    h->ticket_lane[(size_t)ticket] = -3;
+    h->staged_rc = rc;
+    h->staged_err = h->err;
+  }
+  return TEASER_HIP_OK;
 }
 
 int32_t submit_impl(teaser_hip_solver* h, const double* src, const double* dst,
@@ -1417,6 +1456,11 @@ int32_t wait_impl(teaser_hip_solver* h, int32_t ticket, teaser_solution_c* out) 
   }
   int32_t rc = flush_staged(h);
   if (rc != TEASER_HIP_OK) return rc;
+  if (h->ticket_lane[(size_t)ticket] == -3) {  // this ticket's own enqueue failed when it left the staging slot
+    h->ticket_lane[(size_t)ticket] = -2;
+    h->err = h->staged_err;
+    return h->staged_rc;
+  }
   if (h->ticket_lane[(size_t)ticket] == -1) {
     h->err = "teaser_hip_wait: this batch is staged behind the batches in flight; wait for an earlier ticket first";
     return TEASER_HIP_ERR_BUSY;
@@ -1444,6 +1488,8 @@ int32_t wait_impl(teaser_hip_solver* h, int32_t ticket, teaser_solution_c* out) 
   for (int b = 0; b < batch; ++b) h->route[(size_t)b] = std::make_pair(li, b);
   h->batch = batch;
   h->have_graph = lane->have_graph;
+  // (the staged batch is NOT moved to the lane just released here: the getters of this batch read that lane's
+  // buffers until the next submit / wait call, which is when flush_staged runs)
   return rc;
 }
 
@@ -1886,7 +1932,7 @@ int32_t teaser_hip_max_clique(teaser_hip_solver* h, const uint64_t* bitmap, int3
   h->total_bm = (int64_t)n * W;
   ProbState& st = h->states[0];
   memset(&st, 0, sizeof(st));
-  st.next_start = heuristic_blocks_per_problem(1);
+  st.next_start = heuristic_blocks_per_problem(1, W);
   for (int k = 0; k < kMaxStarts; ++k) st.start_vertex[k] = -1;
   HIPCHK(h, h->d_desc.ensure(sizeof(ProbDesc)));
   HIPCHK(h, h->d_state.ensure(sizeof(ProbState)));

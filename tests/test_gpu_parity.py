@@ -579,6 +579,27 @@ def test_planted_clique_needs_exact():
         assert c == o["clique"].tolist()
 
 
+def test_max_clique_time_limit_returns_the_incumbent():
+    """graph.cc:44: pmc's time limit ends the search and the incumbent is returned.  A dense random graph whose exact
+    search takes far longer than the limit: status TIME_LIMIT, and what comes back is a valid clique at least as
+    large as the heuristic's.  The limit covers the whole exact stage of the call (every launch gets what is left of
+    it), so the call returns promptly."""
+    import time
+    rng = np.random.default_rng(23)
+    n = 900
+    A = np.triu(rng.uniform(size=(n, n)) < 0.6, 1)
+    bm = oracle.bitmap_from_edges(n, np.argwhere(A))
+    heu = make_solver(inlier_selection_mode=tp.InlierSelectionMode.PMC_HEU)
+    ch, _ = heu.maxClique(bm, n)
+    s = make_solver(max_clique_time_limit=2e-4)
+    t0 = time.perf_counter()
+    c, er = s.maxClique(bm, n)
+    dt = time.perf_counter() - t0
+    assert s.last_status == 5, tp.STATUS_NAMES.get(s.last_status)
+    assert er and len(c) >= len(ch) and is_clique(A | A.T, c)
+    assert dt < 5.0
+
+
 def test_colouring_bound_and_restricted_roots_vs_oracle():
     """Graphs built so the greedy bound is NOT the maximum (several planted cliques of mixed size
     among dense noise): the global colouring bound must leave the larger cliques' vertices
@@ -1214,6 +1235,36 @@ def test_async_batches_match_sync():
     # the synchronous API on the same handle still works between asynchronous batches
     one = s.solve(batches[0][1]["src"], batches[0][1]["dst"])
     assert (one.rotation == want[0][1][1]).all() and s.getInlierMaxClique() == want[0][1][3]
+    del s
+    mem.free()
+
+
+def test_staged_batch_takes_the_first_free_lane():
+    """Depth 2, host inputs: t0, t1 on the lanes, t2 staged.  After wait(t1) lane 1 is free although it is lane 0's
+    turn: the staged batch must move there, and wait(t2) must succeed BEFORE t0 has been waited for (a caller that
+    retries on BUSY used to spin for ever: the staged batch only ever went to lanes[next_lane])."""
+    from util import HipBuffers
+    probs = [[tp.synth_problem(1300 + 10 * k + i, n, 0.8, 0.01) for i, n in enumerate(sz)]
+             for k, sz in enumerate([[700, 300], [512], [900, 65, 400]])]
+    ref = make_solver(**bench_params())
+    want = []
+    for pb in probs:
+        sols = ref.solve_batch([p["src"] for p in pb], [p["dst"] for p in pb])
+        want.append([(o.rotation.copy(), o.translation.copy()) for o in sols])
+    mem = HipBuffers()
+    s = make_solver(**bench_params())
+    s.set_pipeline_depth(2)
+    tickets = []
+    for pb in probs:
+        src, dst, off, n = _packed(pb)
+        tickets.append(s.submit_batch(mem.pinned(src), mem.pinned(dst), off, n, host=True))
+    with pytest.raises(tp.TeaserHipError):
+        s.wait(tickets[2])  # staged: BUSY until an earlier ticket has been waited for
+    for k in (1, 2, 0):
+        out = s.wait(tickets[k])
+        for bi, w in enumerate(want[k]):
+            assert (np.array(out[bi].rotation[:]).reshape(3, 3) == w[0]).all()
+            assert (np.array(out[bi].translation[:]) == w[1]).all()
     del s
     mem.free()
 
