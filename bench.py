@@ -11,9 +11,10 @@ Top-level line = BASELINE.json configs[1] (synthetic N = 10 000 correspondences,
 the largest single-GPU configuration the metric is quoted on).  One STEP = one batched pass of the whole hot
 path (TIM build + pruning -> adjacency bitmap -> max clique -> GNC-TLS rotation -> TLS translation) over
 `--batch` independent problems; EVERY step sees problems it has not seen before.  `value` is measured with the
-point arrays already resident in HBM when the timed region starts (the bench contract); the same loop fed from
-page-locked HOST memory, H2D inside the timer (SURVEY.md 8(d)'s timer scope), is reported next to it as
-config.host_resident.  Steps go through the library's asynchronous batch API (teaser_hip_submit_batch /
+point arrays already resident in HBM when the timed region starts (the bench contract: the median of `--repeats`
+timed regions of exactly K steps each); the same loop fed from page-locked HOST memory, H2D inside the timer
+(SURVEY.md 8(d)'s timer scope), is reported at the top level as `value_host_resident` (+ its ratio to `value`) and
+in detail as config.host_resident.  Steps go through the library's asynchronous batch API (teaser_hip_submit_batch /
 teaser_hip_wait, `--depth` batches on the lanes, plus one staged host batch whose copy runs on the copy stream).
 Multi-GPU: problems are independent, so each rank owns its own problems (weak scaling, no data-path
 collective); the fixed-size result records are all-gathered over RCCL at the end, inside the timed region.
@@ -24,13 +25,18 @@ The `configs` object carries one driver-run line for each of the other GPU confi
              "90 % outliers" rate);
   config3 -- N = 50 000, 99 % outliers, one problem per step (stresses the O(N^2) TIM build and the clique stage);
   config5 -- the 3DMatch pair of examples/teaser_python_fpfh_icp with real FPFH correspondences, batched: 64
-             perturbed copies of the two clouds per step (front-end on the GPU, timed separately).
+             perturbed copies of the two clouds per step (front-end on the GPU, timed separately);
+  scale   -- the reference's DEFAULT path, estimate_scaling = true (registration.h:437), at configs[1]'s size:
+             N = 10 000, 95 % outliers, one problem per step; the step is the scale stage (TRIMs + scalar TLS over
+             5e7 measurements: a device-wide sort of 1e8 endpoints), its roofline is the sort's HBM traffic; the
+             first problem is the one of tests/golden/scale_golden.json and its scale is checked against the
+             oracle's value there.
 Each line: ms/step and registrations/s as the median of `--repeats` timed regions of its own step count, the
 roofline of K1 from HIP events inside those regions, the per-stage device times of one profiled step, and a
 cpu_baseline (N = 1 only).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with:
-  roofline     -- K1 (tim_graph_mfma_kernel, the dominant kernel), from HIP events recorded around that kernel
+  roofline     -- K1 (tim_graph_mfma3_kernel, the dominant kernel), from HIP events recorded around that kernel
                   alone on the stream it runs on, during the timed region: algorithmic flops (20 FP64 flop per
                   pair) against the dense FP64 peak at the top level; what the kernel actually
                   issues (bf16 MFMA + f32 VALU) and the HBM view (algorithmic bytes 48 n + 8 n ceil(n/64) per
@@ -81,9 +87,10 @@ def parse(argv=None):
                          "the latency-bound tail of batch k (clique, GNC, TLS: one workgroup per problem) shares "
                          "the GPU with batch k+1's K1 (2 is that pattern exactly; more only adds contention).  "
                          "1 = strictly one batch at a time")
-    ap.add_argument("--configs", default="4,3,5",
+    ap.add_argument("--configs", default="4,3,5,scale",
                     help="other BASELINE configurations to run after the top-level one ('' = none)")
-    ap.add_argument("--repeats", type=int, default=3, help="timed regions per `configs` line (median reported)")
+    ap.add_argument("--repeats", type=int, default=3,
+                    help="timed regions (of --steps steps each at the top level) per line; the median is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-resident", action="store_true",
                     help="skip the second timed loop fed from page-locked host memory")
@@ -121,8 +128,8 @@ def roofline_object(k1_ms, k1_launches, k1_bytes, k1_pairs, k1_aux_ms, traffic, 
     mfma_tf = rate(K1_MFMA_FLOPS_PER_PAIR * pairs_per_launch) / 1e12
     hbm_gbs = rate(bytes_per_launch) / 1e9
     return {
-        "kernel": "tim_graph_mfma2_kernel (K1: TIM-norm predicate terms u, w on the matrix cores + prune + adjacency "
-                  "bitmap)",
+        "kernel": "tim_graph_mfma3_kernel (K1: TIM-norm predicate terms u, w on the matrix cores, min |d| filter, "
+                  "adjacency bitmap; FP64 fix-up of the flagged 16-pair groups)",
         "bound": "mfma", "achieved": fp64_tf, "peak": FP64_PEAK_TF, "unit": "TFLOP/s",
         "frac": fp64_tf / FP64_PEAK_TF, "traffic": traffic,
         "avg_launch_ms": 1e3 * k1_avg_s, "launches": k1_launches,
@@ -133,8 +140,7 @@ def roofline_object(k1_ms, k1_launches, k1_bytes, k1_pairs, k1_aux_ms, traffic, 
                 "the kernel alone; peak = dense FP64 peak (matrix = vector = 78.6 TFLOP/s): an algorithm-equivalent "
                 "rate.  The kernel issues NO FP64: it decides the same predicate with an exact bf16-split MFMA + f32 "
                 "VALU filter and an FP64 fix-up (bitmap bit-identical), so the pipes it really loads are "
-                "`executed_mfma` (bf16 matrix pipe) and `issue` (SQ counters: VALU busy 74 %, matrix pipe 22 % of the "
-                "SIMD time; DESIGN.md 3).  With --depth > 1 the kernel shares the GPU with the latency-bound tail kernels of "
+                "`executed_mfma` (bf16 matrix pipe) and `issue` (SQ counters of the committed pass: DESIGN.md 3).  With --depth > 1 the kernel shares the GPU with the latency-bound tail kernels of "
                 "the previous batch, which is included in its time",
         "executed_mfma": {"achieved": mfma_tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
                           "frac": mfma_tf / MFMA_BF16_PEAK_TF,
@@ -247,7 +253,8 @@ def _cpu_worker(spec_path):
                 break
         return times
 
-    run(False, 1, 0.0)  # warm-up (OpenMP pool, page faults)
+    if spec.get("warmup", True):
+        run(False, 1, 0.0)  # warm-up (OpenMP pool, page faults)
     out = {"stream": run(False, spec["max_solves"], spec["budget_s"])}
     if spec.get("materialise"):
         out["mat"] = run(True, 2, min(spec["budget_s"], 8.0))
@@ -257,7 +264,8 @@ def _cpu_worker(spec_path):
 _CPU_STATE = {}
 
 
-def cpu_baseline(tp, n, outlier_ratio, nb, seed, max_solves, budget_s, problems=None, extra_kw=None):
+def cpu_baseline(tp, n, outlier_ratio, nb, seed, max_solves, budget_s, problems=None, extra_kw=None, warmup=True,
+                 allow_materialise=True, label=None):
     """Oracle (kind = port: the reference needs Eigen3 + pmc, absent here) on a bounded sample of the
     same workload, built gcc -O3 -fopenmp without -march=native (the reference's default flags,
     CMakeLists.txt:27).  Two forms, SURVEY.md 8(d): (i) STREAMING -- no TIM storage, adjacency bitmap: the faster one,
@@ -275,7 +283,7 @@ def cpu_baseline(tp, n, outlier_ratio, nb, seed, max_solves, budget_s, problems=
     kw.update(extra_kw or {})
     pairs = n * (n - 1) // 2
     tmpdir = tempfile.mkdtemp(prefix="teaser_cpu_")
-    spec = dict(n=n, rho=outlier_ratio, nb=nb, seed=seed, max_solves=max_solves, budget_s=budget_s, kw=kw)
+    spec = dict(n=n, rho=outlier_ratio, nb=nb, seed=seed, max_solves=max_solves, budget_s=budget_s, kw=kw, warmup=warmup)
     if problems is not None:
         arrs = {"count": len(problems)}
         for i, (s_, d_) in enumerate(problems):
@@ -306,10 +314,10 @@ def cpu_baseline(tp, n, outlier_ratio, nb, seed, max_solves, budget_s, problems=
             sweep[str(k)] = round(1e3 * float(np.median(ts)), 2)
         _CPU_STATE["best_threads"] = int(min(sweep, key=lambda k: sweep[k]))
     threads = _CPU_STATE["best_threads"]
-    res = measure(threads, max_solves, budget_s, pairs * 81 < 24e9)
+    res = measure(threads, max_solves, budget_s, allow_materialise and pairs * 81 < 24e9)
     ts = res["stream"]
     med = float(np.median(ts))
-    what = ("N=%d, %.0f%% outliers" % (n, 100 * outlier_ratio)) if problems is None else \
+    what = label if label else ("N=%d, %.0f%% outliers" % (n, 100 * outlier_ratio)) if problems is None else \
         "%d-%d correspondences (real descriptors)" % (min(p[0].shape[1] for p in problems),
                                                       max(p[0].shape[1] for p in problems))
     out = {"value": 1.0 / med, "unit": "registrations/s", "cores": threads, "kind": "port", "host": info,
@@ -327,7 +335,7 @@ def cpu_baseline(tp, n, outlier_ratio, nb, seed, max_solves, budget_s, problems=
             "value": 1.0 / mm, "unit": "registrations/s",
             "sample": "%d solves, median %.1f ms each, TIMs materialised (~%.2f GB), serial mask and "
                       "vector-of-vectors graph build as the reference" % (len(res["mat"]), 1e3 * mm, pairs * 81 / 1e9)}
-    else:
+    elif allow_materialise:
         out["reference_faithful"] = {"value": None, "sample": "infeasible: ~%.0f GB of TIM storage" % (pairs * 81 / 1e9)}
     import shutil
     shutil.rmtree(tmpdir, ignore_errors=True)
@@ -467,6 +475,28 @@ def run_config(tag, tp, torch, runner, args, dev, world, rank, make_workload, st
         line["host_resident"] = {"value": world * B * steps / mh, "unit": "registrations/s",
                                  "ms_per_step": 1e3 * mh / steps}
         del pinned
+    if wl.get("scale_trims"):
+        # the stage that dominates this line is the scale stage (K7): TRIM endpoints -> device-wide sort -> sweep.
+        # Algorithmic HBM bytes per solve: the 2 M endpoints are written once (8 B: float key + tag),
+        # moved by the 4 passes of the float-key radix sort (8 B read + 8 B written each), read and re-written with their
+        # measurement by the order-restoring pass (8 + 16 B), and streamed twice by the sweep (16 B each).
+        m = float(wl["scale_trims"])
+        alg = 2 * m * (8 + 4 * 16 + (8 + 16) + 2 * 16)
+        line["stage_ms"] = stage_breakdown(solver, bufs[0][0], bufs[0][1], offsets, sizes)
+        t_scale = 1e-3 * line["stage_ms"]["tim_graph_ms"]  # ST_TIM: scale stage + the consensus graph behind it
+        line["roofline"] = {
+            "kernel": "scale stage (K7: trim_endpoints_kernel, rocPRIM radix sort on float keys, tls_order_fix_kernel, "
+                      "tls_sweep_* ) + consensus graph",
+            "bound": "hbm", "achieved": alg / t_scale / 1e9 if t_scale > 0 else 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": (alg / t_scale / 1e9 / HBM_PEAK_GBS) if t_scale > 0 else 0.0, "traffic": None,
+            "algorithmic_bytes_per_solve": alg, "stage_ms": 1e3 * t_scale,
+            "note": "HIP events around the scale stage + graph of one profiled solve (untimed extra step)"}
+        line.update(wl.get("extra", {}))
+        if want_cpu and rank == 0:
+            line["cpu_baseline"] = wl["cpu"]()
+        del bufs
+        del solver
+        return line
     if acc["launches"]:
         n_eq = wl.get("n")
         traffic, traffic_src = k1_traffic(B, n_eq) if n_eq else (None, None)
@@ -557,6 +587,40 @@ def config5_workload(tp, args, rank, B, n_batches):
         extra={"front_end_ms_per_pair": round(1e3 * float(np.median(fe)), 3),
                "correspondences_per_problem": [int(sizes_all.min()), int(np.median(sizes_all)), int(sizes_all.max())]},
         cpu=lambda: cpu_baseline(tp, int(np.median(sizes_all)), 0.0, vox, 0, 16, 10.0, problems=probs, extra_kw=kw))
+
+
+def scale_workload(tp, args, rank):
+    """The reference's default path (estimate_scaling = true, registration.h:437) at BASELINE configs[1]'s size: one
+    N = 10 000 problem per step, 95 % outliers, dst scaled by 1.3.  Problem 0 is the first entry of tests/golden/
+    scale_golden.json: its scale estimate must equal the oracle's value recorded there (43 s of CPU) to 1e-9 and its
+    edge count to 2 (a last-ulp difference of the scale moves at most two boundary pairs)."""
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "scale_golden.json")))[0]
+    n, rho, k, nb = int(g["n"]), float(g["outlier_ratio"]), float(g["dst_scale"]), float(g["noise_bound"])
+    pool = []
+    for i in range(3):
+        pr = tp.synth_problem(int(g["seed"]) + 7919 * (i + rank * 3), n, rho, 0.01)
+        pool.append((np.ascontiguousarray(pr["src"].T), np.ascontiguousarray((pr["dst"] * k).T)))
+    solver = tp.RobustRegistrationSolver(solver_params(tp, nb, estimate_scaling=True), device=-1)
+
+    def check(out):
+        o = out[0]
+        assert o.valid == 1
+        if rank == 0:
+            assert abs(o.scale - g["oracle_scale"]) <= 1e-9, (o.scale, g["oracle_scale"])
+            assert abs(int(o.num_edges) - int(g["oracle_edges"])) <= 2, (o.num_edges, g["oracle_edges"])
+
+    m = n * (n - 1) // 2
+    return solver, dict(
+        pool=pool, offsets=np.zeros(1, dtype=np.int64), sizes=np.full(1, n, dtype=np.int32), n=None,
+        problems_per_step=1, check=check, scale_trims=m,
+        workload="estimate_scaling = true (the reference's default) at BASELINE configs[1]'s size: N=%d, %.0f%% outliers, "
+                 "dst scaled by %.1f, noise_bound=%g, one problem per step: %d TRIMs, %d interval endpoints through the "
+                 "scale stage's sort; GNC-TLS, PMC_EXACT, CHAIN" % (n, 100 * rho, k, nb, m, 2 * m),
+        cpu=lambda: cpu_baseline(tp, n, rho, nb, int(g["seed"]), 1, 1.0,
+                                 problems=[(np.ascontiguousarray(pool[0][0].T), np.ascontiguousarray(pool[0][1].T))],
+                                 extra_kw=dict(estimate_scaling=1), warmup=False, allow_materialise=False,
+                                 label="N=%d, %.0f%% outliers, estimate_scaling = true: ONE solve, no warm-up (the "
+                                       "oracle's serial sort of 1e8 endpoints dominates)" % (n, 100 * rho)))
 
 
 def synth_workload(tp, args, rank, tag, B, n, rho, n_batches, cpu_solves, cpu_budget):
@@ -657,7 +721,9 @@ def main():
         allrec = tp.batched.gather_records(rec, world * B, dist if world > 1 else None, device=gather_dev)
         assert allrec.shape[0] == world * B
 
-    elapsed, _ = runner.timed(args.warmup + 1, args.steps, pool, offsets, sizes, False, acc, gather_tail)
+    elapsed_all = [runner.timed(args.warmup + 1 + r * args.steps, args.steps, pool, offsets, sizes, False, acc, gather_tail)[0]
+                   for r in range(max(1, args.repeats))]
+    elapsed = float(np.median(elapsed_all))  # every region times EXACTLY args.steps steps; the median region is reported
     solver.set_profiling(0)
 
     # ---- the same loop fed from page-locked HOST memory: H2D inside the timer ----
@@ -693,6 +759,9 @@ def main():
 
     # ---- the other BASELINE configurations (their own solvers, pools and timed regions) -----------
     want_cpu = world == 1 and not args.no_cpu_baseline
+    top_cpu = None
+    if want_cpu and rank == 0:  # first: its thread sweep (on the headline workload) picks the thread count for all
+        top_cpu = cpu_baseline(tp, n, args.outlier_ratio, args.noise_bound, args.seed, args.cpu_solves, 10.0)
     cfg_lines = {}
     for tag in [c.strip() for c in args.configs.split(",") if c.strip()]:
         if tag == "4":
@@ -704,8 +773,11 @@ def main():
         elif tag == "5":
             mk = lambda: config5_workload(tp, args, rank, 64, 2)
             cfg_lines["config5"] = run_config("config5", tp, torch, runner, args, dev, world, rank, mk, 12, want_cpu)
+        elif tag == "scale":
+            mk = lambda: scale_workload(tp, args, rank)
+            cfg_lines["scale"] = run_config("scale", tp, torch, runner, args, dev, world, rank, mk, 6, want_cpu)
         else:
-            raise SystemExit("bench.py: unknown --configs entry %r (use 3, 4, 5)" % tag)
+            raise SystemExit("bench.py: unknown --configs entry %r (use 3, 4, 5, scale)" % tag)
 
     if rank == 0:
         total_regs = world * B * args.steps
@@ -715,6 +787,9 @@ def main():
             "metric": "registrations/sec at N=%d correspondences, %.0f%% outliers" % (n, 100 * args.outlier_ratio),
             "value": value, "unit": "registrations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step_repeats": [round(1e3 * t / args.steps, 4) for t in elapsed_all],
+            "value_host_resident": host_line["value"] if host_line else None,
+            "host_resident_over_hbm_resident": (host_line["value"] / value) if host_line else None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE,
             "data": "synthetic",
             "config": {"workload": "synthetic N=%d correspondences, %.0f%% outliers, single-MI355X config "
@@ -734,8 +809,8 @@ def main():
                                         traffic, traffic_src, k1_issue()),
             "configs": cfg_lines,
         }
-        if want_cpu:
-            line["cpu_baseline"] = cpu_baseline(tp, n, args.outlier_ratio, args.noise_bound, args.seed, args.cpu_solves, 10.0)
+        if top_cpu is not None:
+            line["cpu_baseline"] = top_cpu
         print(json.dumps(line))
     if dist is not None:
         dist.destroy_process_group()

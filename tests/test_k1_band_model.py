@@ -370,7 +370,9 @@ def test_band3_random_and_adversarial():
     dst[out] = rng.uniform(-1, 1, size=(int(out.sum()), 3))
     dst[~out] += rng.uniform(-0.0057, 0.0057, size=(int((~out).sum()), 3))
     frac, _, _ = check3(src, dst, 0.02, rng, 1_000_000)
-    assert frac > 0.999  # constant band: ~2.4 x the pairs of the w-dependent band, still < 1e-3 of all pairs
+    # constant band: here (dst outliers spread over [-1, 1]^3, R = sqrt 3) 1.3e-3 of the pairs fall inside it, about
+    # four times the w-dependent band's share; ~7e-4 at the bench geometry
+    assert frac > 0.998
     for scale, beta in ((1.0, 0.02), (300.0, 0.1), (0.05, 2e-4)):
         n = 1500
         src = rng.uniform(-1, 1, size=(n, 3)) * scale
