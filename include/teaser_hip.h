@@ -26,6 +26,7 @@
 #ifndef TEASER_HIP_H_
 #define TEASER_HIP_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -339,6 +340,15 @@ TEASER_HIP_API void* teaser_hip_get_stream(teaser_hip_solver* h);
 TEASER_HIP_API const char* teaser_hip_last_error(const teaser_hip_solver* h);
 TEASER_HIP_API int32_t teaser_hip_abi_version(void);
 TEASER_HIP_API int32_t teaser_hip_device_count(void);
+
+/* Page-locked host memory from the HIP runtime THIS library runs on.  teaser_hip_submit_batch(..., INPUT_HOST) moves
+ * the points with one DMA copy per cloud, at PCIe speed only when the runtime knows the pages are locked.  A buffer
+ * pinned by another HIP runtime instance in the same process (e.g. the one a Python framework bundles) is pageable
+ * memory to this one and is staged through an internal bounce buffer: measured 0.87 instead of 0.64 ms per
+ * 128 x 5 k step (profiles/r4u).  No counterpart in the reference (its inputs are Eigen matrices in pageable memory,
+ * registration.h:576-577); the synchronous entries accept any host pointer. */
+TEASER_HIP_API int32_t teaser_hip_host_alloc(size_t bytes, void** out);
+TEASER_HIP_API int32_t teaser_hip_host_free(void* p);
 
 /* Deterministic synthetic problem generator (the reference has none that is
  * seeded -- registration-test.cc:398-431 and teaser_cpp_ply.cc:21-40 use random_device).

@@ -38,7 +38,7 @@ for task in "$@"; do
     k1probe4) timeout 200 $P 128 5000 10 k1 0.9 > $OUT/probe_k1_128x5k.jsonl 2>/dev/null; cat $OUT/probe_k1_128x5k.jsonl ;;
     pipe) timeout 300 $P 64 10000 30 pipe > $OUT/probe_pipe.jsonl 2>/dev/null; cat $OUT/probe_pipe.jsonl ;;
     k1tests) timeout 600 python -m pytest tests -m gpu -q -x -k "k1 or config2 or config3 or config4 or fixture" > $OUT/k1tests.txt 2>&1; echo "rc=$?"; tail -5 $OUT/k1tests.txt ;;
-    tests:*) timeout 900 python -m pytest tests -m gpu -q -x -k "${task#tests:}" > $OUT/tests_sel.txt 2>&1; echo "rc=$?"; tail -8 $OUT/tests_sel.txt ;;
+    tests:*) timeout ${TEST_TIMEOUT:-300} python -m pytest tests -m gpu -q -x -k "${task#tests:}" > $OUT/tests_sel.txt 2>&1; echo "rc=$?"; tail -8 $OUT/tests_sel.txt ;;
     suite) SECONDS=0; TEASER_CERT_DEBUG=$OUT/cert_warmup.txt timeout 1500 python -m pytest tests/ -x -q -m gpu --durations=12 > $OUT/gpu_tests.txt 2>&1; echo "suite rc=$? in ${SECONDS}s"; tail -22 $OUT/gpu_tests.txt ;;
     bench) timeout 1200 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "rc=$?"; cut -c1-700 $OUT/bench.json; tail -3 $OUT/bench.err ;;
     benchq) timeout 400 python bench.py --configs '' --no-cpu-baseline > $OUT/benchq.json 2> $OUT/benchq.err; echo "rc=$?"; cut -c1-500 $OUT/benchq.json; tail -3 $OUT/benchq.err ;;

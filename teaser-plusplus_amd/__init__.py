@@ -119,7 +119,8 @@ EXPORTED_SYMBOLS = [
     "teaser_hip_get_inlier_graph_bitmap", "teaser_hip_get_degrees", "teaser_hip_solve_for_rotation",
     "teaser_hip_solve_for_translation", "teaser_hip_scalar_tls", "teaser_hip_max_clique",
     "teaser_hip_set_profiling", "teaser_hip_get_profile", "teaser_hip_get_stream",
-    "teaser_hip_last_error", "teaser_hip_abi_version", "teaser_hip_device_count",
+    "teaser_hip_last_error", "teaser_hip_abi_version", "teaser_hip_device_count", "teaser_hip_host_alloc",
+    "teaser_hip_host_free",
     "teaser_hip_synth_problem", "teaser_hip_submit_batch", "teaser_hip_wait",
     "teaser_hip_set_pipeline_depth", "teaser_hip_multi_create", "teaser_hip_multi_destroy",
     "teaser_hip_multi_solve_batch", "teaser_hip_multi_route", "teaser_hip_multi_device_count",
@@ -152,6 +153,8 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s is missing: run __graft_entry__.build() (make -C %s)" % (LIB_PATH, _CSRC))
     L = C.CDLL(LIB_PATH)
+    L.teaser_hip_host_alloc.argtypes = [C.c_size_t, C.POINTER(_vp)]
+    L.teaser_hip_host_free.argtypes = [_vp]
     L.teaser_hip_params_default.argtypes = [C.POINTER(ParamsC)]
     L.teaser_hip_solver_create.argtypes = [C.POINTER(ParamsC), C.c_int32, C.POINTER(_vp)]
     L.teaser_hip_solver_destroy.argtypes = [_vp]
@@ -207,6 +210,36 @@ OMP_MAX_THREADS = os.cpu_count() or 1
 
 def device_count():
     return int(lib().teaser_hip_device_count())
+
+
+class PinnedArray:
+    """A float64 array in page-locked host memory of the HIP runtime the library runs on (teaser_hip_host_alloc):
+    what submit_batch(..., host=True) moves at PCIe speed.  `.array` is the numpy view, `.data_ptr()` the address."""
+
+    def __init__(self, source):
+        a = np.ascontiguousarray(source, dtype=np.float64)
+        p = _vp()
+        rc = lib().teaser_hip_host_alloc(C.c_size_t(max(a.nbytes, 8)), C.byref(p))
+        if rc != 0:
+            raise TeaserHipError(rc, "teaser_hip_host_alloc")
+        self._p = p
+        self.array = np.ctypeslib.as_array((C.c_double * max(a.size, 1)).from_address(p.value))[:a.size].reshape(a.shape)
+        self.array[...] = a
+
+    def data_ptr(self):
+        return self._p.value
+
+    def free(self):
+        if self._p is not None and self._p.value:
+            lib().teaser_hip_host_free(self._p)
+        self._p = None
+        self.array = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 def _colmajor(points, what="points"):
@@ -844,4 +877,4 @@ from . import batched  # noqa: E402,F401  (sharding + record gather for the mult
 
 __all__ = ["batched", "FPFHEstimation", "Matcher", "MultiDeviceSolver", "RobustRegistrationSolver", "RegistrationSolution", "RotationEstimationAlgorithm",
            "InlierSelectionMode", "InlierGraphFormulation", "TeaserHipError", "synth_problem",
-           "device_count", "build", "lib", "LIB_PATH", "EXPORTED_SYMBOLS", "certifier_warmup"]
+           "device_count", "build", "lib", "LIB_PATH", "EXPORTED_SYMBOLS", "certifier_warmup", "PinnedArray"]

@@ -1511,6 +1511,16 @@ extern "C" {
 
 int32_t teaser_hip_abi_version(void) { return TEASER_HIP_ABI_VERSION; }
 
+int32_t teaser_hip_host_alloc(size_t bytes, void** out) {
+  if (!out) return TEASER_HIP_ERR_BAD_ARG;
+  *out = nullptr;
+  return hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? TEASER_HIP_OK : TEASER_HIP_ERR_HIP;
+}
+int32_t teaser_hip_host_free(void* p) {
+  if (!p) return TEASER_HIP_OK;
+  return hipHostFree(p) == hipSuccess ? TEASER_HIP_OK : TEASER_HIP_ERR_HIP;
+}
+
 int32_t teaser_hip_device_count(void) {
   int c = 0;
   if (hipGetDeviceCount(&c) != hipSuccess) return 0;
