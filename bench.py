@@ -763,6 +763,12 @@ def main():
     lat_ms = 1e3 * float(np.median(lat)) if lat else None
     stages = stage_breakdown(solver, s_t, d_t, offsets, sizes)
     del pool
+    # the headline handle goes away before the other configurations create theirs: every handle owns a stream per lane
+    # plus a copy stream, and streams beyond the device's hardware queues share them -- a second live handle put the
+    # copy stream of config 4 behind a lane's kernels (host-resident 0.86 instead of 0.64 ms per step, profiles/r4x)
+    import types
+    runner = types.SimpleNamespace(dist=runner.dist, D=runner.D, gather_dev=runner.gather_dev)
+    del solver
 
     # ---- the other BASELINE configurations (their own solvers, pools and timed regions) -----------
     want_cpu = world == 1 and not args.no_cpu_baseline

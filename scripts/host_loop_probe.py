@@ -22,7 +22,7 @@ pool_h, pool_d = [], []
 for k in range(8):
     src = np.empty((B * n, 3)); dst = np.empty((B * n, 3))
     for b in range(B):
-        pr = tp.synth_problem(1000 + k * B + b, n, 0.95, 0.01)
+        pr = tp.synth_problem(1000 + k * B + b, n, float(os.environ.get("RHO", "0.95")), 0.01)
         src[b * n:(b + 1) * n] = pr["src"].T; dst[b * n:(b + 1) * n] = pr["dst"].T
     pool_h.append((mem.pinned(src), mem.pinned(dst))); pool_d.append((mem.device(src), mem.device(dst)))
 off = np.arange(B, dtype=np.int64) * n; sz = np.full(B, n, dtype=np.int32)

@@ -2165,7 +2165,8 @@ __global__ __launch_bounds__(256) void tim_fixup_group_kernel(const ProbDesc* __
                                                               unsigned int cap, ProbState* __restrict__ states,
                                                               int32_t* __restrict__ deg,
                                                               const unsigned long long* __restrict__ regions,
-                                                              unsigned int regions_per_problem) {
+                                                              unsigned int regions_per_problem,
+                                                              const TimPrep* __restrict__ prep) {
   TAIL_WAVE_PRIO();
   const int prob = blockIdx.y;
   const unsigned int total = work_count[prob];
@@ -2178,10 +2179,24 @@ __global__ __launch_bounds__(256) void tim_fixup_group_kernel(const ProbDesc* __
     if (blockIdx.x == 0 && threadIdx.x == 0) states[prob].k1_overflow = 1;
     return;
   }
+  int32_t* dg = deg + d.pt_off;
+  if (!mfma3_consts(beta, prep[prob].r2_bits).use_mfma) {
+    // this problem ran the FP64 body inside K1 (no filter, no worklist, no degree atomics): its degrees are the row
+    // popcounts (what a separate degree launch did for these problems)
+    const uint64_t* bm = bitmap + d.bm_off;
+    const int lane = threadIdx.x & 63;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < n; row += gridDim.x * 4) {
+      const uint64_t* r = bm + (int64_t)row * W;
+      int c = 0;
+      for (int w = lane; w < W; w += 64) c += __popcll(r[w]);
+      c = wave_sum_i(c);
+      if (lane == 0) dg[row] = c;
+    }
+    return;
+  }
   const double* ps = src + 3 * d.pt_off;
   const double* pd = dst + 3 * d.pt_off;
   unsigned int* bm32 = reinterpret_cast<unsigned int*>(bitmap + d.bm_off);
-  int32_t* dg = deg + d.pt_off;
   EdgeConst kc;
   kc.beta = beta;
   kc.beta2 = beta * beta;
@@ -2472,13 +2487,14 @@ void launch_tim_graph_mfma(hipStream_t s, int phase, const ProbDesc* d_desc, int
   } else {
     // problems whose geometry the filter cannot handle ran the FP64 body inside K1 (no degree atomics
     // there): their degrees come from the row-popcount pass, which skips every other problem
-    hipLaunchKernelGGL(degree_kernel, dim3(batch >= 64 ? 8 : 64, batch), dim3(256), 0, s, d_desc, d_bitmap, d_deg,
-                       prep, beta, form3 ? 2 : form2 ? 1 : 0);
+    if (!form3)  // (the group fix-up of the third formulation does this itself)
+      hipLaunchKernelGGL(degree_kernel, dim3(batch >= 64 ? 8 : 64, batch), dim3(256), 0, s, d_desc, d_bitmap, d_deg,
+                         prep, beta, form2 ? 1 : 0);
     if (form3)  // a wave per region of the largest problem (up to 2048 workgroups per problem)
       hipLaunchKernelGGL(tim_fixup_group_kernel,
                          dim3((unsigned)std::max<int64_t>(4, std::min<int64_t>(2048, (regs_per_problem + 3) / 4)), batch),
                          dim3(256), 0, s, d_desc, batch, d_src, d_dst, d_bitmap, beta, work, work_count,
-                         (unsigned int)seg_cap, d_state, d_deg, regions, (unsigned int)regs_per_problem);
+                         (unsigned int)seg_cap, d_state, d_deg, regions, (unsigned int)regs_per_problem, prep);
     else
     hipLaunchKernelGGL(tim_fixup_kernel, dim3(std::max(4, std::min(512, 1024 / std::max(batch, 1))), batch), dim3(256), 0, s, d_desc, batch, d_src, d_dst, d_bitmap,
                        beta, work, work_count, (unsigned int)seg_cap, d_state, d_deg,
@@ -3194,12 +3210,14 @@ __global__ __launch_bounds__(256) void peel_round_kernel(const ProbDesc* __restr
                                                          ProbState* __restrict__ states,
                                                          const uint64_t* __restrict__ cur_mask,
                                                          uint64_t* __restrict__ nxt_mask,
-                                                         int32_t* __restrict__ next_count) {
+                                                         int32_t* __restrict__ next_count /* [batch] counts, [batch] arrivals */,
+                                                         int batch) {
   TAIL_WAVE_PRIO();
   __shared__ unsigned long long neww;
+  __shared__ int is_last;
   const ProbDesc d = descs[blockIdx.y];
-  const ProbState* st = states + blockIdx.y;
-  if (st->peel_done) return;
+  ProbState* st = states + blockIdx.y;
+  if (st->peel_done) return;  // (every workgroup of the problem sees the same value: it changes only at the end of a launch)
   const uint64_t* cur = cur_mask + d.w_off;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // (a workgroup walks several 64-vertex tiles: the grid is kept small for large batches, where most
@@ -3227,23 +3245,25 @@ __global__ __launch_bounds__(256) void peel_round_kernel(const ProbDesc* __restr
     }
     __syncthreads();
   }
-}
-
-__global__ void peel_finish_kernel(ProbState* __restrict__ states, int32_t* __restrict__ next_count,
-                                   int batch) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= batch) return;
-  ProbState* st = states + p;
-  if (!st->peel_done) {
-    const int c = next_count[p];
+  // the round's verdict (what a separate one-thread-per-problem launch used to do: three launches less on the serial
+  // chain of a batch): the problem's LAST workgroup to get here reads the survivor count and updates the state
+  if (threadIdx.x == 0) {
+    __threadfence();
+    is_last = atomicAdd(next_count + batch + blockIdx.y, 1) == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (is_last && threadIdx.x == 0) {
+    __threadfence();
+    const int c = __hip_atomic_load(next_count + blockIdx.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (c == st->alive_count) st->peel_done = 1;  // fixpoint
     st->alive_count = c;
     if (c <= st->lb) {
       st->proven = 1;
       st->peel_done = 1;
     }
+    __hip_atomic_store(next_count + blockIdx.y, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(next_count + batch + blockIdx.y, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  next_count[p] = 0;
 }
 
 void launch_select_best(hipStream_t s, const ProbDesc* d_desc, int batch, int max_W,
@@ -3264,9 +3284,7 @@ void launch_peel_rounds(hipStream_t s, const ProbDesc* d_desc, int batch, int ma
   const int gx = std::min(max_W, std::max(8, 2048 / batch));
   for (int r = 0; r < rounds; ++r) {
     hipLaunchKernelGGL(peel_round_kernel, dim3(gx, batch), dim3(256), 0, s, d_desc, d_bitmap,
-                       d_state, cur, nxt, d_next_count);
-    hipLaunchKernelGGL(peel_finish_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, d_state,
-                       d_next_count, batch);
+                       d_state, cur, nxt, d_next_count, batch);
     uint64_t* t = cur;
     cur = nxt;
     nxt = t;

@@ -49,6 +49,18 @@ using namespace thip;
 __global__ __launch_bounds__(256) void hdr_fetch_kernel(const uint4* __restrict__ host, uint4* __restrict__ dev, int n16) {
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dev[i] = host[i];
 }
+// Host inputs of an asynchronous batch moved by a KERNEL reading the page-locked host arrays over PCIe instead of two
+// SDMA copies (TEASER_HIP_H2D=kernel; diagnostic).  Motivation: while an SDMA transfer of the next batch is in flight,
+// every small kernel of the batches on the lanes runs 12-20 us longer (hdr_fetch 7 -> 25, peel_round 6 -> 16 us:
+// profiles/r4y), ~0.15 ms on the serial chain of a 128 x 5 k step.  Outcome: worse -- the copy kernel's workgroups
+// queue for CU slots behind K1.
+__global__ __launch_bounds__(256) void host_inputs_kernel(const uint4* __restrict__ src_h, const uint4* __restrict__ dst_h,
+                                                          uint4* __restrict__ src_d, uint4* __restrict__ dst_d, int64_t n16) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) {
+    src_d[i] = src_h[i];
+    dst_d[i] = dst_h[i];
+  }
+}
 __global__ __launch_bounds__(256) void state_push_kernel(const uint2* __restrict__ dev, uint2* __restrict__ host, int n8) {
   TAIL_WAVE_PRIO();
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n8; i += gridDim.x * 256) host[i] = dev[i];
@@ -855,7 +867,8 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
   // descs | initial states | tim offsets | peel counters (zero) | K1 prep + worklist counter (zero):
   // ONE device block, filled by ONE H2D copy per solve (no memsets, no per-array copies)
   const size_t b_desc = sizeof(ProbDesc) * (size_t)batch, b_state = sizeof(ProbState) * (size_t)batch,
-               b_off = 8 * (size_t)batch, b_next = 4 * (size_t)batch, b_prep = (size_t)tim_prep_bytes(batch);
+               b_off = 8 * (size_t)batch, b_next = 8 * (size_t)batch /* peel: survivor counts, arrivals */,
+               b_prep = (size_t)tim_prep_bytes(batch);
   auto al256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t o_desc = 0, o_state = al256(o_desc + b_desc), o_off = al256(o_state + b_state),
                o_next = al256(o_off + b_off), o_prep = al256(o_next + b_next),
@@ -1425,8 +1438,32 @@ int32_t submit_impl(teaser_hip_solver* h, const double* src, const double* dst,
     HIPCHK(h, is.src.ensure((size_t)std::max<int64_t>(tot, 1) * 24));
     HIPCHK(h, is.dst.ensure((size_t)std::max<int64_t>(tot, 1) * 24));
     if (tot > 0) {
-      HIPCHK(h, hipMemcpyAsync(is.src.p, src, (size_t)tot * 24, hipMemcpyHostToDevice, h->copy_stream));
-      HIPCHK(h, hipMemcpyAsync(is.dst.p, dst, (size_t)tot * 24, hipMemcpyHostToDevice, h->copy_stream));
+      // TEASER_HIP_H2D = dma (default: hipMemcpyAsync, two SDMA copies; pageable memory is staged by the runtime) |
+      // kernel (host_inputs_kernel, when both arrays are page-locked memory the device can read in place: measured
+      // SLOWER -- its workgroups wait for slots behind K1: 0.89 vs 0.65 ms per 128 x 5 k step, profiles/r4z -- kept
+      // as a diagnostic)
+      static const int h2d_env = [] {
+        const char* e = getenv("TEASER_HIP_H2D");
+        return (e && e[0] == 'k') ? 2 : 1;
+      }();
+      auto device_readable = [](const void* p) {
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+          (void)hipGetLastError();
+          return false;
+        }
+        return a.type == hipMemoryTypeHost && a.devicePointer != nullptr;
+      };
+      const bool by_kernel = h2d_env != 1 && ((size_t)tot * 24) % 16 == 0 && device_readable(src) && device_readable(dst);
+      if (by_kernel) {
+        hipLaunchKernelGGL(host_inputs_kernel, dim3(64), dim3(256), 0, h->copy_stream, reinterpret_cast<const uint4*>(src),
+                           reinterpret_cast<const uint4*>(dst), is.src.as<uint4>(), is.dst.as<uint4>(),
+                           (int64_t)((size_t)tot * 24 / 16));
+        HIPCHK(h, hipGetLastError());
+      } else {
+        HIPCHK(h, hipMemcpyAsync(is.src.p, src, (size_t)tot * 24, hipMemcpyHostToDevice, h->copy_stream));
+        HIPCHK(h, hipMemcpyAsync(is.dst.p, dst, (size_t)tot * 24, hipMemcpyHostToDevice, h->copy_stream));
+      }
     }
     HIPCHK(h, hipEventRecord(is.ready, h->copy_stream));
     is.in_use = true;
@@ -1952,11 +1989,11 @@ int32_t teaser_hip_max_clique(teaser_hip_solver* h, const uint64_t* bitmap, int3
   HIPCHK(h, h->d_start_cliques.ensure((size_t)n * 4 * kMaxStarts));
   HIPCHK(h, h->d_alive_a.ensure((size_t)W * 8));
   HIPCHK(h, h->d_alive_b.ensure((size_t)W * 8));
-  HIPCHK(h, h->d_next_count.ensure(4));
+  HIPCHK(h, h->d_next_count.ensure(8));
   HIPCHK(h, hipMemcpyAsync(h->d_desc.p, &d, sizeof(d), hipMemcpyHostToDevice, s));
   HIPCHK(h, hipMemcpyAsync(h->d_state.p, &st, sizeof(st), hipMemcpyHostToDevice, s));
   HIPCHK(h, hipMemcpyAsync(h->d_bitmap.p, bitmap, (size_t)n * W * 8, hipMemcpyHostToDevice, s));
-  HIPCHK(h, hipMemsetAsync(h->d_next_count.p, 0, 4, s));
+  HIPCHK(h, hipMemsetAsync(h->d_next_count.p, 0, 8, s));
   const ProbDesc* dd = h->d_desc.as<ProbDesc>();
   ProbState* ds = h->d_state.as<ProbState>();
   const bool exact = (mode == TEASER_INLIER_PMC_EXACT);
