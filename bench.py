@@ -89,6 +89,10 @@ def parse(argv=None):
                          "1 = strictly one batch at a time")
     ap.add_argument("--configs", default="4,3,5,scale",
                     help="other BASELINE configurations to run after the top-level one ('' = none)")
+    ap.add_argument("--config-depth", default="config3=4,config5=3,scale=3",
+                    help="batches in flight per `configs` line (default for the others: --depth).  The lines whose solves "
+                         "need the host-driven bound-closing stage (colouring bound / exact search) are latency-bound per "
+                         "lane, not K1-bound: more lanes overlap them (profiles/r5d, r5h)")
     ap.add_argument("--repeats", type=int, default=3,
                     help="timed regions (of --steps steps each at the top level) per line; the median is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -449,12 +453,21 @@ def stage_breakdown(solver, s_t, d_t, offsets, sizes, reps=3):
 def run_config(tag, tp, torch, runner, args, dev, world, rank, make_workload, steps, want_cpu):
     """One `configs` line: median of args.repeats timed regions of `steps` steps each."""
     solver, wl = make_workload()
-    runner_c = Runner(torch, runner.dist, solver, runner.D, runner.gather_dev)
-    solver.set_pipeline_depth(runner.D)
+    depth = runner.D
+    for item in filter(None, args.config_depth.split(",")):
+        k, _, v = item.partition("=")
+        if k.strip() == tag:
+            depth = max(1, int(v))
+    runner_c = Runner(torch, runner.dist, solver, depth, runner.gather_dev)
+    solver.set_pipeline_depth(depth)
     bufs = [(torch.from_numpy(s).to(dev), torch.from_numpy(d).to(dev)) for s, d in wl["pool"]]
     offsets, sizes = wl["offsets"], wl["sizes"]
     B = wl["problems_per_step"]
-    runner_c.run_steps(0, max(args.warmup, runner.D), bufs, offsets, sizes, False)
+    # every lane sees every distinct batch before the timed region (a lane's arenas grow to the largest batch it has
+    # met: with ragged batches -- config 5 -- a first meeting inside the timed region is a hipMalloc there)
+    for o in range(len(bufs)):  # lane j <- batch (o + j) mod len(bufs)
+        runner_c.run_steps(o, depth, bufs, offsets, sizes, False)
+    runner_c.run_steps(0, args.warmup, bufs, offsets, sizes, False)
     last = runner_c.run_steps(0, 1, bufs, offsets, sizes, False)
     wl["check"](last)  # the work is not skipped and is right
     solver.set_profiling(2)
@@ -470,13 +483,13 @@ def run_config(tag, tp, torch, runner, args, dev, world, rank, make_workload, st
         "value": world * B * steps / med, "unit": "registrations/s", "ms_per_step": 1e3 * med / steps,
         "ms_per_registration": 1e3 * med / (steps * B),
         "ms_per_step_repeats": [round(1e3 * t / steps, 4) for t in times],
-        "distinct_batches": len(bufs), "inputs": "resident in HBM", "n_gpus": world,
+        "distinct_batches": len(bufs), "batches_in_flight": depth, "inputs": "resident in HBM", "n_gpus": world,
     }
     if not args.no_host_resident:
         # page-locked by the runtime the LIBRARY runs on (teaser_hip_host_alloc): memory pinned by torch's bundled HIP
         # runtime is pageable to it and would be staged (config 4: 0.87 instead of 0.69 ms per step, r4u)
         pinned = [(tp.PinnedArray(s), tp.PinnedArray(d)) for s, d in wl["pool"]]
-        runner_c.run_steps(0, runner.D + 1, pinned, offsets, sizes, True)
+        runner_c.run_steps(0, depth + 1, pinned, offsets, sizes, True)
         th = [runner_c.timed(1 + r * steps, steps, pinned, offsets, sizes, True)[0] for r in range(max(1, args.repeats))]
         mh = float(np.median(th))
         line["host_resident"] = {"value": world * B * steps / mh, "unit": "registrations/s",

@@ -70,6 +70,16 @@ print("top", round(d["value"]), d["ms_per_step"], d["config"].get("host_resident
 c=d["configs"]["config4"]; print("c4", round(c["value"]), c["ms_per_step"], c.get("host_resident"), c["stage_ms"])
 PY
       ;;
+    cfgdepth)  # the `configs` lines in $CFGS at the depths in $DEPTHS (batches in flight), per environment group in $ENVS
+      IFS=";" read -ra GRPS <<< "${ENVS:-X=0}"
+      for g in "${GRPS[@]}"; do for d in ${DEPTHS:-2 3 4}; do
+        cd_arg=$(for c in config3 config4 config5 scale; do printf "%s=%s," $c $d; done)
+        env $g timeout 400 python bench.py --configs "${CFGS:-3}" --config-depth "$cd_arg" --no-cpu-baseline --no-latency --no-host-resident --steps 20 --repeats 2 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1])
+for k,c in d['configs'].items():
+    if isinstance(c,dict) and 'ms_per_step' in c: print('$g depth $d %s: %.1f reg/s, %.4f ms/step %s' % (k, c['value'], c['ms_per_step'], c['ms_per_step_repeats']))"
+      done; done | tee $OUT/config_depths.txt ;;
     benchprof)
       PROF_TIMEOUT=600 prof bench_prof --kernel-trace --stats --output-format csv -d $OUT/bench_prof -o t -- python $R/bench.py --configs '' --no-cpu-baseline --no-latency --no-host-resident
       grep '^{' $OUT/bench_prof.log | tail -1 > $OUT/bench_under_rocprof.json
@@ -105,6 +115,9 @@ PY
     c5) timeout 300 python scripts/profile_config5.py batch > $OUT/config5_run.jsonl 2> $OUT/config5_run.err; echo "rc=$?"; cut -c1-600 $OUT/config5_run.jsonl; grep -i "k4\|exact" $OUT/config5_run.err | tail -5 ;;
     stages) timeout 300 python scripts/profile_stages.py > $OUT/stages.log 2>&1; timeout 200 python scripts/profile_stages.py big >> $OUT/stages.log 2>&1; grep '^{' $OUT/stages.log > $OUT/stages.jsonl; cut -c1-420 $OUT/stages.jsonl ;;
     scale) timeout 400 python scripts/profile_scale.py > $OUT/scale.jsonl 2> $OUT/scale.err; echo "rc=$?"; cut -c1-400 $OUT/scale.jsonl ;;
+    scalebench) timeout 300 python scripts/profile_scale.py bench > $OUT/scale_bench.jsonl 2> $OUT/scale_bench.err; echo "rc=$?"; cut -c1-1500 $OUT/scale_bench.jsonl; tail -3 $OUT/scale_bench.err ;;
+    scaleprof) timeout ${PROF_TIMEOUT:-400} rocprofv3 --kernel-trace --stats -d $OUT/scale_prof -o sp -- python scripts/profile_scale.py bench > $OUT/scale_prof.log 2>&1; echo "rc=$?"
+      f=$(find $OUT/scale_prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/scale_kernel_stats.csv && cut -c1-150 $f | head -24 ;;
     k1occ)  # K1 alone at 1 / 2 / 3 workgroups per CU (unused dynamic LDS limits the occupancy)
       for v in 20 23; do for pad in 0 30000 60000; do
         TEASER_K1_VARIANT=$v TEASER_K1_LDS_PAD=$pad timeout 60 $P 64 10000 5 one 2>/dev/null | sed "s/^{/{\"lds_pad\":$pad,\"v\":$v,/" | cut -c1-140
@@ -125,6 +138,14 @@ for n in names:
     print("%-32s %7.2f %7.2f %7.2f | %7.2f %7.2f %7.2f" % (n,f(1,0,0),f(1,1,0),f(1,0,1),f(3,0,0),f(3,1,0),f(3,0,1)))
 PY
       ;;
+    pipecfg)  # scripts/pipe_config.py per "args" in $PIPES (semicolon-separated) x env group in $ENVS
+      IFS=";" read -ra GRPS <<< "${ENVS:-X=0}"; IFS=";" read -ra PP <<< "${PIPES:-50000 0.99 1 3 24}"
+      for g in "${GRPS[@]}"; do for a in "${PP[@]}"; do echo -n "$g | "; env $g timeout 120 python scripts/pipe_config.py $a 2>/dev/null | tail -1; done; done | tee $OUT/pipe_config.txt ;;
+    hosttrace)  # host-side time stamps of the asynchronous path (submit / wait / finisher threads), config 3 at depth ${D3:-3}
+      TEASER_HIP_HOST_TRACE=1 timeout 120 python scripts/pipe_config.py ${PIPE1:-50000 0.99 1 ${D3:-3} 12} > $OUT/host_trace.json 2> $OUT/host_trace.txt; cat $OUT/host_trace.json; grep host-trace $OUT/host_trace.txt | tail -${HT_LINES:-130} ;;
+    timeline3)  # kernel trace of config 3 through the pipeline at depth ${D3:-3}
+      PROF_TIMEOUT=300 prof tl3 --kernel-trace --output-format csv -d $OUT/tl3 -o t -- python $R/scripts/pipe_config.py 50000 0.99 1 ${D3:-3} 12
+      python scripts/trace_timeline.py $(find $OUT/tl3 -name "*kernel_trace.csv" | head -1) 30 > $OUT/timeline3.txt 2>&1; tail -150 $OUT/timeline3.txt | cut -c1-160 ;;
     timeline)
       PROF_TIMEOUT=600 prof tl --kernel-trace --output-format csv -d $OUT/tl -o t -- python $R/bench.py --configs '' --no-cpu-baseline --no-latency --no-host-resident --steps 16 --warmup 2 --pool 6
       python scripts/trace_timeline.py $(find $OUT/tl -name "*kernel_trace.csv" | head -1) > $OUT/timeline.txt 2>&1; tail -60 $OUT/timeline.txt | cut -c1-200 ;;

@@ -152,6 +152,11 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise ImportError("%s is missing: run __graft_entry__.build() (make -C %s)" % (LIB_PATH, _CSRC))
+    # One hardware queue per lane: HIP multiplexes its streams onto GPU_MAX_HW_QUEUES (default 4) hardware queues, and
+    # two lanes of a deeper pipeline that share one run one after the other (N = 50 k, 3 batches in flight: 1.52 ms per
+    # step with 4 queues, 1.19 with 8; profiles/r5d).  Read by the runtime when it initialises -- i.e. before this
+    # library's first HIP call; a value the user exported wins.  The library's own constructor does the same for C++.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     L = C.CDLL(LIB_PATH)
     L.teaser_hip_host_alloc.argtypes = [C.c_size_t, C.POINTER(_vp)]
     L.teaser_hip_host_free.argtypes = [_vp]

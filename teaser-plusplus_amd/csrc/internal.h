@@ -158,7 +158,8 @@ constexpr int kExactCounterInts = 96;   // 2 ints per task queue (8 queues), the
 void launch_exact_count(hipStream_t s, const ProbDesc* d_desc, ExactProb* d_probs, int nprob, int max_W,
                         const uint64_t* d_bitmap, const uint64_t* d_alive, const int32_t* d_deg,
                         const ProbState* d_state, const int32_t* d_xlist, const int32_t* d_keep,
-                        uint64_t* d_cand_bits /* [sum W] by w_off */, uint64_t* d_x_bits /* [sum W] */);
+                        uint64_t* d_cand_bits /* [sum W] by w_off */, uint64_t* d_x_bits /* [sum W] */,
+                        bool speculative = false /* slot = problem of the batch; proven problems only leave a marker */);
 // step 2: search order (roots first, the rest by ascending degree) + compact adjacency
 void launch_exact_build(hipStream_t s, const ProbDesc* d_desc, const ExactProb* d_probs, int nprob, int max_W,
                         int max_n2, const uint64_t* d_bitmap, const int32_t* d_deg, const uint64_t* d_cand_bits,

@@ -882,6 +882,13 @@ void launch_exact_clique(hipStream_t s, ExactProb* d_probs, int nprob, int total
                      passes);
 }
 
+// Speculative launches (sel == nullptr: the stage is enqueued behind the peel BEFORE the host knows which problems it
+// left open, solver.hip): a slot is a problem of the batch, and the kernels of a problem that is already proven -- or
+// whose incumbent is outside the palette -- return at once.
+__device__ __forceinline__ bool colour_not_needed(const ProbState& st, int n) {
+  return st.proven || n < 2 || st.lb < 2 || st.lb > kColourMaxLb;
+}
+
 // ------------------------------------------------------------------------------------------
 // Set-up of the compact problems on the device (what exact_stage used to do on the host with one
 // hipMemcpy per root row, a host sort and a stream sync per problem).
@@ -897,16 +904,28 @@ __global__ __launch_bounds__(256) void exact_count_kernel(const ProbDesc* __rest
                                                           const int32_t* __restrict__ xlist,
                                                           const int32_t* __restrict__ keep,
                                                           uint64_t* __restrict__ cand_bits,
-                                                          uint64_t* __restrict__ x_bits) {
+                                                          uint64_t* __restrict__ x_bits, int speculative) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int red4[4];
   __shared__ int kept;
   ExactProb* pb = probs + blockIdx.x;
-  const int p = pb->prob;
+  // speculative (enqueued before the host knows the open problems): slot = problem, the colouring bound ran iff the
+  // incumbent fits the palette; a proven problem only leaves its marker (n2 = 0, ctrl[5] = -2)
+  const int p = speculative ? (int)blockIdx.x : pb->prob;
   const ProbDesc d = descs[p];
   const int W = d.W, tid = threadIdx.x;
   const int lb = states[p].lb;
-  const int xc = pb->use_x ? states[p].x_count : -1;  // -1: the colouring bound did not run for this problem
+  if (speculative && (states[p].proven || d.n < 2)) {
+    if (tid == 0) {
+      pb->prob = p;
+      pb->n2 = 0;
+      pb->ctrl[5] = -2;
+      pb->ctrl[6] = -2;
+    }
+    return;
+  }
+  const bool coloured = speculative ? !colour_not_needed(states[p], d.n) : pb->use_x != 0;
+  const int xc = coloured ? states[p].x_count : -1;  // -1: the colouring bound did not run for this problem
   uint64_t* Xb = reinterpret_cast<uint64_t*>(smem);  // W
   uint64_t* Cb = Xb + ((W + 1) & ~1);                // W
   const uint64_t* al = alive + d.w_off;
@@ -977,6 +996,7 @@ __global__ __launch_bounds__(256) void exact_count_kernel(const ProbDesc* __rest
   __syncthreads();
   if (tid == 0) {
     const bool proven = xc == 0 || (xc > 0 && xc <= kRootPruneCap && nx == 0);  // no root can lie in a larger clique
+    pb->prob = p;
     pb->n2 = proven ? 0 : n2;
     pb->W2 = (n2 + 63) / 64;
     pb->n_roots = use_x ? nx : n2;
@@ -991,13 +1011,13 @@ __global__ __launch_bounds__(256) void exact_count_kernel(const ProbDesc* __rest
 void launch_exact_count(hipStream_t s, const ProbDesc* d_desc, ExactProb* d_probs, int nprob, int max_W,
                         const uint64_t* d_bitmap, const uint64_t* d_alive, const int32_t* d_deg,
                         const ProbState* d_state, const int32_t* d_xlist, const int32_t* d_keep,
-                        uint64_t* d_cand_bits, uint64_t* d_x_bits) {
+                        uint64_t* d_cand_bits, uint64_t* d_x_bits, bool speculative) {
   if (nprob <= 0) return;
   const size_t lds = (size_t)2 * ((max_W + 1) & ~1) * 8;
   static DynLdsOptIn optin;
   if (lds > 48 * 1024) optin.ensure(reinterpret_cast<const void*>(exact_count_kernel), (int)lds);
   hipLaunchKernelGGL(exact_count_kernel, dim3(nprob), dim3(256), lds, s, d_desc, d_probs, d_bitmap, d_alive, d_deg,
-                     d_state, d_xlist, d_keep, d_cand_bits, d_x_bits);
+                     d_state, d_xlist, d_keep, d_cand_bits, d_x_bits, speculative ? 1 : 0);
 }
 
 // step 2a, one workgroup per problem: roots (ascending index) to order[0 .. nx), the other candidates as a list
@@ -1245,8 +1265,9 @@ __global__ __launch_bounds__(256) void colour_init_kernel(const ProbDesc* __rest
                                                           uint64_t* __restrict__ colbits /* [sum W] */,
                                                           uint64_t* __restrict__ classbits /* [kColourClasses][sum W] */,
                                                           int64_t total_w, int64_t total_n) {
-  const int p = sel[blockIdx.y];
+  const int p = sel ? sel[blockIdx.y] : (int)blockIdx.y;
   const ProbDesc d = descs[p];
+  if (!sel && colour_not_needed(states[p], d.n)) return;
   const int lb = states[p].lb;
   const int lane = threadIdx.x & 63;
   int32_t* cnt = counts + (int64_t)blockIdx.y * (kColourRounds + 2);
@@ -1305,8 +1326,9 @@ __global__ __launch_bounds__(256) void colour_assign_kernel(const ProbDesc* __re
                                                             int count_idx, const uint64_t* __restrict__ alive,
                                                             uint64_t* __restrict__ bid_snapshot) {
   __shared__ unsigned long long Fs[4][kColourMaxWords];
-  const int p = sel[blockIdx.y];
+  const int p = sel ? sel[blockIdx.y] : (int)blockIdx.y;
   const ProbDesc d = descs[p];
+  if (!sel && colour_not_needed(states[p], d.n)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // all-in rounds: the bidders of this round = the survivors still without a colour NOW (colbits is stable while
   // the assign step runs; the resolve step, which updates it, reads this snapshot)
@@ -1382,8 +1404,9 @@ __global__ __launch_bounds__(256) void colour_resolve_kernel(const ProbDesc* __r
                                                              uint64_t* __restrict__ colbits,
                                                              const uint64_t* __restrict__ bidders /* this round's */,
                                                              int round, int last, int count_idx, int next_idx) {
-  const int p = sel[blockIdx.y];
+  const int p = sel ? sel[blockIdx.y] : (int)blockIdx.y;
   const ProbDesc d = descs[p];
+  if (!sel && colour_not_needed(states[p], d.n)) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int32_t* cnt = counts + (int64_t)blockIdx.y * (kColourRounds + 2);
   const int count = cnt[count_idx];
@@ -1432,8 +1455,9 @@ __global__ __launch_bounds__(256) void colour_finish_kernel(const ProbDesc* __re
                                                             const int32_t* __restrict__ sel,
                                                             const ProbState* __restrict__ states,
                                                             int32_t* __restrict__ tent) {
-  const int p = sel[blockIdx.y];
+  const int p = sel ? sel[blockIdx.y] : (int)blockIdx.y;
   const ProbDesc d = descs[p];
+  if (!sel && colour_not_needed(states[p], d.n)) return;
   const int xc = min(states[p].x_count, kRootPruneCap);
   for (int i = blockIdx.x * 256 + threadIdx.x; i < xc; i += gridDim.x * 256) tent[d.pt_off + i] = 0;
 }
@@ -1454,8 +1478,9 @@ __global__ __launch_bounds__(256) void root_prune_kernel(const ProbDesc* __restr
                                                          int32_t* __restrict__ count) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int wsum_[4];
-  const int p = sel[blockIdx.z];
+  const int p = sel ? sel[blockIdx.z] : (int)blockIdx.z;
   const ProbDesc d = descs[p];
+  if (!sel && colour_not_needed(states[p], d.n)) return;
   const int xc = states[p].x_count;
   if (xc > kRootPruneCap || (int)blockIdx.y >= xc) return;
   const int lb = states[p].lb;

@@ -9,11 +9,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
-
-#include <chrono>
 
 #include "internal.h"
 
@@ -67,6 +70,37 @@ __global__ __launch_bounds__(256) void state_push_kernel(const uint2* __restrict
 }
 
 namespace {
+
+// TEASER_HIP_HOST_TRACE=1 (diagnostics): host-side time stamps of the asynchronous path (submit / wait on the caller's
+// thread, the halves of a batch's finish on the lanes' finisher threads), printed when the handle is destroyed
+struct HostTrace {
+  struct Rec { int64_t ns; const void* who; const char* what; };
+  std::mutex m;
+  std::vector<Rec> recs;
+  const bool on = getenv("TEASER_HIP_HOST_TRACE") != nullptr;
+  void mark(const void* who, const char* what) {
+    if (!on) return;
+    const int64_t t = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    std::lock_guard<std::mutex> lk(m);
+    if (recs.size() < 200000) recs.push_back({t, who, what});
+  }
+  void dump() {
+    if (!on) return;
+    std::lock_guard<std::mutex> lk(m);
+    if (recs.empty()) return;
+    const size_t from = recs.size() > 400 ? recs.size() - 400 : 0;  // the last steps
+    const int64_t t0 = recs[from].ns;
+    for (size_t i = from; i < recs.size(); ++i)
+      fprintf(stderr, "[host-trace] %10.1f us  %p  %s\n", (recs[i].ns - t0) * 1e-3, recs[i].who, recs[i].what);
+    recs.clear();
+  }
+};
+HostTrace g_trace;
+
+// One hardware queue per lane (see enqueue_on_lane): the HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES
+// (default 4) hardware queues; lanes that share one serialise.  Effective when this library is loaded before the
+// runtime initialises (its first HIP call); never overrides a value the user exported.
+__attribute__((constructor)) void runtime_defaults() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
 
 struct DevBuf {
   void* p = nullptr;
@@ -135,6 +169,21 @@ enum Stage { ST_H2D = 0, ST_TIM, ST_DEG, ST_HEU, ST_PEEL, ST_EXACT, ST_ROT, ST_T
 
 }  // namespace
 
+// A lane's finisher: the thread that runs the second half of an asynchronous batch (solve_packed_finish: the host
+// sync, and -- when the heuristic clique is not yet proven maximal -- the host-driven colouring bound and exact
+// search with their own syncs) as soon as the batch is enqueued, instead of the caller's thread inside
+// teaser_hip_wait.  The bound-closing stages of batches on different lanes then overlap each other and the next
+// batch's enqueue: with ONE host thread they ran one after the other inside wait(), however deep the pipeline
+// (config 3: 1.62 ms per step at depth 2, 3, 4 and 6 alike, profiles/r5b).
+struct LaneFinisher {
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  std::atomic<int> state{0};  // 0 idle, 1 batch posted, 2 batch finished (outputs in `out`), 3 quit
+  std::vector<teaser_solution_c> out;
+  int32_t rc = TEASER_HIP_OK;
+};
+
 struct teaser_hip_solver {
   teaser_params_c params;
   int device = 0;
@@ -178,6 +227,14 @@ struct teaser_hip_solver {
   PinnedBuf pin_states;  // D2H landing zone of the problem states
   PinnedBuf pin_in;      // H2D staging of the problem descriptors / initial states
   PinnedBuf pin_pts;     // H2D staging of pageable caller point arrays (teaser_hip_solve_batch)
+  PinnedBuf pin_ep;      // D2H landing zone of the speculative bound stage's per-problem results (ExactProb)
+  // The bound-closing stage (colouring bound, root filter, candidate sizes) needs the host only to know WHICH problems
+  // the peel left open.  When the previous batch had open problems, the next one enqueues that stage for every problem
+  // right behind the peel (the kernels of a proven problem return at once): the solve keeps ONE host sync, and the
+  // ~40 launches come from the thread that enqueues everything else (several finisher threads launching at once cost
+  // 40-60 us per launch, profiles/r5e).  TEASER_HIP_SPEC_BOUNDS=0 disables.
+  bool spec_bounds_next = false;
+  int last_unproven = 0;
 
   // ---- state carried from the enqueue half of a solve to its finish half -----------------
   struct Pending {
@@ -185,6 +242,7 @@ struct teaser_hip_solver {
     const double* d_dst = nullptr;
     int batch = 0, mode = 0;
     bool need_graph = false;
+    bool spec_bounds = false;  // colouring bound + root filter + sizes already enqueued (results in pin_ep)
     int64_t total_n = 0, tls_stride = 0;
   } pend;
   // ---- asynchronous batches (teaser_hip_submit_batch / teaser_hip_wait): lanes = child handles
@@ -213,6 +271,7 @@ struct teaser_hip_solver {
   hipEvent_t inputs_ready = nullptr;       // host inputs copied (lane stream) -> K1 phase may start
   bool inputs_pending = false;
   bool is_lane = false;
+  std::unique_ptr<LaneFinisher> fin;       // lanes only (TEASER_HIP_FINISHER=0: none, wait() finishes the batch itself)
   struct Job {                             // a submitted, not yet waited-for batch (lanes only)
     bool busy = false;
     std::vector<int64_t> off;
@@ -554,49 +613,59 @@ int32_t close_clique_bounds(teaser_hip_solver* h, int batch, int64_t total_n, bo
     if (st.lb >= 2 && st.lb <= kColourMaxLb) csel.push_back(b);
   }
   h->colour_x.assign((size_t)batch, -1);
+  h->last_unproven = (int)unproven.size();
   if (unproven.empty()) return TEASER_HIP_OK;
   int max_n = 0;
   for (int32_t b : unproven) max_n = std::max(max_n, h->descs[(size_t)b].n);
   const int max_W = (max_n + 63) / 64;
-  HIPCHK(h, h->c_colour.ensure(4 * (size_t)total_n));
-  HIPCHK(h, h->c_tent.ensure(4 * (size_t)total_n));
-  HIPCHK(h, h->c_xlist.ensure(4 * (size_t)total_n));
-  if (!csel.empty()) {
-    StageScope sc(h, ST_COLOUR);
-    HIPCHK(h, h->c_sel.ensure(4 * csel.size()));
-    HIPCHK(h, h->c_list_a.ensure(4 * (size_t)total_n));
-    HIPCHK(h, h->c_list_b.ensure(4 * (size_t)total_n));
-    HIPCHK(h, h->c_counts.ensure(4 * csel.size() * (size_t)(kColourRounds + 2)));
-    HIPCHK(h, h->c_bits.ensure(8 * 10 * (size_t)std::max<int64_t>(h->total_w, 1)));
-    HIPCHK(h, h->c_class.ensure(4 * 8 * (size_t)total_n));
-    HIPCHK(h, hipMemcpyAsync(h->c_sel.p, csel.data(), 4 * csel.size(), hipMemcpyHostToDevice, s));
-    int cmax_n = 0;
-    for (int32_t b : csel) cmax_n = std::max(cmax_n, h->descs[(size_t)b].n);
-    launch_colour_bound(s, dd, h->c_sel.as<int32_t>(), (int)csel.size(), cmax_n,
-                        h->d_bitmap.as<uint64_t>(), final_alive, h->d_clique.as<int32_t>(), ds,
-                        h->c_colour.as<int32_t>(), h->c_tent.as<int32_t>(),
-                        h->c_xlist.as<int32_t>(), h->c_class.as<int32_t>(), h->c_list_a.as<int32_t>(),
-                        h->c_list_b.as<int32_t>(), h->c_counts.as<int32_t>(), h->c_bits.as<uint64_t>(),
-                        std::max<int64_t>(h->total_w, 1), total_n, kColourRounds);
+  std::vector<ExactProb> ep(unproven.size());
+  if (h->pend.spec_bounds) {
+    // enqueued behind the peel (enqueue_bounds_speculative): the results are already on the host
+    const ExactProb* got = reinterpret_cast<const ExactProb*>(h->pin_ep.p);
+    for (size_t k = 0; k < unproven.size(); ++k) ep[k] = got[unproven[k]];
+  } else {
+    HIPCHK(h, h->c_colour.ensure(4 * (size_t)total_n));
+    HIPCHK(h, h->c_tent.ensure(4 * (size_t)total_n));
+    HIPCHK(h, h->c_xlist.ensure(4 * (size_t)total_n));
+    if (!csel.empty()) {
+      StageScope sc(h, ST_COLOUR);
+      HIPCHK(h, h->c_sel.ensure(4 * csel.size()));
+      HIPCHK(h, h->c_list_a.ensure(4 * (size_t)total_n));
+      HIPCHK(h, h->c_list_b.ensure(4 * (size_t)total_n));
+      HIPCHK(h, h->c_counts.ensure(4 * csel.size() * (size_t)(kColourRounds + 2)));
+      HIPCHK(h, h->c_bits.ensure(8 * 10 * (size_t)std::max<int64_t>(h->total_w, 1)));
+      HIPCHK(h, h->c_class.ensure(4 * 8 * (size_t)total_n));
+      HIPCHK(h, hipMemcpyAsync(h->c_sel.p, csel.data(), 4 * csel.size(), hipMemcpyHostToDevice, s));
+      int cmax_n = 0;
+      for (int32_t b : csel) cmax_n = std::max(cmax_n, h->descs[(size_t)b].n);
+      launch_colour_bound(s, dd, h->c_sel.as<int32_t>(), (int)csel.size(), cmax_n,
+                          h->d_bitmap.as<uint64_t>(), final_alive, h->d_clique.as<int32_t>(), ds,
+                          h->c_colour.as<int32_t>(), h->c_tent.as<int32_t>(),
+                          h->c_xlist.as<int32_t>(), h->c_class.as<int32_t>(), h->c_list_a.as<int32_t>(),
+                          h->c_list_b.as<int32_t>(), h->c_counts.as<int32_t>(), h->c_bits.as<uint64_t>(),
+                          std::max<int64_t>(h->total_w, 1), total_n, kColourRounds);
+      HIPCHK(h, hipGetLastError());
+    }
+    // root filter, candidate sets, sizes: one descriptor per open problem
+    StageScope sc_count(h, ST_EXACT);
+    memset(ep.data(), 0, sizeof(ExactProb) * ep.size());
+    for (size_t k = 0; k < unproven.size(); ++k) {
+      ep[k].prob = unproven[k];
+      ep[k].use_x = std::find(csel.begin(), csel.end(), unproven[k]) != csel.end() ? 1 : 0;
+    }
+    HIPCHK(h, h->x_probs.ensure(sizeof(ExactProb) * ep.size()));
+    HIPCHK(h, h->x_xbits.ensure(8 * (size_t)std::max<int64_t>(h->total_w, 1)));
+    HIPCHK(h, hipMemcpyAsync(h->x_probs.p, ep.data(), sizeof(ExactProb) * ep.size(), hipMemcpyHostToDevice, s));
+    launch_exact_count(s, dd, h->x_probs.as<ExactProb>(), (int)ep.size(), max_W, h->d_bitmap.as<uint64_t>(), final_alive,
+                       h->d_deg.as<int32_t>(), ds, h->c_xlist.as<int32_t>(), h->c_tent.as<int32_t>(), spare_alive,
+                       h->x_xbits.as<uint64_t>());
     HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(ep.data(), h->x_probs.p, sizeof(ExactProb) * ep.size(), hipMemcpyDeviceToHost, s));
+    g_trace.mark(h, "bounds: colouring + root filter enqueued");
+    HIPCHK(h, hipStreamSynchronize(s));
+    g_trace.mark(h, "bounds: sizes on the host");
   }
   StageScope sc_exact(h, ST_EXACT);
-  // root filter, candidate sets, sizes: one descriptor per open problem
-  std::vector<ExactProb> ep(unproven.size());
-  memset(ep.data(), 0, sizeof(ExactProb) * ep.size());
-  for (size_t k = 0; k < unproven.size(); ++k) {
-    ep[k].prob = unproven[k];
-    ep[k].use_x = std::find(csel.begin(), csel.end(), unproven[k]) != csel.end() ? 1 : 0;
-  }
-  HIPCHK(h, h->x_probs.ensure(sizeof(ExactProb) * ep.size()));
-  HIPCHK(h, h->x_xbits.ensure(8 * (size_t)std::max<int64_t>(h->total_w, 1)));
-  HIPCHK(h, hipMemcpyAsync(h->x_probs.p, ep.data(), sizeof(ExactProb) * ep.size(), hipMemcpyHostToDevice, s));
-  launch_exact_count(s, dd, h->x_probs.as<ExactProb>(), (int)ep.size(), max_W, h->d_bitmap.as<uint64_t>(), final_alive,
-                     h->d_deg.as<int32_t>(), ds, h->c_xlist.as<int32_t>(), h->c_tent.as<int32_t>(), spare_alive,
-                     h->x_xbits.as<uint64_t>());
-  HIPCHK(h, hipGetLastError());
-  HIPCHK(h, hipMemcpyAsync(ep.data(), h->x_probs.p, sizeof(ExactProb) * ep.size(), hipMemcpyDeviceToHost, s));
-  HIPCHK(h, hipStreamSynchronize(s));
   std::vector<ExactProb> open;
   for (const ExactProb& e : ep) {
     const int b = e.prob;
@@ -757,6 +826,56 @@ int32_t close_clique_bounds(teaser_hip_solver* h, int batch, int64_t total_n, bo
 // --------------------------------------------------------------------------------------------
 // rotation + translation estimators on the current cliques, then the async copy-back of the
 // problem states (no host sync here)
+bool spec_bounds_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("TEASER_HIP_SPEC_BOUNDS");
+    return !(e && atoi(e) == 0);
+  }();
+  return on;
+}
+
+// The first half of close_clique_bounds for EVERY problem of the batch, without the host (see spec_bounds_next): the
+// colouring bound, the root filter and the candidate sizes run behind the peel, guarded on the device by the problem's
+// own state; the per-problem results land in page-locked memory with the same stream order as everything else.
+int32_t enqueue_bounds_speculative(teaser_hip_solver* h, int batch, int64_t total_n) {
+  hipStream_t s = h->stream;
+  const ProbDesc* dd = h->d_desc.as<ProbDesc>();
+  ProbState* ds = h->d_state.as<ProbState>();
+  const uint64_t* final_alive =
+      (kPeelRounds % 2 == 0) ? h->d_alive_a.as<uint64_t>() : h->d_alive_b.as<uint64_t>();
+  uint64_t* spare_alive = (kPeelRounds % 2 == 0) ? h->d_alive_b.as<uint64_t>() : h->d_alive_a.as<uint64_t>();
+  const size_t tw = (size_t)std::max<int64_t>(h->total_w, 1);
+  HIPCHK(h, h->c_colour.ensure(4 * (size_t)total_n));
+  HIPCHK(h, h->c_tent.ensure(4 * (size_t)total_n));
+  HIPCHK(h, h->c_xlist.ensure(4 * (size_t)total_n));
+  HIPCHK(h, h->c_list_a.ensure(4 * (size_t)total_n));
+  HIPCHK(h, h->c_list_b.ensure(4 * (size_t)total_n));
+  HIPCHK(h, h->c_counts.ensure(4 * (size_t)batch * (size_t)(kColourRounds + 2)));
+  HIPCHK(h, h->c_bits.ensure(8 * 10 * tw));
+  HIPCHK(h, h->c_class.ensure(4 * 8 * (size_t)total_n));
+  HIPCHK(h, h->x_probs.ensure(sizeof(ExactProb) * (size_t)batch));
+  HIPCHK(h, h->x_xbits.ensure(8 * tw));
+  HIPCHK(h, h->pin_ep.ensure(sizeof(ExactProb) * (size_t)batch));
+  {
+    StageScope sc(h, ST_COLOUR);
+    launch_colour_bound(s, dd, nullptr, batch, h->max_n, h->d_bitmap.as<uint64_t>(), final_alive,
+                        h->d_clique.as<int32_t>(), ds, h->c_colour.as<int32_t>(), h->c_tent.as<int32_t>(),
+                        h->c_xlist.as<int32_t>(), h->c_class.as<int32_t>(), h->c_list_a.as<int32_t>(),
+                        h->c_list_b.as<int32_t>(), h->c_counts.as<int32_t>(), h->c_bits.as<uint64_t>(), (int64_t)tw, total_n,
+                        kColourRounds);
+  }
+  {
+    StageScope sc(h, ST_EXACT);
+    HIPCHK(h, hipMemsetAsync(h->x_probs.p, 0, sizeof(ExactProb) * (size_t)batch, s));
+    launch_exact_count(s, dd, h->x_probs.as<ExactProb>(), batch, h->max_W, h->d_bitmap.as<uint64_t>(), final_alive,
+                       h->d_deg.as<int32_t>(), ds, h->c_xlist.as<int32_t>(), h->c_tent.as<int32_t>(), spare_alive,
+                       h->x_xbits.as<uint64_t>(), true);
+    HIPCHK(h, hipMemcpyAsync(h->pin_ep.p, h->x_probs.p, sizeof(ExactProb) * (size_t)batch, hipMemcpyDeviceToHost, s));
+  }
+  HIPCHK(h, hipGetLastError());
+  return TEASER_HIP_OK;
+}
+
 int32_t enqueue_estimators(teaser_hip_solver* h) {
   hipStream_t s = h->stream;
   const int batch = h->pend.batch;
@@ -1024,19 +1143,28 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
   h->pend.tls_stride = tls_stride;
   // speculative: the greedy clique is almost always the maximum one, so the estimators are
   // enqueued before the host learns whether the peel closed the bound (one sync per solve)
-  return enqueue_estimators(h);
+  h->pend.spec_bounds = false;
+  int32_t rc = enqueue_estimators(h);
+  if (rc == TEASER_HIP_OK && need_graph && mode == TEASER_INLIER_PMC_EXACT && h->spec_bounds_next && spec_bounds_enabled()) {
+    rc = enqueue_bounds_speculative(h, batch, total_n);
+    h->pend.spec_bounds = rc == TEASER_HIP_OK;
+    g_trace.mark(h, "submit: bound stage enqueued speculatively");
+  }
+  return rc;
 }
 
 // Second half of a solve: the ONE host sync, then the (rare) bound-closing work and the outputs.
 int32_t solve_packed_finish(teaser_hip_solver* h, teaser_solution_c* out, bool* k1_overflow) {
   const int batch = h->pend.batch;
   HIPCHK(h, hipStreamSynchronize(h->stream));
+  g_trace.mark(h, "finish: first sync done");
   memcpy(h->states.data(), h->pin_states.p, sizeof(ProbState) * (size_t)batch);
   *k1_overflow = false;
   for (int b = 0; b < batch; ++b)
     if (h->states[(size_t)b].k1_overflow || h->states[(size_t)b].scale_overflow) *k1_overflow = true;
   if (*k1_overflow) return TEASER_HIP_OK;  // the caller reruns the batch with the FP64 K1 / the 64-bit scale sort
   for (int b = 0; b < batch; ++b) h->heu_size[(size_t)b] = h->states[(size_t)b].lb;
+  h->last_unproven = 0;
   if (h->pend.need_graph && h->pend.mode == TEASER_INLIER_PMC_EXACT) {
     bool changed = false;
     int32_t rc = close_clique_bounds(h, batch, h->pend.total_n, &changed);
@@ -1101,6 +1229,7 @@ int32_t solve_packed(teaser_hip_solver* h, const double* d_src, const double* d_
   int32_t rc = solve_packed_impl(h, d_src, d_dst, pt_off, n, batch, out, false, &overflow);
   if (rc == TEASER_HIP_OK && overflow)
     rc = solve_packed_impl(h, d_src, d_dst, pt_off, n, batch, out, true, &overflow);
+  h->spec_bounds_next = rc == TEASER_HIP_OK && h->last_unproven > 0;
   return rc;
 }
 
@@ -1235,7 +1364,10 @@ int32_t make_lane(teaser_hip_solver* h, teaser_hip_solver** out) {
   return TEASER_HIP_OK;
 }
 
+void finisher_stop(teaser_hip_solver* lane);
+
 void release_handle_resources(teaser_hip_solver* h) {
+  finisher_stop(h);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   DevBuf* bufs[] = {&h->d_desc, &h->d_state, &h->d_src, &h->d_dst, &h->d_bitmap, &h->d_deg,
                     &h->d_clique, &h->d_start_cliques, &h->d_alive_a, &h->d_alive_b,
@@ -1251,6 +1383,7 @@ void release_handle_resources(teaser_hip_solver* h) {
   h->pin_states.release();
   h->pin_in.release();
   h->pin_pts.release();
+  h->pin_ep.release();
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   h->ev_pool.clear();
   if (h->k1_done) (void)hipEventDestroy(h->k1_done);
@@ -1320,6 +1453,87 @@ int32_t ensure_input_sets(teaser_hip_solver* h) {
   return TEASER_HIP_OK;
 }
 
+int32_t finish_lane_job(teaser_hip_solver* lane, teaser_solution_c* out) {
+  const int batch = (int)lane->job.n.size();
+  bool overflow = false;
+  g_trace.mark(lane, "finish: begin");
+  int32_t rc = solve_packed_finish(lane, out, &overflow);
+  g_trace.mark(lane, "finish: end");
+  if (rc == TEASER_HIP_OK && overflow)  // K1 fix-up list overflowed: this batch again, all-FP64 K1
+    rc = solve_packed_impl(lane, lane->job.d_src, lane->job.d_dst, lane->job.off.data(), lane->job.n.data(), batch, out,
+                           true, &overflow);
+  if (rc != TEASER_HIP_OK) (void)hipStreamSynchronize(lane->stream);
+  return rc;
+}
+
+void finisher_main(teaser_hip_solver* lane) {
+  LaneFinisher* f = lane->fin.get();
+  (void)hipSetDevice(lane->device);
+  for (;;) {
+    {
+      std::unique_lock<std::mutex> lk(f->m);
+      f->cv.wait(lk, [&] { return f->state.load(std::memory_order_acquire) == 1 || f->state.load() == 3; });
+      if (f->state.load() == 3) return;
+    }
+    f->rc = finish_lane_job(lane, f->out.data());
+    {
+      std::lock_guard<std::mutex> lk(f->m);
+      f->state.store(2, std::memory_order_release);
+    }
+    f->cv.notify_all();
+  }
+}
+
+bool finisher_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("TEASER_HIP_FINISHER");
+    return !(e && atoi(e) == 0);
+  }();
+  return on;
+}
+
+void finisher_post(teaser_hip_solver* lane) {
+  if (!lane->fin) {
+    lane->fin.reset(new LaneFinisher());
+    lane->fin->th = std::thread(finisher_main, lane);
+  }
+  LaneFinisher* f = lane->fin.get();
+  f->out.resize(lane->job.n.size());
+  {
+    std::lock_guard<std::mutex> lk(f->m);
+    f->state.store(1, std::memory_order_release);
+  }
+  f->cv.notify_all();
+}
+
+// blocks until the posted batch is finished; a short spin first (the usual case: the finisher is a few microseconds
+// from done, a futex wake-up costs more than that)
+int32_t finisher_collect(teaser_hip_solver* lane, teaser_solution_c* out) {
+  LaneFinisher* f = lane->fin.get();
+  for (int spin = 0; spin < 20000 && f->state.load(std::memory_order_acquire) != 2; ++spin) __builtin_ia32_pause();
+  if (f->state.load(std::memory_order_acquire) != 2) {
+    std::unique_lock<std::mutex> lk(f->m);
+    f->cv.wait(lk, [&] { return f->state.load(std::memory_order_acquire) == 2; });
+  }
+  memcpy(out, f->out.data(), sizeof(teaser_solution_c) * f->out.size());
+  f->state.store(0, std::memory_order_release);
+  return f->rc;
+}
+
+void finisher_stop(teaser_hip_solver* lane) {
+  if (!lane->fin) return;
+  LaneFinisher* f = lane->fin.get();
+  {
+    std::unique_lock<std::mutex> lk(f->m);
+    // (a posted batch is finished first: its kernels reference the lane's arenas)
+    f->cv.wait(lk, [&] { return f->state.load() != 1; });
+    f->state.store(3);
+  }
+  f->cv.notify_all();
+  if (f->th.joinable()) f->th.join();
+  lane->fin.reset();
+}
+
 // everything of a batch that needs no host sync, on lane `idx` (free); src / dst are device pointers
 int32_t enqueue_on_lane(teaser_hip_solver* h, int idx, int32_t ticket, const double* d_src, const double* d_dst,
                         const int64_t* pt_off, const int32_t* n, int batch, int in_set) {
@@ -1331,6 +1545,7 @@ int32_t enqueue_on_lane(teaser_hip_solver* h, int idx, int32_t ticket, const dou
   }
   lane->params = h->params;
   lane->profiling = h->profiling;
+  lane->spec_bounds_next = h->spec_bounds_next;
   lane->job.off.assign(pt_off, pt_off + batch);
   lane->job.n.assign(n, n + batch);
   lane->job.d_src = d_src;
@@ -1361,6 +1576,7 @@ int32_t enqueue_on_lane(teaser_hip_solver* h, int idx, int32_t ticket, const dou
   h->ticket_lane[(size_t)ticket] = idx;
   h->last_lane = idx;
   h->next_lane = (idx + 1) % h->depth;
+  if (finisher_enabled()) finisher_post(lane);
   return TEASER_HIP_OK;
 }
 
@@ -1505,15 +1721,10 @@ int32_t wait_impl(teaser_hip_solver* h, int32_t ticket, teaser_solution_c* out) 
   const int li = h->ticket_lane[(size_t)ticket];
   teaser_hip_solver* lane = h->lanes[(size_t)li];
   const int batch = (int)lane->job.n.size();
-  bool overflow = false;
-  rc = solve_packed_finish(lane, out, &overflow);
-  if (rc == TEASER_HIP_OK && overflow)  // K1 fix-up list overflowed: this batch again, all-FP64 K1
-    rc = solve_packed_impl(lane, lane->job.d_src, lane->job.d_dst, lane->job.off.data(),
-                           lane->job.n.data(), batch, out, true, &overflow);
-  if (rc != TEASER_HIP_OK) {
-    h->err = lane->err;
-    (void)hipStreamSynchronize(lane->stream);
-  }
+  rc = (lane->fin && lane->fin->state.load(std::memory_order_acquire) != 0) ? finisher_collect(lane, out)
+                                                                             : finish_lane_job(lane, out);
+  if (rc != TEASER_HIP_OK) h->err = lane->err;
+  h->spec_bounds_next = rc == TEASER_HIP_OK && lane->last_unproven > 0;
   profile_end(lane);
   h->prof = lane->prof;
   lane->job.busy = false;
@@ -1630,6 +1841,7 @@ int32_t teaser_hip_solver_destroy(teaser_hip_solver* h) {
   h->lanes.clear();
   release_handle_resources(h);
   delete h;
+  g_trace.dump();
   return TEASER_HIP_OK;
 }
 
@@ -2040,13 +2252,19 @@ int32_t teaser_hip_submit_batch(teaser_hip_solver* h, const double* src, const d
     return TEASER_HIP_ERR_UNSUPPORTED;
   }
   (void)hipSetDevice(h->device);
-  return submit_impl(h, src, dst, point_offset, n, batch, flags, ticket);
+  g_trace.mark(h, "submit: begin");
+  const int32_t rc = submit_impl(h, src, dst, point_offset, n, batch, flags, ticket);
+  g_trace.mark(h, "submit: end");
+  return rc;
 }
 
 int32_t teaser_hip_wait(teaser_hip_solver* h, int32_t ticket, teaser_solution_c* out) {
   if (!h || !out) return TEASER_HIP_ERR_BAD_ARG;
   (void)hipSetDevice(h->device);
-  return wait_impl(h, ticket, out);
+  g_trace.mark(h, "wait: begin");
+  const int32_t rc = wait_impl(h, ticket, out);
+  g_trace.mark(h, "wait: end");
+  return rc;
 }
 
 int32_t teaser_hip_set_pipeline_depth(teaser_hip_solver* h, int32_t depth) {
