@@ -1181,6 +1181,28 @@ def _packed(probs):
     return src, dst, off, n
 
 
+def test_async_paths_agree_across_host_modes():
+    """The asynchronous path has three host-side modes since round 4: the second half of a batch on the caller's thread
+    (TEASER_HIP_FINISHER=0), on the lane's finisher thread, and with the bound stage enqueued speculatively behind the
+    peel.  Seven batches alternating between "all closed by the peel" and "open problems" (tests/async_digest.py)
+    must give the same cliques, inlier lists, R and t, bit for bit, in all three -- and the open problems must
+    really have gone through the colouring bound."""
+    import json
+    import os
+    import subprocess
+    import sys
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "async_digest.py")
+    got = []
+    for fin, spec in (("0", "0"), ("1", "0"), ("1", "1")):
+        env = dict(os.environ, TEASER_HIP_FINISHER=fin, TEASER_HIP_SPEC_BOUNDS=spec)
+        p = subprocess.run([sys.executable, script], capture_output=True, text=True, env=env, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        got.append(json.loads(p.stdout.strip().splitlines()[-1]))
+    assert got[0]["coloured"] >= 12, got  # 6 open problems x 2 input modes went through the colouring bound
+    assert got[0]["digest"] == got[1]["digest"] == got[2]["digest"], got
+    assert got[0]["coloured"] == got[1]["coloured"] == got[2]["coloured"]
+
+
 def test_async_batches_match_sync():
     """Four ragged batches in flight over three lanes (device inputs, then host inputs): every problem
     is identical -- clique, inliers, R, t bit for bit -- to the synchronous batched solve."""
