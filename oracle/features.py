@@ -28,12 +28,16 @@ def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
-def estimate_normals(points, radius, centred=False):
-    """pcl::NormalEstimation with setRadiusSearch(radius), viewpoint (0, 0, 0); points n x 3 -> n x 3."""
+def estimate_normals(points, radius, centred=False, fused=True):
+    """pcl::NormalEstimation with setRadiusSearch(radius), viewpoint (0, 0, 0); points n x 3 -> n x 3.
+    fused (default): the covariance accumulators as an FMA-contracting build of the reference compiles them -- the
+    form its fixtures were generated with (features_oracle.c, feat_estimate_normals); fused=False: every operation
+    rounded; centred=True: PCL >= 1.10's accumulation relative to the first neighbour."""
     p = _f32(points)
     out = np.zeros_like(p)
+    form = 1 if centred else (0 if fused else 2)
     rc = lib().feat_estimate_normals(p.ctypes.data_as(_fp), C.c_int32(p.shape[0]), C.c_double(radius),
-                                     C.c_int32(int(centred)), out.ctypes.data_as(_fp))
+                                     C.c_int32(form), out.ctypes.data_as(_fp))
     assert rc == 0
     return out
 
@@ -48,9 +52,9 @@ def compute_fpfh(points, normals, radius):
     return out
 
 
-def fpfh_features(points, normal_radius=0.03, fpfh_radius=0.05, centred=False):
+def fpfh_features(points, normal_radius=0.03, fpfh_radius=0.05, centred=False, fused=True):
     """teaser::FPFHEstimation::computeFPFHFeatures (reference teaser/src/fpfh.cc:15-43)."""
-    nv = estimate_normals(points, normal_radius, centred)
+    nv = estimate_normals(points, normal_radius, centred, fused)
     return compute_fpfh(points, nv, fpfh_radius), nv
 
 

@@ -184,9 +184,21 @@ static void eigen33_smallest(const float* cov, float* eval, float* evec) {
 }
 
 /* pcl::NormalEstimation::computeFeature with setRadiusSearch(radius), viewpoint (0, 0, 0).
- * centred != 0: PCL >= 1.10's computeMeanAndCovarianceMatrix (accumulates relative to the first neighbour);
- * 0: the earlier form (raw coordinates).  normals: n x 3 floats (NaN when < 3 neighbours). */
-FEAT_API int feat_estimate_normals(const float* pts, int32_t n, double radius, int32_t centred, float* normals) {
+ * form 0 (the default of the Python wrapper): pcl::computeMeanAndCovarianceMatrix on the raw coordinates
+ *   (common/centroid.hpp: `accu[k] += p.a * p.b` ... `cov = accu[k] - accu[6] * accu[6]`) AS A BUILD WITH FMA
+ *   CONTRACTION COMPILES IT -- the reference's CMake turns -march=native on when PCL was built with it
+ *   (CMakeLists.txt:27, 62-71), and GCC then fuses exactly these multiply-adds.  The covariance of a 2 cm
+ *   neighbourhood a metre from the origin is the difference of numbers 10^4 times larger, so whether the products are
+ *   rounded before they are added moves the normals by ~1e-3 rad -- and decides the reference's fixtures: with the
+ *   fused form the matcher fixture (matcher-test.cc:46-85) is reproduced EXACTLY, all 189 pairs in order, and the
+ *   bunny FPFH fixture agrees on all 13 101 bins with ONE forced near-tie; with every operation rounded (form 2) 174
+ *   pairs and six forced near-ties (tests/test_features_oracle.py).  Nothing else in this file is contracted: the
+ *   fused covariance alone reproduces what a whole-file -mfma -ffp-contract=fast build of this restatement gives.
+ * form 1: PCL >= 1.10's computeMeanAndCovarianceMatrix (accumulates relative to the first neighbour), not fused.
+ * form 2: form 0 without fused operations (a generic x86-64 build).
+ * normals: n x 3 floats (NaN when < 3 neighbours). */
+FEAT_API int feat_estimate_normals(const float* pts, int32_t n, double radius, int32_t form, float* normals) {
+  const int centred = form == 1, fused = form == 0;
 #pragma omp parallel
   {
     nbr_t* nb = (nbr_t*)malloc((size_t)n * sizeof(nbr_t));
@@ -207,18 +219,32 @@ FEAT_API int feat_estimate_normals(const float* pts, int32_t n, double radius, i
       }
       for (int j = 0; j < k; ++j) {
         const float x = pts[3 * nb[j].idx] - K[0], y = pts[3 * nb[j].idx + 1] - K[1], z = pts[3 * nb[j].idx + 2] - K[2];
-        acc[0] += x * x; acc[1] += x * y; acc[2] += x * z;
-        acc[3] += y * y; acc[4] += y * z; acc[5] += z * z;
+        if (fused) {
+          acc[0] = fmaf(x, x, acc[0]); acc[1] = fmaf(x, y, acc[1]); acc[2] = fmaf(x, z, acc[2]);
+          acc[3] = fmaf(y, y, acc[3]); acc[4] = fmaf(y, z, acc[4]); acc[5] = fmaf(z, z, acc[5]);
+        } else {
+          acc[0] += x * x; acc[1] += x * y; acc[2] += x * z;
+          acc[3] += y * y; acc[4] += y * z; acc[5] += z * z;
+        }
         acc[6] += x; acc[7] += y; acc[8] += z;
       }
       for (int i = 0; i < 9; ++i) acc[i] /= (float)k;
       float cov[9];
-      cov[0] = acc[0] - acc[6] * acc[6];
-      cov[1] = acc[1] - acc[6] * acc[7];
-      cov[2] = acc[2] - acc[6] * acc[8];
-      cov[4] = acc[3] - acc[7] * acc[7];
-      cov[5] = acc[4] - acc[7] * acc[8];
-      cov[8] = acc[5] - acc[8] * acc[8];
+      if (fused) {
+        cov[0] = fmaf(-acc[6], acc[6], acc[0]);
+        cov[1] = fmaf(-acc[6], acc[7], acc[1]);
+        cov[2] = fmaf(-acc[6], acc[8], acc[2]);
+        cov[4] = fmaf(-acc[7], acc[7], acc[3]);
+        cov[5] = fmaf(-acc[7], acc[8], acc[4]);
+        cov[8] = fmaf(-acc[8], acc[8], acc[5]);
+      } else {
+        cov[0] = acc[0] - acc[6] * acc[6];
+        cov[1] = acc[1] - acc[6] * acc[7];
+        cov[2] = acc[2] - acc[6] * acc[8];
+        cov[4] = acc[3] - acc[7] * acc[7];
+        cov[5] = acc[4] - acc[7] * acc[8];
+        cov[8] = acc[5] - acc[8] * acc[8];
+      }
       cov[3] = cov[1];
       cov[6] = cov[2];
       cov[7] = cov[5];

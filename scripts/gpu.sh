@@ -116,8 +116,14 @@ for k,c in d['configs'].items():
     stages) timeout 300 python scripts/profile_stages.py > $OUT/stages.log 2>&1; timeout 200 python scripts/profile_stages.py big >> $OUT/stages.log 2>&1; grep '^{' $OUT/stages.log > $OUT/stages.jsonl; cut -c1-420 $OUT/stages.jsonl ;;
     scale) timeout 400 python scripts/profile_scale.py > $OUT/scale.jsonl 2> $OUT/scale.err; echo "rc=$?"; cut -c1-400 $OUT/scale.jsonl ;;
     scalebench) timeout 300 python scripts/profile_scale.py bench > $OUT/scale_bench.jsonl 2> $OUT/scale_bench.err; echo "rc=$?"; cut -c1-1500 $OUT/scale_bench.jsonl; tail -3 $OUT/scale_bench.err ;;
-    scaleprof) timeout ${PROF_TIMEOUT:-400} rocprofv3 --kernel-trace --stats -d $OUT/scale_prof -o sp -- python scripts/profile_scale.py bench > $OUT/scale_prof.log 2>&1; echo "rc=$?"
-      f=$(find $OUT/scale_prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/scale_kernel_stats.csv && cut -c1-150 $f | head -24 ;;
+    scaleprof)
+      prof scale_prof --kernel-trace --stats --output-format csv -d $OUT/scale_prof -o t -- python $R/scripts/profile_scale.py bench
+      f=$(find $OUT/scale_prof -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/scale_kernel_stats.csv && python - <<PY
+import csv
+for r in csv.DictReader(open("$OUT/scale_kernel_stats.csv")):
+    print("%-70s calls %5s avg %9.1f us  %5s %%" % (r["Name"].replace("thip::","").replace("(anonymous namespace)::","")[:70], r["Calls"], float(r["AverageNs"])/1e3, r["Percentage"]))
+PY
+      ;;
     k1occ)  # K1 alone at 1 / 2 / 3 workgroups per CU (unused dynamic LDS limits the occupancy)
       for v in 20 23; do for pad in 0 30000 60000; do
         TEASER_K1_VARIANT=$v TEASER_K1_LDS_PAD=$pad timeout 60 $P 64 10000 5 one 2>/dev/null | sed "s/^{/{\"lds_pad\":$pad,\"v\":$v,/" | cut -c1-140

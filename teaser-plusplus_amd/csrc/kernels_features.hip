@@ -21,7 +21,8 @@
 // reductions (the same operation sequence as the CPU oracle: results are bit-identical to it).  libm's
 // float functions are not portable to the last bit, so acos / atan2 / sin / cos are evaluated from IEEE
 // double basic operations in a fixed order (the oracle uses the same formulas).  This file is compiled
-// with -ffp-contract=off like the rest of the library: no product-add is ever fused.
+// with -ffp-contract=off like the rest of the library: no product-add is fused by the compiler; the ONE place where the
+// reference's fixtures need fused multiply-adds -- the covariance accumulators of the normals -- says so explicitly.
 #include "internal.h"
 
 namespace thip {
@@ -284,23 +285,26 @@ __global__ __launch_bounds__(128) void feat_normals_kernel(const float* __restri
     return;
   }
   const Nbr* nb = list + offsets[q];
-  // computeMeanAndCovarianceMatrix: nine float accumulators over the RAW coordinates, in list order
+  // computeMeanAndCovarianceMatrix: nine float accumulators over the RAW coordinates, in list order,
   float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int j = 0; j < k; ++j) {
     const int i = nb[j].idx;
     const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
-    acc[0] += x * x; acc[1] += x * y; acc[2] += x * z;
-    acc[3] += y * y; acc[4] += y * z; acc[5] += z * z;
+    // FUSED multiply-adds, as an FMA-contracting (-march=native) build of the reference compiles PCL's
+    // `accu[k] += p.a * p.b` -- the form the reference's fixtures were generated with (oracle/features_oracle.c,
+    // feat_estimate_normals form 0: the matcher fixture's 189 pairs depend on it)
+    acc[0] = __builtin_fmaf(x, x, acc[0]); acc[1] = __builtin_fmaf(x, y, acc[1]); acc[2] = __builtin_fmaf(x, z, acc[2]);
+    acc[3] = __builtin_fmaf(y, y, acc[3]); acc[4] = __builtin_fmaf(y, z, acc[4]); acc[5] = __builtin_fmaf(z, z, acc[5]);
     acc[6] += x; acc[7] += y; acc[8] += z;
   }
   for (int i = 0; i < 9; ++i) acc[i] /= (float)k;
   float cov[9];
-  cov[0] = acc[0] - acc[6] * acc[6];
-  cov[1] = acc[1] - acc[6] * acc[7];
-  cov[2] = acc[2] - acc[6] * acc[8];
-  cov[4] = acc[3] - acc[7] * acc[7];
-  cov[5] = acc[4] - acc[7] * acc[8];
-  cov[8] = acc[5] - acc[8] * acc[8];
+  cov[0] = __builtin_fmaf(-acc[6], acc[6], acc[0]);  // (`accu[k] - accu[6] * accu[6]`, fused likewise)
+  cov[1] = __builtin_fmaf(-acc[6], acc[7], acc[1]);
+  cov[2] = __builtin_fmaf(-acc[6], acc[8], acc[2]);
+  cov[4] = __builtin_fmaf(-acc[7], acc[7], acc[3]);
+  cov[5] = __builtin_fmaf(-acc[7], acc[8], acc[4]);
+  cov[8] = __builtin_fmaf(-acc[8], acc[8], acc[5]);
   cov[3] = cov[1];
   cov[6] = cov[2];
   cov[7] = cov[5];
