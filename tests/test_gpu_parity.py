@@ -361,6 +361,42 @@ def test_solve_estimate_scaling_large_vs_oracle(n, rho, scale, seed):
         check_solution_parity(s, sol, o)
 
 
+def test_estimate_scaling_bitmap_differences_over_many_seeds():
+    """the bitmap-difference log over >= 50 seeds.  Fifty more problems on the device-wide-sort
+    path (725..1400 points, 50..90 % outliers, scales 0.3..3): scale within 1e-9 of the oracle's, and every bit of the
+    consensus bitmap compared; a difference is only tolerated ON the boundary, as above."""
+    rng = np.random.default_rng(20250923)
+    for k in range(50):
+        n = int(rng.integers(725, 1401))
+        rho = float(rng.uniform(0.5, 0.9))
+        scale = float(np.exp(rng.uniform(np.log(0.3), np.log(3.0))))
+        pr = tp.synth_problem(777000 + k, n, rho, 0.01)
+        dst = pr["dst"] * scale
+        nb = 0.01 * scale
+        p = bench_params(estimate_scaling=True, noise_bound=nb)
+        s = make_solver(**p)
+        sol = s.solve(pr["src"], dst)
+        o = oracle.solve(pr["src"], dst, **oracle_params(p))
+        assert sol.valid and o["valid"] and abs(sol.scale - o["scale"]) <= 1e-9, (k, n, sol.scale, o["scale"])
+        _, ref = oracle.inlier_bitmap(pr["src"], dst, nb, 1.0, True)
+        x = s.getInlierGraphBitmap() ^ ref
+        diff = int(np.unpackbits(x.view(np.uint8)).sum())
+        same_scale = np.float64(sol.scale).tobytes() == np.float64(o["scale"]).tobytes()
+        SCALE_DIFF_LOG.append(dict(n=n, seed=777000 + k, outlier_ratio=round(rho, 3), scale_bitwise_equal=bool(same_scale),
+                                   scale_abs_diff=abs(sol.scale - o["scale"]), bitmap_bits_differing=diff))
+        assert diff == 0 if same_scale else diff <= 2, (k, n, diff)
+        if diff:
+            beta = 2 * nb
+            for i, w in zip(*np.nonzero(x)):
+                for b in range(64):
+                    if (int(x[i, w]) >> b) & 1:
+                        j = w * 64 + b
+                        va = np.linalg.norm(pr["src"][:, j] - pr["src"][:, i])
+                        vb = np.linalg.norm(dst[:, j] - dst[:, i])
+                        for sh in (sol.scale, o["scale"]):
+                            assert abs(abs(vb / va - sh) - beta / va) <= 1e-9
+
+
 def test_estimate_scaling_bitmap_difference_log():
     """How often the large-n estimate_scaling bitmap differs from the oracle's: the cases
     above are summarised into gpurun_out/scale_bitmap_diff.json (copied to profiles/ by the round's scripts)."""
@@ -368,12 +404,12 @@ def test_estimate_scaling_bitmap_difference_log():
     import os
 
     from util import ROOT
-    assert len(SCALE_DIFF_LOG) >= 3  # (runs after the parametrised cases, same module, same process)
+    assert len(SCALE_DIFF_LOG) >= 3  # (runs after the cases above, same module, same process: 56 in a full run)
     out = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
     doc = dict(cases=SCALE_DIFF_LOG, cases_with_differing_bits=sum(1 for c in SCALE_DIFF_LOG if c["bitmap_bits_differing"]))
     json.dump(doc, open(os.path.join(out, "scale_bitmap_diff.json"), "w"), indent=1)
-    assert doc["cases_with_differing_bits"] <= 1
+    assert doc["cases_with_differing_bits"] <= max(1, len(SCALE_DIFF_LOG) // 10)
 
 
 def test_estimate_scaling_batch_small_problems():
