@@ -533,6 +533,8 @@ def run_config(tag, tp, torch, runner, args, dev, world, rank, make_workload, st
     line["stage_ms"] = stage_breakdown(solver, bufs[i0][0], bufs[i0][1], offsets[i0] if per_buffer else offsets,
                                        sizes[i0] if per_buffer else sizes)
     line.update(wl.get("extra", {}))
+    if "extra_fn" in wl:
+        line.update(wl["extra_fn"]())
     if want_cpu and rank == 0:
         line["cpu_baseline"] = wl["cpu"]()
     del bufs
@@ -600,6 +602,21 @@ def config5_workload(tp, args, rank, B, n_batches):
             R = np.array(out[b].rotation[:]).reshape(3, 3)
             d, _ = cKDTree(Bi.astype(np.float64)).query(Ai.astype(np.float64) @ R.T + np.array(out[b].translation[:]))
             assert (d < vox).mean() > 0.3, (b, (d < vox).mean())
+        # the selected inliers of the first problems ARE a clique of the consensus graph the library built, the exact
+        # search ran to completion on them (status OK), and -- copy b is the pair moved by (Rm_b, tv_b), so
+        # R_b Rm_b^T is the pair's own rotation for EVERY copy -- the 64 estimates agree with each other
+        for b in range(min(4, B)):
+            cl = solver.getInlierMaxClique(b)
+            bm = solver.getInlierGraphBitmap(b)
+            assert len(cl) == out[b].clique_size and out[b].status == 0
+            for u in cl:
+                row = bm[u]
+                assert all((int(row[v >> 6]) >> (v & 63)) & 1 for v in cl if v != u), (b, u)
+        rel = [np.array(out[b].rotation[:]).reshape(3, 3) @ truth[0][b][0].T for b in range(B)]
+        ang = np.array([[np.degrees(np.arccos(np.clip((np.trace(a.T @ c) - 1) / 2, -1, 1))) for c in rel] for a in rel])
+        spread = np.median(ang, axis=1)  # per copy: median angle to the other copies' estimates
+        check.rotation_spread_deg = [float(np.median(spread)), float(spread.max())]
+        assert (spread < 10.0).mean() >= 0.8, check.rotation_spread_deg
 
     sizes_all = np.concatenate(szs)
     return solver, dict(
@@ -607,6 +624,8 @@ def config5_workload(tp, args, rank, B, n_batches):
         workload="BASELINE configs[4]: 3DMatch pair of examples/teaser_python_fpfh_icp (voxel 0.05), %d perturbed "
                  "copies per step, real FPFH correspondences (%d-%d per problem), noise_bound=%g, GNC-TLS 10000 "
                  "iterations / 1e-16, PMC_EXACT" % (B, sizes_all.min(), sizes_all.max(), vox),
+        extra_fn=lambda: {"rotation_agreement_across_copies_deg": {"median": round(check.rotation_spread_deg[0], 3),
+                                                                    "max": round(check.rotation_spread_deg[1], 3)}},
         extra={"front_end_ms_per_pair": round(1e3 * float(np.median(fe)), 3),
                "correspondences_per_problem": [int(sizes_all.min()), int(np.median(sizes_all)), int(sizes_all.max())]},
         cpu=lambda: cpu_baseline(tp, int(np.median(sizes_all)), 0.0, vox, 0, 16, 10.0, problems=probs, extra_kw=kw))
