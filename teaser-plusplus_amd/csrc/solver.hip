@@ -1434,8 +1434,12 @@ int32_t ensure_input_sets(teaser_hip_solver* h) {
     // lane's stream has its copies ordered behind that lane's kernels (measured: the 0.55 ms copy of a staged
     // batch started 2.3 ms late, profiles/r3d).  TEASER_HIP_COPY_STREAM: 0 = the parent's own stream (idle
     // while asynchronous batches are in flight), 1 = a stream of its own, 2 = a high-priority stream of its own.
+    // Round 3 (4 hardware queues) needed 2.  With one hardware queue per lane (round 4) the parent's stream is the
+    // best of the three: 128 x 5 k from host memory 0.67 ms per step (0 ) / 0.68 (1) / 0.85 (2) against 0.63 from
+    // HBM, 64 x 10 k 1.055 / 1.17 / 1.06 against 1.05 (profiles/r4f/copy_stream_modes.txt) -- a high-priority
+    // queue that is busy 88 % of the step delays every small kernel of the tail chain.
     const char* ev = getenv("TEASER_HIP_COPY_STREAM");
-    const int mode = ev ? atoi(ev) : 2;
+    const int mode = ev ? atoi(ev) : 0;
     if (mode == 0) {
       h->copy_stream = h->stream;
     } else if (mode == 1) {
