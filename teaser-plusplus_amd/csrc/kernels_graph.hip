@@ -2203,27 +2203,46 @@ __global__ __launch_bounds__(256) void tim_fixup_group_kernel(const ProbDesc* __
   kc.m2beta2 = -2.0 * kc.beta2;
   kc.beta4 = kc.beta2 * kc.beta2;
   kc.s_hat = 1.0;
-  const int lane = threadIdx.x & 63, q = lane & 15, sub = lane >> 4;
+  const int lane = threadIdx.x & 63, q = lane & 15, sub = lane >> 4, wave = threadIdx.x >> 6;
   const int rq = (q & 3) + 8 * (q >> 2);
-  auto resolve = [&](unsigned long long it, bool valid) {
+  // STAGED = true (items of a region): all items of a region come from ONE K1 wave, i.e. one 64-row tile.  Its 64 points
+  // are staged once per region in the wave's LDS slice, and outside the diagonal tile the 16 provisional bits of an item
+  // are read from the TRANSPOSED copy, where they sit in one word (bitmap row `col`, word of the row tile).  Per item:
+  // one broadcast fetch of the column point and one word, instead of 17 points and 16 words on 16 different bitmap
+  // rows (1.8 KB of sectors per item: that traffic, not the arithmetic, was the kernel's 0.175 ms per 64 x 10 k launch).
+  __shared__ double row_pts[4][64][6];
+  const uint64_t* bm64 = bitmap + d.bm_off;
+  auto resolve = [&](unsigned long long it, bool valid, auto staged, int tile) {
+    constexpr bool STAGED = decltype(staged)::value;
     int r = (int)((it >> 16) & 0xffff) + rq, col = (int)(it & 0xffff);
     valid = valid && r < n && col < n && r != col;
-    r = valid ? r : 0;
+    r = valid ? r : (STAGED ? tile * 64 : 0);
     col = valid ? col : 0;
     // every load up front: the two points and the word that holds the provisional bit
-    const double sx = ps[3 * r], sy = ps[3 * r + 1], sz = ps[3 * r + 2];
-    const double dx = pd[3 * r], dy = pd[3 * r + 1], dz = pd[3 * r + 2];
+    double sx, sy, sz, dx, dy, dz;
+    if (STAGED) {
+      const double* rp = row_pts[wave][r & 63];
+      sx = rp[0]; sy = rp[1]; sz = rp[2]; dx = rp[3]; dy = rp[4]; dz = rp[5];
+    } else {
+      sx = ps[3 * r]; sy = ps[3 * r + 1]; sz = ps[3 * r + 2];
+      dx = pd[3 * r]; dy = pd[3 * r + 1]; dz = pd[3 * r + 2];
+    }
     const double cx = ps[3 * col], cy = ps[3 * col + 1], cz = ps[3 * col + 2];
     const double ex = pd[3 * col], ey = pd[3 * col + 1], ez = pd[3 * col + 2];
     unsigned int* wp = bm32 + 2 * ((int64_t)r * W + (col >> 6)) + ((col >> 5) & 1);
-    const unsigned int word = *wp;
+    const unsigned int bit = 1u << (col & 31);
+    bool prov;
+    if (STAGED && (r >> 6) != (col >> 6)) {  // (uniform over the 16 lanes of an item)
+      prov = ((bm64[(int64_t)col * W + (r >> 6)] >> (r & 63)) & 1ull) != 0ull;
+    } else {
+      prov = (*wp & bit) != 0u;
+    }
     const double ax = cx - sx, ay = cy - sy, az = cz - sz, bx = ex - dx, by = ey - dy, bz = ez - dz;
     bool unc, shortp;
     bool e = tim_edge_fast(ax, ay, az, bx, by, bz, kc, &unc, &shortp);
     e |= shortp;
     if (unc) e = tim_edge_exact(ax, ay, az, bx, by, bz, beta);
-    const unsigned int bit = 1u << (col & 31);
-    if (!valid || ((word & bit) != 0u) == e) return;
+    if (!valid || prov == e) return;
     atomicXor(wp, bit);
     atomicAdd(dg + r, e ? 1 : -1);
     if ((r >> 6) != (col >> 6)) {  // the transposed copy
@@ -2237,17 +2256,28 @@ __global__ __launch_bounds__(256) void tim_fixup_group_kernel(const ProbDesc* __
   for (unsigned int rg = wv; rg < regions_per_problem; rg += nwv) {
     const unsigned long long mine = reg[(size_t)rg * kRegionWords + lane];
     const int cnt = (int)__builtin_amdgcn_readfirstlane((unsigned int)mine);
+    if (cnt <= 0) continue;
+    // the region's row tile (from its first item), staged: lane l holds point 64 tile + l
+    const int tile = (int)((((unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)mine, 1)) >> 16) & 0xffffu) >> 6;
+    {
+      const int pr = min(tile * 64 + lane, n - 1);
+      double* rp = row_pts[wave][lane];
+      rp[0] = ps[3 * pr]; rp[1] = ps[3 * pr + 1]; rp[2] = ps[3 * pr + 2];
+      rp[3] = pd[3 * pr]; rp[4] = pd[3 * pr + 1]; rp[5] = pd[3 * pr + 2];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // wave-private LDS slice: same-wave ordering suffices
 #pragma nounroll
     for (int base = 1; base <= cnt; base += 4) {
       const int k = base + sub;
       const unsigned int lo = (unsigned int)__shfl((int)(unsigned int)mine, k & 63, 64);
       const unsigned int hi = (unsigned int)__shfl((int)(unsigned int)(mine >> 32), k & 63, 64);
-      resolve(((unsigned long long)hi << 32) | lo, k <= cnt);
+      resolve(((unsigned long long)hi << 32) | lo, k <= cnt, std::true_type(), tile);
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the next region overwrites the slice)
   }
   const unsigned long long* seg = work + (size_t)prob * cap;
   const unsigned int ngrp = gridDim.x * 16;
-  for (unsigned int w = (blockIdx.x * 256 + threadIdx.x) >> 4; w < total; w += ngrp) resolve(seg[w], true);
+  for (unsigned int w = (blockIdx.x * 256 + threadIdx.x) >> 4; w < total; w += ngrp) resolve(seg[w], true, std::false_type(), 0);
 }
 
 // FP64 resolution of the worklist: one thread per pair, bits rewritten with atomics (a row word

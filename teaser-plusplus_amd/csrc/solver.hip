@@ -265,6 +265,7 @@ struct teaser_hip_solver {
   // K1 stream whenever several tails are in flight.
   hipStream_t k1_stream = nullptr;         // parent: owner; lane: borrowed from the parent
   bool shared_k1_stream = false;
+  bool k1_kernel_only = false;  // TEASER_HIP_K1_STREAM=2: ONLY the K1 kernel on the shared stream; header, pre-pass and fix-up stay on the lane's
   int tail_cus = 0;            // > 0: CU partition between the K1 stream and the lanes' tail streams (make_lane)
   bool tail_cu_block = false;  // which units: false = spread over the device, true = one contiguous block
   hipEvent_t k1_phase_done = nullptr;      // recorded on k1_stream after the fix-up
@@ -1025,7 +1026,8 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
       HIPCHK(h, h->d_work.ensure(8 * (size_t)tim_work_items(n, batch) + 64));
     }
   }
-  if (mfma_k1 && h->is_lane && h->k1_stream) {
+  const bool k1_only = mfma_k1 && h->is_lane && h->k1_stream && h->k1_kernel_only;
+  if (mfma_k1 && h->is_lane && h->k1_stream && !k1_only) {
     s1 = h->k1_stream;
     if (h->inputs_pending) {  // host inputs are being copied on the lane's stream
       HIPCHK(h, hipEventRecord(h->inputs_ready, s));
@@ -1065,17 +1067,28 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
         // lanes (asynchronous batches in flight) run their K1 kernels one after the other: this
         // lane's starts when the previously submitted lane's has finished, so that a K1 shares the
         // GPU only with the latency-bound tail stages of the batches before it
-        if (phase == 1 && h->wait_before_k1 && s1 == s) {
+        if (phase == 1 && h->wait_before_k1 && s1 == s && !k1_only) {
           HIPCHK(h, hipStreamWaitEvent(s, h->wait_before_k1, 0));
           h->wait_before_k1 = nullptr;
         }
+        // (k1_only: the kernel alone goes to the shared low-priority stream, chained to the lane's stream by events on
+        // both sides; the K1 kernels of all lanes then follow each other on that stream)
+        hipStream_t sp = (k1_only && phase == 1) ? h->k1_stream : s1;
+        if (k1_only && phase == 1) {
+          HIPCHK(h, hipEventRecord(h->inputs_ready, s));
+          HIPCHK(h, hipStreamWaitEvent(sp, h->inputs_ready, 0));
+        }
         {
-          StageScope sc(h, phase == 1 ? ST_TIM : ST_TIMAUX, s1);
-          launch_tim_graph_mfma(s1, phase, dd, batch, max_n, wo, d_src, d_dst, h->d_pk.p, h->d_prep.p,
+          StageScope sc(h, phase == 1 ? ST_TIM : ST_TIMAUX, sp);
+          launch_tim_graph_mfma(sp, phase, dd, batch, max_n, wo, d_src, d_dst, h->d_pk.p, h->d_prep.p,
                                 h->d_work.p, cap, h->d_bitmap.as<uint64_t>(), ds, h->d_deg.as<int32_t>(),
                                 P.noise_bound, P.cbar2);
         }
-        if (phase == 1 && h->k1_done && s1 == s && h->stagger_point == 1) {
+        if (k1_only && phase == 1) {
+          HIPCHK(h, hipEventRecord(h->k1_phase_done, sp));
+          HIPCHK(h, hipStreamWaitEvent(s, h->k1_phase_done, 0));
+        }
+        if (phase == 1 && h->k1_done && s1 == s && !k1_only && h->stagger_point == 1) {
           HIPCHK(h, hipEventRecord(h->k1_done, s));
           h->k1_recorded = true;
         }
@@ -1314,6 +1327,7 @@ int32_t make_lane(teaser_hip_solver* h, teaser_hip_solver** out) {
   lane->device = h->device;
   lane->params = h->params;
   lane->stagger_point = h->stagger_point;
+  lane->k1_kernel_only = h->k1_kernel_only;
   lane->is_lane = true;
   memset(&lane->prof, 0, sizeof(lane->prof));
   int prio_least = 0, prio_greatest = 0;
@@ -1828,7 +1842,10 @@ int32_t teaser_hip_solver_create(const teaser_params_c* params, int32_t device,
     h->stagger_k1 = atoi(e) != 0;
     if (atoi(e) >= 1 && atoi(e) <= 3) h->stagger_point = atoi(e);
   }
-  if (const char* e = getenv("TEASER_HIP_K1_STREAM")) h->shared_k1_stream = atoi(e) != 0;
+  if (const char* e = getenv("TEASER_HIP_K1_STREAM")) {
+    h->shared_k1_stream = atoi(e) != 0;
+    h->k1_kernel_only = atoi(e) == 2;
+  }
   if (const char* e = getenv("TEASER_HIP_TAIL_CUS")) h->tail_cus = std::max(0, atoi(e));
   if (const char* e = getenv("TEASER_HIP_TAIL_CU_BLOCK")) h->tail_cu_block = atoi(e) != 0;
   *out = h;
