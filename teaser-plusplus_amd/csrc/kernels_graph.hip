@@ -2827,6 +2827,9 @@ __device__ __forceinline__ int greedy_one_start(
 
     // ---- phase 3: compact adjacency A[r][k] bit l = edge(cand[r], cand[64k+l]) -------------
     const int Wc = (pc + 63) >> 6;
+    // A lane needs ONE bit of a row per 64-candidate group: it loads the 32-bit half that holds it, so that FOUR rows
+    // (kCapW loads each) are in flight per wave in the registers two rows of 64-bit words took -- the gather is a chain
+    // of dependent round trips to L2 (r3d/heu_trace: 143 us of a start's ~200), not a matter of bytes
     int cw[kCapW], cb[kCapW];
     unsigned int vmask = 0;
 #pragma unroll
@@ -2834,35 +2837,40 @@ __device__ __forceinline__ int greedy_one_start(
       const int idx = 64 * k + lane;
       const bool ok = idx < pc;
       const int c = ok ? cand[idx] : 0;
-      cw[k] = c >> 6;
-      cb[k] = c & 63;
+      cw[k] = c >> 5;   // 32-bit word of the row
+      cb[k] = c & 31;
       vmask |= ok ? (1u << k) : 0u;
     }
-    for (int r = wave; r < pc; r += 2 * kGreedyWaves) {
-      const int r2 = r + kGreedyWaves;
-      const bool has2 = r2 < pc;
-      const uint64_t* ru = bm + (int64_t)cand[r] * W;
-      const uint64_t* rv = bm + (int64_t)cand[has2 ? r2 : r] * W;
-      uint64_t x[kCapW], y[kCapW];
+    const unsigned int* bm32 = reinterpret_cast<const unsigned int*>(bm);
+    constexpr int kRowsInFlight = 4;
+    for (int r = wave; r < pc; r += kRowsInFlight * kGreedyWaves) {
+      const unsigned int* rp[kRowsInFlight];
+      bool has[kRowsInFlight];
 #pragma unroll
-      for (int k = 0; k < kCapW; ++k) {
-        x[k] = (k < Wc) ? ru[cw[k]] : 0ull;
-        y[k] = (k < Wc) ? rv[cw[k]] : 0ull;
+      for (int j = 0; j < kRowsInFlight; ++j) {
+        const int rj = r + j * kGreedyWaves;
+        has[j] = rj < pc;
+        rp[j] = bm32 + 2 * ((int64_t)cand[has[j] ? rj : r] * W);
       }
-      uint64_t mx = 0, my = 0;
+      unsigned int x[kRowsInFlight][kCapW];
+#pragma unroll
+      for (int j = 0; j < kRowsInFlight; ++j)
+#pragma unroll
+        for (int k = 0; k < kCapW; ++k) x[j][k] = (k < Wc) ? rp[j][cw[k]] : 0u;
+      uint64_t m[kRowsInFlight] = {0, 0, 0, 0};
 #pragma unroll
       for (int k = 0; k < kCapW; ++k) {
         const bool ok = (vmask >> k) & 1u;
-        const uint64_t bx = __ballot(ok && ((x[k] >> cb[k]) & 1ull));
-        const uint64_t by = __ballot(ok && ((y[k] >> cb[k]) & 1ull));
-        if (lane == k) {
-          mx = bx;
-          my = by;
+#pragma unroll
+        for (int j = 0; j < kRowsInFlight; ++j) {
+          const uint64_t b = __ballot(ok && ((x[j][k] >> cb[k]) & 1u));
+          if (lane == k) m[j] = b;
         }
       }
       if (lane < Wc) {
-        A[r * kCapStride + lane] = mx;
-        if (has2) A[r2 * kCapStride + lane] = my;
+#pragma unroll
+        for (int j = 0; j < kRowsInFlight; ++j)
+          if (has[j]) A[(r + j * kGreedyWaves) * kCapStride + lane] = m[j];
       }
     }
     if (tid < 16) {
