@@ -13,6 +13,16 @@
 #   c3prof, c5prof   rocprofv3 --kernel-trace --stats of one config-3 / config-5 run
 #   stages           per-stage HIP-event times (scripts/profile_stages.py [+ big])
 #   scale            estimate_scaling = true at N = 10 k (scripts/profile_scale.py)
+#   scalebench       the three problems of bench.py's `configs.scale` line: synchronous with every stage timed, then pipelined
+#   scaleprof        the same under rocprofv3 --kernel-trace --stats (kernel table of the scale line)
+#   benchenv         headline only, one run per environment group in $ENVS ("A=1 B=2;C=3"), $BENCH_EXTRA = extra bench.py flags
+#   bench4           bench.py --configs 4 (HBM-resident and host-resident rates of the headline and of config 4)
+#   cfgdepth         the `configs` lines in $CFGS at the depths in $DEPTHS, per environment group in $ENVS
+#   pipecfg          scripts/pipe_config.py (a synthetic workload through the asynchronous API, nothing else in the process) per
+#                    "n rho batch depth steps" in $PIPES x environment group in $ENVS
+#   hosttrace        TEASER_HIP_HOST_TRACE=1: host-side time stamps of submit / wait / the finisher threads (config 3, depth $D3)
+#   timeline3        kernel trace of config 3 through the pipeline at depth $D3 (scripts/trace_timeline.py)
+#   c5env, stagesenv config 5 / per-stage times per environment group in $ENVS
 #   pipe             k1_probe pipe mode (depths / schedules)
 TAG=${1:-x}; shift
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/$TAG
