@@ -174,11 +174,18 @@ TEASER_HIP_API int32_t teaser_hip_solve_batch_device(teaser_hip_solver* h, const
  * solutions.  With 2 batches in flight the host enqueues batch k+1 while the GPU runs batch k,
  * and the latency-bound tail of batch k (clique, GNC, TLS: one workgroup per problem) shares the GPU
  * with batch k+1's K1.  Results are identical to teaser_hip_solve_batch_device (same kernels).
+ * Since round 4 the second half of a batch (the lane's host sync and, when the peel left problems open, the
+ * colouring bound / exact search with their own syncs) runs on an INTERNAL finisher thread of the lane as soon
+ * as the batch is enqueued; wait collects its result.  The caller's contract is unchanged: ONE calling thread,
+ * tickets in any order; the threads are joined by teaser_hip_solver_destroy / teaser_hip_set_pipeline_depth.
+ * Lanes want one hardware queue each: the library exports GPU_MAX_HW_QUEUES=8 when it is loaded (never over a
+ * value already set); a process that initialised the HIP runtime before loading it should export that itself.
  *   flags = TEASER_HIP_INPUT_DEVICE: src/dst are packed DEVICE arrays (as solve_batch_device), which
  *           must stay valid and unmodified until the matching wait;
  *   flags = TEASER_HIP_INPUT_HOST:   src/dst are packed HOST arrays of the same layout (problem b =
- *           points [offset[b], offset[b]+n[b])); page-locked memory (hipHostMalloc /
- *           hipHostRegister) is copied asynchronously at PCIe speed on a dedicated copy stream, and
+ *           points [offset[b], offset[b]+n[b])); page-locked memory (teaser_hip_host_alloc: memory pinned by
+ *           ANOTHER HIP runtime in the process is pageable to this one) is copied asynchronously at PCIe speed
+ *           on a stream of the handle that is otherwise idle, and
  *           must stay valid until wait.  ONE host batch beyond the lanes is accepted (depth + 1 in
  *           flight): its copy starts at once, hidden behind the kernels of the batches on the lanes,
  *           and it is enqueued on the first lane that frees up, at the next submit / wait call --
