@@ -1629,7 +1629,16 @@ int32_t submit_impl(teaser_hip_solver* h, const double* src, const double* dst,
   if (rc != TEASER_HIP_OK) return rc;
   rc = flush_staged(h);
   if (rc != TEASER_HIP_OK) return rc;
-  const int idx = h->next_lane;
+  // the lane whose turn it is if it is free, else the first free one (tickets may be waited for in any order: with
+  // depth 3, after wait(t1) lane 1 is free while it may be lane 0's turn -- found by tests/test_host_threads.py)
+  int idx = h->next_lane;
+  for (int k = 0; k < h->depth; ++k) {
+    const int cand = (h->next_lane + k) % h->depth;
+    if (!h->lanes[(size_t)cand]->job.busy) {
+      idx = cand;
+      break;
+    }
+  }
   const bool lane_free = !h->lanes[(size_t)idx]->job.busy && !h->staged.active;
   const bool host = (flags & TEASER_HIP_INPUT_HOST) != 0;
   if (!lane_free && (!host || h->staged.active)) {

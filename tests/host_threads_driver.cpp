@@ -1,0 +1,118 @@
+// Stress driver of the asynchronous batch API's HOST side (tests/test_host_threads.py): csrc/solver.hip against the
+// HIP stub, under ThreadSanitizer or AddressSanitizer.  Random interleavings of submit (device / host inputs), wait in
+// any order, getters, depth changes and synchronous solves, with the stub "peel" alternating between batches it closes
+// and batches it leaves open (so the speculative bound stage switches on and off).  Checks the API's own contract:
+// every ticket is waited for exactly once, BUSY only when every lane (and the staging slot) is taken, the solutions of
+// a batch have the batch's sizes.
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#include "teaser_hip.h"
+
+extern std::atomic<unsigned> g_stub_open_mask;
+extern std::atomic<int> g_stub_launches;
+
+#define CHECK(cond)                                                        \
+  do {                                                                     \
+    if (!(cond)) {                                                         \
+      std::fprintf(stderr, "CHECK failed: %s (line %d)\n", #cond, __LINE__); \
+      std::exit(3);                                                        \
+    }                                                                      \
+  } while (0)
+
+struct Pending { int32_t ticket; int batch; int first_n; bool host; };
+
+int main(int argc, char** argv) {
+  const int iters = argc > 1 ? std::atoi(argv[1]) : 400;
+  std::mt19937 rng(argc > 2 ? std::atoi(argv[2]) : 7);
+  teaser_params_c P;
+  CHECK(teaser_hip_params_default(&P) == TEASER_HIP_OK);
+  P.estimate_scaling = 0;
+  teaser_hip_solver* h = nullptr;
+  CHECK(teaser_hip_solver_create(&P, 0, &h) == TEASER_HIP_OK);
+  int depth = 3;
+  CHECK(teaser_hip_set_pipeline_depth(h, depth) == TEASER_HIP_OK);
+  std::vector<double> src(3 * 4096), dst(3 * 4096);
+  for (size_t i = 0; i < src.size(); ++i) src[i] = dst[i] = (double)(i % 97) * 0.01;
+  std::vector<Pending> pend;
+  std::vector<teaser_solution_c> out(64);
+  int submitted = 0, waited = 0, busy = 0, staged_busy = 0;
+  for (int it = 0; it < iters; ++it) {
+    const int action = (int)(rng() % 10);
+    if (action < 5) {  // submit
+      const int batch = 1 + (int)(rng() % 8);
+      std::vector<int32_t> n((size_t)batch);
+      std::vector<int64_t> off((size_t)batch);
+      int64_t tot = 0;
+      for (int b = 0; b < batch; ++b) {
+        n[(size_t)b] = 1 + (int32_t)(rng() % 300);
+        off[(size_t)b] = tot;
+        tot += n[(size_t)b];
+      }
+      g_stub_open_mask.store((rng() % 3 == 0) ? 0u : (unsigned)rng());  // every third batch: all closed by the peel
+      const bool host = (rng() & 1) != 0;
+      int32_t t = -1;
+      const int32_t rc = teaser_hip_submit_batch(h, src.data(), dst.data(), off.data(), n.data(), batch,
+                                                 host ? TEASER_HIP_INPUT_HOST : TEASER_HIP_INPUT_DEVICE, &t);
+      if (rc == TEASER_HIP_OK) {
+        pend.push_back({t, batch, n[0], host});
+        ++submitted;
+        CHECK((int)pend.size() <= depth + 1);
+      } else {
+        CHECK(rc == TEASER_HIP_ERR_BUSY);
+        CHECK((int)pend.size() >= depth);  // refused only when every lane is taken
+        ++busy;
+      }
+    } else if (action < 9) {  // wait for a random outstanding ticket
+      if (pend.empty()) continue;
+      const size_t k = rng() % pend.size();
+      const int32_t rc = teaser_hip_wait(h, pend[k].ticket, out.data());
+      if (rc == TEASER_HIP_ERR_BUSY) {  // a staged batch: only legal while an earlier ticket is outstanding
+        CHECK(pend[k].host && pend.size() > 1);
+        ++staged_busy;
+        continue;
+      }
+      CHECK(rc == TEASER_HIP_OK);
+      CHECK(out[0].n == pend[k].first_n);
+      int32_t buf[512];
+      int64_t len = 512;
+      CHECK(teaser_hip_get_max_clique(h, 0, buf, &len) == TEASER_HIP_OK);  // getters address the batch just waited for
+      pend.erase(pend.begin() + (long)k);
+      ++waited;
+    } else if (pend.empty()) {  // idle: change the depth or run a synchronous batch on the parent
+      if (rng() & 1) {
+        depth = 1 + (int)(rng() % 4);
+        CHECK(teaser_hip_set_pipeline_depth(h, depth) == TEASER_HIP_OK);
+      } else {
+        int32_t n1[2] = {40, 17};
+        int64_t off1[2] = {0, 40};
+        g_stub_open_mask.store((unsigned)rng());
+        CHECK(teaser_hip_solve_batch_device(h, src.data(), dst.data(), off1, n1, 2, out.data()) == TEASER_HIP_OK);
+        CHECK(out[1].n == 17);
+      }
+    } else {
+      CHECK(teaser_hip_set_pipeline_depth(h, 2) == TEASER_HIP_ERR_BUSY);  // refused while batches are in flight
+    }
+  }
+  // leave some batches in flight on purpose half of the time: destroy must stop the finisher threads cleanly
+  if (rng() & 1)
+    while (!pend.empty()) {
+      const int32_t rc = teaser_hip_wait(h, pend.front().ticket, out.data());
+      if (rc == TEASER_HIP_ERR_BUSY) {
+        pend.push_back(pend.front());
+        pend.erase(pend.begin());
+        continue;
+      }
+      CHECK(rc == TEASER_HIP_OK);
+      pend.erase(pend.begin());
+      ++waited;
+    }
+  const size_t left = pend.size();
+  CHECK(teaser_hip_solver_destroy(h) == TEASER_HIP_OK);
+  std::printf("submitted %d waited %d left_in_flight %zu busy %d staged_busy %d stub_launches %d\n", submitted, waited, left,
+              busy, staged_busy, g_stub_launches.load());
+  return 0;
+}
