@@ -33,12 +33,28 @@ struct double2 { double x, y; };
 #define __shared__ static
 #define __launch_bounds__(...)
 #define __restrict__
-#define hipLaunchKernelGGL(...) ((void)0)
+// The three kernels solver.hip launches itself (header fetch, state push, host inputs) are grid-stride copy loops: they
+// are RUN here, every (block, thread) of the launch one after the other on the calling thread, so that the "device"
+// header and the page-locked state mirror hold what they hold on a GPU.
+#define hipLaunchKernelGGL(k, g, b, l, s, ...) stub_run_grid((g), (b), [&] { k(__VA_ARGS__); })
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_fence(...) ((void)0)
 #define __threadfence() ((void)0)
 #define __syncthreads() ((void)0)
-extern dim3 blockIdx, threadIdx, gridDim, blockDim;
+struct stub_dim3_ { unsigned x, y, z; };
+extern thread_local stub_dim3_ blockIdx, threadIdx, gridDim, blockDim;  // (thread-local: lanes launch from several threads)
+
+template <class F>
+inline void stub_run_grid(dim3 g, dim3 b, F f) {
+  gridDim = {g.x, g.y, g.z};
+  blockDim = {b.x, b.y, b.z};
+  for (unsigned bx = 0; bx < g.x; ++bx)
+    for (unsigned tx = 0; tx < b.x; ++tx) {
+      blockIdx = {bx, 0, 0};
+      threadIdx = {tx, 0, 0};
+      f();
+    }
+}
 
 inline hipError_t hipMalloc(void** p, size_t n) { *p = std::calloc(n ? n : 1, 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
 template <typename T> inline hipError_t hipMalloc(T** p, size_t n) { return hipMalloc(reinterpret_cast<void**>(p), n); }

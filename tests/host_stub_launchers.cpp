@@ -9,9 +9,11 @@
 
 #include "internal.h"
 
-dim3 blockIdx, threadIdx, gridDim, blockDim;
+thread_local stub_dim3_ blockIdx, threadIdx, gridDim, blockDim;
 std::atomic<unsigned> g_stub_open_mask{0};  // bit (b & 31) set: problem b of a batch is left open by the "peel"
 std::atomic<int> g_stub_launches{0};
+std::atomic<int> g_stub_exact_searches{0};
+std::atomic<int> g_stub_speculative{0};
 
 namespace thip {
 
@@ -48,17 +50,43 @@ void launch_estimate_fused(hipStream_t, const ProbDesc*, int batch, const double
 void launch_colour_bound(hipStream_t, const ProbDesc*, const int32_t*, int, int, const uint64_t*, const uint64_t*,
                          const int32_t*, ProbState*, int32_t*, int32_t*, int32_t*, int32_t*, int32_t*, int32_t*, int32_t*,
                          uint64_t*, int64_t, int64_t, int) { ++g_stub_launches; }
-void launch_exact_count(hipStream_t, const ProbDesc*, ExactProb* probs, int nprob, int, const uint64_t*, const uint64_t*,
+void launch_exact_count(hipStream_t, const ProbDesc* dd, ExactProb* probs, int nprob, int, const uint64_t*, const uint64_t*,
                         const int32_t*, const ProbState* ds, const int32_t*, const int32_t*, uint64_t*, uint64_t*,
                         bool speculative) {
   ++g_stub_launches;
-  for (int k = 0; k < nprob; ++k) {  // "the colouring bound closed it": n2 = 0
+  if (speculative) ++g_stub_speculative;
+  for (int k = 0; k < nprob; ++k) {
     const int p = speculative ? k : probs[k].prob;
     probs[k].prob = p;
-    probs[k].n2 = 0;
     probs[k].lb = ds[p].lb;
-    probs[k].ctrl[5] = 0;
-    probs[k].ctrl[6] = 0;
+    // every third problem: "the colouring bound left roots" -> the exact search has to run (pools, arenas, retries);
+    // the others: "closed" (n2 = 0)
+    const bool open = (p % 3 == 0) && dd[p].n >= 16 && !(speculative && ds[p].proven);
+    probs[k].n2 = open ? 12 : 0;
+    probs[k].W2 = 1;
+    probs[k].n_roots = open ? 3 : 0;
+    probs[k].use_x = 0;
+    probs[k].max_deg = 6;
+    probs[k].ctrl[5] = open ? 3 : 0;
+    probs[k].ctrl[6] = open ? 3 : 0;
+  }
+}
+void launch_exact_build(hipStream_t, const ProbDesc*, const ExactProb*, int, int, int, const uint64_t*, const int32_t*,
+                        const uint64_t*, const uint64_t*, int32_t*, unsigned long long*, uint64_t*) { ++g_stub_launches; }
+void launch_exact_finish(hipStream_t, const ProbDesc*, const ExactProb*, int, int, const int32_t*, const int32_t*, int32_t*,
+                         ProbState*) { ++g_stub_launches; }
+void launch_exact_clique(hipStream_t, ExactProb* probs, int nprob, int, int, int64_t, const uint64_t*, char* arena,
+                         int64_t arena_bytes, int arena_waves, int32_t*, char* tasks, int64_t task_bytes, int32_t*, int64_t) {
+  static std::atomic<int> calls{0};
+  const int c = calls++;
+  ++g_stub_launches;
+  ++g_stub_exact_searches;
+  arena[(int64_t)arena_waves * arena_bytes - 1] = 1;  // the pools are as large as the launch was told
+  tasks[task_bytes - 1] = 1;
+  for (int k = 0; k < nprob; ++k) {
+    probs[k].ctrl[1] = probs[k].ctrl[0] + ((c + k) % 4 == 0 ? 1 : 0);  // sometimes a larger clique: estimators run again
+    // once per process: an arena overflow (retry with 4 x the arena); now and then: the time limit
+    probs[k].ctrl[4] = (c == 3 && k == 0) ? 1 : ((c % 7 == 5 && k == 0) ? 2 : 0);
   }
 }
 void certifier_warmup_async(int) {}

@@ -13,7 +13,7 @@
 #include "teaser_hip.h"
 
 extern std::atomic<unsigned> g_stub_open_mask;
-extern std::atomic<int> g_stub_launches;
+extern std::atomic<int> g_stub_launches, g_stub_exact_searches, g_stub_speculative;
 
 #define CHECK(cond)                                                        \
   do {                                                                     \
@@ -77,6 +77,7 @@ int main(int argc, char** argv) {
       }
       CHECK(rc == TEASER_HIP_OK);
       CHECK(out[0].n == pend[k].first_n);
+      CHECK(out[0].status == TEASER_HIP_OK || out[0].status == TEASER_HIP_ERR_TIME_LIMIT);  // (the stub's search times out now and then)
       int32_t buf[512];
       int64_t len = 512;
       CHECK(teaser_hip_get_max_clique(h, 0, buf, &len) == TEASER_HIP_OK);  // getters address the batch just waited for
@@ -92,6 +93,18 @@ int main(int argc, char** argv) {
         g_stub_open_mask.store((unsigned)rng());
         CHECK(teaser_hip_solve_batch_device(h, src.data(), dst.data(), off1, n1, 2, out.data()) == TEASER_HIP_OK);
         CHECK(out[1].n == 17);
+        // pageable per-problem pointers: the gather into page-locked staging on four host threads (>= 512 KB of points)
+        const double* sp[24];
+        const double* dp[24];
+        int32_t nn[24];
+        for (int b = 0; b < 24; ++b) {
+          sp[b] = src.data() + 3 * (b % 5);
+          dp[b] = dst.data() + 3 * (b % 7);
+          nn[b] = 1000 + 10 * b;
+        }
+        CHECK(teaser_hip_solve_batch(h, sp, dp, nn, 24, out.data()) == TEASER_HIP_OK);
+        CHECK(out[23].n == 1230);
+        CHECK(teaser_hip_solve(h, src.data(), dst.data(), 50, out.data()) == TEASER_HIP_OK);
       }
     } else {
       CHECK(teaser_hip_set_pipeline_depth(h, 2) == TEASER_HIP_ERR_BUSY);  // refused while batches are in flight
@@ -112,7 +125,8 @@ int main(int argc, char** argv) {
     }
   const size_t left = pend.size();
   CHECK(teaser_hip_solver_destroy(h) == TEASER_HIP_OK);
-  std::printf("submitted %d waited %d left_in_flight %zu busy %d staged_busy %d stub_launches %d\n", submitted, waited, left,
-              busy, staged_busy, g_stub_launches.load());
+  std::printf("submitted %d waited %d left_in_flight %zu busy %d staged_busy %d stub_launches %d exact_searches %d "
+              "speculative_bound_stages %d\n", submitted, waited, left, busy, staged_busy, g_stub_launches.load(),
+              g_stub_exact_searches.load(), g_stub_speculative.load());
   return 0;
 }

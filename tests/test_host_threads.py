@@ -3,8 +3,11 @@
 csrc/solver.hip -- lanes, tickets, the staging slot of host batches, the per-lane finisher threads, the speculative
 bound stage's bookkeeping, destruction with batches in flight -- is compiled by g++ against a host-only stand-in for the
 HIP runtime (tests/hip_stub/hip/hip_runtime.h: device memory = host memory, streams and events complete at once,
-launches do nothing; tests/host_stub_launchers.cpp: the launchers of the other .hip files as no-ops, the estimator
-stub publishes problem states that are "closed by the peel" or "left open" batch by batch).  The numbers are
+the three copy kernels solver.hip launches itself are run on the calling thread, every other launch does nothing;
+tests/host_stub_launchers.cpp: the launchers of the other .hip files as stand-ins -- the "peel" closes a problem or
+leaves it open as the driver says, the "colouring bound" leaves roots for every third open problem, the "exact search"
+now and then finds a larger clique, overflows its arena once, hits the time limit: pools, retries and the second
+estimator pass all run).  The numbers are
 meaningless, the bookkeeping and the threads are the real ones.  tests/host_threads_driver.cpp drives random
 interleavings of submit / wait (any order) / getters / depth changes / synchronous solves and checks the API's contract;
 any sanitizer report fails the run.  ("solver.hip compiled host-only against a stub device layer".)
@@ -44,3 +47,4 @@ def test_async_host_side_is_clean_under_sanitizers(tmp_path, sanitizers, tag):
             assert "Sanitizer" not in p.stderr and "runtime error" not in p.stderr, p.stderr[-3000:]
             words = p.stdout.split()
             assert int(words[1]) > 100 and int(words[3]) > 100  # submitted, waited
+            assert int(words[13]) > 10 and int(words[15]) > 10  # exact searches, speculative bound stages: both paths ran
