@@ -105,6 +105,28 @@ int main(int argc, char** argv) {
         CHECK(teaser_hip_solve_batch(h, sp, dp, nn, 24, out.data()) == TEASER_HIP_OK);
         CHECK(out[23].n == 1230);
         CHECK(teaser_hip_solve(h, src.data(), dst.data(), 50, out.data()) == TEASER_HIP_OK);
+        {  // the getters of the synchronous solve, with exact and with short buffers
+          int32_t ib[64];
+          int64_t len = 64;
+          CHECK(teaser_hip_get_max_clique(h, 0, ib, &len) == TEASER_HIP_OK);
+          len = 64;
+          CHECK(teaser_hip_get_rotation_inliers(h, 0, ib, &len) == TEASER_HIP_OK);
+          len = 64;
+          CHECK(teaser_hip_get_translation_inliers(h, 0, ib, &len) == TEASER_HIP_OK);
+          len = 50;
+          CHECK(teaser_hip_get_degrees(h, 0, ib, &len) == TEASER_HIP_OK && len == 50);
+          uint64_t bm[50];
+          len = 50;
+          CHECK(teaser_hip_get_inlier_graph_bitmap(h, 0, bm, &len) == TEASER_HIP_OK && len == 50);
+          len = 3;  // too short: the needed length comes back, nothing is written past the buffer
+          CHECK(teaser_hip_get_degrees(h, 0, ib, &len) != TEASER_HIP_OK && len == 50);
+          CHECK(teaser_hip_get_max_clique(h, 7, ib, &len) == TEASER_HIP_ERR_BAD_ARG);  // no such problem
+        }
+        {  // MaxCliqueSolver on a caller-supplied bitmap (host pointer): a 5-cycle
+          uint64_t g5[5] = {0x12, 0x5, 0xA, 0x14, 0x9};
+          int32_t cl[5], sz = 0, ex = 0;
+          CHECK(teaser_hip_max_clique(h, g5, 5, cl, &sz, &ex) == TEASER_HIP_OK);
+        }
       }
     } else {
       CHECK(teaser_hip_set_pipeline_depth(h, 2) == TEASER_HIP_ERR_BUSY);  // refused while batches are in flight
