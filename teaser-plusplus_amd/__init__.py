@@ -15,6 +15,7 @@ import ctypes as C
 import enum
 import os
 import subprocess
+import typing
 
 import numpy as np
 
@@ -289,6 +290,24 @@ class RegistrationSolution:
             self.scale, self.translation, self.rotation)
 
 
+class RobustRegistrationSolverParams(typing.NamedTuple):
+    """python/teaserpp_python/__init__.py:23-42, field for field (``RobustRegistrationSolver(*params)``)."""
+    noise_bound: float = 0.01
+    cbar2: float = 1
+    estimate_scaling: bool = True
+    rotation_estimation_algorithm: RotationEstimationAlgorithm = RotationEstimationAlgorithm.GNC_TLS
+    rotation_gnc_factor: float = 1.4
+    rotation_max_iterations: int = 100
+    rotation_cost_threshold: float = 1e-6
+    rotation_tim_graph: InlierGraphFormulation = InlierGraphFormulation.CHAIN
+    inlier_selection_mode: InlierSelectionMode = InlierSelectionMode.PMC_EXACT
+    kcore_heuristic_threshold: float = 0.5
+    use_max_clique: bool = True
+    max_clique_exact_solution: bool = True
+    max_clique_time_limit: int = 3000
+    max_clique_num_threads: int = OMP_MAX_THREADS
+
+
 class RobustRegistrationSolver:
     """Mirror of teaser::RobustRegistrationSolver (registration.h:361-957) on one MI355X.
 
@@ -314,6 +333,8 @@ class RobustRegistrationSolver:
             self.rotation_estimation_algorithm = RotationEstimationAlgorithm(self.rotation_estimation_algorithm)
             self.rotation_tim_graph = InlierGraphFormulation(self.rotation_tim_graph)
             self.inlier_selection_mode = InlierSelectionMode(self.inlier_selection_mode)
+            if not self.max_clique_num_threads:  # registration.h:513: omp_get_max_threads() (ignored on the GPU)
+                self.max_clique_num_threads = OMP_MAX_THREADS
             for k, v in kw.items():
                 if not hasattr(self, k):
                     raise AttributeError(k)
@@ -325,9 +346,48 @@ class RobustRegistrationSolver:
                 setattr(c, name, type(getattr(c, name))(getattr(self, name)))
             return c
 
-    def __init__(self, params=None, device=-1, **kw):
-        if params is None:
-            params = RobustRegistrationSolver.Params(**kw)
+    # teaserpp_python.cc:83-103: the 14 positional / keyword arguments of the second constructor, in order
+    _CTOR_ARGS = ("noise_bound", "cbar2", "estimate_scaling", "rotation_estimation_algorithm",
+                  "rotation_gnc_factor", "rotation_max_iterations", "rotation_cost_threshold",
+                  "rotation_tim_graph", "inlier_selection_mode", "kcore_heuristic_threshold",
+                  "use_max_clique", "max_clique_exact_solution", "max_clique_time_limit",
+                  "max_clique_num_threads")
+
+    @classmethod
+    def _params_from_ctor_args(cls, args, kw):
+        """Constructor argument handling (no device access): returns the Params both constructors mean."""
+        if "params" in kw:
+            if args or len(kw) > 1:
+                raise TypeError("RobustRegistrationSolver(params=...) takes no other solver argument")
+            args, kw = (kw["params"],), {}
+        if len(args) == 1 and (args[0] is None or isinstance(args[0], RobustRegistrationSolver.Params)):
+            if kw:
+                raise TypeError("RobustRegistrationSolver(Params) takes no keyword arguments besides device")
+            params = args[0] if args[0] is not None else RobustRegistrationSolver.Params()
+        else:
+            if len(args) > len(cls._CTOR_ARGS):
+                raise TypeError("RobustRegistrationSolver takes at most %d positional arguments (%d given)"
+                                % (len(cls._CTOR_ARGS), len(args)))
+            given = dict(zip(cls._CTOR_ARGS, args))
+            for k, v in kw.items():
+                if k not in cls._CTOR_ARGS:
+                    raise TypeError("RobustRegistrationSolver got an unexpected keyword argument %r" % k)
+                if k in given:
+                    raise TypeError("RobustRegistrationSolver got multiple values for argument %r" % k)
+                given[k] = v
+            # defaults of the positional constructor == the NamedTuple's (python/teaserpp_python/__init__.py:23-42)
+            params = RobustRegistrationSolver.Params(
+                **dict(RobustRegistrationSolverParams()._asdict(), **given))
+        return params
+
+    def __init__(self, *args, device=None, **kw):
+        """Both reference constructors (teaserpp_python.cc:82-103): ``(Params)`` and the 14
+        positional-or-keyword arguments (``RobustRegistrationSolver(*RobustRegistrationSolverParams(...))``).
+        The device is chosen by the keyword-only ``device`` (default: $TEASER_HIP_DEVICE, else the current
+        HIP device) -- never by position, so a positional ``cbar2`` cannot be mistaken for it."""
+        if device is None:
+            device = int(os.environ.get("TEASER_HIP_DEVICE", "-1"))
+        params = self._params_from_ctor_args(args, kw)
         self._params = params
         self._h = _vp()
         self._lib = lib()
@@ -366,6 +426,12 @@ class RobustRegistrationSolver:
 
     def getParams(self):  # registration.h:914
         return self._params
+
+    @property
+    def params(self):
+        """python/teaserpp_python/__init__.py:52-57: the constructor arguments as a
+        RobustRegistrationSolverParams tuple (here always all 14 fields, also after reset())."""
+        return RobustRegistrationSolverParams(**{k: getattr(self._params, k) for k in self._CTOR_ARGS})
 
     def solve(self, src, dst):  # registration.h:576-577
         s, d = _colmajor(src, "src"), _colmajor(dst, "dst")
@@ -565,6 +631,8 @@ class RobustRegistrationSolver:
         mp = self.getScaleInliersMap(problem)
         mk = self.getScaleInliersMask(problem)
         return [(int(a), int(b)) for a, b in zip(mp[0][mk], mp[1][mk])]
+
+    scale_inliers = property(getScaleInliers)
 
     # TIM products (registration.h:778-824).  The device never materialises them; they are rebuilt
     # here on the host, on request, from the last inputs of solve()/solve_batch().
