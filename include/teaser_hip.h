@@ -242,6 +242,15 @@ TEASER_HIP_API int32_t teaser_hip_comm_create(const uint8_t* id, int32_t rank, i
 TEASER_HIP_API int32_t teaser_hip_comm_destroy(teaser_hip_comm* c);
 TEASER_HIP_API int32_t teaser_hip_comm_gather_solutions(teaser_hip_comm* c, const teaser_solution_c* local,
                                          int64_t n_local, int64_t total, teaser_solution_c* all /* [total] */);
+/* collective: the INDEX SETS behind the parity bar -- getInlierMaxClique, getRotationInliers, getTranslationInliers
+ * (registration.h:770, 713, 744) -- of every problem on every rank, in ONE all-gather of padded int32 blocks.
+ * `h` is the solver whose last solve_batch produced this rank's n_local problems (the lists are read through the
+ * getters below); k_max >= the longest list of ANY problem, the same on every rank (take it from the gathered
+ * solution records: max over clique_size, n_rotation_inliers, n_translation_inliers).  lens [total][3] receives
+ * the list lengths, indices [total][3][k_max] the lists in that order, padded with -1.  A rank holding a list
+ * longer than k_max still takes part (zeroed block) and returns BAD_ARG afterwards. */
+TEASER_HIP_API int32_t teaser_hip_comm_gather_indices(teaser_hip_comm* c, teaser_hip_solver* h, int64_t n_local,
+                                       int64_t total, int32_t k_max, int32_t* lens, int32_t* indices);
 TEASER_HIP_API const char* teaser_hip_comm_last_error(const teaser_hip_comm* c);
 
 /* Getters on the last solve call; `problem` indexes the batch (0 for single solves).  Each copies
@@ -341,6 +350,17 @@ TEASER_HIP_API int32_t teaser_hip_max_clique(teaser_hip_solver* h, const uint64_
 
 /* Profiling / diagnostics. */
 TEASER_HIP_API int32_t teaser_hip_set_profiling(teaser_hip_solver* h, int32_t level /* 0, 1, 2 */);
+/* Route switches among EQUIVALENT paths and tuning knobs of the implementation (no counterpart in the reference;
+ * process-wide, `h` may be NULL).  No value changes a result: the GPU suite compares the routes with each other
+ * and with the oracle.  Names (defaults): "k1_fp64" (0; 1 = the all-FP64 K1 instead of the matrix-core filter),
+ * "fused_estimators" (1), "scale_sort64" (0), "scale_batch" (1), "scale_mid_batch" (1), "spec_bounds" (1),
+ * "finisher" (1), "copy_stream" (0), "h2d_kernel" (0), "depth" (2; lanes of handles created afterwards), "stagger"
+ * (1), "k1_stream" (0), "tail_cus" (0), "tail_cu_block" (0), "k4_lds_stack" (16384), "k4_donate" (1),
+ * "k4_donate_after" / "k4_hungry" / "k4_expand" (-1 = built-in), "k4_debug" (0), "heu_blocks" (0 = built-in),
+ * "greedy_threads" (0 = built-in).  Each also has an environment variable that is read ONCE per
+ * process; the library never calls getenv on a solve path and never modifies the environment.
+ * Returns BAD_ARG for an unknown name. */
+TEASER_HIP_API int32_t teaser_hip_set_option(teaser_hip_solver* h, const char* name, int64_t value);
 TEASER_HIP_API int32_t teaser_hip_get_profile(const teaser_hip_solver* h, teaser_profile_c* out);
 /* The HIP stream (hipStream_t) all kernels of this handle are launched on. */
 TEASER_HIP_API void* teaser_hip_get_stream(teaser_hip_solver* h);

@@ -1,8 +1,10 @@
 // k1_probe -- GPU-box probe (no Python, no torch): K1 scheduling variants and the asynchronous batch
 // pipeline of libteaser_hip.so on the bench workload.  Build: make -C scripts/probe.  Usage:
-//   k1_probe [batch=64] [n=10000] [iters=10] [mode]
-//     mode "k1"   : per TEASER_K1_VARIANT (-1 = FP64, 0, 1): K1 ms per launch (HIP events), step ms
-//                   (synchronous API), FNV hash of two bitmaps (must agree across variants)
+//   k1_probe [batch=64] [n=10000] [iters=10] [mode] [rho=0.95] [variants=fp64,default]
+//     mode "k1"   : per variant in [variants] (comma separated; "fp64" = the all-FP64 route through
+//                   teaser_hip_set_option, "default" = the library's kernel, a NUMBER = TEASER_K1_VARIANT of the LAB
+//                   build, scripts/probe/k1_lab: 100 * log2(chunks) + 10 * plain + pipe): K1 ms per launch (HIP
+//                   events), step ms (synchronous API), FNV hash of two bitmaps (must agree across variants)
 //     mode "pipe" : registrations/s through teaser_hip_submit_batch / teaser_hip_wait for depth 1..4,
 //                   K1 staggering on and off
 //     mode "one"  : only the variant in the environment, `iters` synchronous steps (for rocprofv3)
@@ -89,15 +91,23 @@ int main(int argc, char** argv) {
   const int W = (n + 63) / 64;
   std::vector<uint64_t> bm((size_t)n * W);
 
+  std::vector<std::string> vs;
+  {
+    {
+      std::string list = argc > 6 ? argv[6] : (mode == "one" ? "default" : "fp64,default");
+      size_t at = 0;
+      while (at <= list.size()) {
+        const size_t c = list.find(',', at);
+        vs.push_back(list.substr(at, c == std::string::npos ? std::string::npos : c - at));
+        if (c == std::string::npos) break;
+        at = c + 1;
+      }
+    }
+  }
   if (mode == "k1" || mode == "one") {
-    const char* variants_all[] = {"-1", "11", "12", "20", "21", "22", "23", "27"};
-    std::vector<std::string> vs;
-    if (mode == "one")
-      vs.push_back(getenv("TEASER_K1_VARIANT") ? getenv("TEASER_K1_VARIANT") : "");  // "": the library's default
-    else
-      for (const char* v : variants_all) vs.push_back(v);
     for (const std::string& v : vs) {
-      if (!v.empty()) setenv("TEASER_K1_VARIANT", v.c_str(), 1);
+      CK(teaser_hip_set_option(nullptr, "k1_fp64", v == "fp64" ? 1 : 0));
+      if (v != "fp64" && v != "default") setenv("TEASER_K1_VARIANT", v.c_str(), 1);  // (read by the lab build only)
       teaser_hip_solver* h = nullptr;
       CK(teaser_hip_solver_create(&prm, 0, &h));
       for (int w = 0; w < 2; ++w)
@@ -126,7 +136,7 @@ int main(int argc, char** argv) {
       }
       printf("{\"probe\":\"k1\",\"variant\":%s,\"batch\":%d,\"n\":%d,\"k1_ms\":%.4f,\"aux_ms\":%.4f,\"launches\":%d,"
              "\"step_ms_sync\":%.4f,\"clique0\":%d,\"valid0\":%d,\"bitmap_hash\":\"%016llx\"}\n",
-             v.empty() ? "\"default\"" : v.c_str(), B, n, launches ? k1 / launches : (mode == "one" ? 0.0 : k1 / iters), aux / iters, launches,
+             ("\"" + v + "\"").c_str(), B, n, launches ? k1 / launches : (mode == "one" ? 0.0 : k1 / iters), aux / iters, launches,
              (t1 - t0) / iters, out[0].clique_size, out[0].valid, (unsigned long long)hsh);
       fflush(stdout);
       teaser_hip_solver_destroy(h);
@@ -134,11 +144,14 @@ int main(int argc, char** argv) {
   }
   if (mode == "pipe") {
     struct Cfg { int k1stream, depth, greedy; };
-    const Cfg cfgs[] = {{1, 1, 256}, {1, 2, 256}, {1, 3, 256}, {1, 4, 256}, {1, 3, 512}, {0, 3, 256}, {0, 4, 256}};
+    const Cfg cfgs[] = {{0, 2, 0}, {0, 3, 0}};  // (k1_stream, depth, greedy_threads: 0 = built-in)
+    for (const std::string& v : vs)
     for (const Cfg& cf : cfgs) {
       const int depth = cf.depth;
-      setenv("TEASER_HIP_K1_STREAM", cf.k1stream ? "1" : "0", 1);
-      setenv("TEASER_GREEDY_THREADS", cf.greedy == 512 ? "512" : "256", 1);
+      if (v == "fp64") continue;
+      if (v != "default") setenv("TEASER_K1_VARIANT", v.c_str(), 1);  // (read by the lab build only)
+      CK(teaser_hip_set_option(nullptr, "k1_stream", cf.k1stream));
+      CK(teaser_hip_set_option(nullptr, "greedy_threads", cf.greedy));
       teaser_hip_solver* h = nullptr;
       CK(teaser_hip_solver_create(&prm, 0, &h));
       CK(teaser_hip_set_pipeline_depth(h, depth));
@@ -182,9 +195,9 @@ int main(int argc, char** argv) {
       }
       CK(hipDeviceSynchronize());
       const double t1 = now_ms();
-      printf("{\"probe\":\"pipe\",\"k1_stream\":%d,\"depth\":%d,\"greedy_threads\":%d,\"batch\":%d,\"n\":%d,"
+      printf("{\"probe\":\"pipe\",\"variant\":\"%s\",\"k1_stream\":%d,\"depth\":%d,\"greedy_threads\":%d,\"batch\":%d,\"n\":%d,"
              "\"step_ms\":%.4f,\"reg_per_s\":%.0f,\"k1_ms\":%.4f,\"clique0\":%d}\n",
-             cf.k1stream, depth, cf.greedy, B, n, (t1 - t0) / iters, 1e3 * B * iters / (t1 - t0),
+             v.c_str(), cf.k1stream, depth, cf.greedy, B, n, (t1 - t0) / iters, 1e3 * B * iters / (t1 - t0),
              launches ? k1 / launches : 0.0, out[0].clique_size);
       fflush(stdout);
       teaser_hip_solver_destroy(h);

@@ -119,7 +119,7 @@ EXPORTED_SYMBOLS = [
     "teaser_hip_get_translation_inliers", "teaser_hip_get_input_ordered_translation_inliers",
     "teaser_hip_get_inlier_graph_bitmap", "teaser_hip_get_degrees", "teaser_hip_solve_for_rotation",
     "teaser_hip_solve_for_translation", "teaser_hip_scalar_tls", "teaser_hip_max_clique",
-    "teaser_hip_set_profiling", "teaser_hip_get_profile", "teaser_hip_get_stream",
+    "teaser_hip_set_profiling", "teaser_hip_set_option", "teaser_hip_get_profile", "teaser_hip_get_stream",
     "teaser_hip_last_error", "teaser_hip_abi_version", "teaser_hip_device_count", "teaser_hip_host_alloc",
     "teaser_hip_host_free",
     "teaser_hip_synth_problem", "teaser_hip_submit_batch", "teaser_hip_wait",
@@ -128,7 +128,7 @@ EXPORTED_SYMBOLS = [
     "teaser_hip_solve_for_scale", "teaser_hip_compute_fpfh", "teaser_hip_match_features",
     "teaser_hip_certifier_params_default", "teaser_hip_certify", "teaser_hip_certifier_warmup",
     "teaser_hip_comm_shard", "teaser_hip_comm_unique_id", "teaser_hip_comm_create", "teaser_hip_comm_destroy",
-    "teaser_hip_comm_gather_solutions", "teaser_hip_comm_last_error",
+    "teaser_hip_comm_gather_solutions", "teaser_hip_comm_gather_indices", "teaser_hip_comm_last_error",
 ]
 
 
@@ -199,6 +199,7 @@ def lib():
     L.teaser_hip_multi_route.argtypes = [_vp, C.c_int32, C.POINTER(_vp), _ip]
     L.teaser_hip_multi_device_count.argtypes = [_vp]
     L.teaser_hip_set_profiling.argtypes = [_vp, C.c_int32]
+    L.teaser_hip_set_option.argtypes = [_vp, C.c_char_p, C.c_int64]
     L.teaser_hip_get_profile.argtypes = [_vp, C.POINTER(ProfileC)]
     L.teaser_hip_get_stream.argtypes = [_vp]
     L.teaser_hip_get_stream.restype = _vp
@@ -208,6 +209,14 @@ def lib():
                                            _dp, _dp, _u8p]
     _lib = L
     return L
+
+
+def set_option(name, value):
+    """teaser_hip_set_option: route switches among equivalent paths / tuning knobs (process-wide; see
+    include/teaser_hip.h for the names).  No value changes a result."""
+    rc = lib().teaser_hip_set_option(None, name.encode(), int(value))
+    if rc != 0:
+        raise TeaserHipError(rc, "unknown option %r" % name)
 
 
 # teaserpp_python.OMP_MAX_THREADS (python/teaserpp_python/teaserpp_python.cc:45): host threads

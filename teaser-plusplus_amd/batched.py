@@ -79,9 +79,65 @@ def gather_records(local_records, total, dist=None, device=None):
     return np.concatenate(parts, axis=0) if parts else np.zeros((0, RECORD_DOUBLES))
 
 
-def solve_sharded(solver, srcs, dsts, dist=None, device=None):
+INDEX_LISTS = ("max_clique", "rotation_inliers", "translation_inliers")  # registration.h:770, 713, 744
+
+
+def pack_indices(lists, k_max):
+    """[(max_clique, rotation_inliers, translation_inliers), ...] of this rank's problems -> int32 array
+    [len, 3 + 3 * k_max]: the three lengths, then the three lists padded with -1 to k_max entries each (the layout
+    of teaser_hip_comm_gather_indices, include/teaser_hip.h)."""
+    out = np.full((len(lists), 3 + 3 * k_max), -1, dtype=np.int32)
+    for b, three in enumerate(lists):
+        for k, lst in enumerate(three):
+            a = np.asarray(lst, dtype=np.int32).ravel()
+            if a.size > k_max:
+                raise ValueError("index list of %d entries exceeds k_max %d" % (a.size, k_max))
+            out[b, k] = a.size
+            out[b, 3 + k * k_max:3 + k * k_max + a.size] = a
+    return out
+
+
+def unpack_indices(block, k_max):
+    """Inverse of pack_indices: list of dicts {max_clique, rotation_inliers, translation_inliers} of int lists."""
+    res = []
+    for row in np.asarray(block, dtype=np.int32).reshape(-1, 3 + 3 * k_max):
+        res.append({name: row[3 + k * k_max:3 + k * k_max + int(row[k])].tolist() for k, name in enumerate(INDEX_LISTS)})
+    return res
+
+
+def gather_indices(local_lists, records, dist=None, device=None):
+    """The INDEX SETS of every problem on every rank (the parity bar of the batched mode is on them: identical
+    sorted max clique / rotation / translation inlier lists): ONE all-gather of padded int32 blocks, K_max per list
+    taken from the already gathered records (so it is the same on every rank).  `local_lists`: this rank's problems
+    in shard order, each a (max_clique, rotation_inliers, translation_inliers) triple.  Returns a list of `total`
+    dicts in problem order."""
+    total = records.shape[0]
+    k_max = int(max(1.0, records[:, [F_CLIQUE, F_NROT, F_NTRANS]].max())) if total else 1
+    local = pack_indices(local_lists, k_max)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        if local.shape[0] != total:
+            raise ValueError("single process must hold every problem's lists")
+        return unpack_indices(local, k_max)
+    import torch
+
+    world = dist.get_world_size()
+    bounds = shard_bounds(total, world)
+    cap = max(bounds[r + 1] - bounds[r] for r in range(world))
+    pad = np.full((cap, local.shape[1]), -1, dtype=np.int32)
+    pad[:local.shape[0]] = local
+    t = torch.from_numpy(pad)
+    if device is not None:
+        t = t.to(device)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    parts = [out[r][:bounds[r + 1] - bounds[r]].cpu().numpy() for r in range(world)]
+    return unpack_indices(np.concatenate(parts, axis=0), k_max)
+
+
+def solve_sharded(solver, srcs, dsts, dist=None, device=None, with_indices=False):
     """Solve `len(srcs)` independent problems, sharded over the ranks of `dist`; every rank passes
-    the full problem list (or at least its own shard's entries) and gets all records back."""
+    the full problem list (or at least its own shard's entries) and gets all records back.
+    with_indices=True: also the index sets of EVERY problem (gather_indices): returns (records, indices)."""
     total = len(srcs)
     rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
     world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
@@ -91,4 +147,9 @@ def solve_sharded(solver, srcs, dsts, dist=None, device=None):
         local = pack_records([solver.raw_solution(b) for b in range(hi - lo)], first_index=lo)
     else:
         local = np.zeros((0, RECORD_DOUBLES))
-    return gather_records(local, total, dist, device)
+    records = gather_records(local, total, dist, device)
+    if not with_indices:
+        return records
+    lists = [(solver.getInlierMaxClique(b), solver.getRotationInliers(b), solver.getTranslationInliers(b))
+             for b in range(hi - lo)]
+    return records, gather_indices(lists, records, dist, device)

@@ -153,24 +153,32 @@ const char* teaser_hip_comm_last_error(const teaser_hip_comm* c) {
   return copy.c_str();
 }
 
-int32_t teaser_hip_comm_gather_solutions(teaser_hip_comm* c, const teaser_solution_c* local, int64_t n_local,
-                                         int64_t total, teaser_solution_c* all) {
-  if (!c || total < 0 || n_local < 0 || (n_local > 0 && !local) || (total > 0 && !all)) return TEASER_HIP_ERR_BAD_ARG;
+}  // extern "C"
+
+namespace {
+// ONE all-gather of fixed-size items in problem order: `local` = this rank's n_local items (its shard), `all`
+// [total] receives every rank's items, the same on every rank.  Shards are ragged by at most one item: every rank
+// sends a block of the largest shard's size.  A rank whose item count is wrong still TAKES PART in the collective
+// (with a zeroed block) and reports BAD_ARG afterwards: returning early would leave its peers waiting inside
+// ncclAllGather for ever.
+int32_t allgather_items(teaser_hip_comm* c, const char* who, const void* local, int64_t n_local, int64_t total,
+                        size_t item_bytes, void* all, bool force_bad = false) {
   int64_t first = 0, last = 0;
   (void)teaser_hip_comm_shard(total, c->rank, c->world, &first, &last);
-  // A rank whose record count is wrong still TAKES PART in the collective (with a zeroed block) and reports
-  // BAD_ARG afterwards: returning early would leave its peers waiting inside ncclAllGather for ever.
-  const bool bad_count = n_local != last - first;
+  bool bad_count = n_local != last - first;
   if (bad_count) {
-    c->err = "teaser_hip_comm_gather_solutions: this rank's shard of " + std::to_string(total) + " problems holds " +
+    c->err = std::string(who) + ": this rank's shard of " + std::to_string(total) + " problems holds " +
              std::to_string(last - first) + " records, not " + std::to_string(n_local);
+    n_local = 0;
+  }
+  if (force_bad) {  // (the caller found its own input unusable: c->err says why)
+    bad_count = true;
     n_local = 0;
   }
   if (total == 0) return bad_count ? TEASER_HIP_ERR_BAD_ARG : TEASER_HIP_OK;
   if (hipSetDevice(c->device) != hipSuccess) return TEASER_HIP_ERR_HIP;
-  // shards are ragged by at most one record: every rank sends a block of the largest shard's size
   const int64_t cap = (total + c->world - 1) / c->world;
-  const size_t block = (size_t)cap * sizeof(teaser_solution_c);
+  const size_t block = (size_t)cap * item_bytes;
   auto fail = [&](const char* what, hipError_t e) {
     c->err = std::string(what) + ": " + hipGetErrorString(e);
     return TEASER_HIP_ERR_HIP;
@@ -191,9 +199,8 @@ int32_t teaser_hip_comm_gather_solutions(teaser_hip_comm* c, const teaser_soluti
     if (e != hipSuccess) return fail("hipMalloc", e);
     c->recv_cap = block * (size_t)c->world;
   }
-  std::vector<teaser_solution_c> stage((size_t)cap);
-  std::memset(stage.data(), 0, block);
-  if (n_local > 0) std::memcpy(stage.data(), local, (size_t)n_local * sizeof(teaser_solution_c));
+  std::vector<char> stage(block, 0);
+  if (n_local > 0) std::memcpy(stage.data(), local, (size_t)n_local * item_bytes);
   hipError_t e = hipMemcpyAsync(c->d_send, stage.data(), block, hipMemcpyHostToDevice, c->stream);
   if (e != hipSuccess) return fail("hipMemcpyAsync", e);
   const ncclResult_t nr = rccl().all_gather(c->d_send, c->d_recv, block, ncclUint8, c->comm, c->stream);
@@ -201,7 +208,7 @@ int32_t teaser_hip_comm_gather_solutions(teaser_hip_comm* c, const teaser_soluti
     c->err = std::string("ncclAllGather: ") + rccl().error_string(nr);
     return TEASER_HIP_ERR_HIP;
   }
-  std::vector<teaser_solution_c> got((size_t)cap * (size_t)c->world);
+  std::vector<char> got(block * (size_t)c->world);
   e = hipMemcpyAsync(got.data(), c->d_recv, block * (size_t)c->world, hipMemcpyDeviceToHost, c->stream);
   if (e != hipSuccess) return fail("hipMemcpyAsync", e);
   e = hipStreamSynchronize(c->stream);
@@ -209,9 +216,57 @@ int32_t teaser_hip_comm_gather_solutions(teaser_hip_comm* c, const teaser_soluti
   for (int r = 0; r < c->world; ++r) {
     int64_t f = 0, l = 0;
     (void)teaser_hip_comm_shard(total, r, c->world, &f, &l);
-    if (l > f) std::memcpy(all + f, got.data() + (size_t)r * (size_t)cap, (size_t)(l - f) * sizeof(teaser_solution_c));
+    if (l > f)
+      std::memcpy(static_cast<char*>(all) + (size_t)f * item_bytes, got.data() + (size_t)r * block, (size_t)(l - f) * item_bytes);
   }
   return bad_count ? TEASER_HIP_ERR_BAD_ARG : TEASER_HIP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int32_t teaser_hip_comm_gather_solutions(teaser_hip_comm* c, const teaser_solution_c* local, int64_t n_local,
+                                         int64_t total, teaser_solution_c* all) {
+  if (!c || total < 0 || n_local < 0 || (n_local > 0 && !local) || (total > 0 && !all)) return TEASER_HIP_ERR_BAD_ARG;
+  return allgather_items(c, "teaser_hip_comm_gather_solutions", local, n_local, total, sizeof(teaser_solution_c), all);
+}
+
+int32_t teaser_hip_comm_gather_indices(teaser_hip_comm* c, teaser_hip_solver* h, int64_t n_local, int64_t total,
+                                       int32_t k_max, int32_t* lens, int32_t* indices) {
+  if (!c || total < 0 || n_local < 0 || k_max < 0 || (n_local > 0 && !h) || (total > 0 && (!lens || !indices)))
+    return TEASER_HIP_ERR_BAD_ARG;
+  // item of one problem: 3 lengths, then the three lists padded with -1 to k_max entries each
+  const size_t item_words = 3 + 3 * (size_t)k_max;
+  std::vector<int32_t> local((size_t)n_local * item_words, -1);
+  bool bad = false;
+  typedef int32_t (*getter_t)(teaser_hip_solver*, int32_t, int32_t*, int64_t*);
+  const getter_t getters[3] = {teaser_hip_get_max_clique, teaser_hip_get_rotation_inliers,
+                               teaser_hip_get_translation_inliers};
+  for (int64_t b = 0; b < n_local && !bad; ++b) {
+    int32_t* item = local.data() + (size_t)b * item_words;
+    for (int k = 0; k < 3; ++k) {
+      int64_t len = k_max;
+      const int32_t rc = getters[k](h, (int32_t)b, item + 3 + (size_t)k * (size_t)k_max, &len);
+      if (rc != TEASER_HIP_OK || len > k_max) {  // (a getter writes nothing when the list does not fit)
+        c->err = "teaser_hip_comm_gather_indices: problem " + std::to_string(b) + " of this rank holds a list of " +
+                 std::to_string(len) + " indices (k_max " + std::to_string(k_max) + ", getter status " +
+                 std::to_string(rc) + ")";
+        bad = true;
+        break;
+      }
+      item[k] = (int32_t)len;
+    }
+  }
+  std::vector<int32_t> all((size_t)total * item_words);
+  const int32_t rc = allgather_items(c, "teaser_hip_comm_gather_indices", local.data(), n_local, total,
+                                     item_words * sizeof(int32_t), all.data(), bad);
+  if (rc != TEASER_HIP_OK && rc != TEASER_HIP_ERR_BAD_ARG) return rc;
+  for (int64_t p = 0; p < total; ++p) {
+    const int32_t* item = all.data() + (size_t)p * item_words;
+    std::memcpy(lens + 3 * p, item, 3 * sizeof(int32_t));
+    std::memcpy(indices + (size_t)p * 3 * (size_t)k_max, item + 3, 3 * (size_t)k_max * sizeof(int32_t));
+  }
+  return rc;
 }
 
 }  // extern "C"

@@ -6,6 +6,7 @@
 #include <stdint.h>
 
 #include <atomic>
+#include <mutex>
 #include <vector>
 
 #include "teaser_hip.h"
@@ -75,28 +76,58 @@ struct EstParams {
   int32_t algorithm;  // TEASER_ROT_GNC_TLS / _FGR / _QUATRO
 };
 
-// Opt-in for more than 64 KB of dynamic LDS.  hipFuncSetAttribute applies to the CURRENT device, and
-// handles of several devices (and several host threads) share this process, so the largest size
-// granted so far is tracked per device, lock-free (a racing duplicate call is harmless).
+// Opt-in for more than 48 KB of dynamic LDS.  hipFuncSetAttribute applies to the CURRENT device, and handles of
+// several devices and several host threads (the submitting thread and the lanes' finisher threads launch the same
+// kernels) share this process: the largest size granted so far is tracked per device, and the check, the
+// attribute call and the store are ONE critical section -- two racing first calls (58 KB, then 50 KB landing last)
+// would otherwise leave `granted` at 58 KB with the function set to 50 KB, and every later 58 KB launch failing.
 struct DynLdsOptIn {
   static constexpr int kMaxDevices = 64;
-  std::atomic<int> granted[kMaxDevices];
-  DynLdsOptIn() {
-    for (auto& g : granted) g.store(0);
-  }
+  std::mutex m;
+  int granted[kMaxDevices] = {};
   void ensure(const void* func, int bytes) {
     int dev = 0;
     (void)hipGetDevice(&dev);
     const bool tracked = dev >= 0 && dev < kMaxDevices;
-    if (tracked && granted[dev].load(std::memory_order_acquire) >= bytes) return;
+    std::lock_guard<std::mutex> lk(m);
+    if (tracked && granted[dev] >= bytes) return;
     (void)hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (tracked) {
-      int cur = granted[dev].load();
-      while (cur < bytes && !granted[dev].compare_exchange_weak(cur, bytes)) {
-      }
-    }
+    if (tracked) granted[dev] = bytes;
   }
 };
+
+
+// ---- settings: route switches among EQUIVALENT paths and tuning knobs ----------------------------------------------
+// None of them changes a result (the GPU suite compares the routes).  Each has an environment variable that is read
+// ONCE per process, at the first use of the table; afterwards only teaser_hip_set_option (include/teaser_hip.h)
+// changes a value.  No kernel launcher calls getenv.
+enum Setting {
+  S_K1_FP64,           // 1: the all-FP64 K1 instead of the matrix-core filter          TEASER_HIP_K1_FP64
+  S_FUSED_EST,         // 0: rotation / translation / state hand-over as three launches  TEASER_HIP_FUSED_EST
+  S_SCALE_SORT64,      // 1: 64-bit key sort in the scale stage                          TEASER_SCALE_SORT64
+  S_SCALE_BATCH,       // 0: scale stage one problem at a time                           TEASER_SCALE_BATCH
+  S_SCALE_MID_BATCH,   // 0: no shared sort for mid-size problems                        TEASER_SCALE_MID_BATCH
+  S_SPEC_BOUNDS,       // 0: bound-closing stage only after the host has seen the peel   TEASER_HIP_SPEC_BOUNDS
+  S_FINISHER,          // 0: no finisher threads (wait() finishes the batch itself)      TEASER_HIP_FINISHER
+  S_COPY_STREAM,       // host inputs: 0 parent's stream, 1 own stream, 2 high priority  TEASER_HIP_COPY_STREAM
+  S_H2D_KERNEL,        // 1: host inputs fetched by a kernel instead of SDMA copies      TEASER_HIP_H2D_KERNEL
+  S_DEPTH,             // lanes of a new handle (1..16)                                  TEASER_HIP_DEPTH
+  S_STAGGER,           // 0 off; 1..3: where a lane's K1-done event is recorded          TEASER_HIP_STAGGER
+  S_K1_STREAM,         // 0 / 1 / 2: shared K1 stream schedules                          TEASER_HIP_K1_STREAM
+  S_TAIL_CUS,          // > 0: CU partition between K1 and the tail streams              TEASER_HIP_TAIL_CUS
+  S_TAIL_CU_BLOCK,     //                                                                TEASER_HIP_TAIL_CU_BLOCK
+  S_K4_LDS_STACK,      // bytes of LDS for the exact search's level records              TEASER_K4_LDS_STACK
+  S_K4_DONATE,         // 0: no donation queue in the exact search                       TEASER_K4_DONATE
+  S_K4_DONATE_AFTER,   // -1: built-in                                                   TEASER_K4_DONATE_AFTER
+  S_K4_HUNGRY,         // -1: built-in                                                   TEASER_K4_HUNGRY
+  S_K4_EXPAND,         // -1: built-in number of expansion passes                        TEASER_K4_EXPAND
+  S_K4_DEBUG,          // 1: exact-stage diagnostics on stderr                           TEASER_K4_DEBUG
+  S_HEU_BLOCKS,        // 0: built-in workgroups per problem of the heuristic            TEASER_HEU_BLOCKS
+  S_GREEDY_THREADS,    // 0: built-in; 256 / 512                                         TEASER_GREEDY_THREADS
+  S_COUNT
+};
+int64_t setting(Setting id);
+bool set_setting(const char* name, int64_t value);  // name as in teaser_hip_set_option; false: unknown name
 
 // ---- kernel launchers (implemented in the .hip files) -------------------------------------
 // K1: fused TIM norms + scale pruning + symmetric adjacency bitmap (kernels_graph.hip)
@@ -107,6 +138,8 @@ void launch_tim_graph(hipStream_t s, const ProbDesc* d_desc, int batch, int max_
 int64_t tim_prep_bytes(int batch);
 int64_t tim_operand_bytes(int64_t total_tiles);  // total_tiles = sum of the problems' W
 int64_t tim_work_items(const int32_t* n, int batch);
+// writes the per-problem worklist segments into the host-staged (otherwise zero) prep block of the header upload
+int64_t tim_prep_fill_segments(void* host_prep, const int32_t* n, int batch);
 // phase 1 also leaves the vertex degrees in d_deg (row popcounts accumulated by the kernel)
 void launch_tim_graph_mfma(hipStream_t s, int phase, const ProbDesc* d_desc, int batch, int max_n,
                            int64_t total_tiles, const double* d_src, const double* d_dst,

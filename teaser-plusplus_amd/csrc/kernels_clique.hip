@@ -820,30 +820,33 @@ void launch_exact_clique(hipStream_t s, ExactProb* d_probs, int nprob, int total
   // LDS of a (one-wave) workgroup: Q / Qc, the compact adjacency when it fits, and the wave's stack of small level
   // records (dfs_subtree) -- as long as the total leaves several workgroups per CU
   const size_t lds_base = (((size_t)2 * ((max_W2 + 1) & ~1) * 8 + (size_t)max_lds_bitmap_bytes) + 15) & ~(size_t)15;
-  static const int stack_env = [] {
-    const char* e = getenv("TEASER_K4_LDS_STACK");  // bytes; 0 = every level record in the HBM arena
-    return e ? atoi(e) : 16384;
-  }();
+  const int stack_env = (int)setting(S_K4_LDS_STACK);  // bytes; 0 = every level record in the HBM arena
   const int lds_stack_bytes = (lds_base + (size_t)stack_env <= 56 * 1024) ? (stack_env & ~15) : 0;
   // donation queue of the sequential phase, carved from the END of the task pool: dcap slots of header | candidate
   // set | clique prefix, then the slots' ready flags.  TEASER_K4_DONATE=0: static tasks only (diagnostics).
-  static const bool donate_env = [] {
-    const char* e = getenv("TEASER_K4_DONATE");
-    return !(e && atoi(e) == 0);
-  }();
+  const bool donate_env = setting(S_K4_DONATE) != 0;
   ExactQueues qs;
   qs.dprefix = std::min(64 * max_W2, 512);
   qs.dslot_bytes = (int32_t)((sizeof(ExactTask) + 8 * (size_t)max_W2 + 4 * (size_t)qs.dprefix + 31) & ~(size_t)31);
   qs.dcap = donate_env ? 32768 : 0;
-  static const int after_env = [] { const char* e = getenv("TEASER_K4_DONATE_AFTER"); return e ? atoi(e) : (int)kDonateAfter; }();
-  static const int hungry_env = [] { const char* e = getenv("TEASER_K4_HUNGRY"); return e ? atoi(e) : kMaxHungry; }();
+  const int after_env = setting(S_K4_DONATE_AFTER) >= 0 ? (int)setting(S_K4_DONATE_AFTER) : (int)kDonateAfter;
+  const int hungry_env = setting(S_K4_HUNGRY) >= 0 ? (int)setting(S_K4_HUNGRY) : kMaxHungry;
   qs.donate_after = after_env;
   qs.max_hungry = hungry_env;
-  int64_t donate_bytes = (int64_t)qs.dcap * (qs.dslot_bytes + 4);
-  if (donate_bytes * 2 > task_pool_bytes) {  // (the host sizes the pool for it; a caller with a small pool gets none)
-    qs.dcap = 0;
-    donate_bytes = 0;
+  // The host sizes the pool as primary queues + the full donation queue (close_clique_bounds); a caller with a
+  // smaller pool keeps what the primary queues need -- two task queues of at least 8192 slots -- and gives the
+  // donation queue the rest (fewer slots, none below 1024).  (The first version compared TWICE the donation bytes
+  // with the whole pool, which switched the queue off for every compact graph of ~450 .. 16 000 vertices.)
+  {
+    const int64_t slot_b = (int64_t)((sizeof(ExactTask) + 8 * (size_t)max_W2 + 31) & ~(size_t)31);
+    const int64_t primary_min = std::min<int64_t>(task_pool_bytes / 2, 2 * 8192 * slot_b);
+    const int64_t room = (task_pool_bytes - primary_min) / (qs.dslot_bytes + 4);
+    if (room < qs.dcap) qs.dcap = room >= 1024 ? (int32_t)room : 0;
   }
+  int64_t donate_bytes = (int64_t)qs.dcap * (qs.dslot_bytes + 4);
+  if (setting(S_K4_DEBUG))
+    fprintf(stderr, "[teaser_hip] exact search: donation queue %s (%d slots of %d B, max_W2 %d, pool %.1f MB)\n",
+            qs.dcap > 0 ? "active" : "OFF", (int)qs.dcap, (int)qs.dslot_bytes, max_W2, task_pool_bytes / 1048576.0);
   task_pool_bytes -= donate_bytes;
   qs.dpool = d_task_pool + task_pool_bytes;
   qs.dready = reinterpret_cast<int32_t*>(qs.dpool + (int64_t)qs.dcap * qs.dslot_bytes);
@@ -863,10 +866,9 @@ void launch_exact_clique(hipStream_t s, ExactProb* d_probs, int nprob, int total
   // expansion passes between the roots and the sequential search: every pass turns each task into its children
   // (breadth first; the colouring of a node is done once, by whichever pass reaches it), so that a heavy subtree is
   // cut into many small ones -- the search's wall time is its longest task
-  static const int passes = [] {
-    const char* e = getenv("TEASER_K4_EXPAND");
-    const int v = e ? atoi(e) : kExactExpandPasses;
-    return v < 0 ? 0 : (v > kTaskPrefix - 1 ? kTaskPrefix - 1 : v);
+  const int passes = [] {
+    const int v = setting(S_K4_EXPAND) >= 0 ? (int)setting(S_K4_EXPAND) : kExactExpandPasses;
+    return v > kTaskPrefix - 1 ? kTaskPrefix - 1 : v;
   }();
   (void)hipMemsetAsync(d_counters, 0, (size_t)kExactCounterInts * sizeof(int32_t), s);
   if (qs.dcap > 0) (void)hipMemsetAsync(qs.dready, 0, (size_t)qs.dcap * sizeof(int32_t), s);

@@ -1,0 +1,773 @@
+// kernels_heuristic.hip -- gfx950 kernels of the clique stages that stand in for pmc's compute_cores + pmc_heu
+// (reference graph.cc:58-59, 88-102) on the adjacency bitmap K1 leaves:
+//   K3  greedy_clique_kernel   multi-start greedy clique (lower bound lb, candidate clique) + select_best_kernel
+//   K2  peel_round_kernel      k-core style peel at threshold lb (closes the bound when alive <= lb)
+#include <algorithm>
+#include <utility>
+#include <vector>
+
+#include <cstdio>
+#include <cstdlib>
+
+#include "internal.h"
+#include "wave_utils.h"
+
+namespace thip {
+
+// ------------------------------------------------------------------------------------------
+// greedy clique from one start vertex (one 512-thread workgroup per (start, problem)).
+//   candidates P = common neighbourhood of the clique so far, an LDS bitset over all vertices.
+//   |P| > kCap  : shrink P.  Cheap "static" picks (candidate of largest global degree) while they
+//                 shrink P by >10 %; when they stop doing so P is close to a clique, and a
+//                 streaming vote round (a wave per candidate over its bitmap row in HBM/L2) adds
+//                 every candidate adjacent to all others at once.
+//   |P| <= kCap : the candidates' induced subgraph is gathered ONCE into a compact |P| x |P| bit
+//                 matrix in LDS (lane = candidate column, one ballot per 64 columns); all further
+//                 vote rounds run out of LDS:  d(u) = |N(u) & P|;  every u with d(u) = |P|-1 is
+//                 adjacent to all other candidates and joins at once;  then the candidate with the
+//                 largest d joins and P shrinks to its neighbours.
+// Deterministic: every tie is broken towards the smallest vertex index.
+// ------------------------------------------------------------------------------------------
+constexpr int kGreedyMaxThreads = 512;  // LDS layout is sized for this; the kernel runs with T <= it
+constexpr int kCap = 640;            // compact-mode candidate cap
+constexpr int kCapW = kCap / 64;     // words per compact row
+constexpr int kCapStride = kCapW + 1;  // odd row stride (in 8-byte words): conflict-free ds_read_b64
+
+template <int kGreedyWaves>
+__device__ __forceinline__ int blockN_sum_i(int v, int* red /* kGreedyWaves */) {
+  v = wave_sum_i(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  int s = 0;
+#pragma unroll
+  for (int k = 0; k < kGreedyWaves; ++k) s += red[k];
+  return s;
+}
+template <int kGreedyWaves>
+__device__ __forceinline__ unsigned long long blockN_max_u64(unsigned long long v,
+                                                             unsigned long long* red) {
+  v = wave_max_u64(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  unsigned long long m = 0;
+#pragma unroll
+  for (int k = 0; k < kGreedyWaves; ++k) m = red[k] > m ? red[k] : m;
+  return m;
+}
+
+// T threads per workgroup: 512 (lowest latency when the GPU is otherwise idle) or 256 (4 waves: a
+// workgroup then fits into the slot ONE retiring K1 workgroup frees, which is what lets the tail of a
+// batch run beside the next batch's K1).
+// One start (index sidx) of problem blockIdx.y; returns the clique size (also left in start_size[sidx]).
+template <int kGreedyThreads>
+__device__ __forceinline__ int greedy_one_start(
+    const ProbDesc* __restrict__ descs, const uint64_t* __restrict__ bitmap,
+    const int32_t* __restrict__ deg, ProbState* __restrict__ states,
+    int32_t* __restrict__ start_cliques, int64_t total_n, char* smem, const int sidx) {
+  constexpr int kGreedyWaves = kGreedyThreads / 64;
+  const ProbDesc d = descs[blockIdx.y];
+  const int n = d.n, W = d.W;
+  const int Wpad = (W + 1) & ~1;
+  uint64_t* P = reinterpret_cast<uint64_t*>(smem);                      // Wpad
+  uint64_t* U = P + Wpad;                                               // Wpad (streaming rounds)
+  uint64_t* A = U + Wpad;                                               // kCap * kCapStride
+  uint64_t* Pc = A + kCap * kCapStride;                                 // 16
+  unsigned long long* red64 = reinterpret_cast<unsigned long long*>(Pc + 16);  // kGreedyMaxThreads / 64
+  int* cand = reinterpret_cast<int*>(red64 + kGreedyMaxThreads / 64);   // kCap
+  int* wcnt = cand + kCap;                                              // kGreedyMaxThreads
+  int* red = wcnt + kGreedyMaxThreads;                                  // kGreedyMaxThreads / 64
+  int* misc = red + kGreedyMaxThreads / 64;                             // 8
+
+  ProbState* st = states + blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint64_t* bm = bitmap + d.bm_off;
+  const int32_t* dg = deg + d.pt_off;
+  int32_t* C = start_cliques + (int64_t)sidx * total_n + d.pt_off;
+  // start vertex of this workgroup: the max-(degree, lowest index) vertex of residue class
+  // sidx mod kMaxStarts (pmc_heu grows a clique from every vertex in core order; 16 well spread,
+  // high-degree starts stand in for that).  Workgroup 0 also leaves the degree sum (2 x edges).
+  int v0 = -1;
+  {
+    unsigned long long best = 0, sum = 0;
+    for (int v = sidx + kMaxStarts * tid; v < n; v += kMaxStarts * kGreedyThreads) {
+      const unsigned long long dv = (unsigned int)dg[v];
+      const unsigned long long key = ((dv + 1) << 32) | (0xffffffffu - (unsigned int)v);
+      best = key > best ? key : best;
+    }
+    best = blockN_max_u64<kGreedyWaves>(best, red64);
+    if (best) v0 = (int)(0xffffffffu - (unsigned int)(best & 0xffffffffu));
+    if (sidx == 0) {
+      for (int v = tid; v < n; v += kGreedyThreads) sum += (unsigned int)dg[v];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+      __syncthreads();
+      if (lane == 0) red64[wave] = sum;
+      __syncthreads();
+      if (tid == 0) {
+        unsigned long long tot = 0;
+        for (int k = 0; k < kGreedyWaves; ++k) tot += red64[k];
+        st->deg_sum = tot;
+      }
+      __syncthreads();
+    }
+    if (tid == 0) st->start_vertex[sidx] = v0;
+  }
+  if (v0 < 0 || n <= 0) {
+    if (threadIdx.x == 0) st->start_size[sidx] = 0;
+    return 0;
+  }
+
+  int csize = 1;
+  if (tid == 0) C[0] = v0;
+  int pc = 0;
+  for (int w = tid; w < W; w += kGreedyThreads) {
+    const uint64_t x = bm[(int64_t)v0 * W + w];
+    P[w] = x;
+    pc += __popcll(x);
+  }
+  pc = blockN_sum_i<kGreedyWaves>(pc, red);
+
+  // ---- phase 1: shrink P to at most kCap candidates --------------------------------------
+  bool prefer_vote = false;
+  while (pc > kCap) {
+    if (!prefer_vote) {
+      // static pick: largest global degree, ties to the smallest index
+      unsigned long long key = 0;
+      for (int w = tid; w < W; w += kGreedyThreads) {
+        uint64_t bits = P[w];
+        while (bits) {
+          const int u = w * 64 + __builtin_ctzll(bits);
+          bits &= bits - 1;
+          const unsigned long long k =
+              ((unsigned long long)(unsigned int)dg[u] << 32) | (0xffffffffu - (unsigned int)u);
+          key = k > key ? k : key;
+        }
+      }
+      key = blockN_max_u64<kGreedyWaves>(key, red64);
+      const int u = (int)(0xffffffffu - (unsigned int)(key & 0xffffffffu));
+      if (tid == 0) C[csize] = u;
+      ++csize;
+      int c = 0;
+      __syncthreads();
+      for (int w = tid; w < W; w += kGreedyThreads) {
+        const uint64_t x = P[w] & bm[(int64_t)u * W + w];
+        P[w] = x;
+        c += __popcll(x);
+      }
+      c = blockN_sum_i<kGreedyWaves>(c, red);
+      prefer_vote = (long long)c * 10 > (long long)pc * 9;
+      pc = c;
+      continue;
+    }
+    // streaming vote round over the set bits of P: wave `wave` owns words wave, wave+8, ...
+    if (tid == 0) misc[0] = csize;
+    unsigned long long bestk = 0;
+    for (int w = wave; w < W; w += kGreedyWaves) {
+      uint64_t bits = P[w];
+      uint64_t uni = 0;
+      while (bits) {
+        const int b = __builtin_ctzll(bits);
+        bits &= bits - 1;
+        const int u = w * 64 + b;
+        const uint64_t* ru = bm + (int64_t)u * W;
+        int c = 0;
+        for (int x = lane; x < W; x += 64) c += __popcll(ru[x] & P[x]);
+        c = wave_sum_i(c);
+        if (c == pc - 1) {
+          uni |= 1ull << b;
+        } else {
+          const unsigned long long kk =
+              ((unsigned long long)(unsigned int)(c + 1) << 32) | (0xffffffffu - (unsigned int)u);
+          bestk = kk > bestk ? kk : bestk;
+        }
+      }
+      if (lane == 0) U[w] = uni;
+    }
+    bestk = blockN_max_u64<kGreedyWaves>(bestk, red64);  // (barriers inside: U and misc[0] are visible after)
+    // append the universal candidates (any order: the final clique is re-sorted) and drop them
+    int nU = 0;
+    for (int w = tid; w < W; w += kGreedyThreads) {
+      uint64_t bits = U[w];
+      if (bits) {
+        const int k = __popcll(bits);
+        int pos = atomicAdd(&misc[0], k);
+        nU += k;
+        P[w] &= ~bits;
+        while (bits) {
+          C[pos++] = w * 64 + __builtin_ctzll(bits);
+          bits &= bits - 1;
+        }
+      }
+    }
+    nU = blockN_sum_i<kGreedyWaves>(nU, red);
+    csize += nU;
+    const int left = pc - nU;
+    if (left > 0 && bestk) {
+      const int u = (int)(0xffffffffu - (unsigned int)(bestk & 0xffffffffu));
+      if (tid == 0) C[csize] = u;
+      ++csize;
+      int c = 0;
+      for (int w = tid; w < W; w += kGreedyThreads) {
+        const uint64_t x = P[w] & bm[(int64_t)u * W + w];
+        P[w] = x;
+        c += __popcll(x);
+      }
+      c = blockN_sum_i<kGreedyWaves>(c, red);
+      prefer_vote = (long long)c * 10 > (long long)left * 9;
+      pc = c;
+    } else {
+      pc = 0;
+      __syncthreads();
+    }
+  }
+
+  if (pc > 0) {
+    // ---- phase 2: candidate list in index order (contiguous word chunks per thread) -------
+    const int wpt = (W + kGreedyThreads - 1) / kGreedyThreads;
+    const int w0 = tid * wpt, w1 = min(W, w0 + wpt);
+    int mycnt = 0;
+    for (int w = w0; w < w1; ++w) mycnt += __popcll(P[w]);
+    wcnt[tid] = mycnt;
+    __syncthreads();
+    if (wave == 0) {  // exclusive scan over kGreedyThreads entries (kGreedyWaves per lane)
+      constexpr int kPer = kGreedyWaves;
+      int a[kPer], tot = 0;
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        a[k] = wcnt[kPer * lane + k];
+        tot += a[k];
+      }
+      int incl = tot;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+      }
+      int ex = incl - tot;
+#pragma unroll
+      for (int k = 0; k < kPer; ++k) {
+        wcnt[kPer * lane + k] = ex;
+        ex += a[k];
+      }
+    }
+    __syncthreads();
+    {
+      int pos = wcnt[tid];
+      for (int w = w0; w < w1; ++w) {
+        uint64_t bits = P[w];
+        while (bits) {
+          cand[pos++] = w * 64 + __builtin_ctzll(bits);
+          bits &= bits - 1;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- phase 3: compact adjacency A[r][k] bit l = edge(cand[r], cand[64k+l]) -------------
+    const int Wc = (pc + 63) >> 6;
+    // A lane needs ONE bit of a row per 64-candidate group: it loads the 32-bit half that holds it, so that FOUR rows
+    // (kCapW loads each) are in flight per wave in the registers two rows of 64-bit words took -- the gather is a chain
+    // of dependent round trips to L2 (r3d/heu_trace: 143 us of a start's ~200), not a matter of bytes
+    int cw[kCapW], cb[kCapW];
+    unsigned int vmask = 0;
+#pragma unroll
+    for (int k = 0; k < kCapW; ++k) {
+      const int idx = 64 * k + lane;
+      const bool ok = idx < pc;
+      const int c = ok ? cand[idx] : 0;
+      cw[k] = c >> 5;   // 32-bit word of the row
+      cb[k] = c & 31;
+      vmask |= ok ? (1u << k) : 0u;
+    }
+    const unsigned int* bm32 = reinterpret_cast<const unsigned int*>(bm);
+    constexpr int kRowsInFlight = 4;
+    for (int r = wave; r < pc; r += kRowsInFlight * kGreedyWaves) {
+      const unsigned int* rp[kRowsInFlight];
+      bool has[kRowsInFlight];
+#pragma unroll
+      for (int j = 0; j < kRowsInFlight; ++j) {
+        const int rj = r + j * kGreedyWaves;
+        has[j] = rj < pc;
+        rp[j] = bm32 + 2 * ((int64_t)cand[has[j] ? rj : r] * W);
+      }
+      unsigned int x[kRowsInFlight][kCapW];
+#pragma unroll
+      for (int j = 0; j < kRowsInFlight; ++j)
+#pragma unroll
+        for (int k = 0; k < kCapW; ++k) x[j][k] = (k < Wc) ? rp[j][cw[k]] : 0u;
+      uint64_t m[kRowsInFlight] = {0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < kCapW; ++k) {
+        const bool ok = (vmask >> k) & 1u;
+#pragma unroll
+        for (int j = 0; j < kRowsInFlight; ++j) {
+          const uint64_t b = __ballot(ok && ((x[j][k] >> cb[k]) & 1u));
+          if (lane == k) m[j] = b;
+        }
+      }
+      if (lane < Wc) {
+#pragma unroll
+        for (int j = 0; j < kRowsInFlight; ++j)
+          if (has[j]) A[(r + j * kGreedyWaves) * kCapStride + lane] = m[j];
+      }
+    }
+    if (tid < 16) {
+      const int lo = tid * 64;
+      Pc[tid] = (lo + 64 <= pc) ? ~0ull : (lo < pc ? ((1ull << (pc - lo)) - 1ull) : 0ull);
+    }
+    if (tid == 0) misc[0] = csize;
+    __syncthreads();
+
+    // ---- phase 4: vote rounds on the compact matrix (all in LDS) ---------------------------
+    int pcnt = pc;
+    while (pcnt > 0) {
+      constexpr int kVote = (kCap + kGreedyThreads - 1) / kGreedyThreads;
+      int dv[kVote];
+      bool in[kVote];
+#pragma unroll
+      for (int j = 0; j < kVote; ++j) {
+        const int c = tid + kGreedyThreads * j;
+        in[j] = c < pc && ((Pc[c >> 6] >> (c & 63)) & 1ull);
+        int dd = 0;
+        if (in[j]) {
+          for (int w = 0; w < Wc; ++w) dd += __popcll(A[c * kCapStride + w] & Pc[w]);
+        }
+        dv[j] = dd;
+      }
+      __syncthreads();  // all votes read Pc before it is modified
+      unsigned long long bestk = 0;
+#pragma unroll
+      for (int j = 0; j < kVote; ++j) {
+        const int c = tid + kGreedyThreads * j;
+        const bool isU = in[j] && dv[j] == pcnt - 1;
+        const uint64_t m = __ballot(isU);
+        if (m) {
+          int base = 0;
+          if (lane == 0) base = atomicAdd(&misc[0], __popcll(m));
+          base = __shfl(base, 0, 64);
+          if (isU) {
+            C[base + __popcll(m & ((1ull << lane) - 1ull))] = cand[c];
+            atomicAnd(reinterpret_cast<unsigned long long*>(&Pc[c >> 6]), ~(1ull << (c & 63)));
+          }
+        }
+        if (in[j] && !isU) {
+          const unsigned long long kk =
+              ((unsigned long long)(unsigned int)(dv[j] + 1) << 32) | (0xffffffffu - (unsigned int)c);
+          bestk = kk > bestk ? kk : bestk;
+        }
+      }
+      bestk = blockN_max_u64<kGreedyWaves>(bestk, red64);
+      csize = misc[0];
+      int left = 0;
+      for (int w = 0; w < Wc; ++w) left += __popcll(Pc[w]);
+      __syncthreads();
+      if (left > 0 && bestk) {
+        const int bc = (int)(0xffffffffu - (unsigned int)(bestk & 0xffffffffu));
+        if (tid == 0) {
+          C[csize] = cand[bc];
+          misc[0] = csize + 1;
+        }
+        ++csize;
+        if (tid < Wc) Pc[tid] &= A[bc * kCapStride + tid];
+        __syncthreads();
+        pcnt = 0;
+        for (int w = 0; w < Wc; ++w) pcnt += __popcll(Pc[w]);
+      } else {
+        pcnt = 0;
+      }
+    }
+  }
+  if (tid == 0) st->start_size[sidx] = csize;
+  return csize;
+}
+
+// One round of the closure test (greedy_clique_kernel): keep the alive vertices with >= csize alive neighbours.
+// NOT inlined: its 16 loads in flight per lane would add to the greedy kernel's register peak (167 VGPRs: more
+// than 208 and a greedy wave no longer fits where ONE K1 wave has retired).
+template <int kGreedyThreads>
+__device__ __attribute__((noinline)) void closure_round(const uint64_t* __restrict__ bm, int W, const uint64_t* Pa,
+                                                        uint64_t* Pb, const int* alist, int cnt, int csize, int tid) {
+      // One round = the bitmap rows of every alive vertex (~640 x 1.25 KB at N = 10 k, cold in HBM) against the alive
+  // bitset.  What bounds it is memory-level parallelism, not bytes: one thread per row, and then 16 lanes per row
+  // with one row per group, both left a single memory latency per pass exposed (158 us per round, half of this
+  // workgroup's time: profiles/r3d/heu_trace_*.txt).  Here a group of 16 lanes owns kRowsPerGroup rows at a time
+  // and issues kChunk loads of each before it consumes any: 20 loads in flight per lane (more would push the kernel past
+  // the 208 VGPRs one retiring K1 wave leaves free on a SIMD), 64 rows per workgroup
+  // pass.
+  constexpr int kLanesPerRow = 16, kRowsPerGroup = 4, kChunk = 5;
+  constexpr int kRowsPerPass = kGreedyThreads / kLanesPerRow * kRowsPerGroup;
+  const int gid = tid / kLanesPerRow, sub = tid % kLanesPerRow;
+#pragma unroll 1
+  for (int k0 = 0; k0 < cnt; k0 += kRowsPerPass) {
+    int v[kRowsPerGroup], c[kRowsPerGroup];
+    const uint64_t* row[kRowsPerGroup];
+#pragma unroll
+    for (int r = 0; r < kRowsPerGroup; ++r) {
+      const int k = k0 + gid * kRowsPerGroup + r;
+      v[r] = k < cnt ? alist[k] : -1;
+      row[r] = bm + (int64_t)(v[r] < 0 ? 0 : v[r]) * W;
+      c[r] = 0;
+    }
+#pragma unroll 1
+    for (int x0 = 0; x0 < W; x0 += kLanesPerRow * kChunk) {
+      uint64_t buf[kRowsPerGroup][kChunk];
+#pragma unroll
+      for (int r = 0; r < kRowsPerGroup; ++r)
+#pragma unroll
+        for (int u = 0; u < kChunk; ++u) {
+          const int x = x0 + u * kLanesPerRow + sub;
+          buf[r][u] = (x < W && v[r] >= 0) ? row[r][x] : 0ull;
+        }
+#pragma unroll
+      for (int u = 0; u < kChunk; ++u) {
+        const int x = x0 + u * kLanesPerRow + sub;
+        const uint64_t pa = x < W ? Pa[x] : 0ull;
+#pragma unroll
+        for (int r = 0; r < kRowsPerGroup; ++r) c[r] += __popcll(buf[r][u] & pa);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < kRowsPerGroup; ++r) {
+      int cc = c[r];
+      cc += __shfl_xor(cc, 8, 64);
+      cc += __shfl_xor(cc, 4, 64);
+      cc += __shfl_xor(cc, 2, 64);
+      cc += __shfl_xor(cc, 1, 64);
+      if (v[r] >= 0 && sub == 0 && cc >= csize)
+        atomicOr(reinterpret_cast<unsigned long long*>(&Pb[v[r] >> 6]), 1ull << (v[r] & 63));
+    }
+  }
+}
+
+// Grid (B, batch): B workgroups per problem share the kMaxStarts starts.  Workgroup x begins with start x;
+// further starts come from the problem's queue (ProbState.next_start, initialised to B by the host) until it
+// is empty or the problem is CLOSED: a start whose clique of size c leaves at most c vertices in the peel at
+// threshold c (alive = {deg >= c}; repeatedly keep the vertices with >= c alive neighbours: a clique of c + 1
+// vertices survives every round) has found a maximum clique, and no start
+// fetched later can be selected -- the selection takes the largest clique and breaks ties towards the LOWEST
+// start, starts are fetched in increasing order, and a start once fetched always runs to completion.  So the
+// selected clique is the one all kMaxStarts starts would give, whatever the timing, while in the common case
+// (one start already finds the maximum clique) a problem costs B greedy runs instead of kMaxStarts.
+// B = kMaxStarts (small batches: lowest latency) makes the queue empty from the outset.
+template <int kGreedyThreads>
+__global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
+    const ProbDesc* __restrict__ descs, const uint64_t* __restrict__ bitmap,
+    const int32_t* __restrict__ deg, ProbState* __restrict__ states,
+    int32_t* __restrict__ start_cliques, int64_t total_n) {
+  TAIL_WAVE_PRIO();
+  constexpr int kGreedyWaves = kGreedyThreads / 64;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int next_s;
+  __shared__ int red_c[kGreedyWaves];
+  ProbState* st = states + blockIdx.y;
+  const ProbDesc d = descs[blockIdx.y];
+  int sidx = blockIdx.x;
+  while (sidx < kMaxStarts) {
+    const int csize = greedy_one_start<kGreedyThreads>(descs, bitmap, deg, states, start_cliques, total_n, smem, sidx);
+    if (gridDim.x >= kMaxStarts) break;  // every start has its own workgroup: nothing left to skip
+    // closure test: the peel at threshold csize, in LDS (the start's P / U bitsets are free again)
+    const int W = d.W, tid = threadIdx.x;
+    uint64_t* Pa = reinterpret_cast<uint64_t*>(smem);
+    uint64_t* Pb = Pa + ((W + 1) & ~1);
+    const uint64_t* bm = bitmap + d.bm_off;
+    int cnt = 0;
+    __syncthreads();
+    // alive = { deg >= csize }: a wave builds a word with ONE coalesced load + ballot (a thread per word read its 64
+    // degrees one by one, 64 different cache lines per wave-level load: ~100 us of this test's 177)
+    for (int w = tid >> 6; w < W; w += kGreedyWaves) {
+      const int v = w * 64 + (tid & 63);
+      const uint64_t bits = __ballot(v < d.n && deg[d.pt_off + v] >= csize);
+      if ((tid & 63) == 0) {
+        Pa[w] = bits;
+        cnt += __popcll(bits);
+      }
+    }
+    cnt = blockN_sum_i<kGreedyWaves>(cnt, red_c);  // (barriers inside: Pa is visible after)
+    // Only worth trying when the survivors are few.  The alive vertices are listed (index list in the LDS region of
+    // the start's compact matrix) and their bitmap rows counted against the alive bitset, several rows in flight per
+    // wave (one wave per row was a dependent round trip to L2 per row: 0.7 ms beside K1 in the benchmark).
+    constexpr int kClosureCap = 4096;
+    int* alist = reinterpret_cast<int*>(Pb + ((W + 1) & ~1));  // the A region: >= kCap * kCapStride * 8 bytes
+    for (int round = 0; round < 8 && cnt > csize && cnt <= 2 * csize + 256 && cnt <= kClosureCap; ++round) {
+      if (tid == 0) next_s = 0;
+      for (int w = tid; w < W; w += kGreedyThreads) Pb[w] = 0;
+      __syncthreads();
+      for (int w = tid; w < W; w += kGreedyThreads) {  // (order of the list is irrelevant)
+        uint64_t bits = Pa[w];
+        if (bits) {
+          int pos = atomicAdd(&next_s, __popcll(bits));
+          while (bits) {
+            alist[pos++] = w * 64 + __builtin_ctzll(bits);
+            bits &= bits - 1;
+          }
+        }
+      }
+      __syncthreads();
+      closure_round<kGreedyThreads>(bm, W, Pa, Pb, alist, cnt, csize, tid);
+      __syncthreads();
+      int c2 = 0;
+      for (int w = tid; w < W; w += kGreedyThreads) {
+        const uint64_t x = Pb[w];
+        Pa[w] = x;
+        c2 += __popcll(x);
+      }
+      c2 = blockN_sum_i<kGreedyWaves>(c2, red_c);
+      if (c2 == cnt) break;  // fixpoint above csize: not closed
+      cnt = c2;
+    }
+    if (threadIdx.x == 0) {
+      int nx = kMaxStarts;
+      if (cnt <= csize) {
+        __hip_atomic_store(&st->heu_closed, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else if (!__hip_atomic_load(&st->heu_closed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+        nx = atomicAdd(&st->next_start, 1);
+      }
+      next_s = nx;
+    }
+    __syncthreads();
+    sidx = next_s;
+    __syncthreads();
+  }
+}
+
+// Per problem: choose the best start (largest clique, ties to the lowest start), emit it SORTED
+// into d_clique via an LDS membership bitset, set lb, and initialise the peel: alive = deg >= lb.
+__global__ __launch_bounds__(256) void select_best_kernel(
+    const ProbDesc* __restrict__ descs, const int32_t* __restrict__ deg,
+    ProbState* __restrict__ states, const int32_t* __restrict__ start_cliques, int64_t total_n,
+    int32_t* __restrict__ clique, uint64_t* __restrict__ alive_a, int do_peel) {
+  TAIL_WAVE_PRIO();
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const ProbDesc d = descs[blockIdx.x];
+  const int n = d.n, W = d.W;
+  uint64_t* memb = reinterpret_cast<uint64_t*>(smem);  // W
+  int* wcnt = reinterpret_cast<int*>(memb + ((W + 1) & ~1));  // 256
+  int* red4 = wcnt + 256;
+  ProbState* st = states + blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int best = 0, bs = -1;
+  for (int s = 0; s < kMaxStarts; ++s) {
+    const int sz = st->start_size[s];
+    if (sz > best) {
+      best = sz;
+      bs = s;
+    }
+  }
+  if (n == 1 && best == 0) {  // single vertex: the clique is that vertex
+    if (tid == 0) {
+      clique[d.pt_off] = 0;
+      st->lb = 1;
+      st->clique_size = 1;
+      st->proven = 1;
+      st->peel_done = 1;
+    }
+    return;
+  }
+  for (int w = tid; w < W; w += 256) memb[w] = 0;
+  __syncthreads();
+  if (bs >= 0) {
+    const int32_t* C = start_cliques + (int64_t)bs * total_n + d.pt_off;
+    for (int k = tid; k < best; k += 256) {
+      const int u = C[k];
+      atomicOr(reinterpret_cast<unsigned long long*>(&memb[u >> 6]), 1ull << (u & 63));
+    }
+  }
+  __syncthreads();
+  // enumerate members in ascending order
+  const int wpt = (W + 255) / 256;
+  const int w0 = tid * wpt, w1 = min(W, w0 + wpt);
+  int mycnt = 0;
+  for (int w = w0; w < w1; ++w) mycnt += __popcll(memb[w]);
+  wcnt[tid] = mycnt;
+  __syncthreads();
+  if (wave == 0) {
+    int a0 = wcnt[4 * lane], a1 = wcnt[4 * lane + 1], a2 = wcnt[4 * lane + 2],
+        a3 = wcnt[4 * lane + 3];
+    int tot = a0 + a1 + a2 + a3, incl = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    int ex = incl - tot;
+    wcnt[4 * lane] = ex;
+    wcnt[4 * lane + 1] = ex + a0;
+    wcnt[4 * lane + 2] = ex + a0 + a1;
+    wcnt[4 * lane + 3] = ex + a0 + a1 + a2;
+  }
+  __syncthreads();
+  {
+    int pos = wcnt[tid];
+    int32_t* out = clique + d.pt_off;
+    for (int w = w0; w < w1; ++w) {
+      uint64_t bits = memb[w];
+      while (bits) {
+        out[pos++] = w * 64 + __builtin_ctzll(bits);
+        bits &= bits - 1;
+      }
+    }
+  }
+  // peel init: alive = { v : deg(v) >= lb }   (a clique of lb+1 needs degree >= lb)
+  int alive = 0;
+  if (do_peel) {
+    const int32_t* dg = deg + d.pt_off;
+    uint64_t* al = alive_a + d.w_off;
+    for (int w = tid; w < W; w += 256) {
+      uint64_t bits = 0;
+      const int vmax = min(64, n - w * 64);
+      for (int b = 0; b < vmax; ++b) bits |= (uint64_t)(dg[w * 64 + b] >= best ? 1 : 0) << b;
+      al[w] = bits;
+      alive += __popcll(bits);
+    }
+    alive = block_sum_i(alive, red4);
+  }
+  if (tid == 0) {
+    st->lb = best;
+    st->best_start = bs;
+    st->clique_size = best;
+    st->alive_count = alive;
+    // (closed by the degree count here, or already by a heuristic start's own peel: its clique is then the
+    // largest one, i.e. the one selected above)
+    const int closed = do_peel ? ((alive <= best) || st->heu_closed) : 0;
+    st->proven = closed;
+    st->peel_done = do_peel ? closed : 1;
+  }
+}
+
+size_t greedy_lds_bytes(int max_W) {
+  const size_t Wpad = (size_t)((max_W + 1) & ~1);
+  return Wpad * 8 * 2 + (size_t)kCap * kCapStride * 8 + 16 * 8 + (kGreedyMaxThreads / 64) * 8 + (size_t)kCap * 4 +
+         kGreedyMaxThreads * 4 + (kGreedyMaxThreads / 64) * 4 + 8 * 4;
+}
+
+// workgroups per problem of the heuristic (the host initialises ProbState.next_start with it)
+int heuristic_blocks_per_problem(int batch, int max_W) {
+  const int forced = (int)setting(S_HEU_BLOCKS);  // diagnostics
+  if (forced >= 1 && forced <= kMaxStarts) return forced;
+  // about 128 workgroups in flight: every start in parallel for small batches (lowest latency, the GPU is
+  // otherwise idle), ONE workgroup per problem from 64 problems on (they run beside the next batch's K1, whose
+  // time they inflate: 1 measured 3-5 % faster than 2, 2 6 % faster than 4; profiles/r4l, r4m)
+  // (small graphs -- descriptor correspondences, a few hundred vertices -- are seldom closed by their first start:
+  // four workgroups share the 16 starts there, config 5 x 64: 3.2 -> 0.9 ms of heuristic stage)
+  if (batch >= 64) return max_W >= 32 ? 1 : 4;
+  return std::max(2, std::min(kMaxStarts, 128 / std::max(batch, 1)));
+}
+
+void launch_heuristic(hipStream_t s, const ProbDesc* d_desc, int batch, int max_W,
+                      const uint64_t* d_bitmap, const int32_t* d_deg, ProbState* d_state,
+                      int32_t* d_start_cliques, int64_t total_n, int32_t* d_cand,
+                      int32_t* d_clique) {
+  if (batch <= 0) return;
+  const int nblk = heuristic_blocks_per_problem(batch, max_W);
+  const size_t lds = greedy_lds_bytes(max_W);
+  // Small batches (<= 16 problems = at most one workgroup per CU) run 512-thread workgroups: nothing
+  // competes for the CUs and the gather loops finish sooner (N = 1889: 0.51 vs 0.90 ms).  Larger batches
+  // run 256-thread workgroups, which co-schedule with the next batch's K1 (see the kernel).
+  // Setting greedy_threads = 256 | 512 forces one (diagnostics).
+  const int forced = (int)setting(S_GREEDY_THREADS);
+  const bool wide = forced ? forced == 512 : batch <= 16;
+  static DynLdsOptIn optin256, optin512;  // beyond the 64 KB default dynamic-LDS limit once W >= ~300
+  if (wide) {
+    if (lds > 48 * 1024) optin512.ensure(reinterpret_cast<const void*>(greedy_clique_kernel<512>), (int)lds);
+    hipLaunchKernelGGL(greedy_clique_kernel<512>, dim3(nblk, batch), dim3(512), lds, s, d_desc, d_bitmap,
+                       d_deg, d_state, d_start_cliques, total_n);
+  } else {
+    if (lds > 48 * 1024) optin256.ensure(reinterpret_cast<const void*>(greedy_clique_kernel<256>), (int)lds);
+    hipLaunchKernelGGL(greedy_clique_kernel<256>, dim3(nblk, batch), dim3(256), lds, s, d_desc, d_bitmap,
+                       d_deg, d_state, d_start_cliques, total_n);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// peel rounds at threshold lb: a vertex stays alive iff it has >= lb alive neighbours.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void peel_round_kernel(const ProbDesc* __restrict__ descs,
+                                                         const uint64_t* __restrict__ bitmap,
+                                                         ProbState* __restrict__ states,
+                                                         const uint64_t* __restrict__ cur_mask,
+                                                         uint64_t* __restrict__ nxt_mask,
+                                                         int32_t* __restrict__ next_count /* [batch] counts, [batch] arrivals */,
+                                                         int batch) {
+  TAIL_WAVE_PRIO();
+  __shared__ unsigned long long neww;
+  __shared__ int is_last;
+  const ProbDesc d = descs[blockIdx.y];
+  ProbState* st = states + blockIdx.y;
+  if (st->peel_done) return;  // (every workgroup of the problem sees the same value: it changes only at the end of a launch)
+  const uint64_t* cur = cur_mask + d.w_off;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // (a workgroup walks several 64-vertex tiles: the grid is kept small for large batches, where most
+  // problems are closed already and every workgroup of a launch has to wait for a free slot beside K1)
+  for (int tile = blockIdx.x; tile < d.W; tile += gridDim.x) {
+    const uint64_t aw = cur[tile];
+    if (threadIdx.x == 0) neww = 0;
+    __syncthreads();
+    if (aw) {
+      const int lb = st->lb;
+      const uint64_t* bm = bitmap + d.bm_off;
+      for (int r = wave; r < 64; r += 4) {
+        if (!((aw >> r) & 1ull)) continue;
+        const uint64_t* row = bm + (int64_t)(tile * 64 + r) * d.W;
+        int c = 0;
+        for (int w = lane; w < d.W; w += 64) c += __popcll(row[w] & cur[w]);
+        c = wave_sum_i(c);
+        if (lane == 0 && c >= lb) atomicOr(&neww, 1ull << r);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      nxt_mask[d.w_off + tile] = neww;
+      if (neww) atomicAdd(next_count + blockIdx.y, __popcll(neww));
+    }
+    __syncthreads();
+  }
+  // the round's verdict (what a separate one-thread-per-problem launch used to do: three launches less on the serial
+  // chain of a batch): the problem's LAST workgroup to get here reads the survivor count and updates the state
+  if (threadIdx.x == 0) {
+    __threadfence();
+    is_last = atomicAdd(next_count + batch + blockIdx.y, 1) == (int)gridDim.x - 1;
+  }
+  __syncthreads();
+  if (is_last && threadIdx.x == 0) {
+    __threadfence();
+    const int c = __hip_atomic_load(next_count + blockIdx.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (c == st->alive_count) st->peel_done = 1;  // fixpoint
+    st->alive_count = c;
+    if (c <= st->lb) {
+      st->proven = 1;
+      st->peel_done = 1;
+    }
+    __hip_atomic_store(next_count + blockIdx.y, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(next_count + batch + blockIdx.y, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+void launch_select_best(hipStream_t s, const ProbDesc* d_desc, int batch, int max_W,
+                        const int32_t* d_deg, ProbState* d_state, const int32_t* d_start_cliques,
+                        int64_t total_n, int32_t* d_clique, uint64_t* d_alive_a, int do_peel) {
+  if (batch <= 0) return;
+  const size_t lds = (size_t)((max_W + 1) & ~1) * 8 + 256 * 4 + 4 * 4;
+  hipLaunchKernelGGL(select_best_kernel, dim3(batch), dim3(256), lds, s, d_desc, d_deg, d_state,
+                     d_start_cliques, total_n, d_clique, d_alive_a, do_peel);
+}
+
+void launch_peel_rounds(hipStream_t s, const ProbDesc* d_desc, int batch, int max_W,
+                        const uint64_t* d_bitmap, ProbState* d_state, uint64_t* d_alive_a,
+                        uint64_t* d_alive_b, int32_t* d_next_count, int rounds) {
+  if (batch <= 0) return;
+  uint64_t* cur = d_alive_a;
+  uint64_t* nxt = d_alive_b;
+  const int gx = std::min(max_W, std::max(8, 2048 / batch));
+  for (int r = 0; r < rounds; ++r) {
+    hipLaunchKernelGGL(peel_round_kernel, dim3(gx, batch), dim3(256), 0, s, d_desc, d_bitmap,
+                       d_state, cur, nxt, d_next_count, batch);
+    uint64_t* t = cur;
+    cur = nxt;
+    nxt = t;
+  }
+}
+
+
+}  // namespace thip

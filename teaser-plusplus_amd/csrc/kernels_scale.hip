@@ -576,11 +576,8 @@ static size_t sort_temp_bytes(int64_t m) {
   return bytes > fbytes ? bytes : fbytes;
 }
 
-// 64-bit sort for everything (diagnostics / A-B tests): TEASER_SCALE_SORT64=1
-static bool force_sort64() {  // (read on every call: the A/B test flips it inside one process)
-  const char* e = getenv("TEASER_SCALE_SORT64");
-  return e && atoi(e) != 0;
-}
+// 64-bit sort for everything (setting scale_sort64: the A/B test of the two sort routes)
+static bool force_sort64() { return setting(S_SCALE_SORT64) != 0; }
 
 int64_t scalar_tls_large_workspace_bytes(int64_t n) {
   const int64_t m = 2 * n;

@@ -40,6 +40,64 @@ void launch_fill_identity_clique(hipStream_t s, const ProbDesc* d_desc, int batc
                                  int32_t* d_clique, ProbState* d_state);
 }  // namespace thip
 
+// ---- settings (internal.h) -------------------------------------------------------------------------------------
+namespace thip {
+namespace {
+struct SettingRow {
+  const char* name;  // teaser_hip_set_option name
+  const char* env;   // read once, at the first use of the table
+  int64_t def;
+};
+const SettingRow kSettingRows[S_COUNT] = {
+    {"k1_fp64", "TEASER_HIP_K1_FP64", 0},
+    {"fused_estimators", "TEASER_HIP_FUSED_EST", 1},
+    {"scale_sort64", "TEASER_SCALE_SORT64", 0},
+    {"scale_batch", "TEASER_SCALE_BATCH", 1},
+    {"scale_mid_batch", "TEASER_SCALE_MID_BATCH", 1},
+    {"spec_bounds", "TEASER_HIP_SPEC_BOUNDS", 1},
+    {"finisher", "TEASER_HIP_FINISHER", 1},
+    {"copy_stream", "TEASER_HIP_COPY_STREAM", 0},
+    {"h2d_kernel", "TEASER_HIP_H2D_KERNEL", 0},
+    {"depth", "TEASER_HIP_DEPTH", 2},
+    {"stagger", "TEASER_HIP_STAGGER", 1},
+    {"k1_stream", "TEASER_HIP_K1_STREAM", 0},
+    {"tail_cus", "TEASER_HIP_TAIL_CUS", 0},
+    {"tail_cu_block", "TEASER_HIP_TAIL_CU_BLOCK", 0},
+    {"k4_lds_stack", "TEASER_K4_LDS_STACK", 16384},
+    {"k4_donate", "TEASER_K4_DONATE", 1},
+    {"k4_donate_after", "TEASER_K4_DONATE_AFTER", -1},
+    {"k4_hungry", "TEASER_K4_HUNGRY", -1},
+    {"k4_expand", "TEASER_K4_EXPAND", -1},
+    {"k4_debug", "TEASER_K4_DEBUG", 0},
+    {"heu_blocks", "TEASER_HEU_BLOCKS", 0},
+    {"greedy_threads", "TEASER_GREEDY_THREADS", 0},
+};
+struct SettingTable {
+  std::atomic<int64_t> v[S_COUNT];
+  SettingTable() {
+    for (int i = 0; i < S_COUNT; ++i) {
+      const char* e = getenv(kSettingRows[i].env);
+      v[i].store((e && *e) ? (int64_t)atoll(e) : kSettingRows[i].def);
+    }
+  }
+};
+SettingTable& setting_table() {
+  static SettingTable t;  // (thread-safe initialisation: the environment is read exactly once)
+  return t;
+}
+}  // namespace
+int64_t setting(Setting id) { return setting_table().v[id].load(std::memory_order_relaxed); }
+bool set_setting(const char* name, int64_t value) {
+  if (!name) return false;
+  for (int i = 0; i < S_COUNT; ++i)
+    if (strcmp(name, kSettingRows[i].name) == 0) {
+      setting_table().v[i].store(value, std::memory_order_relaxed);
+      return true;
+    }
+  return false;
+}
+}  // namespace thip
+
 using namespace thip;
 
 // The per-batch header (descriptors | initial states | TIM offsets | zeroed counters) and the problem states
@@ -98,9 +156,19 @@ struct HostTrace {
 HostTrace g_trace;
 
 // One hardware queue per lane (see enqueue_on_lane): the HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES
-// (default 4) hardware queues; lanes that share one serialise.  Effective when this library is loaded before the
-// runtime initialises (its first HIP call); never overrides a value the user exported.
-__attribute__((constructor)) void runtime_defaults() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// (default 4) hardware queues; lanes that share one serialise.  The library does NOT touch the process environment
+// (it used to setenv() from a load-time constructor: a side effect on the host application and a race with its
+// getenv calls).  Export GPU_MAX_HW_QUEUES=8 before the process's first HIP call for the full lane overlap
+// (the Python wrapper does so at import when the variable is unset); a handle created with
+// fewer queues than lanes says so once on stderr.
+void warn_hw_queues_once(int lanes) {
+  static std::atomic<bool> said{false};
+  const char* e = getenv("GPU_MAX_HW_QUEUES");
+  const int q = e ? atoi(e) : 4;
+  if (q < lanes && !said.exchange(true))
+    fprintf(stderr, "[teaser_hip] note: GPU_MAX_HW_QUEUES=%d < %d lanes: batches of different lanes will share a hardware "
+                    "queue (export GPU_MAX_HW_QUEUES=8 before the first HIP call)\n", q, lanes);
+}
 
 struct DevBuf {
   void* p = nullptr;
@@ -495,8 +563,8 @@ int32_t scale_stage_batch(teaser_hip_solver* h, int batch, bool sort64) {
     small.pop_back();
   }
   constexpr int64_t kChunkBytes = (int64_t)8 << 30;
-  static const char* ev = getenv("TEASER_SCALE_BATCH");  // diagnostics: 0 = one problem at a time
-  if (ev && atoi(ev) == 0) small.clear();
+  const bool scale_batch = setting(S_SCALE_BATCH) != 0;  // 0 = one problem at a time
+  if (!scale_batch) small.clear();
   size_t at = 0;
   while (small.size() - at >= 2) {  // (a single small problem takes the per-problem path below)
     std::vector<int32_t> sel;
@@ -542,8 +610,7 @@ int32_t scale_stage_batch(teaser_hip_solver* h, int batch, bool sort64) {
   // kernels around a sort of < 2^24 endpoints) share ONE value sort + one gathering pass + one sweep per chunk of
   // at most kMidChunkTrims TRIMs (kernels_scale.hip); results are bit-identical to the one-problem path.
   std::vector<ScaleSeg> mid;
-  static const char* evm = getenv("TEASER_SCALE_MID_BATCH");  // diagnostics: 0 = one problem at a time
-  const bool mid_on = !(evm && atoi(evm) == 0) && !(ev && atoi(ev) == 0);
+  const bool mid_on = setting(S_SCALE_MID_BATCH) != 0 && scale_batch;
   for (int b = 0; b < batch && mid_on; ++b) {
     const ProbDesc& d = h->descs[(size_t)b];
     if (done[(size_t)b] || d.n < 2 || d.n > kMidScaledN) continue;
@@ -716,7 +783,7 @@ int32_t close_clique_bounds(teaser_hip_solver* h, int batch, int64_t total_n, bo
   const double lim = h->params.max_clique_time_limit;
   const bool limited = lim > 0 && lim < 1e7;
   const auto t_stage = std::chrono::steady_clock::now();
-  static const bool dbg = getenv("TEASER_K4_DEBUG") != nullptr;
+  const bool dbg = setting(S_K4_DEBUG) != 0;
   bool built = false;
   std::vector<ExactProb> run = open;
   for (int attempt = 0; attempt < 8 && !run.empty(); ++attempt) {
@@ -827,13 +894,7 @@ int32_t close_clique_bounds(teaser_hip_solver* h, int batch, int64_t total_n, bo
 // --------------------------------------------------------------------------------------------
 // rotation + translation estimators on the current cliques, then the async copy-back of the
 // problem states (no host sync here)
-bool spec_bounds_enabled() {
-  static const bool on = [] {
-    const char* e = getenv("TEASER_HIP_SPEC_BOUNDS");
-    return !(e && atoi(e) == 0);
-  }();
-  return on;
-}
+bool spec_bounds_enabled() { return setting(S_SPEC_BOUNDS) != 0; }
 
 // The first half of close_clique_bounds for EVERY problem of the batch, without the host (see spec_bounds_next): the
 // colouring bound, the root filter and the candidate sizes run behind the peel, guarded on the device by the problem's
@@ -884,8 +945,7 @@ int32_t enqueue_estimators(teaser_hip_solver* h) {
   ProbState* ds = h->d_state.as<ProbState>();
   const EstParams ep = est_params(h->params);
   // TEASER_HIP_FUSED_EST=0: the three separate launches (rotation, translation, state push) instead of the fused one
-  const char* fe = getenv("TEASER_HIP_FUSED_EST");  // (read per call: the A/B test switches it)
-  const bool fused = !(fe && atoi(fe) == 0);
+  const bool fused = setting(S_FUSED_EST) != 0;
   static_assert(sizeof(ProbState) % 8 == 0, "ProbState is moved in 8-byte pieces");
   HIPCHK(h, h->pin_states.ensure(sizeof(ProbState) * (size_t)batch));
   if (fused) {
@@ -1010,10 +1070,8 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
   HIPCHK(h, h->d_tls_scratch.ensure((size_t)tls_stride * (size_t)batch));
   const bool need_graph = (mode != TEASER_INLIER_NONE) && max_n >= 1;
   // K1 on the matrix cores (fixed scale; worklist items hold 16-bit point indices: n <= 65536)
-  // (TEASER_K1_VARIANT=-1: diagnostics, forces the all-FP64 kernel)
-  const char* k1_env = getenv("TEASER_K1_VARIANT");
-  const bool mfma_k1 = need_graph && !P.estimate_scaling && max_n <= 65536 && !fp64_k1 &&
-                       !(k1_env && atoi(k1_env) < 0);
+  // (setting k1_fp64: the all-FP64 kernel for everything -- the route the overflow rerun and n > 65536 take)
+  const bool mfma_k1 = need_graph && !P.estimate_scaling && max_n <= 65536 && !fp64_k1 && setting(S_K1_FP64) == 0;
   if (need_graph) {
     HIPCHK(h, h->d_bitmap.ensure(8 * (size_t)std::max<int64_t>(bm, 1)));
     HIPCHK(h, h->d_deg.ensure(4 * (size_t)total_n));
@@ -1045,6 +1103,7 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
     memcpy(stage + o_desc, h->descs.data(), b_desc);
     memcpy(stage + o_state, h->states.data(), b_state);
     memcpy(stage + o_off, h->tim_off.data(), b_off);
+    if (mfma_k1) (void)tim_prep_fill_segments(stage + o_prep, n, batch);
     hipLaunchKernelGGL(hdr_fetch_kernel, dim3((unsigned)std::min<size_t>(8, (hdr_bytes / 16 + 255) / 256)), dim3(256), 0,
                        s1, reinterpret_cast<const uint4*>(stage), h->hdr.as<uint4>(), (int)(hdr_bytes / 16));
   }
@@ -1431,6 +1490,7 @@ void release_handle_resources(teaser_hip_solver* h) {
 // host enqueues batch k+1 while the GPU runs batch k, and the one-workgroup-per-problem tail of
 // batch k shares the GPU with batch k+1's K1.
 int32_t ensure_lanes(teaser_hip_solver* h) {
+  if ((int)h->lanes.size() < h->depth) warn_hw_queues_once(h->depth);
   while ((int)h->lanes.size() < h->depth) {
     teaser_hip_solver* lane = nullptr;
     const int32_t rc = make_lane(h, &lane);
@@ -1452,8 +1512,7 @@ int32_t ensure_input_sets(teaser_hip_solver* h) {
     // best of the three: 128 x 5 k from host memory 0.67 ms per step (0 ) / 0.68 (1) / 0.85 (2) against 0.63 from
     // HBM, 64 x 10 k 1.055 / 1.17 / 1.06 against 1.05 (profiles/r4f/copy_stream_modes.txt) -- a high-priority
     // queue that is busy 88 % of the step delays every small kernel of the tail chain.
-    const char* ev = getenv("TEASER_HIP_COPY_STREAM");
-    const int mode = ev ? atoi(ev) : 0;
+    const int mode = (int)setting(S_COPY_STREAM);
     if (mode == 0) {
       h->copy_stream = h->stream;
     } else if (mode == 1) {
@@ -1502,13 +1561,7 @@ void finisher_main(teaser_hip_solver* lane) {
   }
 }
 
-bool finisher_enabled() {
-  static const bool on = [] {
-    const char* e = getenv("TEASER_HIP_FINISHER");
-    return !(e && atoi(e) == 0);
-  }();
-  return on;
-}
+bool finisher_enabled() { return setting(S_FINISHER) != 0; }
 
 void finisher_post(teaser_hip_solver* lane) {
   if (!lane->fin) {
@@ -1528,7 +1581,15 @@ void finisher_post(teaser_hip_solver* lane) {
 // from done, a futex wake-up costs more than that)
 int32_t finisher_collect(teaser_hip_solver* lane, teaser_solution_c* out) {
   LaneFinisher* f = lane->fin.get();
-  for (int spin = 0; spin < 20000 && f->state.load(std::memory_order_acquire) != 2; ++spin) __builtin_ia32_pause();
+  // (bounded by elapsed time, not iterations: ~20 us, after which an exact-search batch is milliseconds away anyway)
+  const auto spin_until = std::chrono::steady_clock::now() + std::chrono::microseconds(20);
+  while (f->state.load(std::memory_order_acquire) != 2 && std::chrono::steady_clock::now() < spin_until) {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    std::this_thread::yield();
+#endif
+  }
   if (f->state.load(std::memory_order_acquire) != 2) {
     std::unique_lock<std::mutex> lk(f->m);
     f->cv.wait(lk, [&] { return f->state.load(std::memory_order_acquire) == 2; });
@@ -1685,10 +1746,7 @@ int32_t submit_impl(teaser_hip_solver* h, const double* src, const double* dst,
       // kernel (host_inputs_kernel, when both arrays are page-locked memory the device can read in place: measured
       // SLOWER -- its workgroups wait for slots behind K1: 0.89 vs 0.65 ms per 128 x 5 k step, profiles/r4z -- kept
       // as a diagnostic)
-      static const int h2d_env = [] {
-        const char* e = getenv("TEASER_HIP_H2D");
-        return (e && e[0] == 'k') ? 2 : 1;
-      }();
+      const int h2d_env = setting(S_H2D_KERNEL) != 0 ? 2 : 1;
       auto device_readable = [](const void* p) {
         hipPointerAttribute_t a;
         if (hipPointerGetAttributes(&a, p) != hipSuccess) {
@@ -1843,20 +1901,16 @@ int32_t teaser_hip_solver_create(const teaser_params_c* params, int32_t device,
     delete h;
     return TEASER_HIP_ERR_HIP;
   }
-  if (const char* e = getenv("TEASER_HIP_DEPTH")) {  // lanes for asynchronous batches
-    const int v = atoi(e);
-    if (v >= 1 && v <= 16) h->depth = v;
+  {  // schedule of the asynchronous batches: the settings' values at creation (internal.h)
+    const int dv = (int)setting(S_DEPTH), sg = (int)setting(S_STAGGER), ks = (int)setting(S_K1_STREAM);
+    if (dv >= 1 && dv <= 16) h->depth = dv;
+    h->stagger_k1 = sg != 0;
+    if (sg >= 1 && sg <= 3) h->stagger_point = sg;
+    h->shared_k1_stream = ks != 0;
+    h->k1_kernel_only = ks == 2;
+    h->tail_cus = std::max(0, (int)setting(S_TAIL_CUS));
+    h->tail_cu_block = setting(S_TAIL_CU_BLOCK) != 0;
   }
-  if (const char* e = getenv("TEASER_HIP_STAGGER")) {
-    h->stagger_k1 = atoi(e) != 0;
-    if (atoi(e) >= 1 && atoi(e) <= 3) h->stagger_point = atoi(e);
-  }
-  if (const char* e = getenv("TEASER_HIP_K1_STREAM")) {
-    h->shared_k1_stream = atoi(e) != 0;
-    h->k1_kernel_only = atoi(e) == 2;
-  }
-  if (const char* e = getenv("TEASER_HIP_TAIL_CUS")) h->tail_cus = std::max(0, atoi(e));
-  if (const char* e = getenv("TEASER_HIP_TAIL_CU_BLOCK")) h->tail_cu_block = atoi(e) != 0;
   *out = h;
   return TEASER_HIP_OK;
 }
@@ -2588,6 +2642,10 @@ int32_t teaser_hip_set_profiling(teaser_hip_solver* h, int32_t level) {
   if (!h || level < 0 || level > 2) return TEASER_HIP_ERR_BAD_ARG;
   h->profiling = level;
   return TEASER_HIP_OK;
+}
+
+int32_t teaser_hip_set_option(teaser_hip_solver*, const char* name, int64_t value) {
+  return set_setting(name, value) ? TEASER_HIP_OK : TEASER_HIP_ERR_BAD_ARG;
 }
 
 int32_t teaser_hip_get_profile(const teaser_hip_solver* h, teaser_profile_c* out) {

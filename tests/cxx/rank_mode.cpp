@@ -7,6 +7,7 @@
 #include <sys/wait.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -97,7 +98,7 @@ int run_rank(int rank, int world, int device, const int* id_pipe) {
   teaser_hip_comm_shard(kTotal, rank, world, &first, &last);
   std::vector<teaser_solution_c> local, all((size_t)kTotal);
   if (solve_range(h, (int)first, (int)last, &local) != TEASER_HIP_OK) return 1;
-  // a wrong record count is refused before any collective starts
+  // a wrong record count is reported (the rank still takes part in the collective, with an empty block)
   if (teaser_hip_comm_gather_solutions(c, local.data(), last - first + 1, kTotal, all.data()) != TEASER_HIP_ERR_BAD_ARG) return 1;
   rc = teaser_hip_comm_gather_solutions(c, local.data(), last - first, kTotal, all.data());
   if (rc != TEASER_HIP_OK) {
@@ -113,7 +114,37 @@ int run_rank(int rank, int world, int device, const int* id_pipe) {
       return 1;
     }
   }
-  if (rank == 0) {  // the sharded job == the single-process job, record for record
+  // the index sets of EVERY problem on every rank (max clique, rotation inliers, translation inliers): one more
+  // all-gather of padded int32 blocks, k_max from the records every rank now holds
+  int32_t k_max = 1;
+  for (const teaser_solution_c& o : all)
+    k_max = std::max(k_max, std::max(o.clique_size, std::max(o.n_rotation_inliers, o.n_translation_inliers)));
+  std::vector<int32_t> lens((size_t)kTotal * 3), idx((size_t)kTotal * 3 * (size_t)k_max);
+  // (a k_max that is too small is reported AFTER the collective: every rank takes part either way)
+  if (last > first && teaser_hip_comm_gather_indices(c, h, last - first, kTotal, 1, lens.data(), idx.data()) != TEASER_HIP_ERR_BAD_ARG) return 1;
+  if (last == first && teaser_hip_comm_gather_indices(c, h, 0, kTotal, 1, lens.data(), idx.data()) != TEASER_HIP_OK) return 1;
+  rc = teaser_hip_comm_gather_indices(c, h, last - first, kTotal, k_max, lens.data(), idx.data());
+  if (rc != TEASER_HIP_OK) {
+    std::fprintf(stderr, "rank %d: gather_indices -> %d (%s)\n", rank, rc, teaser_hip_comm_last_error(c));
+    return 1;
+  }
+  for (int b = 0; b < kTotal; ++b) {
+    const teaser_solution_c& o = all[(size_t)b];
+    const int32_t* L = lens.data() + 3 * (size_t)b;
+    if (L[0] != o.clique_size || L[1] != o.n_rotation_inliers || L[2] != o.n_translation_inliers) {
+      std::fprintf(stderr, "rank %d: index lengths of problem %d disagree with its record\n", rank, b);
+      return 1;
+    }
+    const int32_t* cl = idx.data() + (size_t)b * 3 * (size_t)k_max;
+    for (int k = 0; k < L[0]; ++k)
+      if (cl[k] < 0 || cl[k] >= kN || (k > 0 && cl[k] <= cl[k - 1]) || cl[k] % 5 >= 3) {  // sorted inliers only
+        std::fprintf(stderr, "rank %d: clique of problem %d is wrong at %d\n", rank, b, k);
+        return 1;
+      }
+    for (int k = L[0]; k < k_max; ++k)
+      if (cl[k] != -1) return 1;  // padding
+  }
+  if (rank == 0) {  // the sharded job == the single-process job, record for record and index set for index set
     std::vector<teaser_solution_c> ref;
     if (solve_range(h, 0, kTotal, &ref) != TEASER_HIP_OK) return 1;
     for (int b = 0; b < kTotal; ++b)
@@ -121,7 +152,19 @@ int run_rank(int rank, int world, int device, const int* id_pipe) {
         std::fprintf(stderr, "record %d differs from the single-process solve\n", b);
         return 1;
       }
-    std::printf("rank mode: %d ranks, %d problems, records identical to the single-process solve\n", world, kTotal);
+    typedef int32_t (*getter_t)(teaser_hip_solver*, int32_t, int32_t*, int64_t*);
+    const getter_t getters[3] = {teaser_hip_get_max_clique, teaser_hip_get_rotation_inliers, teaser_hip_get_translation_inliers};
+    std::vector<int32_t> buf((size_t)k_max);
+    for (int b = 0; b < kTotal; ++b)
+      for (int k = 0; k < 3; ++k) {
+        int64_t len = k_max;
+        if (getters[k](h, b, buf.data(), &len) != TEASER_HIP_OK || len != lens[3 * (size_t)b + k] ||
+            std::memcmp(buf.data(), idx.data() + ((size_t)b * 3 + k) * (size_t)k_max, (size_t)len * 4) != 0) {
+          std::fprintf(stderr, "index list %d of problem %d differs from the single-process solve\n", k, b);
+          return 1;
+        }
+      }
+    std::printf("rank mode: %d ranks, %d problems, records and index sets identical to the single-process solve\n", world, kTotal);
     std::fflush(stdout);  // (the rank leaves through _exit)
   }
   teaser_hip_comm_destroy(c);

@@ -20,6 +20,7 @@ namespace thip {
 int64_t tim_prep_bytes(int batch) { return (int64_t)batch * 64 + 64; }
 int64_t tim_operand_bytes(int64_t total_tiles) { return total_tiles * 64; }
 int64_t tim_work_items(const int32_t*, int batch) { return (int64_t)batch * 1024; }
+int64_t tim_prep_fill_segments(void*, const int32_t*, int batch) { return (int64_t)batch * 512; }
 int heuristic_blocks_per_problem(int, int) { return 1; }
 
 void launch_tim_graph_mfma(hipStream_t, int, const ProbDesc*, int, int, int64_t, const double*, const double*, void*, void*,

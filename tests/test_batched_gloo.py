@@ -86,3 +86,65 @@ def test_single_process_gather_is_identity():
     bt = _load_batched()
     rec = bt.pack_records([_fake_solution(i) for i in range(3)])
     assert np.array_equal(bt.gather_records(rec, 3, None), rec)
+
+
+def _fake_lists(idx):
+    """Index sets consistent with _fake_solution(idx): clique of 10 + idx vertices, 9 + idx / 8 + idx inliers."""
+    rng = np.random.default_rng(1000 + idx)
+    clique = np.sort(rng.choice(100 + idx, size=10 + idx, replace=False)).tolist()
+    return clique, list(range(9 + idx)), sorted(rng.choice(10 + idx, size=8 + idx, replace=False).tolist())
+
+
+def _index_worker(rank, world, port, total, q):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        bt = _load_batched()
+        lo, hi = bt.shard_range(total, rank, world)
+        local = bt.pack_records([_fake_solution(i) for i in range(lo, hi)], first_index=lo)
+        allrec = bt.gather_records(local, total, dist)
+        idx = bt.gather_indices([_fake_lists(i) for i in range(lo, hi)], allrec, dist)
+        q.put((rank, idx))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [5, 8, 1])
+def test_index_set_gather_world2_gloo(total):
+    """Every rank can read EVERY problem's max clique / rotation inliers / translation inliers (the lists the
+    parity bar is stated on), identical to what a single process holds, from one padded int32 all-gather."""
+    import torch.multiprocessing as mp
+
+    bt = _load_batched()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_index_worker, args=(r, 2, port, total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rec = bt.pack_records([_fake_solution(i) for i in range(total)])
+    single = bt.gather_indices([_fake_lists(i) for i in range(total)], rec, None)
+    for r in range(2):
+        assert len(got[r]) == total
+        for i in range(total):
+            want = dict(zip(bt.INDEX_LISTS, _fake_lists(i)))
+            assert got[r][i] == want == single[i], (r, i)
+
+
+def test_pack_indices_layout_and_limits():
+    bt = _load_batched()
+    blk = bt.pack_indices([([3, 5, 9], [0, 1], []), ([1], [], [0])], 4)
+    assert blk.dtype == np.int32 and blk.shape == (2, 15)
+    assert blk[0].tolist() == [3, 2, 0, 3, 5, 9, -1, 0, 1, -1, -1, -1, -1, -1, -1]
+    assert bt.unpack_indices(blk, 4)[1] == {"max_clique": [1], "rotation_inliers": [], "translation_inliers": [0]}
+    with pytest.raises(ValueError):
+        bt.pack_indices([([1, 2, 3], [], [])], 2)

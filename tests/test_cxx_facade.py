@@ -271,4 +271,4 @@ def test_rank_mode_on_gpu():
     exe = build_rank_mode()
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "records identical" in out.stdout
+    assert "records and index sets identical" in out.stdout

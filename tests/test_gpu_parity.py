@@ -235,20 +235,19 @@ def test_scale_float_key_sort_matches_the_64_bit_sort():
     FP64 order inside runs of equal float keys (tls_order_fix_kernel); runs too long to fix fall back to the 64-bit
     sort.  Both paths must produce the SAME order, hence bit-identical estimates (the sums then associate
     identically): random data, clusters of doubles that collide as floats (in-run reordering does the work), exact
-    duplicates (ties keep insertion order), and whole solves, single and batched (TEASER_SCALE_SORT64 flips the
+    duplicates (ties keep insertion order), and whole solves, single and batched (the `scale_sort64` option flips the
     path inside this process)."""
-    import os
     rng = np.random.default_rng(14)
     s = make_solver()
 
     def both(fn):
-        os.environ.pop("TEASER_SCALE_SORT64", None)
+        tp.set_option("scale_sort64", 0)
         a = fn()
-        os.environ["TEASER_SCALE_SORT64"] = "1"
+        tp.set_option("scale_sort64", 1)
         try:
             b = fn()
         finally:
-            os.environ.pop("TEASER_SCALE_SORT64", None)
+            tp.set_option("scale_sort64", 0)
         return a, b
 
     n = 400000
@@ -294,13 +293,13 @@ def test_estimate_scaling_degenerate_ties_fall_back_to_the_64_bit_sort():
     dst = 2.0 * src
     p = bench_params(estimate_scaling=True, noise_bound=0.01)
     s = make_solver(**p)
-    os.environ.pop("TEASER_SCALE_SORT64", None)
+    tp.set_option("scale_sort64", 0)
     a = s.solve(src, dst)
-    os.environ["TEASER_SCALE_SORT64"] = "1"
+    tp.set_option("scale_sort64", 1)
     try:
         b = s.solve(src, dst)
     finally:
-        os.environ.pop("TEASER_SCALE_SORT64", None)
+        tp.set_option("scale_sort64", 0)
     assert a.valid and b.valid
     assert np.float64(a.scale).tobytes() == np.float64(b.scale).tobytes()
     assert abs(a.scale - 2.0) < 1e-9
@@ -1349,25 +1348,48 @@ def test_multi_device_fan_out():
     m.close()
 
 
-def test_k1_scheduling_variants_bit_identical(monkeypatch):
-    """TEASER_K1_VARIANT: 0..6 are instruction schedules of the first matrix-core formulation of K1 (A, B from the
-    matrix pipe; 3, 6: 128-VGPR builds; 4..6: plain instead of packed f32 epilogue), 7..11 of the second one
-    (u / w; 11 = round 3's default), 12.. of the third one (min |d| epilogue with group fix-up items: 20 = the default --
-    constant band, transposed words parked in LDS; 12 / 13: stored per column tile; 21 / 22: w-dependent bands; 23:
-    pipelined schedule; 27: 32 column tiles per block), -1 forces the all-FP64 kernel; all bitmaps are identical (and
-    equal the oracle's)."""
+def test_k1_matrix_core_filter_matches_the_fp64_kernel():
+    """The two K1 routes of the product -- the matrix-core filter with its FP64 fix-up, and the all-FP64 kernel that the
+    overflow rerun, n > 65536 and estimate_scaling take (forced here with the `k1_fp64` option) -- produce the same
+    bitmap, and it is the oracle's.  (The scheduling variants of the filter kernel live in the lab build,
+    scripts/probe/k1_lab, which asserts the same identity for each of them.)"""
     pr = tp.synth_problem(61, 4500, 0.9, 0.01)
     _, ref = oracle.inlier_bitmap(pr["src"], pr["dst"], 0.01, 1.0, False)
-    for v in ("-1", "0", "1", "2", "3", "4", "5", "6", "7", "8", "9", "10", "11", "12", "13", "20", "21", "22", "23", "27"):
-        monkeypatch.setenv("TEASER_K1_VARIANT", v)
-        s = make_solver(**bench_params())
-        s.solve(pr["src"], pr["dst"])
-        assert (s.getInlierGraphBitmap() == ref).all(), v
+    try:
+        for v in (1, 0):
+            tp.set_option("k1_fp64", v)
+            s = make_solver(**bench_params())
+            s.solve(pr["src"], pr["dst"])
+            assert (s.getInlierGraphBitmap() == ref).all(), v
+    finally:
+        tp.set_option("k1_fp64", 0)
 
 
-def test_fused_estimators_match_the_separate_kernels(monkeypatch):
+def test_mixed_size_batch_with_one_large_member():
+    """One n = 50 000 problem beside small ones: every problem's counted worklist segment is sized from ITS OWN pair
+    count (prefix offsets in the prep records), so the large member stays on the matrix-core route (no overflow
+    rerun) and every bitmap / clique equals the single-problem solve."""
+    big = tp.synth_problem(7001, 50000, 0.99, 0.01)
+    small = [tp.synth_problem(7100 + k, 1000, 0.9, 0.01) for k in range(15)]
+    probs = small[:7] + [big] + small[7:]
+    s = make_solver(**bench_params())
+    s.set_profiling(2)
+    sols = s.solve_batch([p["src"] for p in probs], [p["dst"] for p in probs])
+    assert s.get_profile()["tim_graph_launches"] == 1  # no all-FP64 rerun of the batch
+    cl = [s.getInlierMaxClique(b) for b in range(len(probs))]
+    deg = [s.getDegrees(b).copy() for b in range(len(probs))]
+    one = make_solver(**bench_params())
+    for b in (0, 7, 15):
+        ref = one.solve(probs[b]["src"], probs[b]["dst"])
+        assert one.getInlierMaxClique() == cl[b]
+        assert (one.getDegrees() == deg[b]).all()
+        assert (ref.rotation == sols[b].rotation).all() and (ref.translation == sols[b].translation).all()
+    assert cl[7] == np.flatnonzero(big["inliers"]).tolist()  # 500 inliers, 99 % outliers: the clique is the inlier set
+
+
+def test_fused_estimators_match_the_separate_kernels():
     """estimate_fused_kernel (rotation + translation + inlier lists + state hand-over in one launch) against the three
-    separate launches (TEASER_HIP_FUSED_EST=0): the GNC-TLS arithmetic is ordered identically, so R, the GNC cost, the
+    separate launches (option fused_estimators = 0): the GNC-TLS arithmetic is ordered identically, so R, the GNC cost, the
     iteration count and the rotation inliers are bit-identical; the translation comes from the window form of the scalar
     TLS (sorted values + prefix sums instead of the endpoint sweep): same estimate to ~1e-15, same inlier list.  Cliques of
     2 .. 512 vertices take the fast route, larger ones (and FGR / QUATRO / COMPLETE) the general route inside the kernel."""
@@ -1375,7 +1397,7 @@ def test_fused_estimators_match_the_separate_kernels(monkeypatch):
     probs = [tp.synth_problem(9000 + seed, n, rho, 0.01) for n, rho, seed in cases]
     res = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("TEASER_HIP_FUSED_EST", mode)
+        tp.set_option("fused_estimators", int(mode))
         s = make_solver(**bench_params())
         out = []
         for pr in probs:
@@ -1402,9 +1424,10 @@ def test_fused_estimators_match_the_separate_kernels(monkeypatch):
                dict(rotation_tim_graph=tp.InlierGraphFormulation.COMPLETE)):
         got = {}
         for mode in ("0", "1"):
-            monkeypatch.setenv("TEASER_HIP_FUSED_EST", mode)
+            tp.set_option("fused_estimators", int(mode))
             s = make_solver(**bench_params(**kw))
             sol = s.solve(probs[0]["src"], probs[0]["dst"])
             got[mode] = (sol.rotation.copy(), sol.translation.copy(), s.getRotationInliers(), s.getTranslationInliers())
         assert (got["0"][0] == got["1"][0]).all() and (got["0"][1] == got["1"][1]).all()
         assert got["0"][2] == got["1"][2] and got["0"][3] == got["1"][3]
+    tp.set_option("fused_estimators", 1)

@@ -1,7 +1,8 @@
 """The N > 1 path with REAL solves: two processes share the visible GPU, each solves its shard
 of a ragged problem list through the C ABI (batched.solve_sharded), the fixed-size result records are
 all-gathered over gloo (RCCL refuses two ranks on one device; the record path is the same) -- and every rank
-ends up with exactly the records one process computes for the whole list."""
+ends up with exactly the records AND the index sets (max clique, rotation / translation inliers: one more padded
+int32 all-gather) one process computes for the whole list."""
 import importlib
 import os
 import socket
@@ -37,9 +38,9 @@ def _worker(rank, world, port, q):
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     try:
         srcs, dsts = _problems(tp)
-        rec = tp.batched.solve_sharded(solver, srcs, dsts, dist)
+        rec, idx = tp.batched.solve_sharded(solver, srcs, dsts, dist, with_indices=True)
         lo, hi = tp.batched.shard_range(len(srcs), rank, world)
-        q.put((rank, rec, (lo, hi)))
+        q.put((rank, rec, (lo, hi), idx))
     finally:
         dist.destroy_process_group()
 
@@ -55,6 +56,8 @@ def test_sharded_solve_matches_single_process(world):
     solver = tp.RobustRegistrationSolver(tp.RobustRegistrationSolver.Params(**PARAMS), device=0)
     solver.solve_batch(srcs, dsts)
     want = tp.batched.pack_records([solver.raw_solution(b) for b in range(len(srcs))], first_index=0)
+    want_idx = [dict(max_clique=solver.getInlierMaxClique(b), rotation_inliers=solver.getRotationInliers(b),
+                     translation_inliers=solver.getTranslationInliers(b)) for b in range(len(srcs))]
     assert want[:, tp.batched.F_VALID].sum() >= len(SIZES) - 2  # (n = 1 and tiny problems are soft failures)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -66,14 +69,15 @@ def test_sharded_solve_matches_single_process(world):
         p.start()
     got = {}
     for _ in procs:
-        r, rec, rng = q.get(timeout=300)
-        got[r] = (rec, rng)
+        r, rec, rng, idx = q.get(timeout=300)
+        got[r] = (rec, rng, idx)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
     bounds = tp.batched.shard_bounds(len(SIZES), world)
     for r in range(world):
-        rec, rng = got[r]
+        rec, rng, idx = got[r]
         assert rng == (bounds[r], bounds[r + 1])
         assert rec.shape == want.shape
         assert np.array_equal(rec, want)  # bit-identical records, global order, on every rank
+        assert idx == want_idx            # and every rank reads every problem's index sets (the parity bar)
