@@ -63,6 +63,8 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_BF16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (not the 2:1-sparsity figure)
 FP64_PEAK_TF = 78.6        # dense FP64 peak of MI355X (matrix = vector), FMA = 2 flops
+VALU_PEAK_GINST = 1024 * 2.4 / 4.0  # G wave64 VALU instructions/s: 256 CUs x 4 SIMDs, 2.4 GHz, 4 cycles each
+K1_VALU_PER_1024_STATIC = 56.0  # steady-state loop body of tim_graph_mfma3_kernel (scripts/k1_isa_stats.py)
 K1_FLOPS_PER_PAIR = 20.0   # algorithmic FP64 flops of the reference predicate
 # executed by K1 per pair: 4 x v_mfma_f32_32x32x16_bf16 (2*32*32*16 flops each) per 1024 pairs
 K1_MFMA_FLOPS_PER_PAIR = 4 * 2 * 32 * 32 * 16 / 1024.0
@@ -93,7 +95,7 @@ def parse(argv=None):
                     help="batches in flight per `configs` line (default for the others: --depth).  The lines whose solves "
                          "need the host-driven bound-closing stage (colouring bound / exact search) are latency-bound per "
                          "lane, not K1-bound: more lanes overlap them (profiles/r5d, r5h)")
-    ap.add_argument("--repeats", type=int, default=3,
+    ap.add_argument("--repeats", type=int, default=5,
                     help="timed regions (of --steps steps each at the top level) per line; the median is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-resident", action="store_true",
@@ -115,14 +117,21 @@ def solver_params(tp, nb, **kw):
 
 
 def roofline_object(k1_ms, k1_launches, k1_bytes, k1_pairs, k1_aux_ms, traffic, traffic_src, issue=None):
-    """roofline of the dominant kernel (K1) from the HIP-event totals of the timed region.
+    """roofline of the dominant kernel (K1) from the HIP-event totals of the timed region: the EXECUTED fraction of
+    each hardware pipe the kernel loads, `frac` = the largest of them, `bound` = that pipe.
 
-    Top level, as the bench contract defines it: ALGORITHMIC work per launch (20 FP64
-    flop per pair for the reference predicate) / the kernel's average launch time, against the dense
-    FP64 peak (78.6 TFLOP/s on MI355X, matrix = vector).  The kernel is compute-side, so the bound is
-    the arithmetic peak, not HBM; it does NOT execute those FP64 flops -- it evaluates the predicate
-    as an exact-bf16-split MFMA + f32 filter with an FP64 fix-up -- so what it actually issues is
-    reported next to it (`executed_mfma`, `issue`), as is the HBM view (`hbm`)."""
+      valu -- vector-ALU issue: executed VALU wave-instructions per launch (pairs x the per-1024-pair count of the
+              committed SQ-counter pass of this kernel, profiles/<round>/k1_sq_counters.json; the compiler's
+              steady-state loop body when no pass is committed) against 1024 SIMDs x clock / 4 cycles per
+              wave64 instruction (MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz);
+      mfma -- issued bf16 matrix flops (4 x v_mfma_f32_32x32x16_bf16 per 1024 pairs = 128 flop / pair) against the
+              dense bf16 peak, 2.5 PFLOP/s;
+      hbm  -- ALGORITHMIC bytes (48 n + 8 n ceil(n/64) per problem) against 8 TB/s; `traffic` = the
+              PMC bytes of the committed FETCH_SIZE / WRITE_SIZE passes.
+    No fraction can exceed 1.  The rate the SURVEY's flop model asks for -- 20 FP64 flop per pair of the reference
+    predicate against the 78.6 TFLOP/s FP64 peak -- is an ALGORITHM-EQUIVALENT figure (the kernel issues no FP64: it
+    decides the same predicate with an exact bf16-split MFMA + f32 filter and an FP64 fix-up, bitmap bit-identical),
+    can exceed 1 and ranks nothing: it is kept nested as `fp64_equivalent`."""
     launches = max(k1_launches, 1)
     k1_avg_s = (k1_ms / launches) * 1e-3
     bytes_per_launch = k1_bytes / launches
@@ -131,29 +140,41 @@ def roofline_object(k1_ms, k1_launches, k1_bytes, k1_pairs, k1_aux_ms, traffic, 
     fp64_tf = rate(K1_FLOPS_PER_PAIR * pairs_per_launch) / 1e12
     mfma_tf = rate(K1_MFMA_FLOPS_PER_PAIR * pairs_per_launch) / 1e12
     hbm_gbs = rate(bytes_per_launch) / 1e9
+    if issue and issue.get("valu_insts_per_1024_pairs"):
+        valu_per_1024, valu_src = float(issue["valu_insts_per_1024_pairs"]), issue.get("source")
+    else:
+        valu_per_1024, valu_src = K1_VALU_PER_1024_STATIC, "steady-state loop body of the compiler's assembly (scripts/k1_isa_stats.py)"
+    valu_ginst = rate(valu_per_1024 * pairs_per_launch / 1024.0) / 1e9
+    pipes = {
+        "valu": {"achieved": valu_ginst, "peak": VALU_PEAK_GINST, "unit": "G wave-instructions/s",
+                 "frac": valu_ginst / VALU_PEAK_GINST, "valu_insts_per_1024_pairs": valu_per_1024, "count_source": valu_src,
+                 "note": "peak = 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction"},
+        "mfma": {"achieved": mfma_tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": mfma_tf / MFMA_BF16_PEAK_TF,
+                 "flops_per_launch": K1_MFMA_FLOPS_PER_PAIR * pairs_per_launch,
+                 "note": "issued bf16 MFMA flops: 4 x v_mfma_f32_32x32x16_bf16 per 1024 pairs = 128 / pair"},
+        "hbm": {"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": bytes_per_launch, "traffic_bytes_per_launch": traffic,
+                "traffic_source": traffic_src},
+    }
+    bound = max(pipes, key=lambda k: pipes[k]["frac"])
+    top = pipes[bound]
     return {
         "kernel": "tim_graph_mfma3_kernel (K1: TIM-norm predicate terms u, w on the matrix cores, min |d| filter, "
                   "adjacency bitmap; FP64 fix-up of the flagged 16-pair groups)",
-        "bound": "mfma", "achieved": fp64_tf, "peak": FP64_PEAK_TF, "unit": "TFLOP/s",
-        "frac": fp64_tf / FP64_PEAK_TF, "traffic": traffic,
+        "bound": bound, "achieved": top["achieved"], "peak": top["peak"], "unit": top["unit"], "frac": top["frac"],
+        "traffic": traffic,
         "avg_launch_ms": 1e3 * k1_avg_s, "launches": k1_launches,
-        "algorithmic_flops_per_launch": K1_FLOPS_PER_PAIR * pairs_per_launch,
         "pairs_per_launch": pairs_per_launch,
         "aux_ms_per_launch": k1_aux_ms / launches,
-        "note": "achieved = 20 FP64 flop/pair (SURVEY.md 8(d), the reference predicate) x pairs / HIP-event time of "
-                "the kernel alone; peak = dense FP64 peak (matrix = vector = 78.6 TFLOP/s): an algorithm-equivalent "
-                "rate.  The kernel issues NO FP64: it decides the same predicate with an exact bf16-split MFMA + f32 "
-                "VALU filter and an FP64 fix-up (bitmap bit-identical), so the pipes it really loads are "
-                "`executed_mfma` (bf16 matrix pipe) and `issue` (SQ counters of the committed pass: DESIGN.md 3).  With --depth > 1 the kernel shares the GPU with the latency-bound tail kernels of "
-                "the previous batch, which is included in its time",
-        "executed_mfma": {"achieved": mfma_tf, "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
-                          "frac": mfma_tf / MFMA_BF16_PEAK_TF,
-                          "flops_per_launch": K1_MFMA_FLOPS_PER_PAIR * pairs_per_launch,
-                          "note": "issued bf16 MFMA flops: 4 x v_mfma_f32_32x32x16_bf16 per 1024 pairs = 128/pair"},
+        "pipes": pipes,
+        "fp64_equivalent": {"achieved": fp64_tf, "peak": FP64_PEAK_TF, "unit": "TFLOP/s", "ratio": fp64_tf / FP64_PEAK_TF,
+                            "algorithmic_flops_per_launch": K1_FLOPS_PER_PAIR * pairs_per_launch,
+                            "note": "20 FP64 flop/pair of the reference predicate (SURVEY.md 8(d)) x pairs / kernel time "
+                                    "against the dense FP64 peak: algorithm-equivalent, NOT an executed fraction (may exceed 1)"},
         "issue": issue,
-        "hbm": {"achieved": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS,
-                "algorithmic_bytes_per_launch": bytes_per_launch,
-                "traffic_bytes_per_launch": traffic, "traffic_source": traffic_src},
+        "note": "frac = the largest EXECUTED pipe fraction of the kernel (valu issue / bf16 mfma / hbm), from HIP events "
+                "around the kernel alone on its stream inside the timed region.  With --depth > 1 the kernel shares the "
+                "GPU with the latency-bound tail kernels of the previous batch, which is included in its time",
     }
 
 
@@ -324,10 +345,13 @@ def cpu_baseline(tp, n, outlier_ratio, nb, seed, max_solves, budget_s, problems=
     what = label if label else ("N=%d, %.0f%% outliers" % (n, 100 * outlier_ratio)) if problems is None else \
         "%d-%d correspondences (real descriptors)" % (min(p[0].shape[1] for p in problems),
                                                       max(p[0].shape[1] for p in problems))
-    out = {"value": 1.0 / med, "unit": "registrations/s", "cores": threads, "kind": "port", "host": info,
+    # `cores` = the cores the host really gives this process (scheduler affinity and cgroup quota), at most the team
+    # size; `threads` = the OpenMP team that was fastest in the sweep (it may oversubscribe the quota)
+    out = {"value": 1.0 / med, "unit": "registrations/s", "cores": min(threads, info["effective_cores"]),
+           "threads": threads, "kind": "port", "host": info,
            "sample": "%d solves of this workload (%s), median %.1f ms each, streaming oracle (no TIM storage), "
-                     "gcc -O3 -fopenmp without -march=native, OMP_NUM_THREADS = %d (the best of the sweep), "
-                     "OMP_PROC_BIND = close" % (len(ts), what, 1e3 * med, threads)}
+                     "gcc -O3 -fopenmp without -march=native, OMP_NUM_THREADS = %d (the best of the sweep) on %d "
+                     "effective cores, OMP_PROC_BIND = close" % (len(ts), what, 1e3 * med, threads, info["effective_cores"])}
     if sweep is not None:
         out["thread_sweep"] = {"ms_per_solve_by_threads": sweep,
                                "note": "median of 3 solves per thread count, one subprocess each; the host reports "
@@ -470,6 +494,10 @@ def run_config(tag, tp, torch, runner, args, dev, world, rank, make_workload, st
     runner_c.run_steps(0, args.warmup, bufs, offsets, sizes, False)
     last = runner_c.run_steps(0, 1, bufs, offsets, sizes, False)
     wl["check"](last)  # the work is not skipped and is right
+    # one untimed region of the same length first (`settle`): the lanes' finisher threads, the exact stage's pools and
+    # the clocks reach their steady state there, not inside the first timed region (config 5's first region used to
+    # run 70 % slower than the others)
+    runner_c.timed(1, steps, bufs, offsets, sizes, False)
     times = []
     for r in range(max(1, args.repeats)):
         t, _ = runner_c.timed(1 + r * steps, steps, bufs, offsets, sizes, False)
@@ -486,6 +514,7 @@ def run_config(tag, tp, torch, runner, args, dev, world, rank, make_workload, st
         "value": world * B * steps / med, "unit": "registrations/s", "ms_per_step": 1e3 * med / steps,
         "ms_per_registration": 1e3 * med / (steps * B),
         "ms_per_step_repeats": [round(1e3 * t / steps, 4) for t in times],
+        "repeat_spread": round((max(times) - min(times)) / med, 4), "settle_steps": steps,
         "distinct_batches": len(bufs), "batches_in_flight": depth, "inputs": "resident in HBM", "n_gpus": world,
     }
     if not args.no_host_resident:
@@ -496,7 +525,7 @@ def run_config(tag, tp, torch, runner, args, dev, world, rank, make_workload, st
         th = [runner_c.timed(1 + r * steps, steps, pinned, offsets, sizes, True)[0] for r in range(max(1, args.repeats))]
         mh = float(np.median(th))
         line["host_resident"] = {"value": world * B * steps / mh, "unit": "registrations/s",
-                                 "ms_per_step": 1e3 * mh / steps}
+                                 "ms_per_step": 1e3 * mh / steps, "over_hbm_resident": med / mh}
         del pinned
     if wl.get("scale_trims"):
         # the stage that dominates this line is the scale stage (K7): TRIM endpoints -> device-wide sort -> sweep.
@@ -524,8 +553,12 @@ def run_config(tag, tp, torch, runner, args, dev, world, rank, make_workload, st
         n_eq = wl.get("n")
         traffic, traffic_src = k1_traffic(B, n_eq) if n_eq else (None, None)
         line["roofline"] = roofline_object(acc["ms"], acc["launches"], acc["bytes"], acc["pairs"], acc["aux"],
-                                           traffic, traffic_src)
-        line["roofline"].pop("note", None)
+                                           traffic, traffic_src, k1_issue())
+        for k in ("note", "issue"):
+            line["roofline"].pop(k, None)
+        for pp in line["roofline"]["pipes"].values():
+            pp.pop("note", None)
+        line["roofline"]["fp64_equivalent"].pop("note", None)
     else:
         line["roofline"] = None
     i0 = 0
@@ -836,6 +869,7 @@ def main():
             "value": value, "unit": "registrations/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "ms_per_step_repeats": [round(1e3 * t / args.steps, 4) for t in elapsed_all],
+            "repeat_spread": round((max(elapsed_all) - min(elapsed_all)) / elapsed, 4),
             "value_host_resident": host_line["value"] if host_line else None,
             "host_resident_over_hbm_resident": (host_line["value"] / value) if host_line else None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE,

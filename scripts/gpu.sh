@@ -2,7 +2,8 @@
 # ONE parameterised GPU-box script (run through gpurun):   bash scripts/gpu.sh <tag> <task> [<task> ...]
 # Every task runs under its own `timeout`; outputs go to gpurun_out/<tag>/ (merged back by gpurun).
 #   smoke            __graft_entry__.smoke()
-#   k1probe          K1 alone: variants -1 / 11..15 on 64 x 10 k (HIP events, bitmap hashes must agree)
+#   k1probe          K1 alone: the all-FP64 route and the product's kernel on 64 x 10 k (HIP events, bitmap hashes must agree)
+#   k1lab            the LAB build's K1 variants ($K1VS; scripts/probe/k1_lab/run.sh), alone and ($K1PIPE=1) under the pipeline
 #   k1tests          the K1 / bitmap parity tests only
 #   tests:<expr>     pytest -m gpu -k <expr>
 #   suite            the whole GPU suite as the driver runs it
@@ -44,6 +45,7 @@ for task in "$@"; do
   echo "=== $task"
   case $task in
     smoke) timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 ;;
+    k1lab) PIPE=$K1PIPE PIPEVS=$K1PIPEVS bash scripts/probe/k1_lab/run.sh $OUT $K1VS ;;
     k1probe) timeout 200 $P 64 10000 10 k1 > $OUT/probe_k1.jsonl 2> $OUT/probe_k1.err; echo "rc=$?"; cat $OUT/probe_k1.jsonl; tail -3 $OUT/probe_k1.err ;;
     k1probe4) timeout 200 $P 128 5000 10 k1 0.9 > $OUT/probe_k1_128x5k.jsonl 2>/dev/null; cat $OUT/probe_k1_128x5k.jsonl ;;
     pipe) timeout 300 $P 64 10000 30 pipe > $OUT/probe_pipe.jsonl 2>/dev/null; cat $OUT/probe_pipe.jsonl ;;

@@ -81,3 +81,36 @@ def test_sharded_solve_matches_single_process(world):
         assert rec.shape == want.shape
         assert np.array_equal(rec, want)  # bit-identical records, global order, on every rank
         assert idx == want_idx            # and every rank reads every problem's index sets (the parity bar)
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """`bench.py --gpus 2 --share-gpu`: the N-rank path of the bench (self-relaunch under torch.distributed.run, one
+    process per rank, per-rank problems, the record all-gather inside the timed region, max-over-ranks timing, rank 0's
+    ONE JSON line) runs end to end on the single-GPU box -- two ranks share the device and gather over gloo -- so it
+    cannot rot until a multi-GPU node runs it.  The two ranks split one GPU, so the whole-job rate must land near the
+    single-process rate of the same per-step work (not near twice it)."""
+    import json
+    import subprocess
+
+    common = ["--steps", "6", "--warmup", "3", "--repeats", "3", "--batch", "16", "--n", "4000", "--configs", "",
+              "--no-cpu-baseline", "--no-latency", "--no-host-resident"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+
+    def run(extra):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra + common, capture_output=True,
+                           text=True, timeout=600, env=env, cwd=ROOT)
+        assert p.returncode == 0, p.stderr[-3000:]
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, p.stdout[-2000:]  # rank 0 prints ONE line
+        return json.loads(lines[0])
+
+    one = run(["--gpus", "1"])
+    two = run(["--gpus", "2", "--share-gpu"])
+    for d, n in ((one, 1), (two, 2)):
+        assert d["n_gpus"] == n and d["steps"] == 6 and d["warmup"] == 3 and d["scaling"] == "weak"
+        assert d["unit"] == "registrations/s" and d["value"] > 0 and d["higher_is_better"] is True
+        assert abs(d["value"] - n * 16 * 6 / (d["ms_per_step"] * 6e-3)) < 1e-6 * d["value"]  # whole-job aggregate
+        r = d["roofline"]
+        assert r["bound"] in r["pipes"] and 0 < r["frac"] <= 1.0 and all(0 <= p["frac"] <= 1.0 for p in r["pipes"].values())
+    assert "gloo" in two["config"]["parallelism"]
+    assert 0.5 * one["value"] < two["value"] < 1.6 * one["value"], (one["value"], two["value"])
