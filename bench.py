@@ -91,7 +91,7 @@ def parse(argv=None):
                          "1 = strictly one batch at a time")
     ap.add_argument("--configs", default="4,3,5,scale",
                     help="other BASELINE configurations to run after the top-level one ('' = none)")
-    ap.add_argument("--config-depth", default="config3=4,config5=3,scale=3",
+    ap.add_argument("--config-depth", default="config3=6,config5=3,scale=3",
                     help="batches in flight per `configs` line (default for the others: --depth).  The lines whose solves "
                          "need the host-driven bound-closing stage (colouring bound / exact search) are latency-bound per "
                          "lane, not K1-bound: more lanes overlap them (profiles/r5d, r5h)")

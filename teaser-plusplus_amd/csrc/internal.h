@@ -218,6 +218,7 @@ constexpr int kColourMaxLb = 4096;  // palette limit (64 LDS words per wave)
 constexpr int kColourRounds = 16;  // one per vertex class (8) + the all-in rounds
 constexpr int kRootPruneCap = 512;   // leftover roots tested by root_prune_kernel (counts in d_tent)
 constexpr int kRootPruneSlices = 32; // workgroups per root
+constexpr int kRootPruneRows = 16;   // grid rows walking the roots (512 workgroups per problem in flight)
 void launch_colour_bound(hipStream_t s, const ProbDesc* d_desc, const int32_t* d_sel, int nsel,
                          int max_n, const uint64_t* d_bitmap, const uint64_t* d_alive,
                          const int32_t* d_clique, ProbState* d_state, int32_t* d_colour,

@@ -199,7 +199,7 @@ struct ExactQueues {
 // counters[] of the donation queue / termination (behind the phase queues' 2 x 8)
 // (one 64-byte line each: thousands of idle waves poll them)
 constexpr int kCntDCount = 32;   // slots reserved
-constexpr int kCntDHead = 48;    // next slot to take
+[[maybe_unused]] constexpr int kCntDHead = 48;    // next slot to take
 constexpr int kCntActive = 64;   // waves holding (or about to take) a task
 constexpr int kCntHungry = 80;   // waves polling for work
 static_assert(kExactCounterInts >= 96, "counters of the donation queue");
@@ -928,6 +928,22 @@ __global__ __launch_bounds__(256) void exact_count_kernel(const ProbDesc* __rest
   }
   const bool coloured = speculative ? !colour_not_needed(states[p], d.n) : pb->use_x != 0;
   const int xc = coloured ? states[p].x_count : -1;  // -1: the colouring bound did not run for this problem
+  if (xc == 0) {
+    // every survivor got a colour: lb is proven (pigeonhole), there is nothing to count.  (The general path below
+    // walked all survivors' degrees from ONE workgroup for the size fields nobody reads: 38 us at N = 50 000.)
+    if (tid == 0) {
+      pb->prob = p;
+      pb->n2 = 0;
+      pb->W2 = 0;
+      pb->n_roots = 0;
+      pb->use_x = 0;
+      pb->lb = lb;
+      pb->max_deg = 0;
+      pb->ctrl[5] = 0;
+      pb->ctrl[6] = 0;
+    }
+    return;
+  }
   uint64_t* Xb = reinterpret_cast<uint64_t*>(smem);  // W
   uint64_t* Cb = Xb + ((W + 1) & ~1);                // W
   const uint64_t* al = alive + d.w_off;
@@ -953,6 +969,22 @@ __global__ __launch_bounds__(256) void exact_count_kernel(const ProbDesc* __rest
   }
   __syncthreads();
   const int nx = kept;
+  if (xc > 0 && xc <= kRootPruneCap && nx == 0) {
+    // the root filter discarded every uncoloured survivor: no root can lie in a clique larger than lb -- proven,
+    // nothing to size (the general path walks every survivor's degree from this one workgroup)
+    if (tid == 0) {
+      pb->prob = p;
+      pb->n2 = 0;
+      pb->W2 = 0;
+      pb->n_roots = 0;
+      pb->use_x = 0;
+      pb->lb = lb;
+      pb->max_deg = 0;
+      pb->ctrl[5] = xc;
+      pb->ctrl[6] = 0;
+    }
+    return;
+  }
   if (use_x && nx > 0) {
     // candidates = surviving neighbours of X: one wave per root row
     const int lane = tid & 63, wave = tid >> 6;
@@ -1253,6 +1285,34 @@ __device__ __forceinline__ unsigned int colour_hash(int v, int round, unsigned i
 constexpr int kColourClasses = 8;
 static_assert(kColourRounds > kColourClasses, "rounds = one per class + the all-in rounds");
 
+// Visit the set bits of a lane's masked row words FOUR at a time: the per-neighbour lookups (colour / tentative colour
+// of vertex u) are independent L2 round trips, and a `while (bits)` loop that loads inside every iteration serialises
+// them (one ~500-cycle trip per neighbour and lane: at N = 50 000 a vertex has up to 1 400 coloured neighbours, 22 per
+// lane -- that chain, not the row's bytes, was the colouring rounds' time).  `words` holds the lane's masked words of
+// the row (word index = base + 64 * k + lane), `look(u)` returns the looked-up value, `use(u, value)` consumes it.
+template <int kWords, typename Look, typename Use>
+__device__ __forceinline__ void visit_bits_batched(const uint64_t (&words)[kWords], int base_word, int lane, Look look, Use use) {
+#pragma unroll
+  for (int k = 0; k < kWords; ++k) {
+    uint64_t bits = words[k];
+    const int u_base = (base_word + 64 * k + lane) * 64;
+    while (bits) {
+      int u[4], val[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        u[j] = bits ? u_base + __builtin_ctzll(bits) : -1;
+        bits &= bits - (bits ? 1ull : 0ull);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) val[j] = u[j] >= 0 ? look(u[j]) : -1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (u[j] >= 0) use(u[j], val[j]);
+    }
+  }
+}
+constexpr int kRowWordsPerLane = 8;  // words of a bitmap row a lane holds at once: 512 words = 32 768 vertices per pass
+
 __device__ __forceinline__ int colour_class(int v) { return (int)(mix32((unsigned int)v * 0x9E3779B9u + 0x51ed27u) & (kColourClasses - 1)); }
 
 __global__ __launch_bounds__(256) void colour_init_kernel(const ProbDesc* __restrict__ descs,
@@ -1347,14 +1407,17 @@ __global__ __launch_bounds__(256) void colour_assign_kernel(const ProbDesc* __re
     F[lane] = 0ull;  // kColourMaxWords == 64 lanes
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     const uint64_t* row = bitmap + d.bm_off + (int64_t)v * d.W;
-    for (int w = lane; w < d.W; w += 64) {
-      uint64_t bits = row[w] & cb[w];  // coloured neighbours only
-      while (bits) {
-        const int u = w * 64 + __builtin_ctzll(bits);
-        bits &= bits - 1;
-        const int cu = col[u];
-        if (cu >= 0) atomicOr(&F[cu >> 6], 1ull << (cu & 63));
+    for (int w0 = 0; w0 < d.W; w0 += 64 * kRowWordsPerLane) {
+      uint64_t words[kRowWordsPerLane];  // every load of the pass issued before the first use
+#pragma unroll
+      for (int k = 0; k < kRowWordsPerLane; ++k) {
+        const int w = w0 + 64 * k + lane;
+        words[k] = w < d.W ? (row[w] & cb[w]) : 0ull;  // coloured neighbours only
       }
+      visit_bits_batched(words, w0, lane, [&](int u) { return col[u]; },
+                         [&](int, int cu) {
+                           if (cu >= 0) atomicOr(&F[cu >> 6], 1ull << (cu & 63));
+                         });
     }
     // wave-private LDS, same-wave ordering: no block barrier needed
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1423,19 +1486,23 @@ __global__ __launch_bounds__(256) void colour_resolve_kernel(const ProbDesc* __r
     const unsigned int pv = colour_hash(v, round, 0xabcdef1u);
     const uint64_t* row = bitmap + d.bm_off + (int64_t)v * d.W;
     bool lose = false;
-    for (int w = lane; w < d.W; w += 64) {
+    for (int w0 = 0; w0 < d.W; w0 += 64 * kRowWordsPerLane) {
       // rivals: neighbours that bid in this round.  (colbits as read here may already hold winners of this very
       // round -- their bids still count, so it is not used to thin the set; a vertex coloured in an EARLIER
       // round cannot hold tv: v chose among the colours its coloured neighbours left free.)
-      uint64_t bits = row[w] & bd[w];
-      while (bits) {
-        const int u = w * 64 + __builtin_ctzll(bits);
-        bits &= bits - 1;
-        if (tn[u] == tv) {
-          const unsigned int pu = colour_hash(u, round, 0xabcdef1u);
-          lose |= (pu > pv) | ((pu == pv) & (u > v));
-        }
+      uint64_t words[kRowWordsPerLane];
+#pragma unroll
+      for (int k = 0; k < kRowWordsPerLane; ++k) {
+        const int w = w0 + 64 * k + lane;
+        words[k] = w < d.W ? (row[w] & bd[w]) : 0ull;
       }
+      visit_bits_batched(words, w0, lane, [&](int u) { return tn[u]; },
+                         [&](int u, int tu) {
+                           if (tu == tv) {
+                             const unsigned int pu = colour_hash(u, round, 0xabcdef1u);
+                             lose |= (pu > pv) | ((pu == pv) & (u > v));
+                           }
+                         });
     }
     const bool lost = __ballot(lose) != 0ull;
     if (lane == 0) {
@@ -1484,34 +1551,63 @@ __global__ __launch_bounds__(256) void root_prune_kernel(const ProbDesc* __restr
   const ProbDesc d = descs[p];
   if (!sel && colour_not_needed(states[p], d.n)) return;
   const int xc = states[p].x_count;
-  if (xc > kRootPruneCap || (int)blockIdx.y >= xc) return;
+  if (xc > kRootPruneCap) return;
   const int lb = states[p].lb;
-  const int x = xlist[d.pt_off + blockIdx.y];
   uint64_t* Rx = reinterpret_cast<uint64_t*>(smem);
   const uint64_t* bm = bitmap + d.bm_off;
   const uint64_t* al = alive + d.w_off;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // gridDim.y workgroup rows walk the roots (the common case is |X| = 0 or a handful: a grid of kRootPruneCap rows
+  // spent 174 us at N = 50 000 dispatching 16 384 workgroups that returned at once)
+  for (int root = blockIdx.y; root < xc; root += gridDim.y) {
+  const int x = xlist[d.pt_off + root];
+  __syncthreads();  // (the previous root's Rx / wsum_ are no longer read)
   for (int w = threadIdx.x; w < d.W; w += 256) Rx[w] = bm[(int64_t)x * d.W + w] & al[w];
   __syncthreads();
   // this block's slice of x's neighbours: words blockIdx.x*4+wave, stride 4*gridDim.x
   int cnt = 0;
   for (int w = blockIdx.x * 4 + wave; w < d.W; w += 4 * gridDim.x) {
     uint64_t bits = Rx[w];
+    // TWO neighbours' rows at a time, eight words of each in flight per lane before the first use: a plain
+    // `for (k = lane; k < W; k += 64)` loop waits for every word in turn (13 dependent HBM round trips per row at
+    // N = 50 000: 170 us for a dozen roots, where the bytes are worth 20)
     while (bits) {
-      const int y = w * 64 + __builtin_ctzll(bits);
+      const int y0 = w * 64 + __builtin_ctzll(bits);
       bits &= bits - 1;
-      const uint64_t* ry = bm + (int64_t)y * d.W;
-      int c = 0;
-      for (int k = lane; k < d.W; k += 64) c += __popcll(ry[k] & Rx[k]);
-      c = wsum(c);
-      cnt += (c >= lb - 1) ? 1 : 0;
+      const bool two = bits != 0ull;
+      const int y1 = two ? w * 64 + __builtin_ctzll(bits) : y0;
+      bits &= bits - (two ? 1ull : 0ull);
+      const uint64_t* r0 = bm + (int64_t)y0 * d.W;
+      const uint64_t* r1 = bm + (int64_t)y1 * d.W;
+      int c0 = 0, c1 = 0;
+      for (int k0 = 0; k0 < d.W; k0 += 64 * 8) {
+        uint64_t a[8], b[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int k = k0 + 64 * j + lane;
+          a[j] = k < d.W ? r0[k] : 0ull;
+          b[j] = (two && k < d.W) ? r1[k] : 0ull;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int k = k0 + 64 * j + lane;
+          const uint64_t m = k < d.W ? Rx[k] : 0ull;
+          c0 += __popcll(a[j] & m);
+          c1 += __popcll(b[j] & m);
+        }
+      }
+      c0 = wsum(c0);
+      c1 = wsum(c1);
+      cnt += (c0 >= lb - 1) ? 1 : 0;
+      cnt += (two && c1 >= lb - 1) ? 1 : 0;
     }
   }
   if (lane == 0) wsum_[wave] = cnt;
   __syncthreads();
   if (threadIdx.x == 0) {
     const int t = wsum_[0] + wsum_[1] + wsum_[2] + wsum_[3];
-    if (t) atomicAdd(&count[d.pt_off + blockIdx.y], t);
+    if (t) atomicAdd(&count[d.pt_off + root], t);
+  }
   }
 }
 
@@ -1556,7 +1652,7 @@ void launch_colour_bound(hipStream_t s, const ProbDesc* d_desc, const int32_t* d
   hipLaunchKernelGGL(colour_finish_kernel, dim3(2, nsel), dim3(256), 0, s, d_desc, d_sel, d_state, d_tent);
   // d_tent[0 .. |X|) now holds zeroed per-root counts of qualifying neighbours
   const int max_W = (max_n + 63) / 64;
-  hipLaunchKernelGGL(root_prune_kernel, dim3(kRootPruneSlices, kRootPruneCap, nsel), dim3(256),
+  hipLaunchKernelGGL(root_prune_kernel, dim3(kRootPruneSlices, kRootPruneRows, nsel), dim3(256),
                      (size_t)max_W * 8, s, d_desc, d_sel, d_bitmap, d_alive, d_state, d_xlist, d_tent);
 }
 

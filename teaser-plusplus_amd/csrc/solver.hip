@@ -740,6 +740,9 @@ int32_t close_clique_bounds(teaser_hip_solver* h, int batch, int64_t total_n, bo
     ProbState& st = h->states[(size_t)b];
     const int xc_raw = e.ctrl[5], xc_kept = e.ctrl[6];
     h->colour_x[(size_t)b] = (xc_raw > 0 && xc_kept == 0) ? 0 : xc_raw;
+    if (setting(S_K4_DEBUG))
+      fprintf(stderr, "[teaser_hip] bound stage, problem %d: |X| = %d uncoloured survivors, %d kept by the root filter, n2 = %d\n",
+              b, xc_raw, xc_kept, e.n2);
     if (e.n2 == 0) {  // lb colours suffice for every survivor / no root can lie in a larger clique
       st.proven = 1;
       continue;
