@@ -1400,8 +1400,9 @@ void launch_tim_graph_mfma(hipStream_t s, int phase, const ProbDesc* d_desc, int
   } else {
     // a wave per region of the largest problem (up to 2048 workgroups per problem); the kernel also counts the
     // degrees of the problems that ran the FP64 body inside K1 (no degree atomics there)
-    hipLaunchKernelGGL(tim_fixup_group_kernel,
-                       dim3((unsigned)std::max<int64_t>(4, std::min<int64_t>(2048, (regs_per_problem + 3) / 4)), batch),
+    const int64_t forced_wgs = setting(S_FIXUP_WGS);
+    const int64_t fix_wgs = forced_wgs > 0 ? forced_wgs : std::min<int64_t>(2048, (regs_per_problem + 3) / 4);
+    hipLaunchKernelGGL(tim_fixup_group_kernel, dim3((unsigned)std::max<int64_t>(4, fix_wgs), batch),
                        dim3(256), 0, s, d_desc, batch, d_src, d_dst, d_bitmap, beta, work, work_count, d_state, d_deg,
                        regions, (unsigned int)regs_per_problem, prep);
   }

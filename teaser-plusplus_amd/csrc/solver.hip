@@ -71,6 +71,7 @@ const SettingRow kSettingRows[S_COUNT] = {
     {"k4_debug", "TEASER_K4_DEBUG", 0},
     {"heu_blocks", "TEASER_HEU_BLOCKS", 0},
     {"greedy_threads", "TEASER_GREEDY_THREADS", 0},
+    {"fixup_wgs", "TEASER_K1_FIXUP_WGS", 0},
 };
 struct SettingTable {
   std::atomic<int64_t> v[S_COUNT];
