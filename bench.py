@@ -64,7 +64,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_BF16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (not the 2:1-sparsity figure)
 FP64_PEAK_TF = 78.6        # dense FP64 peak of MI355X (matrix = vector), FMA = 2 flops
 VALU_PEAK_GINST = 1024 * 2.4 / 4.0  # G wave64 VALU instructions/s: 256 CUs x 4 SIMDs, 2.4 GHz, 4 cycles each
-K1_VALU_PER_1024_STATIC = 56.0  # steady-state loop body of tim_graph_mfma3_kernel (scripts/k1_isa_stats.py)
+K1_VALU_PER_1024_STATIC = 64.0  # steady-state loop body of tim_graph_mfma3_kernel (scripts/k1_isa_stats.py)
 K1_FLOPS_PER_PAIR = 20.0   # algorithmic FP64 flops of the reference predicate
 # executed by K1 per pair: 4 x v_mfma_f32_32x32x16_bf16 (2*32*32*16 flops each) per 1024 pairs
 K1_MFMA_FLOPS_PER_PAIR = 4 * 2 * 32 * 32 * 16 / 1024.0

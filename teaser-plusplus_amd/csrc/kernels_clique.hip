@@ -1335,7 +1335,12 @@ __global__ __launch_bounds__(256) void colour_init_kernel(const ProbDesc* __rest
   int32_t* cnt = counts + (int64_t)blockIdx.y * (kColourRounds + 2);
   if (blockIdx.x == 0 && threadIdx.x == 0) states[p].x_count = 0;  // (the rounds that append to X come later)
   const int npad = d.W * 64;
-  for (int v = blockIdx.x * 256 + threadIdx.x; v < npad; v += gridDim.x * 256) {  // a wave = one 64-vertex word
+  const int wave = threadIdx.x >> 6;
+  __shared__ int wcount[4][kColourClasses];
+  __shared__ int wbase[kColourClasses];
+  for (int v0 = blockIdx.x * 256; v0 < npad; v0 += gridDim.x * 256) {  // (block-uniform trip count: barriers inside)
+    const int v = v0 + threadIdx.x;  // a wave = one 64-vertex word
+    const bool word = v < npad;      // (npad is a multiple of 64: uniform over the wave)
     const bool in = v < d.n;
     const bool al = in && ((alive[d.w_off + (v >> 6)] >> (v & 63)) & 1ull);
     int c = al ? -1 : -3;
@@ -1354,28 +1359,43 @@ __global__ __launch_bounds__(256) void colour_init_kernel(const ProbDesc* __rest
     }
     const int cls = colour_class(v);
     const uint64_t mcol = __ballot(c >= 0);
-    if (lane == 0) colbits[d.w_off + (v >> 6)] = mcol;
+    if (lane == 0 && word) colbits[d.w_off + (v >> 6)] = mcol;
+    // the class bit sets and the class lists: every uncoloured survivor goes to the list of its class.  The list
+    // positions come from ONE atomic per workgroup and class (a wave-level atomic per class -- 782 waves on the same
+    // eight counters at N = 50 000 -- serialised in L2: 75 us for a kernel that touches 400 KB)
+    uint64_t mk[kColourClasses];
 #pragma unroll
     for (int k = 0; k < kColourClasses; ++k) {
-      const uint64_t mk = __ballot(c == -1 && cls == k);
-      if (lane == 0) classbits[(int64_t)k * total_w + d.w_off + (v >> 6)] = mk;
+      mk[k] = __ballot(c == -1 && cls == k);
+      if (lane == 0 && word) classbits[(int64_t)k * total_w + d.w_off + (v >> 6)] = mk[k];
+      if (lane == k) wcount[wave][k] = __builtin_popcountll(mk[k]);
     }
-    // the class lists: every uncoloured survivor goes to the list of its class (one atomic per wave and class)
+    __syncthreads();
+    if (threadIdx.x < kColourClasses) {
+      const int k = threadIdx.x;
+      const int tot = wcount[0][k] + wcount[1][k] + wcount[2][k] + wcount[3][k];
+      wbase[k] = tot ? atomicAdd(&cnt[k], tot) : 0;
+    }
+    __syncthreads();
+    if (c == -1) {
+      int base = wbase[cls];
+      for (int w = 0; w < wave; ++w) base += wcount[w][cls];
+      uint64_t m = 0;
 #pragma unroll
-    for (int k = 0; k < kColourClasses; ++k) {
-      const uint64_t m = __ballot(c == -1 && cls == k);
-      if (m) {
-        int base = 0;
-        if (lane == __builtin_ctzll(m)) base = atomicAdd(&cnt[k], __builtin_popcountll(m));
-        base = __shfl(base, __builtin_ctzll(m), 64);
-        if (c == -1 && cls == k)
-          list0[(int64_t)k * total_n + d.pt_off + base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = v;
-      }
+      for (int k = 0; k < kColourClasses; ++k) m = (cls == k) ? mk[k] : m;
+      list0[(int64_t)cls * total_n + d.pt_off + base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = v;
     }
+    __syncthreads();  // (wcount / wbase are rewritten by the next pass)
   }
 }
 
-__global__ __launch_bounds__(256) void colour_assign_kernel(const ProbDesc* __restrict__ descs,
+// waves per workgroup of the colouring rounds (a wave per listed vertex): the resolve step appends its losers with one
+// atomic per workgroup, so it wants large workgroups.  The assign step alone is faster with 4-wave workgroups (24.8 vs
+// 28.3 us per launch at N = 50 000), but with six solves in flight the pipeline is faster with 16 (0.844 ms per solve
+// against 0.853 with 8 and 0.866 with 4: four times fewer workgroups for the dispatcher; profiles/r5k)
+constexpr int kColourWaves = 16, kAssignWaves = 16;
+
+__global__ __launch_bounds__(64 * kAssignWaves) void colour_assign_kernel(const ProbDesc* __restrict__ descs,
                                                             const int32_t* __restrict__ sel,
                                                             const uint64_t* __restrict__ bitmap,
                                                             ProbState* __restrict__ states,
@@ -1387,7 +1407,7 @@ __global__ __launch_bounds__(256) void colour_assign_kernel(const ProbDesc* __re
                                                             const uint64_t* __restrict__ colbits, int round,
                                                             int count_idx, const uint64_t* __restrict__ alive,
                                                             uint64_t* __restrict__ bid_snapshot) {
-  __shared__ unsigned long long Fs[4][kColourMaxWords];
+  __shared__ unsigned long long Fs[kAssignWaves][kColourMaxWords];
   const int p = sel ? sel[blockIdx.y] : (int)blockIdx.y;
   const ProbDesc d = descs[p];
   if (!sel && colour_not_needed(states[p], d.n)) return;
@@ -1395,14 +1415,14 @@ __global__ __launch_bounds__(256) void colour_assign_kernel(const ProbDesc* __re
   // all-in rounds: the bidders of this round = the survivors still without a colour NOW (colbits is stable while
   // the assign step runs; the resolve step, which updates it, reads this snapshot)
   if (bid_snapshot && blockIdx.x == 0)
-    for (int w = threadIdx.x; w < d.W; w += 256) bid_snapshot[d.w_off + w] = alive[d.w_off + w] & ~colbits[d.w_off + w];
+    for (int w = threadIdx.x; w < d.W; w += 64 * kAssignWaves) bid_snapshot[d.w_off + w] = alive[d.w_off + w] & ~colbits[d.w_off + w];
   const int count = counts[(int64_t)blockIdx.y * (kColourRounds + 2) + count_idx];
   int32_t* col = colour + d.pt_off;
   const int lb = states[p].lb;
   const int nw = (lb + 63) >> 6;
   unsigned long long* F = Fs[wave];
   const uint64_t* cb = colbits + d.w_off;
-  for (int it = blockIdx.x * 4 + wave; it < count; it += gridDim.x * 4) {
+  for (int it = blockIdx.x * kAssignWaves + wave; it < count; it += gridDim.x * kAssignWaves) {
     const int v = list[d.pt_off + it];
     F[lane] = 0ull;  // kColourMaxWords == 64 lanes
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1456,7 +1476,7 @@ __global__ __launch_bounds__(256) void colour_assign_kernel(const ProbDesc* __re
 
 // winners commit their colour; everybody still uncoloured goes to the next round's list (after the last round:
 // to X)
-__global__ __launch_bounds__(256) void colour_resolve_kernel(const ProbDesc* __restrict__ descs,
+__global__ __launch_bounds__(64 * kColourWaves) void colour_resolve_kernel(const ProbDesc* __restrict__ descs,
                                                              const int32_t* __restrict__ sel,
                                                              const uint64_t* __restrict__ bitmap,
                                                              ProbState* __restrict__ states,
@@ -1469,6 +1489,7 @@ __global__ __launch_bounds__(256) void colour_resolve_kernel(const ProbDesc* __r
                                                              uint64_t* __restrict__ colbits,
                                                              const uint64_t* __restrict__ bidders /* this round's */,
                                                              int round, int last, int count_idx, int next_idx) {
+  __shared__ int lostv[kColourWaves];
   const int p = sel ? sel[blockIdx.y] : (int)blockIdx.y;
   const ProbDesc d = descs[p];
   if (!sel && colour_not_needed(states[p], d.n)) return;
@@ -1478,45 +1499,60 @@ __global__ __launch_bounds__(256) void colour_resolve_kernel(const ProbDesc* __r
   int32_t* col = colour + d.pt_off;
   const int32_t* tn = tent + d.pt_off;
   const uint64_t* bd = bidders + d.w_off;
-  const uint64_t* cb = colbits + d.w_off;
-  for (int it = blockIdx.x * 4 + wave; it < count; it += gridDim.x * 4) {
-    const int v = list[d.pt_off + it];
-    if (col[v] != -1) continue;  // (-2: already in X)
-    const int tv = tn[v];
-    const unsigned int pv = colour_hash(v, round, 0xabcdef1u);
-    const uint64_t* row = bitmap + d.bm_off + (int64_t)v * d.W;
+  // (block-uniform trip count: the losers of a pass are appended to the next list with ONE atomic per workgroup --
+  // a returning atomic per losing vertex on the list's single counter serialised in L2: 5 000 losers of the first
+  // all-in round at N = 50 000 took 55 us that way)
+  for (int it0 = blockIdx.x * kColourWaves; it0 < count; it0 += gridDim.x * kColourWaves) {
+    const int it = it0 + wave;
+    const int v = it < count ? list[d.pt_off + it] : -1;
+    const bool consider = v >= 0 && col[v] == -1;  // (-2: already in X)
     bool lose = false;
-    for (int w0 = 0; w0 < d.W; w0 += 64 * kRowWordsPerLane) {
-      // rivals: neighbours that bid in this round.  (colbits as read here may already hold winners of this very
-      // round -- their bids still count, so it is not used to thin the set; a vertex coloured in an EARLIER
-      // round cannot hold tv: v chose among the colours its coloured neighbours left free.)
-      uint64_t words[kRowWordsPerLane];
+    if (consider) {
+      const int tv = tn[v];
+      const unsigned int pv = colour_hash(v, round, 0xabcdef1u);
+      const uint64_t* row = bitmap + d.bm_off + (int64_t)v * d.W;
+      for (int w0 = 0; w0 < d.W; w0 += 64 * kRowWordsPerLane) {
+        // rivals: neighbours that bid in this round.  (colbits may already hold winners of this very round -- their
+        // bids still count, so it is not used to thin the set; a vertex coloured in an EARLIER round cannot hold tv:
+        // v chose among the colours its coloured neighbours left free.)
+        uint64_t words[kRowWordsPerLane];
 #pragma unroll
-      for (int k = 0; k < kRowWordsPerLane; ++k) {
-        const int w = w0 + 64 * k + lane;
-        words[k] = w < d.W ? (row[w] & bd[w]) : 0ull;
+        for (int k = 0; k < kRowWordsPerLane; ++k) {
+          const int w = w0 + 64 * k + lane;
+          words[k] = w < d.W ? (row[w] & bd[w]) : 0ull;
+        }
+        visit_bits_batched(words, w0, lane, [&](int u) { return tn[u]; },
+                           [&](int u, int tu) {
+                             if (tu == tv) {
+                               const unsigned int pu = colour_hash(u, round, 0xabcdef1u);
+                               lose |= (pu > pv) | ((pu == pv) & (u > v));
+                             }
+                           });
       }
-      visit_bits_batched(words, w0, lane, [&](int u) { return tn[u]; },
-                         [&](int u, int tu) {
-                           if (tu == tv) {
-                             const unsigned int pu = colour_hash(u, round, 0xabcdef1u);
-                             lose |= (pu > pv) | ((pu == pv) & (u > v));
-                           }
-                         });
+      const bool lost = __ballot(lose) != 0ull;
+      if (lane == 0) {
+        if (!lost) {  // the winner commits its colour
+          col[v] = tv;
+          atomicOr(reinterpret_cast<unsigned long long*>(colbits + d.w_off + (v >> 6)), 1ull << (v & 63));
+        }
+        lostv[wave] = lost ? v : -1;
+      }
+    } else if (lane == 0) {
+      lostv[wave] = -1;
     }
-    const bool lost = __ballot(lose) != 0ull;
-    if (lane == 0) {
-      if (!lost) {
-        col[v] = tv;
-        atomicOr(reinterpret_cast<unsigned long long*>(colbits + d.w_off + (v >> 6)), 1ull << (v & 63));
-      } else if (last) {
-        xlist[d.pt_off + atomicAdd(&states[p].x_count, 1)] = v;
-      } else {
-        next_list[d.pt_off + atomicAdd(&cnt[next_idx], 1)] = v;
+    __syncthreads();
+    if (wave == 0) {  // everybody still uncoloured goes to the next round's list (after the last round: to X)
+      const int x = lane < kColourWaves ? lostv[lane] : -1;
+      const uint64_t m = __ballot(x >= 0);
+      if (m) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(last ? &states[p].x_count : &cnt[next_idx], __builtin_popcountll(m));
+        base = __shfl(base, 0, 64);
+        if (x >= 0) (last ? xlist : next_list)[d.pt_off + base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = x;
       }
     }
+    __syncthreads();  // (lostv is rewritten by the next pass)
   }
-  (void)cb;
 }
 
 // the per-root counters of root_prune_kernel (indexed by position in X)
@@ -1639,13 +1675,16 @@ void launch_colour_bound(hipStream_t s, const ProbDesc* d_desc, const int32_t* d
     const int next_idx = cls ? kColourClasses : kColourClasses + j + 1;
     // (a wave per listed vertex, as many in flight as the GPU holds -- every wave is a chain of dependent
     // gathers; the all-in rounds see a small fraction of the vertices: a smaller grid starts sooner)
-    const int g = cls ? std::max(1, (max_n / kColourClasses + 3) / 4 + 64) : std::min((max_n + 3) / 4, 1024);
+    auto grid_for = [&](int waves) {
+      return cls ? std::max(1, (max_n / kColourClasses + waves - 1) / waves + 64 / waves)
+                 : std::min((max_n + waves - 1) / waves, 4096 / waves);
+    };
     uint64_t* snapshot = d_bits + (int64_t)(kColourClasses + 1) * total_w;
     const uint64_t* bidders = cls ? classbits + (int64_t)r * total_w : snapshot;
-    hipLaunchKernelGGL(colour_assign_kernel, dim3(g, nsel), dim3(256), 0, s, d_desc, d_sel, d_bitmap, d_state,
+    hipLaunchKernelGGL(colour_assign_kernel, dim3(grid_for(kAssignWaves), nsel), dim3(64 * kAssignWaves), 0, s, d_desc, d_sel, d_bitmap, d_state,
                        d_colour, d_tent, cur, d_counts, d_xlist, colbits, r, count_idx, d_alive,
                        cls ? static_cast<uint64_t*>(nullptr) : snapshot);
-    hipLaunchKernelGGL(colour_resolve_kernel, dim3(g, nsel), dim3(256), 0, s, d_desc, d_sel, d_bitmap, d_state,
+    hipLaunchKernelGGL(colour_resolve_kernel, dim3(grid_for(kColourWaves), nsel), dim3(64 * kColourWaves), 0, s, d_desc, d_sel, d_bitmap, d_state,
                        d_colour, d_tent, cur, nxt, d_counts, d_xlist, colbits, bidders, r, r == rounds - 1 ? 1 : 0,
                        count_idx, next_idx);
   }

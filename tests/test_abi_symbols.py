@@ -67,19 +67,27 @@ def test_bench_cli_parses_without_gpu():
 
 
 def test_bench_roofline_object():
-    """The roofline arithmetic of bench.py on the r1g numbers (64 x N=10k per launch, 1.414 ms)."""
+    """The roofline arithmetic of bench.py (64 x N = 10 k per launch, 0.80 ms): executed-pipe fractions, the largest
+    one at the top level, none above 1; the FP64-equivalent ratio nested (it MAY exceed 1)."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     pairs = 64 * 10000 * 9999 // 2
     byts = 64 * (48 * 10000 + 8 * 10000 * 157)
-    r = bench.roofline_object(k1_ms=20 * 1.414, k1_launches=20, k1_bytes=20 * byts, k1_pairs=20 * pairs,
-                              k1_aux_ms=20 * 0.15, traffic=2.5e9, traffic_src="profiles/x")
-    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 78.6
-    assert abs(r["avg_launch_ms"] - 1.414) < 1e-9 and r["launches"] == 20
-    assert abs(r["achieved"] - 20 * pairs / 1.414e-3 / 1e12) < 1e-6 and abs(r["frac"] - r["achieved"] / 78.6) < 1e-12
-    assert abs(r["executed_mfma"]["achieved"] - 128 * pairs / 1.414e-3 / 1e12) < 1e-6
-    assert abs(r["hbm"]["achieved"] - byts / 1.414e-3 / 1e9) < 1e-6 and r["traffic"] == 2.5e9
+    issue = dict(valu_insts_per_1024_pairs=77.6, source="profiles/x/k1_sq_counters.json")
+    r = bench.roofline_object(k1_ms=20 * 0.80, k1_launches=20, k1_bytes=20 * byts, k1_pairs=20 * pairs,
+                              k1_aux_ms=20 * 0.15, traffic=1.78e9, traffic_src="profiles/x", issue=issue)
+    assert set(r["pipes"]) == {"valu", "mfma", "hbm"}
+    assert r["bound"] == "valu" and r["unit"] == "G wave-instructions/s" and r["peak"] == 1024 * 2.4 / 4
+    assert abs(r["avg_launch_ms"] - 0.80) < 1e-9 and r["launches"] == 20
+    assert abs(r["achieved"] - 77.6 * pairs / 1024 / 0.80e-3 / 1e9) < 1e-6 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert r["frac"] == max(p["frac"] for p in r["pipes"].values()) and all(0 <= p["frac"] <= 1 for p in r["pipes"].values())
+    assert abs(r["pipes"]["mfma"]["achieved"] - 128 * pairs / 0.80e-3 / 1e12) < 1e-6 and r["pipes"]["mfma"]["peak"] == 2500.0
+    assert abs(r["pipes"]["hbm"]["achieved"] - byts / 0.80e-3 / 1e9) < 1e-6 and r["traffic"] == 1.78e9
+    f = r["fp64_equivalent"]
+    assert abs(f["achieved"] - 20 * pairs / 0.80e-3 / 1e12) < 1e-6 and f["peak"] == 78.6 and f["ratio"] > 1.0
+    r0 = bench.roofline_object(20 * 0.80, 20, 20 * byts, 20 * pairs, 0.0, None, None)  # no counter pass committed
+    assert r0["pipes"]["valu"]["valu_insts_per_1024_pairs"] == bench.K1_VALU_PER_1024_STATIC
     z = bench.roofline_object(0.0, 0, 0, 0, 0.0, None, None)  # no launches: no division by zero
     assert z["achieved"] == 0.0 and z["traffic"] is None
