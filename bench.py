@@ -375,9 +375,13 @@ def relaunch_as_ranks(args):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    # (the ranks take their arguments from the environment: torch.distributed.run's argparse rejects `--n 4000` behind the
+    # script path as an ambiguous abbreviation of its own --nnodes / --nproc-per-node / --node-rank ...)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__),
+           "--gpus", str(args.gpus)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               TEASER_BENCH_ARGV=json.dumps(sys.argv[1:]))
     os.execvpe(cmd[0], cmd, env)
 
 
@@ -725,7 +729,7 @@ def synth_workload(tp, args, rank, tag, B, n, rho, n_batches, cpu_solves, cpu_bu
 def main():
     if len(sys.argv) >= 3 and sys.argv[1] == "--cpu-worker":
         return _cpu_worker(sys.argv[2])
-    args = parse()
+    args = parse(json.loads(os.environ["TEASER_BENCH_ARGV"]) if "RANK" in os.environ and "TEASER_BENCH_ARGV" in os.environ else None)
     if args.gpus > 1 and "RANK" not in os.environ:
         relaunch_as_ranks(args)  # does not return
     rank = int(os.environ.get("RANK", "0"))
