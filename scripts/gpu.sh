@@ -54,11 +54,6 @@ for task in "$@"; do
     suite) SECONDS=0; TEASER_CERT_DEBUG=$OUT/cert_warmup.txt timeout 1500 python -m pytest tests/ -x -q -m gpu --durations=12 > $OUT/gpu_tests.txt 2>&1; echo "suite rc=$? in ${SECONDS}s"; tail -22 $OUT/gpu_tests.txt ;;
     bench) timeout 1200 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "rc=$?"; cut -c1-700 $OUT/bench.json; tail -3 $OUT/bench.err ;;
     benchq) timeout 400 python bench.py --configs '' --no-cpu-baseline > $OUT/benchq.json 2> $OUT/benchq.err; echo "rc=$?"; cut -c1-500 $OUT/benchq.json; tail -3 $OUT/benchq.err ;;
-    benchv)  # headline only, per K1 variant in $K1VS
-      for v in ${K1VS:-20 21 22}; do TEASER_K1_VARIANT=$v timeout 300 python bench.py --configs '' --no-cpu-baseline --no-latency --no-host-resident --steps 40 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
-print('variant $v: %.0f reg/s, %.4f ms/step, K1 %.4f ms, aux %.4f ms' % (d['value'], d['ms_per_step'], r['avg_launch_ms'], r['aux_ms_per_launch']))"; done | tee $OUT/bench_variants.txt ;;
     benchenv)  # headline only, one run per environment setting in $ENVS (semicolon-separated "A=1 B=2" groups)
       IFS=";" read -ra GRPS <<< "${ENVS}"
       for g in "${GRPS[@]}"; do env $g timeout 300 python bench.py $BENCH_EXTRA --configs '' --no-cpu-baseline --no-latency --no-host-resident --steps 40 2>/dev/null | python -c "
@@ -136,13 +131,6 @@ for r in csv.DictReader(open("$OUT/scale_kernel_stats.csv")):
     print("%-70s calls %5s avg %9.1f us  %5s %%" % (r["Name"].replace("thip::","").replace("(anonymous namespace)::","")[:70], r["Calls"], float(r["AverageNs"])/1e3, r["Percentage"]))
 PY
       ;;
-    k1occ)  # K1 alone at 1 / 2 / 3 workgroups per CU (unused dynamic LDS limits the occupancy)
-      for v in 20 23; do for pad in 0 30000 60000; do
-        TEASER_K1_VARIANT=$v TEASER_K1_LDS_PAD=$pad timeout 60 $P 64 10000 5 one 2>/dev/null | sed "s/^{/{\"lds_pad\":$pad,\"v\":$v,/" | cut -c1-140
-      done; done | tee $OUT/k1_occupancy.jsonl ;;
-    pcsample)  # stochastic PC sampling of K1 alone (beta feature: short timeout, nothing else in the call depends on it)
-      (cd /tmp && TEASER_K1_VARIANT=${K1V:-20} timeout 120 rocprofv3 --pc-sampling-beta-enabled --pc-sampling-unit ${PCS_UNIT:-time} --pc-sampling-method ${PCS_METHOD:-host_trap} --pc-sampling-interval ${PCS_INT:-1} --output-format csv json -d $OUT/pcs -o t -- $P 64 10000 3 one) > $OUT/pcs.log 2>&1; echo "pcs rc=$?"; tail -5 $OUT/pcs.log | cut -c1-300; ls -la $OUT/pcs 2>/dev/null | head ;;
-    k1trace) for v in 40 42; do TEASER_K1_VARIANT=$v timeout 60 $P 64 10000 3 one 2>&1 | grep -i "K1 cycles\|k1_ms" | cut -c1-330 | tail -2; done | tee $OUT/k1_phase_trace.txt ;;
     valurate) timeout 300 $R/scripts/probe/valu_rate 2.0 > $OUT/valu_rate.jsonl 2>&1; echo "rc=$?"; python - <<PY
 import json
 rows=[json.loads(l) for l in open("$OUT/valu_rate.jsonl") if l.startswith("{") and "inst" in l]

@@ -384,7 +384,6 @@ constexpr int kRegionItems = kRegionWords - 1;
 
 // ------------------------------------------------------------------------------------------
 // Operands and band constants of the u / w algebra
-// K1, second formulation ("u / w"): the epilogue shrinks from 5.5 packed to 4 plain f32 VALU per pair.
 //
 // With A = |s_j - s_i|^2 (src), B = |d_j - d_i|^2 (dst):   | sqrt A - sqrt B | <= beta
 //   <=>  sqrt A + sqrt B <= beta   or   d := u^2 + w <= 0,   u = B - A - beta^2,  w = -4 beta^2 A
@@ -392,17 +391,12 @@ constexpr int kRegionItems = kRegionWords - 1;
 // the Gram terms, so they come straight out of the matrix pipe: u over 42 K slots (18 + 18 coordinate products of
 // the exact three-way bf16 split, 6 for the per-point constants m_i - n_i - beta^2 and m_j - n_j) = three chained
 // v_mfma_f32_32x32x16_bf16, w over 13 slots (two-piece operands: w is multiplied by nothing and only needs
-// ~1e-4 relative accuracy) = one more -- four MFMAs per 32 x 32 tile as before.  The points are centred AND scaled
-// per problem by g in (1, sqrt 2] such that 4 (g beta)^2 is a power of two: the factor of w is then an exponent
-// shift of the column operands, exact.  Per accumulator PAIR the VALU issues eight instructions, no branch:
-// d = fma(u, u, w), -band = fma(w, K2, -K0) (w <= 0), the two band edges d -+ band, and one v_alignbit per edge
-// and value collecting sign(d + band) (the edge bit: certainly an edge) and sign(d - band); the two signs differ
-// <=> the pair lies inside the error band.  K0 is raised to >= 4 beta^4 (mfma2_consts), which puts every short
-// pair (S <= beta: A, B <= beta^2, |d| <= 4 beta^4) inside the band by construction, so the `S <= beta` branch
-// needs no test of its own.  A lane's in-band masks (one 32-bit word per column half tile) are parked in LDS
-// (lds_xb) and harvested BEHIND the column loop, wave-parallel, into the wave's own region of the fix-up worklist
-// (count word + 31 items, plain stores; only an overflowing wave touches the atomic segment list): a returning
-// atomic plus dependent stores at the end of every wave was what bounded the kernel (1.20 -> 0.93 ms).
+// ~1e-4 relative accuracy) = one more -- four MFMAs per 32 x 32 tile.  The points are centred AND scaled per
+// problem by g in (1, sqrt 2] such that 4 (g beta)^2 is a power of two: the factor of w is then an exponent shift
+// of the column operands, exact.  mfma2_consts below is the per-VALUE band K2 |w| + K0 of an earlier epilogue (two
+// band edges per value); the product's kernel uses the constant band of mfma3_consts, which builds on it (the
+// admission test, G, and K0 >= 4 beta^4: every short pair -- S <= beta: A, B <= beta^2, |d| <= 4 beta^4 -- lies
+// inside the band by construction, so the `S <= beta` branch needs no test of its own).
 //
 // Error budget in the scaled system (u = 2^-24, R = max |scaled centred point|, beta = g beta_0):
 //   eps_u = kEpsU2 u R^2 bounds |u~ - u*|: f32 rounding of the scaled centred coordinates 16 u R^2 (8 per cloud),
@@ -414,8 +408,8 @@ constexpr int kRegionItems = kRegionWords - 1;
 //   with lam = 2 beta R, eta = eps_u / lam:  |d~ - d*| <= [ (eta + u) |d~| + eta |w~| + K0' ] / (1 - eta),
 //     K0' = eps_u lam + eps_u^2 + kappa eps_A (1 + eta) (kappa = 4 beta^2), so sign(d~) is trusted iff
 //     |d~| > K2 |w~| + K0,  K2 = eta / (1 - 2 eta - 2u),  K0 = (K0' + G) / (1 - 2 eta - 2u) + 2 K2 kappa eps_A
-//     (G: the gap between the reference's rounded double predicate and the exact one, as in the first
-//     formulation), both x 1.001 and rounded outwards;
+//     (G: the gap between the reference's rounded double predicate and the exact one), both x 1.001 and
+//     rounded outwards;
 //   short pairs: S <= beta implies A, B <= beta^2, hence u* in [-2 beta^2, 0], w* in [-4 beta^4, 0] and |d*| <= 4 beta^4;
 //     K0 >= short_d (mfma2_consts: that bound plus the error terms) keeps |d~| <= band for all of them: they go to
 //     the fix-up individually, where the reference expression decides.
@@ -592,8 +586,8 @@ __device__ __forceinline__ Mfma2Const mfma2_consts(double beta_d, unsigned int r
 }
 
 // ==========================================================================================
-// K1, third formulation ("min |d|"): the u / w algebra and operands of the second one, with the error band taken
-// off the per-pair path.  Per accumulator value the VALU now issues 2.5 instructions instead of 6:
+// K1, the matrix-core filter ("min |d|"): the u / w algebra and operands above, with the error band taken off the
+// per-pair path.  Per accumulator value the VALU issues 2.5 instructions:
 //   d = fma(u, u, w)                         (the provisional edge bit is sign(d), collected by one v_alignbit)
 //   m = min3(m, |d_0|, |d_1|)                (one v_min3_f32 per two values: the smallest |d| of the lane's 16 pairs
 //                                             of a 32 x 32 tile)
@@ -603,9 +597,9 @@ __device__ __forceinline__ Mfma2Const mfma2_consts(double beta_d, unsigned int r
 // bits (and degrees) that differ from the provisional ones.  Nothing is parked in LDS: the lane's group flags of
 // the whole block row (8 column tiles x 4 half tiles = 32 bits) live in one register.
 //
-// The band is a CONSTANT per problem (WBAND = false) or the second formulation's K2 |w| + K0 (WBAND = true, one
-// more fma per value).  Constant band, in the scaled system of the second formulation (eps_u, eps_w = kappa eps_A
-// as there; u~ = u* + e_u, w~ = w* + e_w, d~ = fl(u~^2 + w~)):  |w*| <= kappa (2R)^2 = (4 beta R)^2 =: Wm.
+// The band is a CONSTANT per problem (a per-value band K2 |w| + K0 flags four times fewer lane-tiles but costs one more
+// fma per value: measured slower).  In the scaled system of the operands (eps_u, eps_w = kappa eps_A as above;
+// u~ = u* + e_u, w~ = w* + e_w, d~ = fl(u~^2 + w~)):  |w*| <= kappa (2R)^2 = (4 beta R)^2 =: Wm.
 //   (A) |u*| <= U0 := 4 beta R (1 + 1e-3) + 2 eps_u:  |u~^2 + w~ - d*| <= 2 U0 eps_u + eps_u^2 + eps_w =: E, so
 //       |d~| > C >= (E + G) / (1 - 4u) implies sign(d~) = sign(d*) and |d*| > G (the gap between the reference's
 //       rounded double predicate and the exact one);
@@ -642,7 +636,7 @@ __device__ __forceinline__ Mfma3Const mfma3_consts(double beta_d, unsigned int r
   const float C0 = E / (1.0f - 4.0f * u) * 1.001f * up;
   const float short_d = (4.0f * b2 * b2 * (1.0f + 16.0f * u) + 4.0f * b2 * eps_u + eps_u * eps_u + eps_w) * 1.001f * up;
   c.C = (C0 > short_d ? C0 : short_d) * 1.00001f;
-  // (same admission as the second formulation; a band dominated by the short-pair term would flag most lane-tiles)
+  // (same admission as mfma2_consts; a band dominated by the short-pair term would flag most lane-tiles)
   c.use_mfma = (c2.use_mfma && c.C == c.C && c.C < 1e30f && short_d <= 16.0f * C0) ? 1 : 0;
   return c;
 }
@@ -1114,7 +1108,7 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma3_kernel(
     __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(degacc, deg_rsrc, (unsigned int)(I * 64 + lane) * 4u, 0, 0);
 }
 
-// FP64 resolution of the third formulation's GROUP items: 16 lanes per item, lane q owns the pair
+// FP64 resolution of the filter's GROUP items: 16 lanes per item, lane q owns the pair
 // (row0 + (q & 3) + 8 (q >> 2), col).  The bitmap holds the filter's provisional bit sign(d~); a pair whose reference
 // predicate disagrees flips its bit(s) with one atomicXor each (row-major copy; transposed copy outside diagonal
 // blocks) and the two degrees follow.  Every bit is owned by exactly one lane of one item, so the plain read of the

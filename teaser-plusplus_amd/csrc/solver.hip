@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void hdr_fetch_kernel(const uint4* __restrict_
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n16; i += gridDim.x * 256) dev[i] = host[i];
 }
 // Host inputs of an asynchronous batch moved by a KERNEL reading the page-locked host arrays over PCIe instead of two
-// SDMA copies (TEASER_HIP_H2D=kernel; diagnostic).  Motivation: while an SDMA transfer of the next batch is in flight,
+// SDMA copies (setting h2d_kernel = 1; diagnostic).  Motivation: while an SDMA transfer of the next batch is in flight,
 // every small kernel of the batches on the lanes runs 12-20 us longer (hdr_fetch 7 -> 25, peel_round 6 -> 16 us:
 // profiles/r4y), ~0.15 ms on the serial chain of a 128 x 5 k step.  Outcome: worse -- the copy kernel's workgroups
 // queue for CU slots behind K1.
@@ -1746,7 +1746,7 @@ int32_t submit_impl(teaser_hip_solver* h, const double* src, const double* dst,
     HIPCHK(h, is.src.ensure((size_t)std::max<int64_t>(tot, 1) * 24));
     HIPCHK(h, is.dst.ensure((size_t)std::max<int64_t>(tot, 1) * 24));
     if (tot > 0) {
-      // TEASER_HIP_H2D = dma (default: hipMemcpyAsync, two SDMA copies; pageable memory is staged by the runtime) |
+      // setting h2d_kernel: 0 = dma (default: hipMemcpyAsync, two SDMA copies; pageable memory is staged by the runtime) | 1 =
       // kernel (host_inputs_kernel, when both arrays are page-locked memory the device can read in place: measured
       // SLOWER -- its workgroups wait for slots behind K1: 0.89 vs 0.65 ms per 128 x 5 k step, profiles/r4z -- kept
       // as a diagnostic)
