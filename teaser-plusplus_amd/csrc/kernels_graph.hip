@@ -653,7 +653,7 @@ constexpr unsigned long long kGroupItem = 1ull << 63;  // worklist item: 16 rows
 
 // The product's instantiation (launch_tim_graph_mfma); the lab build (scripts/probe/k1_lab) times the others.
 constexpr bool kK1Pipe = false, kK1Plain = true;
-constexpr int kK1Chunks = 1;
+constexpr int kK1Chunks = 1, kK1Occ = 3;
 
 // PIPE: software-pipelined schedule.  The wave works on QUARTER tiles (32 x 32) with two accumulator sets: while the
 // matrix pipe runs the four MFMAs of quarter k + 1, the vector ALU runs the epilogue of quarter k -- interleaved
@@ -664,6 +664,9 @@ constexpr int kK1Chunks = 1;
 // a packed f32 instruction beside MFMAs above two plain ones).  Measured (profiles/r5a/k1_lab.jsonl, 64 x 10 k, kernel
 // alone): flat + packed 0.693 ms, flat + PLAIN 0.658, PIPE + packed 0.719, PIPE + plain 0.697; CHUNKS 2 / 4 with the
 // flat schedule 0.74 / 0.81 (packed), 0.72 / 0.73 (plain); under the two-lane pipeline 0.876 (packed) / 0.846 (plain).
+// OCC = 4 (the 128-VGPR build, four workgroups per CU: lab variants 1000 / 1010) spills 264 bytes, 14 scratch
+// accesses per column tile: 1.01 ms packed, 1.26 ms plain (profiles/r5p) -- the fourth wave needs a kernel with a
+// smaller live set (one accumulator set, row operands in LDS), not a register cap.
 // CHUNKS: column chunks (of kMfmaColTiles tiles) a block walks with the same four waves.
 template <bool PIPE, bool PLAIN, int OCC, int CHUNKS>
 __global__ __launch_bounds__(256, OCC) void tim_graph_mfma3_kernel(
@@ -1323,12 +1326,13 @@ int64_t tim_prep_fill_segments(void* host_prep, const int32_t* n, int batch) {
 // Lab build only (scripts/probe/k1_lab): the schedule / geometry of the kernel is picked per launch from
 // TEASER_K1_VARIANT so that a probe can time them side by side.  Every variant produces the same bitmap
 // (scripts/probe/k1_lab/k1_lab.py asserts it).  The product library has ONE instantiation and reads no environment.
-struct K1Variant { int pipe, plain, chunks; };
+struct K1Variant { int pipe, plain, chunks, occ4; };
 static K1Variant k1_lab_variant() {
   const char* ev = getenv("TEASER_K1_VARIANT");
   const int v = ev ? atoi(ev) : 0;
-  // v = 100 * chunks_log2 + 10 * plain + pipe
+  // v = 1000 * occ4 + 100 * chunks_log2 + 10 * plain + pipe   (occ4: the 128-VGPR build, four workgroups per CU)
   K1Variant k;
+  k.occ4 = (v / 1000) % 10 != 0;
   k.pipe = v % 10 != 0;
   k.plain = (v / 10) % 10 != 0;
   k.chunks = 1 << ((v / 100) % 10);
@@ -1371,8 +1375,9 @@ void launch_tim_graph_mfma(hipStream_t s, int phase, const ProbDesc* d_desc, int
     hipLaunchKernelGGL(tim_prep_consts_kernel, dim3((batch + 63) / 64), dim3(64), 0, s, prep, batch, beta);
   } else if (phase == 1) {
     const int gyr = (T + kMfmaRowTiles - 1) / kMfmaRowTiles;
-#define TIM_K1_LAUNCH(PIPE, PLAIN, CHUNKS)                                                                        \
-  hipLaunchKernelGGL((tim_graph_mfma3_kernel<PIPE, PLAIN, 3, CHUNKS>), dim3(tim_mfma_blocks(T, CHUNKS), batch),   \
+#define TIM_K1_LAUNCH(PIPE, PLAIN, CHUNKS) TIM_K1_LAUNCH_OCC(PIPE, PLAIN, kK1Occ, CHUNKS)
+#define TIM_K1_LAUNCH_OCC(PIPE, PLAIN, OCC, CHUNKS)                                                               \
+  hipLaunchKernelGGL((tim_graph_mfma3_kernel<PIPE, PLAIN, OCC, CHUNKS>), dim3(tim_mfma_blocks(T, CHUNKS), batch), \
                      dim3(256), 0, s, d_desc, d_src, d_dst, reinterpret_cast<const TimOperandTile2*>(d_pk), prep, \
                      d_bitmap, beta, gyr, work, work_count, d_state, d_deg, regions)
 #ifdef TEASER_K1_LAB
@@ -1382,15 +1387,20 @@ void launch_tim_graph_mfma(hipStream_t s, int phase, const ProbDesc* d_desc, int
     else if (lab.chunks == 2) { TIM_K1_LAUNCH(PIPE, PLAIN, 2); } \
     else { TIM_K1_LAUNCH(PIPE, PLAIN, 4); }                      \
   }
-    TIM_K1_LAB_CASE(false, false)
-    TIM_K1_LAB_CASE(false, true)
-    TIM_K1_LAB_CASE(true, false)
-    TIM_K1_LAB_CASE(true, true)
+    if (lab.occ4) {
+      if (lab.plain) { TIM_K1_LAUNCH_OCC(false, true, 4, 1); } else { TIM_K1_LAUNCH_OCC(false, false, 4, 1); }
+    } else {
+      TIM_K1_LAB_CASE(false, false)
+      TIM_K1_LAB_CASE(false, true)
+      TIM_K1_LAB_CASE(true, false)
+      TIM_K1_LAB_CASE(true, true)
+    }
 #undef TIM_K1_LAB_CASE
 #else
     TIM_K1_LAUNCH(kK1Pipe, kK1Plain, kK1Chunks);
 #endif
 #undef TIM_K1_LAUNCH
+#undef TIM_K1_LAUNCH_OCC
   } else {
     // a wave per region of the largest problem (up to 2048 workgroups per problem); the kernel also counts the
     // degrees of the problems that ran the FP64 body inside K1 (no degree atomics there)
