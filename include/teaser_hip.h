@@ -357,7 +357,7 @@ TEASER_HIP_API int32_t teaser_hip_set_profiling(teaser_hip_solver* h, int32_t le
  * "finisher" (1), "copy_stream" (0), "h2d_kernel" (0), "depth" (2; lanes of handles created afterwards), "stagger"
  * (1), "k1_stream" (0), "tail_cus" (0), "tail_cu_block" (0), "k4_lds_stack" (16384), "k4_donate" (1),
  * "k4_donate_after" / "k4_hungry" / "k4_expand" (-1 = built-in), "k4_debug" (0), "heu_blocks" (0 = built-in),
- * "greedy_threads" (0 = built-in), "fixup_wgs" (0 = built-in).  Each also has an environment variable that is read ONCE per
+ * "greedy_threads" (0 = built-in), "fixup_wgs" (0 = built-in), "k4_waves" (0 = built-in: 4096).  Each also has an environment variable that is read ONCE per
  * process; the library never calls getenv on a solve path and never modifies the environment.
  * Returns BAD_ARG for an unknown name. */
 TEASER_HIP_API int32_t teaser_hip_set_option(teaser_hip_solver* h, const char* name, int64_t value);

@@ -125,6 +125,7 @@ enum Setting {
   S_HEU_BLOCKS,        // 0: built-in workgroups per problem of the heuristic            TEASER_HEU_BLOCKS
   S_GREEDY_THREADS,    // 0: built-in; 256 / 512                                         TEASER_GREEDY_THREADS
   S_FIXUP_WGS,         // 0: built-in; workgroups per problem of the K1 fix-up           TEASER_K1_FIXUP_WGS
+  S_K4_WAVES,          // 0: built-in; persistent waves of the exact search's phases     TEASER_K4_WAVES
   S_COUNT
 };
 int64_t setting(Setting id);

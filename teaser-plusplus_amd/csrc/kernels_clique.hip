@@ -107,14 +107,25 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v) {
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
   return ((uint64_t)hi << 32) | lo;
 }
-template <int WN>
+// LDS: the adjacency rows are the copy staged in LDS (stage_problem).  The row fetch is THE latency of the loop --
+// find the vertex, fetch its row, mask, repeat: a dependent chain per coloured vertex -- and through a generic pointer
+// it was a flat_load (~300 cycles; the colouring was 88 % of the sequential search's time, 23 k cycles per node at
+// config 5); with the address space known it is a ds_read (LDS) or a global_load.
+template <int WN, bool LDS>
 __device__ int colour_sort_small(const uint64_t* __restrict__ bitmap, const uint64_t* P, int pcount, int need,
                                  int32_t* order, int32_t* colour) {
+  typedef const __attribute__((address_space(3))) uint64_t* lds_rows_t;
+  typedef const __attribute__((address_space(1))) uint64_t* glb_rows_t;
   const int lane = threadIdx.x;
   uint64_t Q[WN], Qc[WN];
 #pragma unroll
   for (int w = 0; w < WN; ++w) Q[w] = uniform64(P[w]);
-  int remaining = pcount, k = 0, m = 0;
+  // The recorded (vertex, colour) pairs are parked one per LANE and written 64 at a time.  Stored one by one from
+  // inside the loop (through generic pointers: flat stores into the level record, which may live in the HBM arena),
+  // every iteration's wait for its row -- a full vmcnt / lgkmcnt drain, because flat operations return out of order --
+  // also waited for the previous iteration's stores to be acknowledged: ~650 cycles per coloured vertex, 45 k per
+  // call, 88 % of the sequential search's time (config 5: 69 candidates per call on average).
+  int remaining = pcount, k = 0, m = 0, mbase = 0, myu = 0, myk = 0;
   while (remaining > 0) {
     if (k + remaining <= need) break;
     ++k;
@@ -126,10 +137,19 @@ __device__ int colour_sort_small(const uint64_t* __restrict__ bitmap, const uint
       for (int w = WN - 1; w >= 0; --w)
         if (u < 0 && Qc[w] != 0ull) u = w * 64 + 63 - __builtin_clzll(Qc[w]);
       if (u < 0) break;
-      const uint64_t* ru = bitmap + (int64_t)u * WN;
+      uint64_t row[WN];
+      if (LDS) {
+        lds_rows_t ru = (lds_rows_t)bitmap + u * WN;
+#pragma unroll
+        for (int w = 0; w < WN; ++w) row[w] = ru[w];
+      } else {
+        glb_rows_t ru = (glb_rows_t)bitmap + (int64_t)u * WN;
+#pragma unroll
+        for (int w = 0; w < WN; ++w) row[w] = ru[w];
+      }
 #pragma unroll
       for (int w = 0; w < WN; ++w) {
-        Qc[w] &= ~uniform64(ru[w]);
+        Qc[w] &= ~uniform64(row[w]);
         if (w == (u >> 6)) {
           Qc[w] &= ~(1ull << (u & 63));
           Q[w] &= ~(1ull << (u & 63));
@@ -137,26 +157,46 @@ __device__ int colour_sort_small(const uint64_t* __restrict__ bitmap, const uint
       }
       --remaining;
       if (k > need) {
-        if (lane == 0) {
-          order[m] = u;
-          colour[m] = k;
+        if (lane == m - mbase) {
+          myu = u;
+          myk = k;
         }
         ++m;
+        if (m - mbase == 64) {
+          order[mbase + lane] = myu;
+          colour[mbase + lane] = myk;
+          mbase = m;
+        }
       }
     }
+  }
+  if (lane < m - mbase) {
+    order[mbase + lane] = myu;
+    colour[mbase + lane] = myk;
   }
   __syncthreads();
   return m;
 }
-__device__ __forceinline__ int colour_sort_any(const uint64_t* __restrict__ bitmap, int W, const uint64_t* P, int pcount,
-                                               int need, uint64_t* Q, uint64_t* Qc, int32_t* order, int32_t* colour) {
+__device__ __forceinline__ int colour_sort_any(const uint64_t* __restrict__ bitmap, bool bm_lds, int W, const uint64_t* P,
+                                               int pcount, int need, uint64_t* Q, uint64_t* Qc, int32_t* order, int32_t* colour) {
+#define COLOUR_SMALL_CASE(N)                                                                   \
+  case N:                                                                                      \
+    return bm_lds ? colour_sort_small<N, true>(bitmap, P, pcount, need, order, colour)         \
+                  : colour_sort_small<N, false>(bitmap, P, pcount, need, order, colour);
   switch (W) {
-    case 1: return colour_sort_small<1>(bitmap, P, pcount, need, order, colour);
-    case 2: return colour_sort_small<2>(bitmap, P, pcount, need, order, colour);
-    case 3: return colour_sort_small<3>(bitmap, P, pcount, need, order, colour);
-    case 4: return colour_sort_small<4>(bitmap, P, pcount, need, order, colour);
+    COLOUR_SMALL_CASE(1)
+    COLOUR_SMALL_CASE(2)
+    COLOUR_SMALL_CASE(3)
+    COLOUR_SMALL_CASE(4)
+    // (round 5: up to 512 vertices -- the larger compact graphs of a descriptor batch, 300 - 400 vertices, hold most of
+    // the batch's search nodes and were colouring with the lane-spread version)
+    COLOUR_SMALL_CASE(5)
+    COLOUR_SMALL_CASE(6)
+    COLOUR_SMALL_CASE(7)
+    COLOUR_SMALL_CASE(8)
     default: return colour_sort(bitmap, W, P, pcount, need, Q, Qc, order, colour);
   }
+#undef COLOUR_SMALL_CASE
 }
 
 // ------------------------------------------------------------------------------------------
@@ -202,6 +242,8 @@ constexpr int kCntDCount = 32;   // slots reserved
 [[maybe_unused]] constexpr int kCntDHead = 48;    // next slot to take
 constexpr int kCntActive = 64;   // waves holding (or about to take) a task
 constexpr int kCntHungry = 80;   // waves polling for work
+constexpr int kCntMaxSteps = 88; // diagnostics (phase 3): the largest number of search nodes one wave handled,
+constexpr int kCntBusyWaves = 89; //                       and the number of waves that handled any
 static_assert(kExactCounterInts >= 96, "counters of the donation queue");
 constexpr int kDonateLevels = 256;   // depth up to which a wave remembers its level records (LDS, 8 bytes each)
 constexpr unsigned int kDonateEvery = 32;  // search nodes between two looks at the hungry counter
@@ -212,6 +254,7 @@ constexpr int kMaxHungry = 64;       // pollers the launch keeps; further idle w
 struct WaveCtx {
   ExactProb* pb;
   const uint64_t* bmrows;
+  bool bm_lds;  // bmrows is the copy staged in LDS
   int W;
   char* arena;
   int64_t arena_bytes;
@@ -352,7 +395,7 @@ __device__ int dfs_subtree(WaveCtx& cx, int32_t* __restrict__ best_clique, int c
   int32_t* order = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(P) + p_b);
   int32_t* colour = order + (align16((int64_t)pc * 4) / 4);
   __syncthreads();
-  const int m = colour_sort_any(cx.bmrows, W, P, pc, best - csize, cx.Q, cx.Qc, order, colour);
+  const int m = colour_sort_any(cx.bmrows, cx.bm_lds, W, P, pc, best - csize, cx.Q, cx.Qc, order, colour);
   if (lane == 0) {
     L->pcount = pc;
     L->m = m;
@@ -454,7 +497,7 @@ __device__ int dfs_subtree(WaveCtx& cx, int32_t* __restrict__ best_clique, int c
       int32_t* norder = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(NP) + p_b);
       int32_t* ncolour = norder + (align16((int64_t)cnt * 4) / 4);
       ++csize;
-      const int nm = colour_sort_any(cx.bmrows, W, NP, cnt, best - csize, cx.Q, cx.Qc, norder, ncolour);
+      const int nm = colour_sort_any(cx.bmrows, cx.bm_lds, W, NP, cnt, best - csize, cx.Q, cx.Qc, norder, ncolour);
       if (lane == 0) {
         NL->pcount = cnt;
         NL->m = nm;
@@ -495,7 +538,7 @@ __device__ int expand_node(WaveCtx& cx, int32_t* __restrict__ best_clique, int q
   int32_t* colour = order + (align16((int64_t)pc * 4) / 4);
   uint64_t* NP = reinterpret_cast<uint64_t*>(arena + noff + hdr_b);
   __syncthreads();
-  const int m = colour_sort_any(cx.bmrows, W, P, pc, best - csize, cx.Q, cx.Qc, order, colour);
+  const int m = colour_sort_any(cx.bmrows, cx.bm_lds, W, P, pc, best - csize, cx.Q, cx.Qc, order, colour);
   __syncthreads();
   for (int idx = m - 1; idx >= 0; --idx) {
     best = __hip_atomic_load(best_size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -578,6 +621,7 @@ __device__ __forceinline__ void stage_problem(WaveCtx& cx, ExactProb* pb, const 
   cx.pb = pb;
   cx.W = pb->W2;
   cx.bmrows = bitmap_pool + pb->bm_off;
+  cx.bm_lds = false;
   cx.arena = arena_wave;
   cx.arena_bytes = arena_bytes;
   cx.C = reinterpret_cast<int32_t*>(arena_wave);
@@ -588,6 +632,7 @@ __device__ __forceinline__ void stage_problem(WaveCtx& cx, ExactProb* pb, const 
     for (int64_t k = lane; k < words; k += 64) lds_after_q[k] = cx.bmrows[k];
     __syncthreads();
     cx.bmrows = lds_after_q;
+    cx.bm_lds = true;
   }
 }
 
@@ -682,6 +727,7 @@ __global__ __launch_bounds__(64) void exact_clique_kernel(ExactProb* __restrict_
     int32_t* active = qs.counters + kCntActive;
     int32_t* hungry = qs.counters + kCntHungry;
     bool primary_done = false, am_hungry = false, holding = false;
+    unsigned int wave_steps = 0;
     while (true) {
       // ---- next task: the phase's own queue first, then (sequential phase) what busy waves have given away
       if (holding) {  // the previous task is finished
@@ -712,16 +758,24 @@ __global__ __launch_bounds__(64) void exact_clique_kernel(ExactProb* __restrict_
         // "nobody active" seen first and "queue drained" seen after it means nothing can arrive any more
         int slot = -1, done = 0;
         if (lane == 0) {
+          // The two looks are RELAXED device-scope loads (they read L2, where the atomics land) kept in program order
+          // by waiting for the first before the second is issued.  They used to be agent-scope ACQUIRE loads: every
+          // one of those invalidates the polling CU's vector L1 -- with a poller looking every ~4 us on most CUs the
+          // SEARCHING waves beside them lost their L1 (the level records and adjacency rows they chase), and the search
+          // got slower the more pollers it kept (64: 9 ms, 512: 22 ms, 2048: 49 ms for the same 150 k nodes,
+          // profiles/r5q).  One acquire fence follows a successful claim, before the task's payload is read.
           unsigned long long* qword = reinterpret_cast<unsigned long long*>(&qs.counters[kCntDCount]);
-          const int a = __hip_atomic_load(active, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-          const unsigned long long w = __hip_atomic_load(qword, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+          const int a = __hip_atomic_load(active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          const unsigned long long w = __hip_atomic_load(qword, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const int cnt_d = min((int)(w >> 32), qs.dcap), hd = (int)(w & 0xffffffffull);
           if (hd < cnt_d) {
             atomicAdd(active, 1);
             if (atomicCAS(qword, w, w + 1ull) == w) {
               slot = hd;
-              while (__hip_atomic_load(&qs.dready[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == 0)
+              while (__hip_atomic_load(&qs.dready[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
                 __builtin_amdgcn_s_sleep(1);
+              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             } else {
               atomicSub(active, 1);
             }
@@ -765,6 +819,7 @@ __global__ __launch_bounds__(64) void exact_clique_kernel(ExactProb* __restrict_
       }
       if (q != cur_q) {
         if (pb && lane == 0 && cx.steps) atomicAdd(&pb->ctrl[7], (int)cx.steps);
+        wave_steps += cx.steps;
         cx.steps = 0;
         pb = tpb;
         stage_problem(cx, pb, bitmap_pool, arena_wave, arena_bytes, lds_bm);
@@ -804,6 +859,10 @@ __global__ __launch_bounds__(64) void exact_clique_kernel(ExactProb* __restrict_
       else
         rc = dfs_subtree(cx, best_clique, csize, cnt);
       if (rc && lane == 0) atomicMax(&pb->ctrl[4], rc);
+    }
+    if (PHASE == 3 && lane == 0 && wave_steps + cx.steps > 0) {
+      atomicMax(&qs.counters[kCntMaxSteps], (int)(wave_steps + cx.steps));
+      atomicAdd(&qs.counters[kCntBusyWaves], 1);
     }
   }
   if (pb && lane == 0) {

@@ -72,6 +72,7 @@ const SettingRow kSettingRows[S_COUNT] = {
     {"heu_blocks", "TEASER_HEU_BLOCKS", 0},
     {"greedy_threads", "TEASER_GREEDY_THREADS", 0},
     {"fixup_wgs", "TEASER_K1_FIXUP_WGS", 0},
+    {"k4_waves", "TEASER_K4_WAVES", 0},
 };
 struct SettingTable {
   std::atomic<int64_t> v[S_COUNT];
@@ -803,7 +804,8 @@ int32_t close_clique_bounds(teaser_hip_solver* h, int batch, int64_t total_n, bo
       if (e.lds_bitmap) max_lds = std::max<int64_t>(max_lds, (int64_t)e.n2 * e.W2 * 8);
     }
     // phases 2 and 3 run persistent waves pulling tasks: enough of them to fill the GPU, as far as the arenas allow
-    int arena_waves = std::max(total_waves, 4096);
+    const int forced_waves = (int)setting(S_K4_WAVES);
+    int arena_waves = std::max(total_waves, forced_waves > 0 ? forced_waves : 4096);
     while ((int64_t)arena_waves * arena_bytes > kArenaCap && arena_waves > total_waves) arena_waves = std::max(total_waves, arena_waves / 2);
     if ((int64_t)arena_waves * arena_bytes > kArenaCap) {
       // shrink the root waves of the largest problems until the arenas fit
@@ -859,8 +861,8 @@ int32_t close_clique_bounds(teaser_hip_solver* h, int batch, int64_t total_n, bo
       int32_t qc[kExactCounterInts] = {0};
       (void)hipMemcpy(qc, h->x_ctrl.p, sizeof(qc), hipMemcpyDeviceToHost);
       fprintf(stderr, "[teaser_hip] exact search: %zu problems, %d root waves, %d persistent waves; tasks per depth: %d %d %d %d "
-              "%d %d; given away %d (taken %d)\n", run.size(), total_waves, arena_waves, qc[0], qc[2], qc[4], qc[6], qc[8], qc[10],
-              qc[33], qc[32]);
+              "%d %d; given away %d (taken %d); sequential phase: %d waves searched, the busiest %d nodes\n", run.size(), total_waves,
+              arena_waves, qc[0], qc[2], qc[4], qc[6], qc[8], qc[10], qc[33], qc[32], qc[89], qc[88]);
     }
     std::vector<ExactProb> again;
     for (ExactProb& e : run) {
