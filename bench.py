@@ -779,8 +779,11 @@ def main():
 
     # warm-up (arenas of every lane sized, kernels loaded), then a correctness guard on a batch the timed
     # region will not see again: the work is not skipped and is right
-    runner.run_steps(0, max(args.warmup, D), pool, offsets, sizes, False)
+    # (the guard comes FIRST and the warm-up steps directly in front of the timed region: the host-side check leaves the
+    # GPU idle for a few milliseconds, and a region that starts on an idle, down-clocked GPU ran up to 20 % slower than
+    # the ones behind it -- profiles/r5z)
     k_chk = args.warmup % n_batches
+    runner.run_steps(0, D, pool, offsets, sizes, False)
     out = runner.run_steps(k_chk, 1, pool, offsets, sizes, False)
     for b in range(B):
         R, t, n_in = truth[k_chk][b]
@@ -789,6 +792,7 @@ def main():
         assert o.valid == 1 and n_in <= o.clique_size <= n_in + 3, (o.valid, o.clique_size, n_in)
         assert np.linalg.norm(np.array(o.rotation[:]).reshape(3, 3) - R) < 0.05
         assert np.linalg.norm(np.array(o.translation[:]) - t) < 0.05
+    runner.run_steps(0, max(args.warmup, D), pool, offsets, sizes, False)  # the W warm-up steps
 
     # ---- timed region: EXACTLY args.steps steps, inputs resident in HBM -------------------------
     solver.set_profiling(2)  # HIP events around the K1 kernel only (two per step), inside the timed region
