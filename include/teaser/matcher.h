@@ -3,9 +3,10 @@
 //
 // The reference searches two FLANN kd-trees (exact L2 1-NN in 33 dimensions, matcher.cc:140-170); here both
 // searches are brute-force distance tiles on the GPU, the index bookkeeping (initial matching, cross check,
-// swap, sort + unique: matcher.cc:155-296) is the same.  The reference's normalizePoints (matcher.cc:57-116)
-// only feeds the tuple test; that test draws from rand() seeded with time(NULL) (matcher.cc:214), is not
-// reproducible by construction and is passed `false` by every reference caller: asking for it throws.
+// swap, sort + unique: matcher.cc:155-296) is the same.  The tuple constraint (matcher.cc:223-283) is host
+// arithmetic behind teaser_hip_tuple_test: like the reference it draws its triples from a generator seeded with the
+// clock (the result is not reproducible, by the reference's construction); the reference's normalizePoints
+// (matcher.cc:57-116) moves and scales both clouds alike, which the ratio test cannot see.
 #pragma once
 
 #include <stdexcept>
@@ -35,12 +36,7 @@ class Matcher {
                                                             const FPFHCloud& target_features,
                                                             bool use_absolute_scale = true, bool use_crosscheck = true,
                                                             bool use_tuple_test = true, float tuple_scale = 0) {
-    (void)source_points;
-    (void)target_points;
     (void)use_absolute_scale;
-    if (use_tuple_test && tuple_scale != 0)
-      throw std::invalid_argument("teaser::Matcher: the tuple test (rand() seeded with time(NULL) in the reference) "
-                                  "is not reproducible and not offered; pass use_tuple_test = false");
     if (!h_) {
       const int32_t rc = teaser_hip_solver_create(nullptr, /*device=*/-1, &h_);
       if (rc != TEASER_HIP_OK) {
@@ -59,6 +55,14 @@ class Matcher {
     if (rc != TEASER_HIP_OK)
       throw std::runtime_error(std::string("teaser_hip_match_features status ") + std::to_string(rc) + ": " +
                                teaser_hip_last_error(h_));
+    if (use_tuple_test && tuple_scale != 0) {  // matcher.cc:223
+      static_assert(sizeof(PointXYZ) == 12, "teaser::PointXYZ is three floats");
+      const int32_t rt = teaser_hip_tuple_test(
+          h_, reinterpret_cast<const float*>(source_points.data()), (int32_t)source_points.size(),
+          reinterpret_cast<const float*>(target_points.data()), (int32_t)target_points.size(), tuple_scale, /*seed=*/0,
+          reinterpret_cast<int32_t*>(out.data()), &cnt);
+      if (rt != TEASER_HIP_OK) throw std::runtime_error("teaser_hip_tuple_test status " + std::to_string(rt));
+    }
     out.resize((size_t)cnt);
     return out;
   }

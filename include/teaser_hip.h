@@ -303,15 +303,27 @@ TEASER_HIP_API int32_t teaser_hip_solve_for_scale(teaser_hip_solver* h, const do
  *   match_features -> teaser::Matcher::calculateCorrespondences (teaser/src/matcher.cc:21-301,
  *                     matcher.h:40-44) for use_tuple_test = false: exact L2 nearest neighbours both ways,
  *                     optional cross check, sorted unique (src, dst) pairs.  pairs: room for *n_pairs
- *                     pairs on entry (n_src + n_dst always suffices), count on return.  The tuple test of
- *                     the reference draws from rand() seeded with time(NULL) (matcher.cc:214): not
- *                     reproducible by construction and unused by every reference caller -- not offered. */
+ *                     pairs on entry (n_src + n_dst always suffices), count on return.
+ *   tuple_test     -> the tuple constraint of the same function (matcher.cc:223-283, use_tuple_test = true with
+ *                     tuple_scale != 0), applied to the pairs match_features returned: 100 x n_pairs random
+ *                     triples of correspondences, a triple is kept when its three side lengths in the source
+ *                     cloud and in the target cloud agree within the factor tuple_scale (l_i s < l_j < l_i / s);
+ *                     the correspondences of the kept triples, sorted and unique, replace the list (host
+ *                     arithmetic in float like the reference; no device needed, `h` may be NULL).  The reference
+ *                     draws from rand() seeded with time(NULL), i.e. its result is not reproducible; here
+ *                     seed = 0 means "seed from the clock" (the reference's behaviour), any other value gives a
+ *                     reproducible draw (splitmix64).  The reference's normalizePoints (matcher.cc:57-116) moves
+ *                     and scales both clouds alike, which the ratio test cannot see: not needed.
+ *                     tuple_scale <= 0: nothing to do (the reference skips the test for tuple_scale == 0). */
 TEASER_HIP_API int32_t teaser_hip_compute_fpfh(teaser_hip_solver* h, const float* cloud_xyz, int32_t n,
                                 double normal_radius, double fpfh_radius, float* fpfh_out,
                                 float* normals_out);
 TEASER_HIP_API int32_t teaser_hip_match_features(teaser_hip_solver* h, const float* src_feat, int32_t n_src,
                                   const float* dst_feat, int32_t n_dst, int32_t dim, int32_t use_crosscheck,
                                   int32_t* pairs, int64_t* n_pairs);
+TEASER_HIP_API int32_t teaser_hip_tuple_test(teaser_hip_solver* h, const float* src_xyz, int32_t n_src,
+                              const float* dst_xyz, int32_t n_dst, float tuple_scale, uint64_t seed,
+                              int32_t* pairs /* in / out */, int64_t* n_pairs /* in / out */);
 
 /* DRS rotation certifier: teaser::DRSCertifier::certify(R, src, dst, theta) (teaser/src/certification.cc:39-190,
  * teaser/include/teaser/certification.h:53-239).  Parameters as DRSCertifier::Params (certification.h:71-104;

@@ -125,7 +125,7 @@ EXPORTED_SYMBOLS = [
     "teaser_hip_synth_problem", "teaser_hip_submit_batch", "teaser_hip_wait",
     "teaser_hip_set_pipeline_depth", "teaser_hip_multi_create", "teaser_hip_multi_destroy",
     "teaser_hip_multi_solve_batch", "teaser_hip_multi_route", "teaser_hip_multi_device_count",
-    "teaser_hip_solve_for_scale", "teaser_hip_compute_fpfh", "teaser_hip_match_features",
+    "teaser_hip_solve_for_scale", "teaser_hip_compute_fpfh", "teaser_hip_match_features", "teaser_hip_tuple_test",
     "teaser_hip_certifier_params_default", "teaser_hip_certify", "teaser_hip_certifier_warmup",
     "teaser_hip_comm_shard", "teaser_hip_comm_unique_id", "teaser_hip_comm_create", "teaser_hip_comm_destroy",
     "teaser_hip_comm_gather_solutions", "teaser_hip_comm_gather_indices", "teaser_hip_comm_last_error",
@@ -187,6 +187,7 @@ def lib():
     _fp = C.POINTER(C.c_float)
     L.teaser_hip_compute_fpfh.argtypes = [_vp, _fp, C.c_int32, C.c_double, C.c_double, _fp, _fp]
     L.teaser_hip_match_features.argtypes = [_vp, _fp, C.c_int32, _fp, C.c_int32, C.c_int32, C.c_int32, _ip, _i64p]
+    L.teaser_hip_tuple_test.argtypes = [_vp, _fp, C.c_int32, _fp, C.c_int32, C.c_float, C.c_uint64, _ip, _i64p]
     L.teaser_hip_certify.argtypes = [_vp, C.c_void_p, _dp, _dp, _dp, _dp, C.c_int32, C.c_void_p, _dp, C.c_int32]
     L.teaser_hip_max_clique.argtypes = [_vp, _u64p, C.c_int32, _ip, _ip, _ip]
     L.teaser_hip_submit_batch.argtypes = [_vp, _vp, _vp, _i64p, _ip, C.c_int32, C.c_int32, _ip]
@@ -802,11 +803,11 @@ class Matcher:
         self._solver = RobustRegistrationSolver(device=device)
 
     def calculateCorrespondences(self, source_points, target_points, source_features, target_features,
-                                 use_absolute_scale=True, use_crosscheck=True, use_tuple_test=False,
-                                 tuple_scale=0.0):
-        if use_tuple_test and tuple_scale != 0:
-            raise ValueError("the reference's tuple test draws from rand() seeded with time(NULL) "
-                             "(matcher.cc:214): not reproducible, not offered")
+                                 use_absolute_scale=True, use_crosscheck=True, use_tuple_test=True,
+                                 tuple_scale=0.0, tuple_seed=0):
+        """matcher.h:40-44 (same defaults: the tuple test is requested but tuple_scale = 0 skips it, matcher.cc:223).
+        tuple_seed: 0 seeds the tuple test from the clock like the reference (srand(time(NULL))), any other value
+        makes it reproducible."""
         a = np.ascontiguousarray(source_features, dtype=np.float32)
         b = np.ascontiguousarray(target_features, dtype=np.float32)
         if a.ndim != 2 or b.ndim != 2 or a.shape[1] != b.shape[1]:
@@ -817,7 +818,25 @@ class Matcher:
         s = self._solver
         s._check(s._lib.teaser_hip_match_features(s._h, _ptr(a, fp), a.shape[0], _ptr(b, fp), b.shape[0], a.shape[1],
                                                   1 if use_crosscheck else 0, _ptr(out, _ip), C.byref(cnt)))
+        if use_tuple_test and tuple_scale != 0:
+            return tuple_test(source_points, target_points, out[:cnt.value], tuple_scale, tuple_seed)
         return [tuple(int(v) for v in row) for row in out[:cnt.value]]
+
+
+def tuple_test(source_points, target_points, pairs, tuple_scale, seed=0):
+    """The tuple constraint of Matcher::advancedMatching (matcher.cc:223-283) on a list of (src, dst) pairs: host
+    arithmetic, no GPU needed.  Returns the surviving pairs, sorted and unique."""
+    sp = np.ascontiguousarray(np.asarray(source_points, dtype=np.float32).reshape(-1, 3))
+    tp_ = np.ascontiguousarray(np.asarray(target_points, dtype=np.float32).reshape(-1, 3))
+    pr = np.ascontiguousarray(np.asarray(pairs, dtype=np.int32).reshape(-1, 2)).copy()
+    cnt = C.c_int64(pr.shape[0])
+    fp = C.POINTER(C.c_float)
+    rc = lib().teaser_hip_tuple_test(None, _ptr(sp, fp), sp.shape[0], _ptr(tp_, fp), tp_.shape[0],
+                                     C.c_float(float(tuple_scale)), C.c_uint64(int(seed)),
+                                     _ptr(pr, _ip) if pr.size else None, C.byref(cnt))
+    if rc != 0:
+        raise TeaserHipError(rc, "teaser_hip_tuple_test")
+    return [tuple(int(v) for v in row) for row in pr[:cnt.value]]
 
 
 class CertifierParamsC(C.Structure):

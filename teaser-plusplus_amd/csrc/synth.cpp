@@ -9,8 +9,11 @@
 //            inlier pair passes the 2*nb TIM test: the inliers form a clique);
 //   outliers exactly round(rho*N) distinct indices (seeded Fisher-Yates prefix),
 //            dst ~ U(ball(centre R*(1/2,1/2,1/2)+t, radius sqrt3/2)).
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <ctime>
+#include <utility>
 #include <vector>
 
 #include "teaser_hip.h"
@@ -96,5 +99,49 @@ extern "C" int32_t teaser_hip_synth_problem(uint64_t seed, int32_t n, double out
     for (int k = 0; k < 9; ++k) R_out[k] = R[k];
   if (t_out)
     for (int k = 0; k < 3; ++k) t_out[k] = t[k];
+  return TEASER_HIP_OK;
+}
+
+// The tuple constraint of teaser::Matcher::advancedMatching (reference teaser/src/matcher.cc:223-283), host
+// arithmetic in float as there.  seed = 0: seeded from the clock (the reference: srand(time(NULL))).
+extern "C" int32_t teaser_hip_tuple_test(teaser_hip_solver*, const float* src_xyz, int32_t n_src, const float* dst_xyz,
+                                         int32_t n_dst, float tuple_scale, uint64_t seed, int32_t* pairs,
+                                         int64_t* n_pairs) {
+  if (!n_pairs || *n_pairs < 0 || n_src < 0 || n_dst < 0 || (*n_pairs > 0 && (!pairs || !src_xyz || !dst_xyz)))
+    return TEASER_HIP_ERR_BAD_ARG;
+  const int64_t ncorr = *n_pairs;
+  if (!(tuple_scale > 0.0f) || ncorr == 0) return TEASER_HIP_OK;  // matcher.cc:223: skipped for tuple_scale == 0
+  for (int64_t k = 0; k < ncorr; ++k)
+    if (pairs[2 * k] < 0 || pairs[2 * k] >= n_src || pairs[2 * k + 1] < 0 || pairs[2 * k + 1] >= n_dst)
+      return TEASER_HIP_ERR_BAD_ARG;
+  SplitMix64 rng(seed ? seed : (uint64_t)time(nullptr));
+  auto dist = [](const float* p, int a, int b) {
+    const float dx = p[3 * a] - p[3 * b], dy = p[3 * a + 1] - p[3 * b + 1], dz = p[3 * a + 2] - p[3 * b + 2];
+    return std::sqrt(dx * dx + dy * dy + dz * dz);
+  };
+  const float scale = tuple_scale;
+  const int64_t trials = ncorr * 100;  // matcher.cc:231
+  std::vector<std::pair<int32_t, int32_t>> kept;
+  for (int64_t i = 0; i < trials; ++i) {
+    const int64_t r0 = (int64_t)(rng.next() % (uint64_t)ncorr), r1 = (int64_t)(rng.next() % (uint64_t)ncorr),
+                  r2 = (int64_t)(rng.next() % (uint64_t)ncorr);
+    const int i0 = pairs[2 * r0], j0 = pairs[2 * r0 + 1], i1 = pairs[2 * r1], j1 = pairs[2 * r1 + 1], i2 = pairs[2 * r2],
+              j2 = pairs[2 * r2 + 1];
+    const float li0 = dist(src_xyz, i0, i1), li1 = dist(src_xyz, i1, i2), li2 = dist(src_xyz, i2, i0);
+    const float lj0 = dist(dst_xyz, j0, j1), lj1 = dist(dst_xyz, j1, j2), lj2 = dist(dst_xyz, j2, j0);
+    if ((li0 * scale < lj0) && (lj0 < li0 / scale) && (li1 * scale < lj1) && (lj1 < li1 / scale) && (li2 * scale < lj2) &&
+        (lj2 < li2 / scale)) {  // matcher.cc:267-268
+      kept.emplace_back(i0, j0);
+      kept.emplace_back(i1, j1);
+      kept.emplace_back(i2, j2);
+    }
+  }
+  std::sort(kept.begin(), kept.end());  // matcher.cc:299-300 (every kept pair is one of the input pairs: it fits)
+  kept.erase(std::unique(kept.begin(), kept.end()), kept.end());
+  for (size_t k = 0; k < kept.size(); ++k) {
+    pairs[2 * k] = kept[k].first;
+    pairs[2 * k + 1] = kept[k].second;
+  }
+  *n_pairs = (int64_t)kept.size();
   return TEASER_HIP_OK;
 }

@@ -66,6 +66,14 @@ def test_matcher_vs_oracle_and_fixture():
     assert m2 == [tuple(r) for r in F.match(fo, fs, crosscheck=False).tolist()]
     m3 = tp.Matcher().calculateCorrespondences(None, None, fs, fo, False, True, False, 0)
     assert sorted((b, a) for a, b in m3) == m
+    # with the tuple constraint (matcher.cc:223-283; the one argument combination the binding used to refuse): a sorted
+    # subset of the cross-checked matches, reproducible with a seed, clock-seeded like the reference without one
+    m4 = tp.Matcher().calculateCorrespondences(G["matcher_object"], G["matcher_scene"], fo, fs, False, True, True, 0.95,
+                                               tuple_seed=7)
+    assert m4 == sorted(set(m4)) and set(m4) <= set(m) and 0 < len(m4) <= len(m)
+    assert m4 == tp.tuple_test(G["matcher_object"], G["matcher_scene"], m, 0.95, seed=7)
+    m5 = tp.Matcher().calculateCorrespondences(G["matcher_object"], G["matcher_scene"], fo, fs, False, True, True, 0.95)
+    assert set(m5) <= set(m)
 
 
 def test_matcher_self_matching():
