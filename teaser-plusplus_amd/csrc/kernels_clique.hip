@@ -96,65 +96,46 @@ __device__ int colour_sort(const uint64_t* __restrict__ bitmap, int W, const uin
   return m;
 }
 
-// The same colouring for graphs of up to 256 vertices (W <= 4 words: real descriptor graphs such as BASELINE config 5
-// after the bounds have thinned them), entirely in wave-UNIFORM registers.  The generic version spreads a bit set
-// over the lanes, one word each, and pays a ballot + shuffle + LDS round trip + barrier per coloured vertex -- with
-// three words, 61 idle lanes and ~0.4 us per vertex (58 us per search node at config 5, whose tree is a thin spine
-// of ~90 dependent levels: the search's wall time IS the per-node cost).  Here Q and Qc are W scalars, the highest
-// set bit is a scalar instruction, and the only memory access per vertex is its adjacency row (a broadcast load made
-// uniform with readfirstlane).  Same order, same classes, same output as the generic version.
-__device__ __forceinline__ uint64_t uniform64(uint64_t v) {
-  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-  return ((uint64_t)hi << 32) | lo;
-}
-// LDS: the adjacency rows are the copy staged in LDS (stage_problem).  The row fetch is THE latency of the loop --
-// find the vertex, fetch its row, mask, repeat: a dependent chain per coloured vertex -- and through a generic pointer
-// it was a flat_load (~300 cycles; the colouring was 88 % of the sequential search's time, 23 k cycles per node at
-// config 5); with the address space known it is a ds_read (LDS) or a global_load.
+// Greedy colouring of a SMALL candidate set (up to 8 words = 512 vertices), one bit-set word per LANE.
+// Same order, same classes, same output as the generic version (colour_sort): class k is built by repeatedly taking the
+// HIGHEST remaining candidate u and removing u and its neighbours from the class's candidates -- a dependent chain of
+// one step per coloured vertex (the graphs are dense: no parallelism across steps), so what matters is the length of
+// a step.  Here a step is ~20 vector instructions and ONE LDS round trip: the highest set bit per lane, a 3-step DPP
+// maximum over the 8 word lanes, the whole adjacency row in one ds_read (lane w reads word w), two masks.
+// History (profiles/r5q): the colouring is 88 % of the sequential search's time.  The lane-spread generic version
+// paid a ballot + shuffle + LDS round trip + barrier per vertex (~0.4 us); the wave-UNIFORM version of rounds 3 - 5
+// (Q, Qc in scalar registers, the row fetched word by word and made uniform with readfirstlane) ran ~60 dependent
+// scalar instructions per step, ~450 cycles -- 45 k cycles per call at config 5 (69 candidates on average).
+// LDS: the adjacency rows are the copy staged in LDS (stage_problem); otherwise they are read from the global pool.
 template <int WN, bool LDS>
 __device__ int colour_sort_small(const uint64_t* __restrict__ bitmap, const uint64_t* P, int pcount, int need,
                                  int32_t* order, int32_t* colour) {
+  static_assert(WN >= 1 && WN <= 8, "one word per lane of the first row quad pair");
   typedef const __attribute__((address_space(3))) uint64_t* lds_rows_t;
   typedef const __attribute__((address_space(1))) uint64_t* glb_rows_t;
   const int lane = threadIdx.x;
-  uint64_t Q[WN], Qc[WN];
-#pragma unroll
-  for (int w = 0; w < WN; ++w) Q[w] = uniform64(P[w]);
-  // The recorded (vertex, colour) pairs are parked one per LANE and written 64 at a time.  Stored one by one from
-  // inside the loop (through generic pointers: flat stores into the level record, which may live in the HBM arena),
-  // every iteration's wait for its row -- a full vmcnt / lgkmcnt drain, because flat operations return out of order --
-  // also waited for the previous iteration's stores to be acknowledged: ~650 cycles per coloured vertex, 45 k per
-  // call, 88 % of the sequential search's time (config 5: 69 candidates per call on average).
+  uint64_t Q = lane < WN ? P[lane] : 0ull;
+  // The recorded (vertex, colour) pairs are parked one per LANE and written 64 at a time (stored one by one from inside
+  // the loop, through generic pointers into a level record that may live in the HBM arena, every step's wait for its
+  // row also waited for the previous step's stores).
   int remaining = pcount, k = 0, m = 0, mbase = 0, myu = 0, myk = 0;
   while (remaining > 0) {
     if (k + remaining <= need) break;
     ++k;
-#pragma unroll
-    for (int w = 0; w < WN; ++w) Qc[w] = Q[w];
+    uint64_t Qc = Q;
     while (true) {
-      int u = -1;
-#pragma unroll
-      for (int w = WN - 1; w >= 0; --w)
-        if (u < 0 && Qc[w] != 0ull) u = w * 64 + 63 - __builtin_clzll(Qc[w]);
+      // highest remaining candidate: per-lane highest bit, maximum over lanes 0 .. 7 (lanes >= WN hold no bits)
+      int hb = Qc ? lane * 64 + 63 - __builtin_clzll(Qc) : -1;
+      hb = max(hb, __builtin_amdgcn_update_dpp(hb, hb, 0xb1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]: lane ^ 1
+      hb = max(hb, __builtin_amdgcn_update_dpp(hb, hb, 0x4e, 0xf, 0xf, false));   // quad_perm [2,3,0,1]: lane ^ 2
+      hb = max(hb, __builtin_amdgcn_update_dpp(hb, hb, 0x141, 0xf, 0xf, false));  // row_half_mirror: lane ^ 7
+      const int u = __builtin_amdgcn_readfirstlane(hb);
       if (u < 0) break;
-      uint64_t row[WN];
-      if (LDS) {
-        lds_rows_t ru = (lds_rows_t)bitmap + u * WN;
-#pragma unroll
-        for (int w = 0; w < WN; ++w) row[w] = ru[w];
-      } else {
-        glb_rows_t ru = (glb_rows_t)bitmap + (int64_t)u * WN;
-#pragma unroll
-        for (int w = 0; w < WN; ++w) row[w] = ru[w];
-      }
-#pragma unroll
-      for (int w = 0; w < WN; ++w) {
-        Qc[w] &= ~uniform64(row[w]);
-        if (w == (u >> 6)) {
-          Qc[w] &= ~(1ull << (u & 63));
-          Q[w] &= ~(1ull << (u & 63));
-        }
-      }
+      uint64_t row = 0ull;
+      if (lane < WN) row = LDS ? ((lds_rows_t)bitmap)[u * WN + lane] : ((glb_rows_t)bitmap)[(int64_t)u * WN + lane];
+      const uint64_t bit = (lane == (u >> 6)) ? (1ull << (u & 63)) : 0ull;
+      Qc &= ~(row | bit);
+      Q &= ~bit;
       --remaining;
       if (k > need) {
         if (lane == m - mbase) {
