@@ -114,6 +114,7 @@ __device__ int colour_sort_small(const uint64_t* __restrict__ bitmap, const uint
   typedef const __attribute__((address_space(3))) uint64_t* lds_rows_t;
   typedef const __attribute__((address_space(1))) uint64_t* glb_rows_t;
   const int lane = threadIdx.x;
+  const int lw = lane < WN ? lane : WN - 1;  // (lanes >= WN hold no bits: they re-read the last word, which changes nothing)
   uint64_t Q = lane < WN ? P[lane] : 0ull;
   // The recorded (vertex, colour) pairs are parked one per LANE and written 64 at a time (stored one by one from inside
   // the loop, through generic pointers into a level record that may live in the HBM arena, every step's wait for its
@@ -126,13 +127,13 @@ __device__ int colour_sort_small(const uint64_t* __restrict__ bitmap, const uint
     while (true) {
       // highest remaining candidate: per-lane highest bit, maximum over lanes 0 .. 7 (lanes >= WN hold no bits)
       int hb = Qc ? lane * 64 + 63 - __builtin_clzll(Qc) : -1;
-      hb = max(hb, __builtin_amdgcn_update_dpp(hb, hb, 0xb1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]: lane ^ 1
-      hb = max(hb, __builtin_amdgcn_update_dpp(hb, hb, 0x4e, 0xf, 0xf, false));   // quad_perm [2,3,0,1]: lane ^ 2
-      hb = max(hb, __builtin_amdgcn_update_dpp(hb, hb, 0x141, 0xf, 0xf, false));  // row_half_mirror: lane ^ 7
+      // (old = INT_MIN, the identity of max: lets the compiler fold the move into v_max_i32_dpp)
+      hb = max(hb, __builtin_amdgcn_update_dpp(INT_MIN, hb, 0xb1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]: lane ^ 1
+      hb = max(hb, __builtin_amdgcn_update_dpp(INT_MIN, hb, 0x4e, 0xf, 0xf, false));   // quad_perm [2,3,0,1]: lane ^ 2
+      hb = max(hb, __builtin_amdgcn_update_dpp(INT_MIN, hb, 0x141, 0xf, 0xf, false));  // row_half_mirror: lane ^ 7
       const int u = __builtin_amdgcn_readfirstlane(hb);
       if (u < 0) break;
-      uint64_t row = 0ull;
-      if (lane < WN) row = LDS ? ((lds_rows_t)bitmap)[u * WN + lane] : ((glb_rows_t)bitmap)[(int64_t)u * WN + lane];
+      const uint64_t row = LDS ? ((lds_rows_t)bitmap)[u * WN + lw] : ((glb_rows_t)bitmap)[(int64_t)u * WN + lw];
       const uint64_t bit = (lane == (u >> 6)) ? (1ull << (u & 63)) : 0ull;
       Qc &= ~(row | bit);
       Q &= ~bit;
