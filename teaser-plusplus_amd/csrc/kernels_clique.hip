@@ -115,6 +115,10 @@ __device__ int colour_sort_small(const uint64_t* __restrict__ bitmap, const uint
   typedef const __attribute__((address_space(1))) uint64_t* glb_rows_t;
   const int lane = threadIdx.x;
   const int lw = lane < WN ? lane : WN - 1;  // (lanes >= WN hold no bits: they re-read the last word, which changes nothing)
+  // (wave-uniform by construction, but loaded / derived per lane by the callers: as scalars the class loop's control
+  // flow and the parking slot stay on the scalar unit)
+  pcount = __builtin_amdgcn_readfirstlane(pcount);
+  need = __builtin_amdgcn_readfirstlane(need);
   uint64_t Q = lane < WN ? P[lane] : 0ull;
   // The recorded (vertex, colour) pairs are parked one per LANE and written 64 at a time (stored one by one from inside
   // the loop, through generic pointers into a level record that may live in the HBM arena, every step's wait for its
