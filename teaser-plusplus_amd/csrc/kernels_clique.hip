@@ -96,12 +96,14 @@ __device__ int colour_sort(const uint64_t* __restrict__ bitmap, int W, const uin
   return m;
 }
 
-// Greedy colouring of a SMALL candidate set (up to 8 words = 512 vertices), one bit-set word per LANE.
+// Greedy colouring of a SMALL candidate set (up to 16 words = 1024 vertices: every compact graph whose adjacency is
+// staged in LDS), one bit-set word per LANE.
 // Same order, same classes, same output as the generic version (colour_sort): class k is built by repeatedly taking the
 // HIGHEST remaining candidate u and removing u and its neighbours from the class's candidates -- a dependent chain of
 // one step per coloured vertex (the graphs are dense: no parallelism across steps), so what matters is the length of
 // a step.  Here a step is ~20 vector instructions and ONE LDS round trip: the highest set bit per lane, a 3-step DPP
-// maximum over the 8 word lanes, the whole adjacency row in one ds_read (lane w reads word w), two masks.
+// maximum over the 8 word lanes (4 steps for 9 - 16 words), the whole adjacency row in one ds_read (lane w reads word
+// w), two masks.
 // History (profiles/r5q): the colouring is 88 % of the sequential search's time.  The lane-spread generic version
 // paid a ballot + shuffle + LDS round trip + barrier per vertex (~0.4 us); the wave-UNIFORM version of rounds 3 - 5
 // (Q, Qc in scalar registers, the row fetched word by word and made uniform with readfirstlane) ran ~60 dependent
@@ -110,7 +112,7 @@ __device__ int colour_sort(const uint64_t* __restrict__ bitmap, int W, const uin
 template <int WN, bool LDS>
 __device__ int colour_sort_small(const uint64_t* __restrict__ bitmap, const uint64_t* P, int pcount, int need,
                                  int32_t* order, int32_t* colour) {
-  static_assert(WN >= 1 && WN <= 8, "one word per lane of the first row quad pair");
+  static_assert(WN >= 1 && WN <= 16, "one word per lane of the first DPP row");
   typedef const __attribute__((address_space(3))) uint64_t* lds_rows_t;
   typedef const __attribute__((address_space(1))) uint64_t* glb_rows_t;
   const int lane = threadIdx.x;
@@ -129,12 +131,13 @@ __device__ int colour_sort_small(const uint64_t* __restrict__ bitmap, const uint
     ++k;
     uint64_t Qc = Q;
     while (true) {
-      // highest remaining candidate: per-lane highest bit, maximum over lanes 0 .. 7 (lanes >= WN hold no bits)
+      // highest remaining candidate: per-lane highest bit, maximum over lanes 0 .. 7 / 15 (lanes >= WN hold no bits)
       int hb = Qc ? lane * 64 + 63 - __builtin_clzll(Qc) : -1;
       // (old = INT_MIN, the identity of max: lets the compiler fold the move into v_max_i32_dpp)
       hb = max(hb, __builtin_amdgcn_update_dpp(INT_MIN, hb, 0xb1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]: lane ^ 1
       hb = max(hb, __builtin_amdgcn_update_dpp(INT_MIN, hb, 0x4e, 0xf, 0xf, false));   // quad_perm [2,3,0,1]: lane ^ 2
       hb = max(hb, __builtin_amdgcn_update_dpp(INT_MIN, hb, 0x141, 0xf, 0xf, false));  // row_half_mirror: lane ^ 7
+      if (WN > 8) hb = max(hb, __builtin_amdgcn_update_dpp(INT_MIN, hb, 0x140, 0xf, 0xf, false));  // row_mirror: lane ^ 15
       const int u = __builtin_amdgcn_readfirstlane(hb);
       if (u < 0) break;
       const uint64_t row = LDS ? ((lds_rows_t)bitmap)[u * WN + lw] : ((glb_rows_t)bitmap)[(int64_t)u * WN + lw];
@@ -174,12 +177,20 @@ __device__ __forceinline__ int colour_sort_any(const uint64_t* __restrict__ bitm
     COLOUR_SMALL_CASE(2)
     COLOUR_SMALL_CASE(3)
     COLOUR_SMALL_CASE(4)
-    // (round 5: up to 512 vertices -- the larger compact graphs of a descriptor batch, 300 - 400 vertices, hold most of
-    // the batch's search nodes and were colouring with the lane-spread version)
+    // (round 5: up to 1024 vertices, it ended at 256 -- the larger compact graphs of a descriptor batch, 300 - 400
+    // vertices, hold most of the batch's search nodes and were colouring with the lane-spread version)
     COLOUR_SMALL_CASE(5)
     COLOUR_SMALL_CASE(6)
     COLOUR_SMALL_CASE(7)
     COLOUR_SMALL_CASE(8)
+    COLOUR_SMALL_CASE(9)
+    COLOUR_SMALL_CASE(10)
+    COLOUR_SMALL_CASE(11)
+    COLOUR_SMALL_CASE(12)
+    COLOUR_SMALL_CASE(13)
+    COLOUR_SMALL_CASE(14)
+    COLOUR_SMALL_CASE(15)
+    COLOUR_SMALL_CASE(16)
     default: return colour_sort(bitmap, W, P, pcount, need, Q, Qc, order, colour);
   }
 #undef COLOUR_SMALL_CASE

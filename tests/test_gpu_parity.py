@@ -593,6 +593,28 @@ def test_random_graph_cliques_vs_oracle():
     assert n_exact > 0  # the device B&B was actually exercised
 
 
+def test_mid_size_graph_cliques_vs_oracle():
+    """Compact graphs of 9 .. 16 bit-set words (513 .. 1024 vertices: adjacency staged in LDS, colouring with one word
+    per lane and the four-step DPP maximum) and just beyond (17 words: the generic colouring): sparse enough for the
+    oracle's search to finish in seconds, dense enough that the device search runs."""
+    rng = np.random.default_rng(16)
+    s = make_solver()
+    n_exact = 0
+    for n, p in ((600, 0.12), (760, 0.10), (900, 0.08), (1020, 0.08), (1080, 0.07)):
+        A = np.triu(rng.uniform(size=(n, n)) < p, 1)
+        members = np.sort(rng.choice(n, size=9, replace=False))  # a planted 9-clique above the random graph's 5 - 6
+        A[np.ix_(members, members)] |= np.triu(np.ones((9, 9), dtype=bool), 1)
+        bm = oracle.bitmap_from_edges(n, np.argwhere(A))
+        c, er = s.maxClique(bm, n)
+        o = oracle.max_clique(bm, n)
+        n_exact += int(er)
+        assert len(c) == len(o["clique"]) >= 9, (n, len(c), len(o["clique"]))
+        assert is_clique(A | A.T, c) and c == sorted(c)
+        if o["unique"]:
+            assert c == o["clique"].tolist()
+    assert n_exact > 0
+
+
 def test_planted_clique_needs_exact():
     """A planted clique hidden among higher-degree decoys: greedy start vertices miss it, the
     exact stage must find it."""
