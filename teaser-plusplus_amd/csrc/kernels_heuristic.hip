@@ -82,14 +82,6 @@ __device__ __forceinline__ int greedy_one_start(
 
   ProbState* st = states + blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#ifdef TEASER_GREEDY_TRACE
-  unsigned long long tt[8];
-  int ti = 0, npick = 0, nvote = 0, nround = 0;
-#define GT_MARK() do { __syncthreads(); tt[ti++] = __builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define GT_MARK() do {} while (0)
-#endif
-  GT_MARK();
   const uint64_t* bm = bitmap + d.bm_off;
   const int32_t* dg = deg + d.pt_off;
   int32_t* C = start_cliques + (int64_t)sidx * total_n + d.pt_off;
@@ -136,17 +128,10 @@ __device__ __forceinline__ int greedy_one_start(
     pc += __popcll(x);
   }
   pc = blockN_sum_i<kGreedyWaves>(pc, red);
-  GT_MARK();
-#ifdef TEASER_GREEDY_TRACE
-  const int pc0 = pc;
-#endif
 
   // ---- phase 1: shrink P to at most kCap candidates --------------------------------------
   bool prefer_vote = false;
   while (pc > kCap) {
-#ifdef TEASER_GREEDY_TRACE
-    if (prefer_vote) ++nvote; else ++npick;
-#endif
     if (!prefer_vote) {
       // static pick: largest global degree, ties to the smallest index
       unsigned long long key = 0;
@@ -237,11 +222,6 @@ __device__ __forceinline__ int greedy_one_start(
       __syncthreads();
     }
   }
-
-  GT_MARK();
-#ifdef TEASER_GREEDY_TRACE
-  const int pc1 = pc;
-#endif
   if (pc > 0) {
     // ---- phase 2: candidate list in index order (contiguous word chunks per thread) -------
     const int wpt = (W + kGreedyThreads - 1) / kGreedyThreads;
@@ -283,8 +263,6 @@ __device__ __forceinline__ int greedy_one_start(
       }
     }
     __syncthreads();
-
-    GT_MARK();
     // ---- phase 3: compact adjacency A[r][k] bit l = edge(cand[r], cand[64k+l]) -------------
     const int Wc = (pc + 63) >> 6;
     // A lane needs ONE bit of a row per 64-candidate group: it loads the 32-bit half that holds it, so that FOUR rows
@@ -339,14 +317,9 @@ __device__ __forceinline__ int greedy_one_start(
     }
     if (tid == 0) misc[0] = csize;
     __syncthreads();
-
-    GT_MARK();
     // ---- phase 4: vote rounds on the compact matrix (all in LDS) ---------------------------
     int pcnt = pc;
     while (pcnt > 0) {
-#ifdef TEASER_GREEDY_TRACE
-      ++nround;
-#endif
       constexpr int kVote = (kCap + kGreedyThreads - 1) / kGreedyThreads;
       int dv[kVote];
       bool in[kVote];
@@ -403,14 +376,6 @@ __device__ __forceinline__ int greedy_one_start(
       }
     }
   }
-  GT_MARK();
-#ifdef TEASER_GREEDY_TRACE
-  if (tid == 0 && blockIdx.y == 0 && sidx < 2)
-    printf("[greedy trace] start %d n %d: |N(v0)| %d -> %d after %d picks + %d vote rounds; cycles: select %llu, P init %llu, "
-           "phase1 %llu, phase2 %llu, gather %llu, phase4 %llu (%d rounds); clique %d\n", sidx, n, pc0, pc1, npick, nvote,
-           tt[1] - tt[0], 0ull, tt[2] - tt[1], ti > 4 ? tt[3] - tt[2] : 0ull, ti > 4 ? tt[4] - tt[3] : 0ull,
-           ti > 5 ? tt[5] - tt[4] : 0ull, nround, csize);
-#endif
   if (tid == 0) st->start_size[sidx] = csize;
   return csize;
 }
