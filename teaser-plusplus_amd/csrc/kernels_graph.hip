@@ -360,11 +360,17 @@ __device__ __forceinline__ void bf16_split3(float v, unsigned int* h, unsigned i
   const float r2 = r1 - __uint_as_float(*m << 16);
   *l = bf16_rne(r2);
 }
-// nibble q>>2 of the 16 column bits -> bits 8 (q>>2) + (q&3): the rows of half h = 0
-__device__ __forceinline__ unsigned int spread_nibbles(unsigned int v) {
-  v = (v | (v << 8)) & 0x00FF00FFu;
-  v = (v | (v << 4)) & 0x0F0F0F0Fu;
-  return v;
+// (a & m) | (b & ~m) as ONE v_bfi / v_bitop3
+__device__ __forceinline__ unsigned int bit_select(unsigned int m, unsigned int a, unsigned int b) {
+  return __builtin_amdgcn_bitop3_b32(m, a, b, 0xCA);  // (written with & | ^ the compiler re-associates three selects into nine instructions)
+}
+// The epilogue's column bits of one lane arrive as four bytes {bit 7: row 3 of group g, bits 6..3: junk (exponent bits
+// that came along with the sign), bits 2..0: rows 2, 1, 0}.  lo = the bytes of lane half h = 0 (rows 8 g + 0..3), hi =
+// those of h = 1 (rows 8 g + 4..7) -> the column's 32 row bits in order.  Every select masks the junk off.
+__device__ __forceinline__ unsigned int merge_gap_bytes(unsigned int lo, unsigned int hi) {
+  const unsigned int even = bit_select(0x07070707u, lo, lo >> 4);  // nibble 2 g = rows 8 g + 0..3 (odd nibbles: junk)
+  const unsigned int odd = bit_select(0x70707070u, hi << 4, hi);   // nibble 2 g + 1 = rows 8 g + 4..7
+  return bit_select(0x0F0F0F0Fu, even, odd);
 }
 
 // Offset of a buffer store / atomic that must do nothing: beyond every descriptor's num_records (bitmaps stay
@@ -811,10 +817,14 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma3_kernel(
         v1 = (selfq == 2 * qp + 1) ? INFINITY : v1;
       }
       m = __builtin_fminf(__builtin_fminf(m, v0), v1);
-      colbits = __builtin_amdgcn_alignbit(colbits, __float_as_uint(d1), 31);
+      // value 2 qp + 1 opens a group of four rows when qp is odd: it enters with FIVE bits (its sign on top of four
+      // exponent bits), which leaves a gap that the merge of the two lane halves masks off (finish_tile)
+      colbits = __builtin_amdgcn_alignbit(colbits, __float_as_uint(d1), (qp & 1) ? 27 : 31);
       colbits = __builtin_amdgcn_alignbit(colbits, __float_as_uint(d0), 31);
     }
-    flags = (flags << 1) | ((m > thr) ? 0u : 1u);
+    // flags = 2 flags + !(m > thr): the compare's lane mask is the carry-in of flags + flags (the compiler's own
+    // sequence was compare, select, shift, or)
+    asm("v_cmp_nlt_f32_e32 vcc, %2, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(flags) : "v"(m), "s"(thr) : "vcc");
     return colbits;
   };
   // stage j = 16 of the bit transposes: after v_permlane16_swap(x, x) the first result holds {own, partner} and the
@@ -828,10 +838,9 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma3_kernel(
     unsigned int tw[2], ow[2];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
-      unsigned int s0 = spread_nibbles(tr[0][rt]) << (4 * h);
-      unsigned int s1 = spread_nibbles(tr[1][rt]) << (4 * h);
-      const auto r = __builtin_amdgcn_permlane32_swap(s0, s1, false, false);
-      tw[rt] = r[0] | r[1];
+      // r[0]: the 16 bits of half h = 0 (rows 8 g + 0..3 of the column), r[1]: those of h = 1 (rows 8 g + 4..7)
+      const auto r = __builtin_amdgcn_permlane32_swap(tr[0][rt], tr[1][rt], false, false);
+      tw[rt] = merge_gap_bytes(r[0], r[1]);
       // row-major words = the 32 x 32 bit transpose of the column words inside each half: 5 butterfly stages over
       // lane distance j = 16 .. 1 (the lower lane of a pair keeps x & m and takes (partner << j) & ~m, the upper one
       // keeps x & ~m and takes (partner >> j) & m).  The partner's word comes through the VALU's own cross-lane
@@ -848,19 +857,19 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma3_kernel(
         const int j = 16 >> st;
         unsigned int p;
         switch (st) {
-          case 1: p = __builtin_amdgcn_update_dpp(0u, x, 0x128, 0xf, 0xf, false); break;  // row_ror:8
+          case 1: p = __builtin_amdgcn_update_dpp(0u, x, 0x128, 0xf, 0xf, true); break;  // row_ror:8
           case 2:
-            p = __builtin_amdgcn_update_dpp(0u, x, 0x141, 0xf, 0xf, false);   // row_half_mirror: lane ^ 7
-            p = __builtin_amdgcn_update_dpp(0u, p, 0x1b, 0xf, 0xf, false);    // quad_perm [3,2,1,0]: lane ^ 3
+            p = __builtin_amdgcn_update_dpp(0u, x, 0x141, 0xf, 0xf, true);   // row_half_mirror: lane ^ 7
+            p = __builtin_amdgcn_update_dpp(0u, p, 0x1b, 0xf, 0xf, true);    // quad_perm [3,2,1,0]: lane ^ 3
             break;
-          case 3: p = __builtin_amdgcn_update_dpp(0u, x, 0x4e, 0xf, 0xf, false); break;   // quad_perm [2,3,0,1]
-          default: p = __builtin_amdgcn_update_dpp(0u, x, 0xb1, 0xf, 0xf, false); break;  // quad_perm [1,0,3,2]
+          case 3: p = __builtin_amdgcn_update_dpp(0u, x, 0x4e, 0xf, 0xf, true); break;   // quad_perm [2,3,0,1]
+          default: p = __builtin_amdgcn_update_dpp(0u, x, 0xb1, 0xf, 0xf, true); break;  // quad_perm [1,0,3,2]
         }
         const bool up = (lane & j) != 0;
         const unsigned int shifted = __builtin_amdgcn_alignbit(p, p, up ? j : 32 - j);
         const unsigned int km[5] = {0x0000FFFFu, 0x00FF00FFu, 0x0F0F0F0Fu, 0x33333333u, 0x55555555u};
         const unsigned int keep = up ? ~km[st] : km[st];
-        x = ((x ^ shifted) & keep) ^ shifted;  // v_bfi_b32 keep, x, shifted
+        x = bit_select(keep, x, shifted);
       }
       ow[rt] = x;  // lane (r, half ct): the 32 column bits (ct) of row 32 rt + r
     }
@@ -873,7 +882,7 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma3_kernel(
     lds_own[wave][lane][(J - Jbase) & (kMfmaColTiles - 1)] = ownw;
     degacc += __builtin_popcountll(ownw);
     // rows beyond n hold no bits (clamped: the padding repeats the last point); the diagonal tile has no transposed copy
-    const uint64_t trw_out = (!diag && j0 + lane < n) ? (trw & rowmask) : 0ull;
+    const uint64_t trw_out = diag ? 0ull : (trw & rowmask);  // (columns beyond n: the flush stores no such row)
     lds_tr[(J - Jbase) & (kMfmaColTiles - 1)][lane][wave] = trw_out;
   };
 
