@@ -63,8 +63,9 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_BF16_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (not the 2:1-sparsity figure)
 FP64_PEAK_TF = 78.6        # dense FP64 peak of MI355X (matrix = vector), FMA = 2 flops
+L1_PEAK_GBS = 256 * 64 * 2.4  # vector L1 / texture-address path: 64 B per clock and CU
 VALU_PEAK_GINST = 1024 * 2.4 / 4.0  # G wave64 VALU instructions/s: 256 CUs x 4 SIMDs, 2.4 GHz, 4 cycles each
-K1_VALU_PER_1024_STATIC = 64.0  # steady-state loop body of tim_graph_mfma3_kernel (scripts/k1_isa_stats.py)
+K1_VALU_PER_1024_STATIC = 56.0  # steady-state loop body of tim_graph_mfma3_kernel (scripts/k1_isa_stats.py)
 K1_FLOPS_PER_PAIR = 20.0   # algorithmic FP64 flops of the reference predicate
 # executed by K1 per pair: 4 x v_mfma_f32_32x32x16_bf16 (2*32*32*16 flops each) per 1024 pairs
 K1_MFMA_FLOPS_PER_PAIR = 4 * 2 * 32 * 32 * 16 / 1024.0
@@ -156,6 +157,18 @@ def roofline_object(k1_ms, k1_launches, k1_bytes, k1_pairs, k1_aux_ms, traffic, 
                 "algorithmic_bytes_per_launch": bytes_per_launch, "traffic_bytes_per_launch": traffic,
                 "traffic_source": traffic_src},
     }
+    if issue and issue.get("vmem_insts_per_1024_pairs"):
+        # every vector-memory instruction of the kernel moves 64 lanes x 16 bytes (operand loads, 128-bit bitmap stores;
+        # the 64-bit stores and the degree atomics are counted as if they did): 1 KB through the CU's one address unit
+        vm = float(issue["vmem_insts_per_1024_pairs"])
+        l1_gbs = rate(vm * pairs_per_launch / 1024.0 * 1024.0) / 1e9
+        pipes["l1"] = {"achieved": l1_gbs, "peak": L1_PEAK_GBS, "unit": "GB/s", "frac": l1_gbs / L1_PEAK_GBS,
+                       "vmem_insts_per_1024_pairs": vm, "count_source": issue.get("source"),
+                       "measured_ta_busy_frac_kernel_alone": issue.get("ta_busy_frac"),
+                       "note": "vector-memory wave-instructions x 1 KB against 256 CUs x 64 B/clk x 2.4 GHz (vector L1 / "
+                               "texture-address path); the address units are BUSY for about twice that minimum "
+                               "(measured_ta_busy_frac_kernel_alone), and removing the loop's operand loads shortens the "
+                               "kernel by 40 % (profiles/r5t): this path, not the VALU, is what a faster K1 has to relieve"}
     bound = max(pipes, key=lambda k: pipes[k]["frac"])
     top = pipes[bound]
     return {
@@ -172,7 +185,7 @@ def roofline_object(k1_ms, k1_launches, k1_bytes, k1_pairs, k1_aux_ms, traffic, 
                             "note": "20 FP64 flop/pair of the reference predicate (SURVEY.md 8(d)) x pairs / kernel time "
                                     "against the dense FP64 peak: algorithm-equivalent, NOT an executed fraction (may exceed 1)"},
         "issue": issue,
-        "note": "frac = the largest EXECUTED pipe fraction of the kernel (valu issue / bf16 mfma / hbm), from HIP events "
+        "note": "frac = the largest EXECUTED pipe fraction of the kernel (valu issue / bf16 mfma / hbm / vector L1), from HIP events "
                 "around the kernel alone on its stream inside the timed region.  With --depth > 1 the kernel shares the "
                 "GPU with the latency-bound tail kernels of the previous batch, which is included in its time",
     }
@@ -211,7 +224,8 @@ def k1_issue():
         return None
     k, src = hit
     keep = {f: k[f] for f in ("valu_busy_frac", "mfma_busy_frac", "valu_insts_per_1024_pairs",
-                              "wave_issue_frac", "wave_wait_frac", "wave_stall_frac") if f in k}
+                              "wave_issue_frac", "wave_wait_frac", "wave_stall_frac", "vmem_insts_per_1024_pairs",
+                              "ta_busy_frac", "l1_hit_rate", "ta_addr_fifo_full_frac") if f in k}
     return dict(keep, source=src) if keep else None
 
 

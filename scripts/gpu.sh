@@ -96,10 +96,12 @@ for k,c in d['configs'].items():
       prof kt --kernel-trace --output-format csv -d $OUT/kt -o t -- $K
       prof sq1 --pmc $SQ1 --output-format csv -d $OUT/sq1 -o t -- $K
       prof sq2 --pmc $SQ2 --output-format csv -d $OUT/sq2 -o t -- $K
+      prof sq3 --pmc SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD --output-format csv -d $OUT/sq3 -o t -- $K
+      prof ta1 --pmc TA_TA_BUSY_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum --output-format csv -d $OUT/ta1 -o t -- $K
       prof fetch --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -o t -- $K
       prof write --pmc WRITE_SIZE --output-format csv -d $OUT/write -o t -- $K
       python scripts/summarize_pmc.py $(find $OUT/fetch -name "*counter_collection.csv") $(find $OUT/write -name "*counter_collection.csv") $OUT/pmc_traffic.json 64 10000 | grep -i "tim_graph"
-      python scripts/summarize_k1.py $OUT/k1_sq_counters.json 64 10000 $(find $OUT/kt -name "*kernel_trace.csv") $(find $OUT/sq1 -name "*counter_collection.csv") $(find $OUT/sq2 -name "*counter_collection.csv") | cut -c1-700 ;;
+      python scripts/summarize_k1.py $OUT/k1_sq_counters.json 64 10000 $(find $OUT/kt -name "*kernel_trace.csv") $(find $OUT/sq1 $OUT/sq2 $OUT/sq3 $OUT/ta1 -name "*counter_collection.csv") | cut -c1-900 ;;
     cliquepmc)
       i=0
       for set in "$LDS1" "$LDS2"; do

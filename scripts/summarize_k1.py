@@ -47,6 +47,14 @@ def main():
         k["valu_insts_per_1024_pairs"] = c["SQ_INSTS_VALU"] / (pairs / 1024)
     if "SQ_INSTS_MFMA" in c:
         k["mfma_insts_per_1024_pairs"] = c["SQ_INSTS_MFMA"] / (pairs / 1024)
+    if "SQ_INSTS_VMEM_RD" in c:
+        k["vmem_insts_per_1024_pairs"] = (c["SQ_INSTS_VMEM_RD"] + c.get("SQ_INSTS_VMEM_WR", 0.0)) / (pairs / 1024)
+    if "TA_TA_BUSY_sum" in c:  # summed over the 256 texture-address units (one per CU)
+        k["ta_busy_frac"] = c["TA_TA_BUSY_sum"] / 256.0 / cyc
+    if "TCP_TOTAL_CACHE_ACCESSES_sum" in c and "TCP_TCC_READ_REQ_sum" in c and c["TCP_TOTAL_CACHE_ACCESSES_sum"] > 0:
+        k["l1_hit_rate"] = 1.0 - c["TCP_TCC_READ_REQ_sum"] / c["TCP_TOTAL_CACHE_ACCESSES_sum"]
+    if "SQ_VMEM_TA_ADDR_FIFO_FULL" in c:  # summed over the CUs' sequencers
+        k["ta_addr_fifo_full_frac"] = c["SQ_VMEM_TA_ADDR_FIFO_FULL"] / 256.0 / cyc
     if "SQ_WAVE_CYCLES" in c:
         wc = c["SQ_WAVE_CYCLES"]
         for name, src in (("wave_issue_frac", "SQ_ACTIVE_INST_ANY"), ("wave_wait_frac", "SQ_WAIT_ANY"),

@@ -87,6 +87,11 @@ def test_bench_roofline_object():
     assert abs(r["pipes"]["hbm"]["achieved"] - byts / 0.80e-3 / 1e9) < 1e-6 and r["traffic"] == 1.78e9
     f = r["fp64_equivalent"]
     assert abs(f["achieved"] - 20 * pairs / 0.80e-3 / 1e12) < 1e-6 and f["peak"] == 78.6 and f["ratio"] > 1.0
+    # a counter pass that also holds the vector-memory instruction count adds the vector-L1 pipe (1 KB per instruction)
+    r1 = bench.roofline_object(20 * 0.80, 20, 20 * byts, 20 * pairs, 0.0, None, None,
+                               issue=dict(issue, vmem_insts_per_1024_pairs=3.04, ta_busy_frac=0.65))
+    assert set(r1["pipes"]) == {"valu", "mfma", "hbm", "l1"} and r1["pipes"]["l1"]["peak"] == 256 * 64 * 2.4
+    assert abs(r1["pipes"]["l1"]["achieved"] - 3.04 * pairs / 0.80e-3 / 1e9) < 1e-6 and 0 < r1["pipes"]["l1"]["frac"] < 1
     r0 = bench.roofline_object(20 * 0.80, 20, 20 * byts, 20 * pairs, 0.0, None, None)  # no counter pass committed
     assert r0["pipes"]["valu"]["valu_insts_per_1024_pairs"] == bench.K1_VALU_PER_1024_STATIC
     z = bench.roofline_object(0.0, 0, 0, 0, 0.0, None, None)  # no launches: no division by zero
