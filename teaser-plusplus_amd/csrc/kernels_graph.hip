@@ -425,15 +425,16 @@ constexpr float kEpsU2 = 680.0f;
 constexpr float kEpsA2 = 1300.0f;
 
 // Packed operands of one 64-point tile (tile t of a problem = points 64 t .. 64 t + 63, padded with copies of the
-// problem's last point; tiles are indexed like the bitmap's row words, ProbDesc.w_off + t): 256 B per
+// problem's last point; tiles are indexed like the bitmap's row words, ProbDesc.w_off + t): 224 B per
 // correspondence.  Laid out so that the 64 lanes of a wave -- lane = (h, c), c = point within a 32-point group,
 // lane half h holding K slots 8h..8h+7 -- load 1 KB of CONSECUTIVE memory per MFMA operand:
 // [32-point group][MFMA][h][c].  (A first layout with 128 B per point made every such load touch 32 separate
 // 128-B lines: the vector L1 was the kernel's hidden bottleneck.)
 struct TimOperandTile2 {
-  uint4 a[2][4][2][32];
-  uint4 b[2][4][2][32];
+  uint4 a[2][4][2][32];  // row side: the u chain's three operands, then the w MFMA's
+  uint4 b[2][3][2][32];  // column side: three operands -- the w MFMA multiplies the u chain's FIRST one again (below)
 };
+constexpr int kTimColOperands = 3;
 
 // scale g and kappa = 4 (g beta)^2 = 2^kexp (the smallest power of two above 4 beta^2)
 __device__ __forceinline__ double pow2_d(int e) {  // 2^e for -1022 <= e <= 1023
@@ -488,48 +489,62 @@ __global__ __launch_bounds__(256) void tim_prep_pack2_kernel(const ProbDesc* __r
     const double beta2s = pow2_d(kexp - 2);  // (g beta)^2 = kappa / 4, exact
     const float delta_row = (float)(nb_d - na_d - beta2s);  // m_i - n_i - beta^2 (this point as a ROW)
     const float delta_col = (float)(nb_d - na_d);           // m_j - n_j          (this point as a COLUMN)
-    unsigned short A[64], B[64];  // K slots 0..47: the u chain, 48..63: the w MFMA
-    for (int k = 0; k < 64; ++k) { A[k] = 0; B[k] = 0; }
+    // K slots.  Column side B[0..47] = the three operands of the u chain; row side A[0..47] the u chain's, A[48..63]
+    // the w MFMA's, which runs over the FIRST column operand B[0..15] again: that operand holds exactly what w needs
+    // from a column point -- the (h, m, h) pieces of the src coordinates, its squared-norm pieces and `one` -- and every
+    // factor that is w's alone (kappa, the row's own norm) sits on the row side, which stays in registers.  One
+    // operand load in four is gone from the column-tile loop, whose load instructions are what bounds the kernel.
+    //   slot  B (column j)                         A, u chain (row i)        A, w (row i)
+    //   3c+0  2 h(s_c)                             h(s_c)                    kappa h(s_c)
+    //   3c+1  2 m(s_c)                             h(s_c)                    kappa h(s_c)
+    //   3c+2  2 h(s_c)                             m(s_c)                    kappa m(s_c)          c = 0, 1, 2
+    //   9,10  -h(n_j), -m(n_j)                     0                         kappa
+    //   11-13 1                                    h, m, l (m_i - n_i - b^2)  -kappa h(n_i), -kappa m(n_i), 0
+    //   16+3c 2 l(s_c), 2 h(s_c), 2 m(s_c)         h, l, m (s_c)                                    (second operand)
+    //   25-27 h, m, l (m_j - n_j)                  1
+    //   28..  the dst coordinates' six products each, negated: (h,h,m,h,l,m) x -2 (h,m,h,l,h,m), 18 slots up to 45
+    unsigned short A[64], B[48];
+    for (int k = 0; k < 64; ++k) A[k] = 0;
+    for (int k = 0; k < 48; ++k) B[k] = 0;
     const float cs[3] = {sx, sy, sz}, cd[3] = {dx, dy, dz};
+    const unsigned short one = 0x3f80;
+    unsigned int h, m, l;
     for (int c = 0; c < 3; ++c) {
-      unsigned int h, m, l;
       bf16_split3(cs[c], &h, &m, &l);  // -A contributes +2 s.s'
-      unsigned short* ua = A + 6 * c;
-      unsigned short* ub = B + 6 * c;
-      ua[0] = h; ua[1] = h; ua[2] = m; ua[3] = h; ua[4] = l; ua[5] = m;
-      ub[0] = bf16_mul_pow2(h, 1, false); ub[1] = bf16_mul_pow2(m, 1, false); ub[2] = ub[0];
-      ub[3] = bf16_mul_pow2(l, 1, false); ub[4] = ub[0]; ub[5] = ub[1];
-      // w = -kappa n_i - kappa n_j + 2 kappa s.s': products (h,h') (h,m') (m,h')
-      unsigned short* wa = A + 48 + 3 * c;
-      unsigned short* wb = B + 48 + 3 * c;
-      wa[0] = h; wa[1] = h; wa[2] = m;
-      wb[0] = bf16_mul_pow2(h, kexp + 1, false); wb[1] = bf16_mul_pow2(m, kexp + 1, false); wb[2] = wb[0];
+      const unsigned short h2 = (unsigned short)bf16_mul_pow2(h, 1, false), m2 = (unsigned short)bf16_mul_pow2(m, 1, false),
+                           l2 = (unsigned short)bf16_mul_pow2(l, 1, false);
+      B[3 * c] = h2; B[3 * c + 1] = m2; B[3 * c + 2] = h2;
+      A[3 * c] = h; A[3 * c + 1] = h; A[3 * c + 2] = m;
+      // w = -kappa n_i - kappa n_j + 2 kappa s.s': products (h,h') (h,m') (m,h'), kappa = 2^kexp on the row side
+      A[48 + 3 * c] = (unsigned short)bf16_mul_pow2(h, kexp, false); A[48 + 3 * c + 1] = A[48 + 3 * c];
+      A[48 + 3 * c + 2] = (unsigned short)bf16_mul_pow2(m, kexp, false);
+      B[16 + 3 * c] = l2; B[16 + 3 * c + 1] = h2; B[16 + 3 * c + 2] = m2;
+      A[16 + 3 * c] = h; A[16 + 3 * c + 1] = l; A[16 + 3 * c + 2] = m;
       bf16_split3(cd[c], &h, &m, &l);  // +B contributes -2 d.d'
-      ua = A + 18 + 6 * c;
-      ub = B + 18 + 6 * c;
+      unsigned short* ua = A + 28 + 6 * c;
+      unsigned short* ub = B + 28 + 6 * c;
       ua[0] = h; ua[1] = h; ua[2] = m; ua[3] = h; ua[4] = l; ua[5] = m;
       ub[0] = bf16_mul_pow2(h, 1, true); ub[1] = bf16_mul_pow2(m, 1, true); ub[2] = ub[0];
       ub[3] = bf16_mul_pow2(l, 1, true); ub[4] = ub[0]; ub[5] = ub[1];
     }
-    const unsigned short one = 0x3f80;
-    unsigned int h, m, l;
-    bf16_split3(delta_row, &h, &m, &l);
-    A[36] = h; A[37] = m; A[38] = l; B[36] = one; B[37] = one; B[38] = one;
-    bf16_split3(delta_col, &h, &m, &l);
-    A[39] = one; A[40] = one; A[41] = one; B[39] = h; B[40] = m; B[41] = l;
     bf16_split3(na, &h, &m, &l);
-    const unsigned short mk = (unsigned short)bf16_mul_pow2(one, kexp, true);  // -kappa
-    A[57] = h; A[58] = m; B[57] = mk; B[58] = mk;
-    A[59] = one; A[60] = one;
-    B[59] = (unsigned short)bf16_mul_pow2(h, kexp, true); B[60] = (unsigned short)bf16_mul_pow2(m, kexp, true);
+    B[9] = (unsigned short)bf16_mul_pow2(h, 0, true); B[10] = (unsigned short)bf16_mul_pow2(m, 0, true);  // -n_j
+    A[48 + 9] = (unsigned short)bf16_mul_pow2(one, kexp, false); A[48 + 10] = A[48 + 9];                    // kappa
+    B[11] = one; B[12] = one; B[13] = one;
+    A[48 + 11] = (unsigned short)bf16_mul_pow2(h, kexp, true); A[48 + 12] = (unsigned short)bf16_mul_pow2(m, kexp, true);  // -kappa n_i
+    bf16_split3(delta_row, &h, &m, &l);
+    A[11] = h; A[12] = m; A[13] = l;
+    bf16_split3(delta_col, &h, &m, &l);
+    A[25] = one; A[26] = one; A[27] = one; B[25] = h; B[26] = m; B[27] = l;
     TimOperandTile2* tile = ops + d.w_off + (ip >> 6);
     const int gq = (ip >> 5) & 1, cc = ip & 31;
     for (int mf = 0; mf < 4; ++mf)
       for (int hh = 0; hh < 2; ++hh) {
         const unsigned short* pa = A + 16 * mf + 8 * hh;
-        const unsigned short* pb = B + 16 * mf + 8 * hh;
         tile->a[gq][mf][hh][cc] = make_uint4(pa[0] | ((unsigned int)pa[1] << 16), pa[2] | ((unsigned int)pa[3] << 16),
                                              pa[4] | ((unsigned int)pa[5] << 16), pa[6] | ((unsigned int)pa[7] << 16));
+        if (mf == kTimColOperands) continue;
+        const unsigned short* pb = B + 16 * mf + 8 * hh;
         tile->b[gq][mf][hh][cc] = make_uint4(pb[0] | ((unsigned int)pb[1] << 16), pb[2] | ((unsigned int)pb[3] << 16),
                                              pb[4] | ((unsigned int)pb[5] << 16), pb[6] | ((unsigned int)pb[7] << 16));
       }
@@ -735,8 +750,9 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma3_kernel(
   typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
   const __amdgpu_buffer_rsrc_t q_rsrc = __builtin_amdgcn_make_buffer_rsrc(
       (void*)qt, 0, (int)((unsigned int)T * (unsigned int)sizeof(TimOperandTile2)), 0x00020000);
-  auto load_op = [&](int tile, int side, int g, int m) -> uint4 {  // side 0 = a (rows), 1 = b; m = MFMA 0..3
-    const int soff = tile * (int)sizeof(TimOperandTile2) + side * (int)sizeof(TimOperandTile2) / 2 + (g * 4 + m) * 1024;
+  auto load_op = [&](int tile, int side, int g, int m) -> uint4 {  // side 0 = a (rows: m = 0..3), 1 = b (columns: m = 0..2)
+    const int soff = tile * (int)sizeof(TimOperandTile2) +
+                     (side ? (int)offsetof(TimOperandTile2, b) + (g * kTimColOperands + m) * 1024 : (g * 4 + m) * 1024);
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(q_rsrc, lane * 16, soff, 0);
     return make_uint4(v.x, v.y, v.z, v.w);
   };
@@ -749,12 +765,12 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma3_kernel(
   const bool rowvalid = I < T;
   const uint64_t rowmask = !rowvalid ? 0ull : (n - I * 64 >= 64) ? ~0ull : ((1ull << (n - I * 64)) - 1ull);
   const int Jfirst = max(Jbase, I), Jend = min(Jbase + kBlockColTiles, T);  // the wave's column tiles, all chunks
-  uint4 bX[4], bY[4];  // column operands: X = the tile's first 32 columns (ct 0), Y = the other 32 (PIPE only)
+  uint4 bX[kTimColOperands], bY[kTimColOperands];  // column operands: X = the tile's first 32 columns (ct 0), Y = the other 32 (PIPE only)
   {
     const int Jf = min(Jfirst, T - 1);
-    for (int m = 0; m < 4; ++m) bX[m] = load_op(Jf, 1, 0, m);
+    for (int m = 0; m < kTimColOperands; ++m) bX[m] = load_op(Jf, 1, 0, m);
     if (PIPE)
-      for (int m = 0; m < 4; ++m) bY[m] = load_op(Jf, 1, 1, m);
+      for (int m = 0; m < kTimColOperands; ++m) bY[m] = load_op(Jf, 1, 1, m);
   }
   const TimPrep pr = prep[blockIdx.y];  // (uniform address: scalar loads)
   if (!pr.use_mfma) {  // per problem: uniform over the block
@@ -786,12 +802,12 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma3_kernel(
     f32x16 U, W;
   };
   // the four MFMAs of one 32 x 32 quarter tile: u = B - A - beta^2 over 48 K slots (three chained), w = -4 beta^2 A
-  // over 16 (one); w sits between the first two links of the chain
-  auto mf = [&](Acc& a, const bf16x8(&arow)[4], const uint4(&b)[4]) {
+  // over 16 (one, over the chain's first column operand again); w sits between the first two links of the chain
+  auto mf = [&](Acc& a, const bf16x8(&arow)[4], const uint4(&b)[kTimColOperands]) {
     f32x16 z;
     for (int k = 0; k < 16; ++k) z[k] = 0.f;
     a.U = __builtin_amdgcn_mfma_f32_32x32x16_bf16(arow[0], __builtin_bit_cast(bf16x8, b[0]), z, 0, 0, 0);
-    a.W = __builtin_amdgcn_mfma_f32_32x32x16_bf16(arow[3], __builtin_bit_cast(bf16x8, b[3]), z, 0, 0, 0);
+    a.W = __builtin_amdgcn_mfma_f32_32x32x16_bf16(arow[3], __builtin_bit_cast(bf16x8, b[0]), z, 0, 0, 0);
     a.U = __builtin_amdgcn_mfma_f32_32x32x16_bf16(arow[1], __builtin_bit_cast(bf16x8, b[1]), a.U, 0, 0, 0);
     a.U = __builtin_amdgcn_mfma_f32_32x32x16_bf16(arow[2], __builtin_bit_cast(bf16x8, b[2]), a.U, 0, 0, 0);
   };
@@ -893,7 +909,7 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma3_kernel(
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct) {
       const bf16x8 b0 = __builtin_bit_cast(bf16x8, bX[0]), b1 = __builtin_bit_cast(bf16x8, bX[1]);
-      const bf16x8 b2 = __builtin_bit_cast(bf16x8, bX[2]), b3 = __builtin_bit_cast(bf16x8, bX[3]);
+      const bf16x8 b2 = __builtin_bit_cast(bf16x8, bX[2]);
       const int Jn = (ct == 0 || J + 1 >= Jend) ? J : J + 1, gn = ct ^ 1;
       f32x16 z;
       for (int k = 0; k < 16; ++k) z[k] = 0.f;
@@ -901,6 +917,10 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma3_kernel(
       acc[0].U = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[0][0], b0, z, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       acc[1].U = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[1][0], b0, z, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0].W = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[0][3], b0, z, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      acc[1].W = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[1][3], b0, z, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       acc[0].U = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[0][1], b1, acc[0].U, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
@@ -910,11 +930,7 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma3_kernel(
       __builtin_amdgcn_sched_barrier(0);
       acc[1].U = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[1][2], b2, acc[1].U, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      acc[0].W = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[0][3], b3, z, 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      acc[1].W = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[1][3], b3, z, 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      for (int m = 0; m < 4; ++m) bX[m] = load_op(Jn, 1, gn, m);
+      for (int m = 0; m < kTimColOperands; ++m) bX[m] = load_op(Jn, 1, gn, m);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) tr[ct][rt] = epi(acc[rt], DIAG && ct == rt);
@@ -945,21 +961,21 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma3_kernel(
     tr[0][0] = epi(accA, DIAG);
     TIM_K1_INTERLEAVE(kEpiShare);
     __builtin_amdgcn_sched_barrier(0);
-    for (int m = 0; m < 4; ++m) bX[m] = load_op(Jn, 1, 0, m);  // X is free: next tile's first half, used in phase 3
+    for (int m = 0; m < kTimColOperands; ++m) bX[m] = load_op(Jn, 1, 0, m);  // X is free: next tile's first half, used in phase 3
     mf(accA, ar[0], bY);                  // (ct 1, rt 0)
     tr[0][1] = epi(accB, false);
-    __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x020, kTimColOperands, 0);
     TIM_K1_INTERLEAVE(kEpiShare);
     __builtin_amdgcn_sched_barrier(0);
     mf(accB, ar[1], bY);                  // (ct 1, rt 1)
     tr[1][0] = epi(accA, false);
     TIM_K1_INTERLEAVE(kEpiShare);
     __builtin_amdgcn_sched_barrier(0);
-    for (int m = 0; m < 4; ++m) bY[m] = load_op(Jn, 1, 1, m);  // Y is free: next tile's second half, used in phase 1
+    for (int m = 0; m < kTimColOperands; ++m) bY[m] = load_op(Jn, 1, 1, m);  // Y is free: next tile's second half, used in phase 1
     mf(accA, ar[0], bX);                  // next tile's (ct 0, rt 0)
     tr[1][1] = epi(accB, DIAG);
     finish_tile(J, DIAG, tr);
-    __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);
+    __builtin_amdgcn_sched_group_barrier(0x020, kTimColOperands, 0);
     TIM_K1_INTERLEAVE(kEpiShare + 16);
     __builtin_amdgcn_sched_barrier(0);
   };

@@ -172,28 +172,32 @@ def operands2(src64, dst64, beta):
     na = (s.astype(np.float64) ** 2).sum(1)
     nb = (d.astype(np.float64) ** 2).sum(1)
     n = len(s)
+    # the slot table of tim_prep_pack2_kernel: the w MFMA (row slots 48..63) runs over the u chain's FIRST column
+    # operand again, so the column side has 48 slots and B[:, 48:64] below is a copy of B[:, 0:16]
     A, B = np.zeros((n, 64), np.float32), np.zeros((n, 64), np.float32)
     for k in range(3):
         h, m, l = split3(s[:, k])
-        A[:, 6 * k:6 * k + 6] = np.stack([h, h, m, h, l, m], 1)
-        B[:, 6 * k:6 * k + 6] = np.float32(2) * np.stack([h, m, h, l, h, m], 1)
-        A[:, 48 + 3 * k:48 + 3 * k + 3] = np.stack([h, h, m], 1)
-        B[:, 48 + 3 * k:48 + 3 * k + 3] = np.float32(2) * kappa * np.stack([h, m, h], 1)
+        A[:, 3 * k:3 * k + 3] = np.stack([h, h, m], 1)
+        B[:, 3 * k:3 * k + 3] = np.float32(2) * np.stack([h, m, h], 1)
+        A[:, 48 + 3 * k:48 + 3 * k + 3] = kappa * np.stack([h, h, m], 1)
+        A[:, 16 + 3 * k:16 + 3 * k + 3] = np.stack([h, l, m], 1)
+        B[:, 16 + 3 * k:16 + 3 * k + 3] = np.float32(2) * np.stack([l, h, m], 1)
         h, m, l = split3(d[:, k])
-        A[:, 18 + 6 * k:18 + 6 * k + 6] = np.stack([h, h, m, h, l, m], 1)
-        B[:, 18 + 6 * k:18 + 6 * k + 6] = np.float32(-2) * np.stack([h, m, h, l, h, m], 1)
+        A[:, 28 + 6 * k:28 + 6 * k + 6] = np.stack([h, h, m, h, l, m], 1)
+        B[:, 28 + 6 * k:28 + 6 * k + 6] = np.float32(-2) * np.stack([h, m, h, l, h, m], 1)
     beta2s = 2.0 ** (kexp - 2)
-    h, m, l = split3((nb - na - beta2s).astype(np.float32))
-    A[:, 36:39] = np.stack([h, m, l], 1)
-    B[:, 36:39] = 1
-    h, m, l = split3((nb - na).astype(np.float32))
-    A[:, 39:42] = 1
-    B[:, 39:42] = np.stack([h, m, l], 1)
     h, m, l = split3(na.astype(np.float32))
-    A[:, 57:59] = np.stack([h, m], 1)
-    B[:, 57:59] = -kappa
-    A[:, 59:61] = 1
-    B[:, 59:61] = -kappa * np.stack([h, m], 1)
+    B[:, 9:11] = -np.stack([h, m], 1)
+    A[:, 48 + 9:48 + 11] = kappa
+    B[:, 11:14] = 1
+    A[:, 48 + 11:48 + 13] = -kappa * np.stack([h, m], 1)
+    h, m, l = split3((nb - na - beta2s).astype(np.float32))
+    A[:, 11:14] = np.stack([h, m, l], 1)
+    h, m, l = split3((nb - na).astype(np.float32))
+    A[:, 25:28] = 1
+    B[:, 25:28] = np.stack([h, m, l], 1)
+    assert not B[:, 46:].any()
+    B[:, 48:64] = B[:, 0:16]
     r2 = float(max(na.astype(np.float32).max(), nb.astype(np.float32).max()))
     return A, B, r2, g, kexp
 
