@@ -914,6 +914,10 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma3_kernel(
       f32x16 z;
       for (int k = 0; k < 16; ++k) z[k] = 0.f;
       Acc acc[2];
+      // the MFMA burst and the operand loads behind it are issued at raised priority, the epilogue at the default: a
+      // wave's loads win the arbitration against the other waves' vector work (-2 % on the bench step, profiles/r5t;
+      // lowering the priority BEFORE the loads, or one level for the whole loop, gains nothing)
+      __builtin_amdgcn_s_setprio(2);
       acc[0].U = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[0][0], b0, z, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       acc[1].U = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[1][0], b0, z, 0, 0, 0);
@@ -931,6 +935,7 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma3_kernel(
       acc[1].U = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[1][2], b2, acc[1].U, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       for (int m = 0; m < kTimColOperands; ++m) bX[m] = load_op(Jn, 1, gn, m);
+      __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt) tr[ct][rt] = epi(acc[rt], DIAG && ct == rt);
