@@ -926,15 +926,22 @@ __global__ __launch_bounds__(256, OCC) void tim_graph_mfma3_kernel(
       __builtin_amdgcn_sched_barrier(0);
       acc[1].W = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[1][3], b0, z, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
+      // each operand of the next half tile is requested right behind the last MFMA that reads its registers: the
+      // load's way into the address unit runs beside the matrix pipe (0.592 -> 0.576 ms alone, -0.6 % on the bench
+      // step: profiles/r5t/r5t21)
+      bX[0] = load_op(Jn, 1, gn, 0);
+      __builtin_amdgcn_sched_barrier(0);
       acc[0].U = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[0][1], b1, acc[0].U, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       acc[1].U = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[1][1], b1, acc[1].U, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      bX[1] = load_op(Jn, 1, gn, 1);
       __builtin_amdgcn_sched_barrier(0);
       acc[0].U = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[0][2], b2, acc[0].U, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       acc[1].U = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[1][2], b2, acc[1].U, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      for (int m = 0; m < kTimColOperands; ++m) bX[m] = load_op(Jn, 1, gn, m);
+      bX[2] = load_op(Jn, 1, gn, 2);
       __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
