@@ -4,7 +4,7 @@ Writes gpurun_ab/kernels_graph_<name>.hip = csrc/kernels_graph.hip with one ingr
 Variants other than `old` / `touch` produce WRONG bits, so their outputs are forced to zero and their flags dropped
 behind an opaque use (empty graph, no worklist overflow, no fallback: the events time the kernel alone).
   zero      control: outputs zeroed, nothing removed
-  nomfma    no MFMAs (accumulators defined by an empty asm)        halfmfma  two of the four MFMAs per quarter tile
+  nomfma    no MFMAs (accumulators defined by an empty asm)        halfmfma  the u chain's first link and the w MFMA only
   noepi     no epilogue (sign collection, min |d|, flags)           nofinish  no word assembly / transposes / LDS parking
   noload    no column-operand loads in the loop (operands of the first tile reused)
   sameload  the loop's loads always fetch the wave's first column tile
@@ -18,13 +18,20 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 SRC = open(os.path.join(ROOT, "teaser-plusplus_amd", "csrc", "kernels_graph.hip")).read()
 OUT = os.path.join(ROOT, "gpurun_ab")
-LOAD = "      for (int m = 0; m < 4; ++m) bX[m] = load_op(Jn, 1, gn, m);"
+LOADS = ["      bX[%d] = load_op(Jn, 1, gn, %d);" % (m, m) for m in range(3)]  # the three column operands of the next half tile
 EPI = "      for (int rt = 0; rt < 2; ++rt) tr[ct][rt] = epi(acc[rt], DIAG && ct == rt);"
 
 
 def once(s, old, new):
     assert s.count(old) == 1, old
     return s.replace(old, new)
+
+
+def each_load(bd, f):
+    """replace the three operand-load lines of the flat body: f(m) -> replacement line"""
+    for m, l in enumerate(LOADS):
+        bd = once(bd, l, f(m))
+    return bd
 
 
 def zeroed(s):
@@ -55,28 +62,28 @@ def no_mfma(bd, keep=lambda l: False):
 
 VARIANTS = {
     "zero": lambda: zeroed(SRC),
-    "nomfma": lambda: in_body(zeroed(SRC), lambda bd: once(no_mfma(bd), LOAD,
-        '      asm volatile("" : "=v"(acc[0].U), "=v"(acc[0].W), "=v"(acc[1].U), "=v"(acc[1].W) : "v"(b0), "v"(b1), "v"(b2), "v"(b3));\n' + LOAD)),
+    "nomfma": lambda: in_body(zeroed(SRC), lambda bd: once(no_mfma(bd), LOADS[0],
+        '      asm volatile("" : "=v"(acc[0].U), "=v"(acc[0].W), "=v"(acc[1].U), "=v"(acc[1].W) : "v"(b0), "v"(b1), "v"(b2));\n' + LOADS[0])),
     "halfmfma": lambda: in_body(zeroed(SRC), lambda bd: no_mfma(bd, keep=lambda l: not ("b1, acc" in l or "b2, acc" in l))),
     "noepi": lambda: in_body(zeroed(SRC), lambda bd: once(bd, EPI,
         '      for (int rt = 0; rt < 2; ++rt) { asm volatile("" :: "v"(acc[rt].U), "v"(acc[rt].W)); tr[ct][rt] = (unsigned int)lane * 2654435761u + J; }')),
     "nofinish": lambda: in_body(zeroed(SRC), lambda bd: once(bd, "    finish_tile(J, DIAG, tr);",
         '    asm volatile("" :: "v"(tr[0][0]), "v"(tr[0][1]), "v"(tr[1][0]), "v"(tr[1][1]));')),
-    "noload": lambda: in_body(zeroed(SRC), lambda bd: once(bd, LOAD, "      (void)Jn; (void)gn;")),
-    "sameload": lambda: in_body(zeroed(SRC), lambda bd: once(bd, LOAD,
-        "      (void)Jn; for (int m = 0; m < 4; ++m) bX[m] = load_op(Jfirst < T ? Jfirst : T - 1, 1, gn, m);")),
-    "load32": lambda: in_body(zeroed(SRC), lambda bd: once(bd, LOAD,
-        "      for (int m = 0; m < 4; ++m) bX[m].x = __builtin_amdgcn_raw_buffer_load_b32(q_rsrc, lane * 4, Jn * (int)sizeof(TimOperandTile2) + (int)sizeof(TimOperandTile2) / 2 + (gn * 4 + m) * 1024, 0);")),
-    "ldsload": lambda: once(in_body(zeroed(SRC), lambda bd: once(bd, LOAD,
-        "      (void)Jn; for (int m = 0; m < 4; ++m) bX[m] = lds_b[(2 * J + gn) & 1][m][lane];")),
-        "  uint4 bX[4], bY[4];",
-        "  __shared__ uint4 lds_b[2][4][64];\n  lds_b[0][wave][lane] = make_uint4(lane, wave, 1, 2); lds_b[1][wave][lane] = make_uint4(wave, lane, 3, 4);\n  __syncthreads();\n  uint4 bX[4], bY[4];"),
-    "touch": lambda: once(once(in_body(SRC, lambda bd: once(bd, LOAD, LOAD + """
+    "noload": lambda: in_body(zeroed(SRC), lambda bd: each_load(bd, lambda m: "      (void)Jn; (void)gn;")),
+    "sameload": lambda: in_body(zeroed(SRC), lambda bd: each_load(bd, lambda m:
+        "      (void)Jn; bX[%d] = load_op(Jfirst < T ? Jfirst : T - 1, 1, gn, %d);" % (m, m))),
+    "load32": lambda: in_body(zeroed(SRC), lambda bd: each_load(bd, lambda m:
+        "      bX[%d].x = __builtin_amdgcn_raw_buffer_load_b32(q_rsrc, lane * 4, Jn * (int)sizeof(TimOperandTile2) + (int)offsetof(TimOperandTile2, b) + (gn * kTimColOperands + %d) * 1024, 0);" % (m, m))),
+    "ldsload": lambda: once(in_body(zeroed(SRC), lambda bd: each_load(bd, lambda m:
+        "      (void)Jn; bX[%d] = lds_b[(2 * J + gn) & 1][%d][lane];" % (m, m))),
+        "  uint4 bX[kTimColOperands], bY[kTimColOperands];",
+        "  __shared__ uint4 lds_b[2][4][64];\n  lds_b[0][wave][lane] = make_uint4(lane, wave, 1, 2); lds_b[1][wave][lane] = make_uint4(wave, lane, 3, 4);\n  __syncthreads();\n  uint4 bX[kTimColOperands], bY[kTimColOperands];"),
+    "touch": lambda: once(once(in_body(SRC, lambda bd: once(bd, LOADS[2], LOADS[2] + """
       {
         const int half2 = 2 * J + ct + 2, J2 = min(half2 >> 1, Jend - 1), g2 = half2 & 1;
         asm volatile("" :: "v"(touch[ct]));
-        touch[ct] = __builtin_amdgcn_raw_buffer_load_b32(q_rsrc, lane * 64, J2 * (int)sizeof(TimOperandTile2) + (int)sizeof(TimOperandTile2) / 2 + g2 * 4096, 0);
-      }""")), "  uint4 bX[4], bY[4];", "  unsigned int touch[2] = {0u, 0u};\n  uint4 bX[4], bY[4];"),
+        touch[ct] = __builtin_amdgcn_raw_buffer_load_b32(q_rsrc, lane * 64, J2 * (int)sizeof(TimOperandTile2) + (int)offsetof(TimOperandTile2, b) + g2 * kTimColOperands * 1024, 0);
+      }""")), "  uint4 bX[kTimColOperands], bY[kTimColOperands];", "  unsigned int touch[2] = {0u, 0u};\n  uint4 bX[kTimColOperands], bY[kTimColOperands];"),
         "  if (rowvalid)\n    __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(degacc,",
         '  asm volatile("" :: "v"(touch[0]), "v"(touch[1]));\n  if (rowvalid)\n    __builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(degacc,'),
 }
