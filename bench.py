@@ -96,7 +96,7 @@ def parse(argv=None):
                     help="batches in flight per `configs` line (default for the others: --depth).  The lines whose solves "
                          "need the host-driven bound-closing stage (colouring bound / exact search) are latency-bound per "
                          "lane, not K1-bound: more lanes overlap them (profiles/r5d, r5h)")
-    ap.add_argument("--repeats", type=int, default=5,
+    ap.add_argument("--repeats", type=int, default=9,
                     help="timed regions (of --steps steps each at the top level) per line; the median is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-resident", action="store_true",
@@ -171,6 +171,7 @@ def roofline_object(k1_ms, k1_launches, k1_bytes, k1_pairs, k1_aux_ms, traffic, 
                                "kernel by 40 % (profiles/r5t): this path, not the VALU, is what a faster K1 has to relieve"}
     bound = max(pipes, key=lambda k: pipes[k]["frac"])
     top = pipes[bound]
+    measured = k1_measured_valu_peak()
     return {
         "kernel": "tim_graph_mfma3_kernel (K1: TIM-norm predicate terms u, w on the matrix cores, min |d| filter, "
                   "adjacency bitmap; FP64 fix-up of the flagged 16-pair groups)",
@@ -179,6 +180,14 @@ def roofline_object(k1_ms, k1_launches, k1_bytes, k1_pairs, k1_aux_ms, traffic, 
         "avg_launch_ms": 1e3 * k1_avg_s, "launches": k1_launches,
         "pairs_per_launch": pairs_per_launch,
         "aux_ms_per_launch": k1_aux_ms / launches,
+        # flat copies of what the nested objects hold (a record that keeps scalars only still carries them)
+        "frac_valu": pipes["valu"]["frac"], "frac_mfma": pipes["mfma"]["frac"], "frac_hbm": pipes["hbm"]["frac"],
+        "frac_l1": pipes["l1"]["frac"] if "l1" in pipes else None,
+        "traffic_over_algorithmic": (traffic / bytes_per_launch) if (traffic and bytes_per_launch) else None,
+        "valu_peak_assumed": VALU_PEAK_GINST,
+        "valu_peak_measured": measured["peak_ginst"] if measured else None,
+        "frac_valu_at_measured_peak": (valu_ginst / measured["peak_ginst"]) if measured else None,
+        "valu_peak_measurement": measured,
         "pipes": pipes,
         "fp64_equivalent": {"achieved": fp64_tf, "peak": FP64_PEAK_TF, "unit": "TFLOP/s", "ratio": fp64_tf / FP64_PEAK_TF,
                             "algorithmic_flops_per_launch": K1_FLOPS_PER_PAIR * pairs_per_launch,
@@ -227,6 +236,58 @@ def k1_issue():
                               "wave_issue_frac", "wave_wait_frac", "wave_stall_frac", "vmem_insts_per_1024_pairs",
                               "ta_busy_frac", "l1_hit_rate", "ta_addr_fifo_full_frac") if f in k}
     return dict(keep, source=src) if keep else None
+
+
+def k1_measured_valu_peak():
+    """VALU issue peak for K1's ACTUAL instruction mix: the per-opcode cost of scripts/probe/valu_rate (newest committed
+    profiles/<round>/valu_rate.jsonl: independent streams, three waves per SIMD, one MFMA per 14 instructions -- the
+    kernel's own situation; the probe turns times into cycles at its `assumed_ghz`, so cycles / assumed_ghz is TIME and
+    the peak below does not depend on the clock) weighted by the steady-state loop body of the compiler's assembly
+    (newest profiles/<round>/k1_isa_stats.json).  Opcodes the probe does not time take the mean of the timed ones."""
+    import glob
+    rates, ghz, rsrc = {}, None, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "valu_rate.jsonl"))):
+        rr, g = {}, None
+        try:
+            for ln in open(path):
+                if not ln.startswith("{"):
+                    continue
+                r = json.loads(ln)
+                if "assumed_ghz" in r:
+                    g = float(r["assumed_ghz"])
+                if r.get("inst") and r.get("waves_per_simd") == 3 and not r.get("dependent") and r.get("with_mfma"):
+                    rr[r["inst"].split()[0]] = float(r["cycles_per_inst_per_simd"])
+        except Exception:
+            continue
+        if rr and g:
+            rates, ghz, rsrc = rr, g, os.path.relpath(path, ROOT)
+    mix, msrc = None, None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "k1_isa_stats.json"))):
+        try:
+            doc = json.load(open(path))
+            body = next(iter(doc.values()))["loop_body_0"]
+            mix, msrc = body["most_frequent"], os.path.relpath(path, ROOT)
+        except Exception:
+            continue
+    if not rates or not mix:
+        return None
+    alias = {"v_bitop3_b32": "v_bfi_b32", "v_fmac_f32_e32": "v_fmac_f32", "v_cmp_nlt_f32_e32": "v_cmp", "v_lshrrev_b32_e32": "v_and_b32",
+             "v_mov_b32_dpp": "v_mov_b32_dpp"}
+    mean = sum(rates.values()) / len(rates)
+    tot_n, tot_c, timed = 0, 0.0, 0
+    for op, cnt in mix.items():
+        if not op.startswith("v_") or op.startswith("v_mfma"):
+            continue
+        key = alias.get(op, op)
+        hit = next((v for k, v in rates.items() if k == key or k.startswith(key) or key.startswith(k)), None)
+        tot_n += cnt
+        tot_c += cnt * (hit if hit is not None else mean)
+        timed += cnt if hit is not None else 0
+    if not tot_n:
+        return None
+    cyc = tot_c / tot_n
+    return {"cycles_per_valu_inst_at_assumed_ghz": round(cyc, 3), "assumed_ghz": ghz,
+            "peak_ginst": 1024.0 * ghz / cyc, "timed_share_of_mix": round(timed / tot_n, 3), "rate_source": rsrc, "mix_source": msrc}
 
 
 def host_cpu_info():
@@ -344,9 +405,13 @@ def cpu_baseline(tp, n, outlier_ratio, nb, seed, max_solves, budget_s, problems=
 
     sweep = None
     if "best_threads" not in _CPU_STATE:
-        cand = [k for k in (1, 8, 16, 32, 64, 128, 256, 512) if k <= info["os_cpu_count"]]
-        if info["effective_cores"] not in cand:
-            cand.append(info["effective_cores"])
+        # teams up to TWICE the effective cores: a larger team on a cgroup quota is CFS throttling noise (round 5: the
+        # 64-thread team on a 16-core lease gave 37 ms in the sweep and 63 ms in the sample of the same line)
+        eff = info["effective_cores"]
+        cand = [k for k in (1, 2, 4, 8, 16, 32, 64, 128, 256, 512) if k <= min(info["os_cpu_count"], 2 * eff)]
+        for k in (eff, min(2 * eff, info["os_cpu_count"])):
+            if k not in cand:
+                cand.append(k)
         sweep = {}
         for k in sorted(set(cand)):
             ts = measure(k, 3, 4.0, False)["stream"]
@@ -355,7 +420,10 @@ def cpu_baseline(tp, n, outlier_ratio, nb, seed, max_solves, budget_s, problems=
     threads = _CPU_STATE["best_threads"]
     res = measure(threads, max_solves, budget_s, allow_materialise and pairs * 81 < 24e9)
     ts = res["stream"]
-    med = float(np.median(ts))
+    med_sample = float(np.median(ts))
+    # `value` = the best this host does: the sample's median or, if faster, the sweep's figure for the same team
+    med_sweep = 1e-3 * sweep[str(threads)] if sweep is not None and str(threads) in sweep else None
+    med = min(med_sample, med_sweep) if med_sweep else med_sample
     what = label if label else ("N=%d, %.0f%% outliers" % (n, 100 * outlier_ratio)) if problems is None else \
         "%d-%d correspondences (real descriptors)" % (min(p[0].shape[1] for p in problems),
                                                       max(p[0].shape[1] for p in problems))
@@ -365,7 +433,11 @@ def cpu_baseline(tp, n, outlier_ratio, nb, seed, max_solves, budget_s, problems=
            "threads": threads, "kind": "port", "host": info,
            "sample": "%d solves of this workload (%s), median %.1f ms each, streaming oracle (no TIM storage), "
                      "gcc -O3 -fopenmp without -march=native, OMP_NUM_THREADS = %d (the best of the sweep) on %d "
-                     "effective cores, OMP_PROC_BIND = close" % (len(ts), what, 1e3 * med, threads, info["effective_cores"])}
+                     "effective cores, OMP_PROC_BIND = close" % (len(ts), what, 1e3 * med_sample, threads, info["effective_cores"])}
+    out["sample_median_ms"] = round(1e3 * med_sample, 2)
+    if med_sweep:
+        out["sweep_ms_same_team"] = round(1e3 * med_sweep, 2)
+        out["sample_over_sweep"] = round(med_sample / med_sweep, 3)
     if sweep is not None:
         out["thread_sweep"] = {"ms_per_solve_by_threads": sweep,
                                "note": "median of 3 solves per thread count, one subprocess each; the host reports "
@@ -904,6 +976,15 @@ def main():
                        "ms_per_registration": 1e3 * elapsed / (args.steps * B),
                        "single_problem_latency_ms": lat_ms, "inputs": "resident in HBM",
                        "host_resident": host_line, "stage_ms": stages,
+                       # flat copies (a record that keeps scalars only still carries them): SURVEY.md 8(d)'s timer scope
+                       # (inputs in page-locked HOST memory, H2D inside the timed region) and the other BASELINE configs
+                       "host_resident_value": host_line["value"] if host_line else None,
+                       "host_resident_ms_per_step": host_line["ms_per_step"] if host_line else None,
+                       **{"%s_%s" % (tag, k): c.get(k) for tag, c in cfg_lines.items() if isinstance(c, dict)
+                          for k in ("value", "ms_per_step") if c.get(k) is not None},
+                       "min_median_max_ms_per_step": [round(1e3 * min(elapsed_all) / args.steps, 4),
+                                                      round(1e3 * elapsed / args.steps, 4),
+                                                      round(1e3 * max(elapsed_all) / args.steps, 4)],
                        "arithmetic": "FP64 estimators and FP64 reference expression for every pruning decision the "
                                      "K1 filter (exact bf16 split on MFMA + f32 epilogue with a rigorous error band) "
                                      "cannot make; bitmap bit-identical to the FP64 oracle",

@@ -95,7 +95,9 @@ typedef struct teaser_solution_c {
   int32_t heuristic_size;        /* lower bound found by the greedy stage */
   int32_t colour_uncoloured;     /* global colouring bound: survivors left without one of the
                                     heuristic_size colours (0: greedy clique proven maximum without
-                                    search; > 0: they were the only B&B roots; -1: stage not run) */
+                                    search; > 0: they were the only B&B roots; -1: stage not run;
+                                    -2: the degree closure decided the problem -- lb = ub from the vertex
+                                    degrees, graph.cc:83-102 -- before any heuristic ran) */
   int64_t num_edges;             /* edges of the inlier graph */
 } teaser_solution_c;
 

@@ -56,6 +56,8 @@ struct ProbState {
   int32_t heu_closed;    // heuristic: 1 once a start's clique is proven maximum by the degree count
   int32_t next_start;    // heuristic: next start of the problem's queue (host: workgroups per problem)
   int32_t scale_overflow;  // 1: the scale stage's float-key sort met a run it could not fix (host reruns with the 64-bit sort)
+  int32_t deg_closed;    // 1: the degree closure decided the problem (lb = ub from the degrees: no heuristic, no peel)
+  int32_t reserved0;
   int32_t start_vertex[kMaxStarts];
   int32_t start_size[kMaxStarts];
   unsigned long long deg_sum;  // sum of degrees = 2 * edges
@@ -126,6 +128,9 @@ enum Setting {
   S_GREEDY_THREADS,    // 0: built-in; 256 / 512                                         TEASER_GREEDY_THREADS
   S_FIXUP_WGS,         // 0: built-in; workgroups per problem of the K1 fix-up           TEASER_K1_FIXUP_WGS
   S_K4_WAVES,          // 0: built-in; persistent waves of the exact search's phases     TEASER_K4_WAVES
+  S_K4_LB_BONUS,       // diagnostics: the exact search starts with incumbent lb + this (what a better heuristic would buy) TEASER_K4_LB_BONUS
+  S_DEG_CLOSURE,       // 0: no degree closure in front of the greedy heuristic          TEASER_HIP_DEG_CLOSURE
+  S_DEG_CLOSURE_WGS,   // 0: built-in; workgroups per problem of the closure's row launch TEASER_HIP_DEG_CLOSURE_WGS
   S_COUNT
 };
 int64_t setting(Setting id);
@@ -158,6 +163,14 @@ void launch_heuristic(hipStream_t s, const ProbDesc* d_desc, int batch, int max_
                       const uint64_t* d_bitmap, const int32_t* d_deg, ProbState* d_state,
                       int32_t* d_start_cliques /* [kMaxStarts][sum n] */, int64_t total_n,
                       int32_t* d_cand /* [kMaxStarts][sum n] */, int32_t* d_clique /* [sum n] */);
+// degree closure in front of the heuristic (kernels_heuristic.hip): problems whose maximum clique follows from the
+// degrees and the rows of the ~10^3 vertices of largest degree are closed (clique written, state proven,
+// deg_closed = 1); the others are left untouched.  d_scratch: degree_closure_scratch_bytes(batch);
+// d_counters: 2 * batch ints, zero on entry
+int64_t degree_closure_scratch_bytes(int batch);
+void launch_degree_closure(hipStream_t s, const ProbDesc* d_desc, int batch, const uint64_t* d_bitmap,
+                           const int32_t* d_deg, ProbState* d_state, int32_t* d_clique, void* d_scratch,
+                           int32_t* d_counters);
 // k-core style peel at threshold lb
 void launch_peel(hipStream_t s, const ProbDesc* d_desc, int batch, int max_n, int max_W,
                  const uint64_t* d_bitmap, const int32_t* d_deg, ProbState* d_state,

@@ -438,6 +438,455 @@ __device__ __attribute__((noinline)) void closure_round(const uint64_t* __restri
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Degree closure (in front of K3): the bound pmc gets from compute_cores (graph.cc:58-59, 83-102: ub = max_core + 1,
+// return the heuristic's clique when lb == ub), worked out WITHOUT a heuristic from the vertex degrees K1 leaves and
+// ONE gather over the rows of the ~10^3 vertices of largest degree.
+//   A clique of k vertices lies inside D_k = { v : deg v >= k - 1 }, and each of its vertices has >= k - 1 neighbours
+//   inside D_k, i.e. H(v) >= k - 1 with H(v) = max{ j : v has >= j neighbours of degree >= j } (the h-index of the
+//   neighbours' degrees: one step of the h-operator iteration that converges to the core numbers).  Hence
+//       omega <= h1 = max{ k : #{ v : H(v) >= k - 1 } >= k },
+//   and every k-clique lies inside the (k - 1)-core S* of the graph induced on { H >= k - 1 }.  |S*| = k: each vertex
+//   of S* is adjacent to the k - 1 others -- S* IS the maximum clique, and the only one (lb = ub = k: nothing to search,
+//   nothing to select).  |S*| < k: no k-clique, the next feasible k is tried.  |S*| > k: undecided -- the problem is
+//   left to the greedy / peel / exact stages, untouched.
+// The degrees alone (H replaced by deg) do NOT decide the metric's workloads: at N = 10 k, 95 % outliers, 120 - 180
+// outliers have degree >= 499 (the tail of the degree distribution reaches 630 against a mean of 325) and the
+// degree-only bound is 530 - 537 for a clique of 500; with H it is 500 exactly.
+// Work: R = the <= kCoreCap vertices of largest degree, R = { deg >= t }; everything below holds for k - 1 >= t
+// (a smaller clique could use vertices outside R: decline).  R is sorted by (degree desc, index asc); for every row of R
+// the bits of its R-columns are gathered in that order (lane = column, one ballot per 64 columns): the prefix popcounts
+// give H(v) = max_i min(P_i, d_i), and the ballots ARE the row of the compact |R| x |R| adjacency, which is stored.
+// Grid (G, batch): the G workgroups of a problem each work out R and its order (redundantly: cheaper than a launch),
+// gather a slice of the rows, and the LAST workgroup to arrive gives the verdict from the H values and the compact
+// matrix (<= 128 KB, L2-resident): h1, the core peel, the clique in ascending order, the problem state.
+// ------------------------------------------------------------------------------------------
+constexpr int kCoreCap = 2048;     // |R|
+constexpr int kCoreWords = kCoreCap / 64;
+constexpr int kDegBins = kCoreCap; // histogram bins (the last one clamps): a threshold t >= kCoreCap cannot be certified anyway
+constexpr int kDegMaxW = 1024;     // n <= 65536
+constexpr int kDegThreads = 256;
+static_assert(kDegBins % kDegThreads == 0 && (kDegBins / kDegThreads) % 4 == 0, "bins per thread");
+
+// The set bits of the LDS bitset P[0 .. W) as an ascending list (256 threads; csum: kDegThreads ints of scratch).
+template <typename Out>
+__device__ __forceinline__ void list_bits_ascending(const uint64_t* P, int W, Out* out, int* csum, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wpt = (W + kDegThreads - 1) / kDegThreads;
+  const int w0 = tid * wpt, w1 = min(W, w0 + wpt);
+  int mycnt = 0;
+  for (int w = w0; w < w1; ++w) mycnt += __popcll(P[w]);
+  __syncthreads();
+  csum[tid] = mycnt;
+  __syncthreads();
+  if (wave == 0) {
+    const int a0 = csum[4 * lane], a1 = csum[4 * lane + 1], a2 = csum[4 * lane + 2], a3 = csum[4 * lane + 3];
+    const int tot = a0 + a1 + a2 + a3;
+    int incl = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    const int ex = incl - tot;
+    csum[4 * lane] = ex;
+    csum[4 * lane + 1] = ex + a0;
+    csum[4 * lane + 2] = ex + a0 + a1;
+    csum[4 * lane + 3] = ex + a0 + a1 + a2;
+  }
+  __syncthreads();
+  int pos = csum[tid];
+  for (int w = w0; w < w1; ++w) {
+    uint64_t bits = P[w];
+    while (bits) {
+      out[pos++] = w * 64 + __builtin_ctzll(bits);
+      bits &= bits - 1;
+    }
+  }
+  __syncthreads();
+}
+
+// hist[0 .. kBins] (the last bin clamps) -> above[t] = number of entries in the bins ABOVE thread t's chunk of kBins /
+// kDegThreads bins (the clamp bin included).  256 threads; barriers inside.
+template <int kBins>
+__device__ __forceinline__ void suffix_counts(const int* hist, int* above, int tid) {
+  constexpr int kPerT = kBins / kDegThreads;
+  const int lane = tid & 63, wave = tid >> 6;
+  int s = 0;
+#pragma unroll
+  for (int k = 0; k < kPerT; ++k) s += hist[tid * kPerT + k];
+  above[tid] = s;
+  __syncthreads();
+  if (wave == 0) {
+    int a[4], tot = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      a[k] = above[4 * lane + k];
+      tot += a[k];
+    }
+    int incl = tot;  // suffix scan over the lanes
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_down(incl, o, 64);
+      if (lane + o < 64) incl += t;
+    }
+    int ab = incl - tot + hist[kBins];
+#pragma unroll
+    for (int k = 3; k >= 0; --k) {
+      above[4 * lane + k] = ab;
+      ab += a[k];
+    }
+  }
+  __syncthreads();
+}
+
+// Launch 1 of the closure, grid (G, batch): R, its order, H and the compact rows of this workgroup's slice of R.
+__global__ __launch_bounds__(kDegThreads) void degree_closure_rows_kernel(
+    const ProbDesc* __restrict__ descs, const uint64_t* __restrict__ bitmap, const int32_t* __restrict__ deg,
+    ProbState* __restrict__ states, uint64_t* __restrict__ comp_pool /* [batch][kCoreCap][kCoreWords] */,
+    int32_t* __restrict__ h_pool /* [batch][kCoreCap] */, uint32_t* __restrict__ key_pool /* [batch][kCoreCap] */,
+    int32_t* __restrict__ counters /* [batch] |R|, [batch] t; zero on entry (|R| = 0: the closure declined) */, int batch) {
+  TAIL_WAVE_PRIO();
+  __shared__ uint64_t Pa[kDegMaxW];          // { deg >= t } over the vertices
+  __shared__ int hist[kDegBins + 1];         // degree histogram -> slot cursors
+  __shared__ unsigned int slot[kCoreCap];    // (degree << 16) | vertex by tentative slot
+  __shared__ unsigned int keys[kCoreCap];    // the list of R in vertex order, then (degree << 16) | vertex by rank
+  __shared__ int csum[kDegThreads];
+  __shared__ unsigned long long red64[4];
+  const ProbDesc d = descs[blockIdx.y];
+  ProbState* st = states + blockIdx.y;
+  const int n = d.n, W = d.W, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (n < 2 || W > kDegMaxW) return;  // (uniform per problem: every workgroup of it leaves)
+  const int32_t* dg = deg + d.pt_off;
+  const uint64_t* bm = bitmap + d.bm_off;
+  // ---- degree histogram: the degree-only bound h0, the threshold t of R, the slot cursors ---
+  for (int i = tid; i <= kDegBins; i += kDegThreads) hist[i] = 0;
+  __syncthreads();
+  {
+    unsigned long long sum = 0;
+    for (int v0 = tid; v0 < n; v0 += 8 * kDegThreads) {  // (eight independent loads, then the LDS atomics)
+      int dv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) dv[u] = v0 + u * kDegThreads < n ? dg[v0 + u * kDegThreads] : -1;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (dv[u] >= 0) {
+          sum += (unsigned int)dv[u];
+          atomicAdd(&hist[dv[u] < kDegBins ? dv[u] : kDegBins], 1);
+        }
+    }
+    if (blockIdx.x == 0) {  // 2 x edges (the greedy kernel leaves the same number when it runs)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+      if (lane == 0) red64[wave] = sum;
+    }
+  }
+  __syncthreads();
+  if (blockIdx.x == 0 && tid == 0) st->deg_sum = red64[0] + red64[1] + red64[2] + red64[3];
+  suffix_counts<kDegBins>(hist, csum, tid);
+  int h0 = 0, t = kDegBins, m = 0;
+  {
+    constexpr int kPerT = kDegBins / kDegThreads;
+    int c = csum[tid];  // #{deg > last bin of this chunk}
+    unsigned long long tkey = ~0ull;  // min over (j << 32 | count) of the admissible bins j
+    int hcnt[kPerT];
+#pragma unroll
+    for (int k = kPerT - 1; k >= 0; --k) {
+      const int j = tid * kPerT + k;
+      const int above = c;
+      c += hist[j];  // c = #{deg >= j}
+      hist[j] = above;  // the bin's first slot in (degree desc) order
+      hcnt[k] = c;
+      if (c >= j + 1 && j + 1 > h0) h0 = j + 1;
+    }
+    if (tid == 0) hist[kDegBins] = 0;
+    h0 = (int)block_max_u64((unsigned long long)h0, red64);
+    // R = { deg >= t }: the smallest t with |R| <= kCoreCap, but not below 7/8 of the degree bound -- the rows to gather
+    // grow with |R|, the columns per row too, and on the workloads this closure is meant for the clique is within a few
+    // per cent of h0 (500 of 530 - 537 at N = 10 k, 95 % outliers).  A clique smaller than t + 1 is then not certified
+    // here: the problem goes to the greedy / exact stages.
+    const int tmin = (h0 - 1) - (h0 - 1) / 8;
+#pragma unroll
+    for (int k = kPerT - 1; k >= 0; --k) {
+      const int j = tid * kPerT + k;
+      if (hcnt[k] <= kCoreCap && j >= tmin) tkey = ((unsigned long long)j << 32) | (unsigned int)hcnt[k];
+    }
+    tkey = ~block_max_u64(~tkey, red64);
+    if (tkey != ~0ull) {
+      t = (int)(tkey >> 32);
+      m = (int)(tkey & 0xffffffffu);
+    }
+  }
+  // h0 - 1 < t: even the degree bound leaves no clique large enough to lie inside R; m < 2: nothing to decide
+  if (t >= kDegBins || h0 - 1 < t || m < 2) return;
+  // ---- R = { deg >= t } in (degree desc, vertex asc) order ----------------------------------
+  for (int w0 = wave * 8; w0 < W; w0 += 32) {  // (8 words per wave and pass: the degree loads of a pass are independent)
+    int dv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int v = (w0 + u) * 64 + lane;
+      dv[u] = (w0 + u < W && v < n) ? dg[v] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const uint64_t bits = __ballot(dv[u] >= t);
+      if (lane == 0 && w0 + u < W) Pa[w0 + u] = bits;
+    }
+  }
+  __syncthreads();
+  int* listv = reinterpret_cast<int*>(keys);
+  list_bits_ascending(Pa, W, listv, csum, tid);
+  // tentative slots: the bin's range in degree order, the place inside it in arrival order ...
+  {
+    int pv[kCoreCap / kDegThreads], pd[kCoreCap / kDegThreads];
+#pragma unroll
+    for (int q = 0; q < kCoreCap / kDegThreads; ++q) {  // (the degree loads first: independent)
+      const int p = tid + q * kDegThreads;
+      pv[q] = p < m ? listv[p] : -1;
+      pd[q] = p < m ? dg[pv[q]] : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < kCoreCap / kDegThreads; ++q)
+      if (pv[q] >= 0) {
+        const int pos = atomicAdd(&hist[pd[q] < kDegBins ? pd[q] : kDegBins], 1);
+        slot[pos] = ((unsigned int)min(pd[q], 65535) << 16) | (unsigned int)pv[q];
+      }
+  }
+  __syncthreads();
+  // ... then every entry moves to its place by vertex index inside its run of equal degrees (runs are short; the
+  // clamp bin's entries -- degree >= kDegBins -- form one run: their mutual order does not matter to H, it only has
+  // to be the same in every workgroup)
+  unsigned int fin_key[kCoreCap / kDegThreads];
+  int fin_pos[kCoreCap / kDegThreads];
+#pragma unroll
+  for (int q = 0; q < kCoreCap / kDegThreads; ++q) {
+    const int p = tid + q * kDegThreads;
+    fin_pos[q] = -1;
+    if (p < m) {
+      const unsigned int key = slot[p];
+      const unsigned int dk = min(key >> 16, (unsigned int)kDegBins);
+      int lo = p, smaller = 0;
+      while (lo > 0 && min(slot[lo - 1] >> 16, (unsigned int)kDegBins) == dk) {
+        --lo;
+        smaller += (slot[lo] & 0xffffu) < (key & 0xffffu) ? 1 : 0;
+      }
+      for (int hi = p + 1; hi < m && min(slot[hi] >> 16, (unsigned int)kDegBins) == dk; ++hi)
+        smaller += (slot[hi] & 0xffffu) < (key & 0xffffu) ? 1 : 0;
+      fin_key[q] = key;
+      fin_pos[q] = lo + smaller;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < kCoreCap / kDegThreads; ++q)
+    if (fin_pos[q] >= 0) keys[fin_pos[q]] = fin_key[q];
+  __syncthreads();
+  const int ng = (m + 63) >> 6;
+  uint64_t* comp = comp_pool + (size_t)blockIdx.y * kCoreCap * kCoreWords;
+  int32_t* hout = h_pool + (size_t)blockIdx.y * kCoreCap;
+  // ---- this workgroup's slice of the rows: H and the compact row ------------------------------
+  {
+    const int G = gridDim.x;
+    const int per = (((m + G - 1) / G) + 15) & ~15;
+    const int k0 = min(m, (int)blockIdx.x * per), k1 = min(m, k0 + per);
+    const unsigned int* bm32 = reinterpret_cast<const unsigned int*>(bm);
+    constexpr int kRows = 4, kGrp = 8;
+    const uint64_t le_mask = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+    for (int rb = k0 + wave * kRows; rb < k1; rb += 4 * kRows) {
+      const unsigned int* rp[kRows];
+      int hmax[kRows], base[kRows];
+      uint64_t myword[kRows];
+#pragma unroll
+      for (int r = 0; r < kRows; ++r) {
+        const int rr = min(rb + r, k1 - 1);
+        rp[r] = bm32 + 2 * ((int64_t)(keys[rr] & 0xffffu) * W);
+        hmax[r] = 0;
+        base[r] = 0;
+        myword[r] = 0;
+      }
+      for (int g0 = 0; g0 < ng; g0 += kGrp) {
+        unsigned int x[kRows][kGrp];
+        int cbit[kGrp], cdeg[kGrp];
+#pragma unroll
+        for (int q = 0; q < kGrp; ++q) {
+          const int idx = 64 * (g0 + q) + lane;
+          const unsigned int key = idx < m ? keys[idx] : 0u;
+          const int c = (int)(key & 0xffffu);
+          cdeg[q] = idx < m ? (int)(key >> 16) : -1;  // (-1: no such column)
+          cbit[q] = c & 31;
+#pragma unroll
+          for (int r = 0; r < kRows; ++r) x[r][q] = (cdeg[q] >= 0) ? rp[r][c >> 5] : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < kGrp; ++q) {
+          if (g0 + q >= ng) break;
+#pragma unroll
+          for (int r = 0; r < kRows; ++r) {
+            const bool bit = cdeg[q] >= 0 && ((x[r][q] >> cbit[q]) & 1u);
+            const uint64_t mask = __ballot(bit);
+            const int P = base[r] + __popcll(mask & le_mask);
+            if (bit) hmax[r] = max(hmax[r], min(P, cdeg[q]));
+            base[r] += __popcll(mask);
+            if (lane == g0 + q) myword[r] = mask;
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < kRows; ++r) {
+        int hv = hmax[r];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) hv = max(hv, __shfl_xor(hv, o, 64));
+        if (rb + r < k1) {
+          if (lane < kCoreWords) comp[(size_t)(rb + r) * kCoreWords + lane] = myword[r];
+          if (lane == 0) hout[rb + r] = hv;
+        }
+      }
+    }
+  }
+  if (blockIdx.x == 0) {  // what the verdict launch needs besides H and the compact rows
+    uint32_t* kout = key_pool + (size_t)blockIdx.y * kCoreCap;
+    for (int r = tid; r < m; r += kDegThreads) kout[r] = keys[r];
+    if (tid == 0) {
+      counters[blockIdx.y] = m;
+      counters[batch + blockIdx.y] = t;
+    }
+  }
+}
+
+// Launch 2 of the closure, one workgroup per problem: h1 from the H values, the core peel inside the compact graph
+// (its rows come from launch 1: plain loads behind a kernel boundary), the clique in ascending order, the state.
+__global__ __launch_bounds__(kDegThreads) void degree_closure_verdict_kernel(
+    const ProbDesc* __restrict__ descs, ProbState* __restrict__ states, int32_t* __restrict__ clique,
+    const uint64_t* __restrict__ comp_pool, const int32_t* __restrict__ h_pool, const uint32_t* __restrict__ key_pool,
+    const int32_t* __restrict__ counters, int batch) {
+  TAIL_WAVE_PRIO();
+  __shared__ uint64_t Pa[kDegMaxW];          // the clique over the vertices
+  __shared__ int hist[kCoreCap + 1];         // histogram of the H values
+  __shared__ int hval[kCoreCap];             // H by rank
+  __shared__ uint64_t Sa[kCoreWords], Sb[kCoreWords];
+  __shared__ int csum[kDegThreads];
+  __shared__ unsigned long long red64[4];
+  const int m = counters[blockIdx.x], t = counters[batch + blockIdx.x];
+  if (m < 2) return;
+  const ProbDesc d = descs[blockIdx.x];
+  ProbState* st = states + blockIdx.x;
+  const int W = d.W, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ng = (m + 63) >> 6;
+  const uint64_t* comp = comp_pool + (size_t)blockIdx.x * kCoreCap * kCoreWords;
+  const int32_t* hout = h_pool + (size_t)blockIdx.x * kCoreCap;
+  const uint32_t* keys = key_pool + (size_t)blockIdx.x * kCoreCap;
+  constexpr int kHBins = kCoreCap;  // H <= |R| - 1
+  for (int i = tid; i <= kHBins; i += kDegThreads) hist[i] = 0;
+  __syncthreads();
+  for (int r = tid; r < m; r += kDegThreads) {
+    const int hv = hout[r];
+    hval[r] = hv;
+    atomicAdd(&hist[hv < kHBins ? hv : kHBins], 1);
+  }
+  __syncthreads();
+  suffix_counts<kHBins>(hist, csum, tid);
+  constexpr int kPerH = kHBins / kDegThreads;
+  int kmax = kHBins;  // candidates k <= kmax
+  for (int attempt = 0; attempt < 8; ++attempt) {
+    // the largest feasible k <= kmax: #{H >= k - 1} >= k
+    int kb = 0;
+    {
+      int c = csum[tid];
+#pragma unroll
+      for (int k = kPerH - 1; k >= 0; --k) {
+        const int j = tid * kPerH + k;
+        c += hist[j];  // #{H >= j}
+        if (c >= j + 1 && j + 1 <= kmax && j + 1 > kb) kb = j + 1;
+      }
+    }
+    const int k = (int)block_max_u64((unsigned long long)kb, red64);
+    if (k < 2 || k - 1 < t) return;  // a clique this small could use vertices outside R: undecided
+    // S = { H >= k - 1 }, peeled at threshold k - 1 inside the compact graph
+    __syncthreads();
+    for (int g = wave; g < kCoreWords; g += 4) {
+      const int r = 64 * g + lane;
+      const uint64_t bits = __ballot(r < m && hval[r] >= k - 1);
+      if (lane == 0) Sa[g] = bits;
+    }
+    __syncthreads();
+    int cnt = 0;
+    for (int g = 0; g < ng; ++g) cnt += __popcll(Sa[g]);
+    bool fix = false;
+    for (int round = 0; round < 64 && cnt >= k && !fix; ++round) {
+      if (tid < kCoreWords) Sb[tid] = 0;
+      __syncthreads();
+      for (int r = tid; r < m; r += kDegThreads) {
+        if (!((Sa[r >> 6] >> (r & 63)) & 1ull)) continue;
+        const uint64_t* rowp = comp + (size_t)r * kCoreWords;
+        int c = 0;
+        for (int g0 = 0; g0 < ng; g0 += 8) {  // (eight independent loads at a time)
+          uint64_t row[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            row[u] = g0 + u < ng ? rowp[g0 + u] : 0ull;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) c += __popcll(row[u] & Sa[min(g0 + u, kCoreWords - 1)]);
+        }
+        if (c >= k - 1) atomicOr(reinterpret_cast<unsigned long long*>(&Sb[r >> 6]), 1ull << (r & 63));
+      }
+      __syncthreads();
+      int c2 = 0;
+      for (int g = 0; g < ng; ++g) c2 += __popcll(Sb[g]);
+      fix = c2 == cnt;
+      cnt = c2;
+      __syncthreads();
+      if (tid < kCoreWords) Sa[tid] = Sb[tid];
+      __syncthreads();
+    }
+    if (cnt >= k && !fix) return;  // (64 rounds without a fixpoint: give up)
+    if (cnt > k) return;           // a (k - 1)-core larger than k: undecided
+    if (cnt < k) {                 // no k-clique: the next feasible size
+      kmax = k - 1;
+      continue;
+    }
+    // S* = Sa: k vertices, each adjacent to the k - 1 others.  Emit it in ascending vertex order.
+    for (int w = tid; w < W; w += kDegThreads) Pa[w] = 0;
+    __syncthreads();
+    for (int r = tid; r < m; r += kDegThreads)
+      if ((Sa[r >> 6] >> (r & 63)) & 1ull) {
+        const int v = (int)(keys[r] & 0xffffu);
+        atomicOr(reinterpret_cast<unsigned long long*>(&Pa[v >> 6]), 1ull << (v & 63));
+      }
+    __syncthreads();
+    list_bits_ascending(Pa, W, clique + d.pt_off, csum, tid);
+    if (tid == 0) {
+      st->lb = k;
+      st->best_start = -1;
+      st->clique_size = k;
+      st->alive_count = k;
+      st->proven = 1;
+      st->peel_done = 1;
+      st->heu_closed = 1;
+      st->deg_closed = 1;
+    }
+    return;
+  }
+}
+
+int64_t degree_closure_scratch_bytes(int batch) {
+  return (int64_t)std::max(batch, 1) * ((int64_t)kCoreCap * kCoreWords * 8 + (int64_t)kCoreCap * 8);
+}
+
+void launch_degree_closure(hipStream_t s, const ProbDesc* d_desc, int batch, const uint64_t* d_bitmap,
+                           const int32_t* d_deg, ProbState* d_state, int32_t* d_clique, void* d_scratch,
+                           int32_t* d_counters) {
+  if (batch <= 0) return;
+  const int forced = (int)setting(S_DEG_CLOSURE_WGS);
+  const int G = forced > 0 ? std::min(forced, 64) : std::max(1, std::min(16, 1024 / batch));
+  uint64_t* comp = reinterpret_cast<uint64_t*>(d_scratch);
+  int32_t* hp = reinterpret_cast<int32_t*>(comp + (size_t)batch * kCoreCap * kCoreWords);
+  uint32_t* kp = reinterpret_cast<uint32_t*>(hp + (size_t)batch * kCoreCap);
+  hipLaunchKernelGGL(degree_closure_rows_kernel, dim3(G, batch), dim3(kDegThreads), 0, s, d_desc, d_bitmap, d_deg, d_state,
+                     comp, hp, kp, d_counters, batch);
+  hipLaunchKernelGGL(degree_closure_verdict_kernel, dim3(batch), dim3(kDegThreads), 0, s, d_desc, d_state, d_clique, comp, hp,
+                     kp, d_counters, batch);
+}
+
 // Grid (B, batch): B workgroups per problem share the kMaxStarts starts.  Workgroup x begins with start x;
 // further starts come from the problem's queue (ProbState.next_start, initialised to B by the host) until it
 // is empty or the problem is CLOSED: a start whose clique of size c leaves at most c vertices in the peel at
@@ -459,6 +908,7 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
   __shared__ int next_s;
   __shared__ int red_c[kGreedyWaves];
   ProbState* st = states + blockIdx.y;
+  if (st->deg_closed) return;  // decided by the degree closure (written by an EARLIER launch: uniform for the problem)
   const ProbDesc d = descs[blockIdx.y];
   int sidx = blockIdx.x;
   while (sidx < kMaxStarts) {
@@ -543,6 +993,7 @@ __global__ __launch_bounds__(256) void select_best_kernel(
   int* wcnt = reinterpret_cast<int*>(memb + ((W + 1) & ~1));  // 256
   int* red4 = wcnt + 256;
   ProbState* st = states + blockIdx.x;
+  if (st->deg_closed) return;  // clique, bounds and verdict are the degree closure's
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int best = 0, bs = -1;
   for (int s = 0; s < kMaxStarts; ++s) {

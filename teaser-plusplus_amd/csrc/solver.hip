@@ -73,6 +73,9 @@ const SettingRow kSettingRows[S_COUNT] = {
     {"greedy_threads", "TEASER_GREEDY_THREADS", 0},
     {"fixup_wgs", "TEASER_K1_FIXUP_WGS", 0},
     {"k4_waves", "TEASER_K4_WAVES", 0},
+    {"k4_lb_bonus", "TEASER_K4_LB_BONUS", 0},
+    {"deg_closure", "TEASER_HIP_DEG_CLOSURE", 1},
+    {"deg_closure_wgs", "TEASER_HIP_DEG_CLOSURE_WGS", 0},
 };
 struct SettingTable {
   std::atomic<int64_t> v[S_COUNT];
@@ -282,7 +285,7 @@ struct teaser_hip_solver {
 
   DevBuf d_desc, d_state, d_src, d_dst, d_bitmap, d_deg, d_clique, d_start_cliques, d_alive_a,
       d_alive_b, d_next_count, d_weights, d_rot_inl, d_trans_inl, d_tls_scratch, d_tim_off,
-      d_pk, d_prep, d_work;
+      d_pk, d_prep, d_work, d_core;
   // colouring bound
   DevBuf c_sel, c_colour, c_tent, c_xlist, c_list_a, c_list_b, c_counts, c_bits, c_class;
   std::vector<int32_t> colour_x;  // |X| per problem of the last solve (-1: stage not run)
@@ -305,6 +308,11 @@ struct teaser_hip_solver {
   // 40-60 us per launch, profiles/r5e).  TEASER_HIP_SPEC_BOUNDS=0 disables.
   bool spec_bounds_next = false;
   int last_unproven = 0;
+  // The degree closure (kernels_heuristic.hip) decides the metric's workloads from the degrees alone.  Once a whole
+  // batch of this handle has been closed that way, the next batch does not enqueue greedy / select / peel at all (they
+  // would run beside the next K1 only to find every problem decided); a problem the closure then leaves open costs
+  // one more host round trip (solve_packed_finish) and switches the launches back on.
+  bool skip_heuristic_next = false;
 
   // ---- state carried from the enqueue half of a solve to its finish half -----------------
   struct Pending {
@@ -313,6 +321,8 @@ struct teaser_hip_solver {
     int batch = 0, mode = 0;
     bool need_graph = false;
     bool spec_bounds = false;  // colouring bound + root filter + sizes already enqueued (results in pin_ep)
+    bool closure = false;             // the degree closure ran in front of the heuristic stage
+    bool heuristic_enqueued = true;   // greedy / select / peel enqueued by the first half (false: the closure is trusted)
     int64_t total_n = 0, tls_stride = 0;
   } pend;
   // ---- asynchronous batches (teaser_hip_submit_batch / teaser_hip_wait): lanes = child handles
@@ -715,6 +725,16 @@ int32_t close_clique_bounds(teaser_hip_solver* h, int batch, int64_t total_n, bo
                           h->c_list_b.as<int32_t>(), h->c_counts.as<int32_t>(), h->c_bits.as<uint64_t>(),
                           std::max<int64_t>(h->total_w, 1), total_n, kColourRounds);
       HIPCHK(h, hipGetLastError());
+      if (setting(S_K4_DEBUG)) {  // diagnostics only: the work lists of the colouring rounds of the first selected problem
+        int32_t cc[kColourRounds + 2] = {0};
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(cc, h->c_counts.p, sizeof(cc), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[teaser_hip] colouring bound, problem %d: class lists", csel[0]);
+        for (int k = 0; k < 8; ++k) fprintf(stderr, " %d", cc[k]);
+        fprintf(stderr, "; all-in lists");
+        for (int k = 8; k < kColourRounds + 2; ++k) fprintf(stderr, " %d", cc[k]);
+        fprintf(stderr, "\n");
+      }
     }
     // root filter, candidate sets, sizes: one descriptor per open problem
     StageScope sc_count(h, ST_EXACT);
@@ -776,6 +796,7 @@ int32_t close_clique_bounds(teaser_hip_solver* h, int batch, int64_t total_n, bo
     e.arena_bytes = (arena + 255) & ~(int64_t)255;
     e.lds_bitmap = ((int64_t)e.n2 * e.W2 * 8 <= kExactLdsBitmapBytes) ? 1 : 0;
     e.ctrl[0] = e.ctrl[1] = e.lb;
+    e.ctrl[0] += (int)setting(S_K4_LB_BONUS);  // (diagnostics; 0 in the product: the incumbent is the recorded clique)
     e.ctrl[2] = e.ctrl[3] = e.ctrl[4] = 0;
   }
   HIPCHK(h, h->x_order.ensure(4 * (size_t)o_order));
@@ -983,6 +1004,35 @@ int32_t enqueue_estimators(teaser_hip_solver* h) {
   return TEASER_HIP_OK;
 }
 
+// K3 + selection (+ the peel in PMC_EXACT mode) of the current batch; every kernel skips the problems the degree
+// closure has decided.
+int32_t enqueue_heuristic_stage(teaser_hip_solver* h, int batch, int mode, bool record_stagger) {
+  hipStream_t s = h->stream;
+  const ProbDesc* dd = h->d_desc.as<ProbDesc>();
+  ProbState* ds = h->d_state.as<ProbState>();
+  const int64_t total_n = std::max<int64_t>(h->total_n, 1);
+  {
+    StageScope sc(h, ST_HEU);
+    launch_heuristic(s, dd, batch, h->max_W, h->d_bitmap.as<uint64_t>(), h->d_deg.as<int32_t>(), ds,
+                     h->d_start_cliques.as<int32_t>(), total_n, nullptr, h->d_clique.as<int32_t>());
+    if (record_stagger && h->k1_done && h->stagger_point == 2) {
+      HIPCHK(h, hipEventRecord(h->k1_done, s));
+      h->k1_recorded = true;
+    }
+    launch_select_best(s, dd, batch, h->max_W, h->d_deg.as<int32_t>(), ds,
+                       h->d_start_cliques.as<int32_t>(), total_n, h->d_clique.as<int32_t>(),
+                       h->d_alive_a.as<uint64_t>(), mode == TEASER_INLIER_PMC_EXACT ? 1 : 0);
+  }
+  if (mode == TEASER_INLIER_PMC_EXACT) {
+    StageScope sc(h, ST_PEEL);
+    launch_peel_rounds(s, dd, batch, h->max_W, h->d_bitmap.as<uint64_t>(), ds,
+                       h->d_alive_a.as<uint64_t>(), h->d_alive_b.as<uint64_t>(),
+                       h->d_next_count.as<int32_t>(), kPeelRounds);
+  }
+  HIPCHK(h, hipGetLastError());
+  return TEASER_HIP_OK;
+}
+
 // First half of a solve: everything that can be enqueued without a host sync.
 int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const double* d_dst,
                              const int64_t* pt_off, const int32_t* n, int batch, bool fp64_k1) {
@@ -1004,6 +1054,8 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
   h->cur_src = d_src;
   h->cur_dst = d_dst;
   h->have_graph = false;
+  h->pend.closure = false;
+  h->pend.heuristic_enqueued = true;
   h->colour_x.assign((size_t)batch, -1);
   int64_t bm = 0, wo = 0, tims = 0, maxpt = 0;
   int max_n = 0;
@@ -1047,13 +1099,13 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
   h->total_bm = bm;
   h->total_w = wo;
   h->total_tims = tims;
-  const int max_W = h->max_W;
   const int64_t total_n = std::max<int64_t>(maxpt, 1);
 
   // descs | initial states | tim offsets | peel counters (zero) | K1 prep + worklist counter (zero):
   // ONE device block, filled by ONE H2D copy per solve (no memsets, no per-array copies)
   const size_t b_desc = sizeof(ProbDesc) * (size_t)batch, b_state = sizeof(ProbState) * (size_t)batch,
-               b_off = 8 * (size_t)batch, b_next = 8 * (size_t)batch /* peel: survivor counts, arrivals */,
+               b_off = 8 * (size_t)batch,
+               b_next = 16 * (size_t)batch /* peel: survivor counts, arrivals; degree closure: failures, arrivals */,
                b_prep = (size_t)tim_prep_bytes(batch);
   auto al256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t o_desc = 0, o_state = al256(o_desc + b_desc), o_off = al256(o_state + b_state),
@@ -1172,17 +1224,22 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
       StageScope sc(h, ST_DEG);
       launch_degrees(s, dd, batch, max_n, h->d_bitmap.as<uint64_t>(), h->d_deg.as<int32_t>(), ds);
     }
-    {
+    // Degree closure (PMC_EXACT: the answer must be THE maximum clique, which is what the closure proves): problems
+    // whose clique follows from the degrees are closed before any heuristic runs.  When the previous batch of this
+    // handle was closed entirely, the greedy / select / peel launches are not even enqueued: the finish half runs
+    // them (heuristic_stage) for the problems the closure left open, should there be any.
+    const bool closure = mode == TEASER_INLIER_PMC_EXACT && max_n <= 65536 && setting(S_DEG_CLOSURE) != 0;
+    if (closure) {
       StageScope sc(h, ST_HEU);
-      launch_heuristic(s, dd, batch, max_W, h->d_bitmap.as<uint64_t>(), h->d_deg.as<int32_t>(), ds,
-                       h->d_start_cliques.as<int32_t>(), total_n, nullptr, h->d_clique.as<int32_t>());
-      if (mfma_k1 && h->k1_done && h->stagger_point == 2) {
-        HIPCHK(h, hipEventRecord(h->k1_done, s));
-        h->k1_recorded = true;
-      }
-      launch_select_best(s, dd, batch, max_W, h->d_deg.as<int32_t>(), ds,
-                         h->d_start_cliques.as<int32_t>(), total_n, h->d_clique.as<int32_t>(),
-                         h->d_alive_a.as<uint64_t>(), mode == TEASER_INLIER_PMC_EXACT ? 1 : 0);
+      HIPCHK(h, h->d_core.ensure((size_t)degree_closure_scratch_bytes(batch)));
+      launch_degree_closure(s, dd, batch, h->d_bitmap.as<uint64_t>(), h->d_deg.as<int32_t>(), ds,
+                            h->d_clique.as<int32_t>(), h->d_core.p, h->d_next_count.as<int32_t>() + 2 * (size_t)batch);
+    }
+    h->pend.closure = closure;
+    h->pend.heuristic_enqueued = !(closure && h->skip_heuristic_next);
+    if (h->pend.heuristic_enqueued) {
+      int32_t rc = enqueue_heuristic_stage(h, batch, mode, mfma_k1);
+      if (rc != TEASER_HIP_OK) return rc;
     }
     if (mode == TEASER_INLIER_KCORE_HEU) {  // graph.cc:58-81
       if (max_n > 65536) {
@@ -1196,13 +1253,7 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
                              h->c_colour.as<int32_t>(), h->c_tent.as<int32_t>(), h->d_clique.as<int32_t>(),
                              P.kcore_heuristic_threshold);
     }
-    if (mode == TEASER_INLIER_PMC_EXACT) {
-      StageScope sc(h, ST_PEEL);
-      launch_peel_rounds(s, dd, batch, max_W, h->d_bitmap.as<uint64_t>(), ds,
-                         h->d_alive_a.as<uint64_t>(), h->d_alive_b.as<uint64_t>(),
-                         h->d_next_count.as<int32_t>(), kPeelRounds);
-    }
-    if (mfma_k1 && h->k1_done && h->stagger_point == 3) {
+    if (mfma_k1 && h->k1_done && (h->stagger_point == 3 || (h->stagger_point == 2 && !h->pend.heuristic_enqueued))) {
       HIPCHK(h, hipEventRecord(h->k1_done, s));
       h->k1_recorded = true;
     }
@@ -1223,7 +1274,8 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
   // enqueued before the host learns whether the peel closed the bound (one sync per solve)
   h->pend.spec_bounds = false;
   int32_t rc = enqueue_estimators(h);
-  if (rc == TEASER_HIP_OK && need_graph && mode == TEASER_INLIER_PMC_EXACT && h->spec_bounds_next && spec_bounds_enabled()) {
+  if (rc == TEASER_HIP_OK && need_graph && mode == TEASER_INLIER_PMC_EXACT && h->spec_bounds_next && spec_bounds_enabled() &&
+      h->pend.heuristic_enqueued) {
     rc = enqueue_bounds_speculative(h, batch, total_n);
     h->pend.spec_bounds = rc == TEASER_HIP_OK;
     g_trace.mark(h, "submit: bound stage enqueued speculatively");
@@ -1241,7 +1293,30 @@ int32_t solve_packed_finish(teaser_hip_solver* h, teaser_solution_c* out, bool* 
   for (int b = 0; b < batch; ++b)
     if (h->states[(size_t)b].k1_overflow || h->states[(size_t)b].scale_overflow) *k1_overflow = true;
   if (*k1_overflow) return TEASER_HIP_OK;  // the caller reruns the batch with the FP64 K1 / the 64-bit scale sort
+  if (h->pend.closure) {
+    // problems the degree closure left open: the heuristic stage runs now if it was not enqueued behind the closure
+    // (it is enqueued there as long as the previous batch had such problems)
+    int open = 0;
+    for (int b = 0; b < batch; ++b) open += h->states[(size_t)b].deg_closed ? 0 : 1;
+    if (open > 0 && !h->pend.heuristic_enqueued) {
+      g_trace.mark(h, "finish: heuristic stage for the problems the degree closure left open");
+      int32_t rc = enqueue_heuristic_stage(h, batch, h->pend.mode, false);
+      if (rc == TEASER_HIP_OK) rc = enqueue_estimators(h);
+      if (rc != TEASER_HIP_OK) return rc;
+      HIPCHK(h, hipStreamSynchronize(h->stream));
+      memcpy(h->states.data(), h->pin_states.p, sizeof(ProbState) * (size_t)batch);
+    }
+    h->skip_heuristic_next = open == 0;
+  }
   for (int b = 0; b < batch; ++b) h->heu_size[(size_t)b] = h->states[(size_t)b].lb;
+  if (setting(S_K4_DEBUG) && batch <= 4)  // diagnostics only: what the greedy starts found
+    for (int b = 0; b < batch; ++b) {
+      const ProbState& st = h->states[(size_t)b];
+      fprintf(stderr, "[teaser_hip] heuristic, problem %d: lb %d (start %d), degree closure %d, proven %d, alive %d; starts (vertex:size):",
+              b, st.lb, st.best_start, st.deg_closed, st.proven, st.alive_count);
+      for (int k = 0; k < kMaxStarts; ++k) fprintf(stderr, " %d:%d", st.start_vertex[k], st.start_size[k]);
+      fprintf(stderr, "\n");
+    }
   h->last_unproven = 0;
   if (h->pend.need_graph && h->pend.mode == TEASER_INLIER_PMC_EXACT) {
     bool changed = false;
@@ -1265,7 +1340,7 @@ int32_t solve_packed_finish(teaser_hip_solver* h, teaser_solution_c* out, bool* 
     o.clique_size = st.clique_size;
     o.heuristic_size = h->heu_size[(size_t)b];
     o.clique_exact_run = h->exact_run[(size_t)b];
-    o.colour_uncoloured = b < (int)h->colour_x.size() ? h->colour_x[(size_t)b] : -1;
+    o.colour_uncoloured = st.deg_closed ? -2 : (b < (int)h->colour_x.size() ? h->colour_x[(size_t)b] : -1);
     o.num_edges = (int64_t)(st.deg_sum / 2);
     if (st.clique_size <= 1) {  // registration.cc:643-647
       o.valid = 0;
@@ -1451,7 +1526,7 @@ void release_handle_resources(teaser_hip_solver* h) {
   DevBuf* bufs[] = {&h->d_desc, &h->d_state, &h->d_src, &h->d_dst, &h->d_bitmap, &h->d_deg,
                     &h->d_clique, &h->d_start_cliques, &h->d_alive_a, &h->d_alive_b,
                     &h->d_next_count, &h->d_weights, &h->d_rot_inl, &h->d_trans_inl,
-                    &h->d_tls_scratch, &h->d_tim_off, &h->d_pk, &h->d_prep, &h->d_work, &h->hdr, &h->x_order,
+                    &h->d_tls_scratch, &h->d_tim_off, &h->d_pk, &h->d_prep, &h->d_work, &h->d_core, &h->hdr, &h->x_order,
                     &h->x_src, &h->x_dst, &h->x_bitmap, &h->x_desc, &h->x_state, &h->x_ctrl,
                     &h->x_clique, &h->x_arena, &h->x_probs, &h->x_probs2, &h->x_keys, &h->x_xbits, &h->x_tasks, &h->c_sel, &h->c_colour, &h->c_tent, &h->c_xlist, &h->c_list_a, &h->c_list_b,
                     &h->c_counts, &h->c_bits, &h->c_class,

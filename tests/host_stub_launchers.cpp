@@ -14,6 +14,8 @@ std::atomic<unsigned> g_stub_open_mask{0};  // bit (b & 31) set: problem b of a 
 std::atomic<int> g_stub_launches{0};
 std::atomic<int> g_stub_exact_searches{0};
 std::atomic<int> g_stub_speculative{0};
+std::atomic<unsigned> g_stub_closed_mask{0};  // bit (b & 31) set: problem b of a batch is decided by the "degree closure"
+std::atomic<int> g_stub_heuristic_stages{0};
 
 namespace thip {
 
@@ -29,7 +31,21 @@ void launch_tim_graph(hipStream_t, const ProbDesc*, int, int, const double*, con
                       const ProbState*) { ++g_stub_launches; }
 void launch_degrees(hipStream_t, const ProbDesc*, int, int, const uint64_t*, int32_t*, ProbState*) { ++g_stub_launches; }
 void launch_heuristic(hipStream_t, const ProbDesc*, int, int, const uint64_t*, const int32_t*, ProbState*, int32_t*, int64_t,
-                      int32_t*, int32_t*) { ++g_stub_launches; }
+                      int32_t*, int32_t*) {
+  ++g_stub_launches;
+  ++g_stub_heuristic_stages;
+}
+int64_t degree_closure_scratch_bytes(int batch) { return (int64_t)batch * 256; }
+void launch_degree_closure(hipStream_t, const ProbDesc* dd, int batch, const uint64_t*, const int32_t*, ProbState* ds, int32_t*,
+                           void*, int32_t*) {
+  ++g_stub_launches;
+  const unsigned closed = g_stub_closed_mask.load();
+  for (int b = 0; b < batch; ++b) {
+    if (dd[b].n < 2 || !((closed >> (b & 31)) & 1u)) continue;
+    ds[b].lb = ds[b].clique_size = 2;
+    ds[b].proven = ds[b].peel_done = ds[b].deg_closed = 1;
+  }
+}
 void launch_select_best(hipStream_t, const ProbDesc*, int, int, const int32_t*, ProbState*, const int32_t*, int64_t,
                         int32_t*, uint64_t*, int) { ++g_stub_launches; }
 void launch_peel_rounds(hipStream_t, const ProbDesc* dd, int batch, int, const uint64_t*, ProbState* ds, uint64_t*,
@@ -37,6 +53,7 @@ void launch_peel_rounds(hipStream_t, const ProbDesc* dd, int batch, int, const u
   ++g_stub_launches;
   const unsigned open = g_stub_open_mask.load();
   for (int b = 0; b < batch; ++b) {  // what the heuristic + peel leave behind: an incumbent, proven or not
+    if (ds[b].deg_closed) continue;
     ds[b].lb = dd[b].n >= 2 ? 2 : dd[b].n;
     ds[b].clique_size = ds[b].lb;
     ds[b].proven = ((open >> (b & 31)) & 1u) ? 0 : 1;

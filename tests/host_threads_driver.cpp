@@ -12,7 +12,8 @@
 
 #include "teaser_hip.h"
 
-extern std::atomic<unsigned> g_stub_open_mask;
+extern std::atomic<unsigned> g_stub_open_mask, g_stub_closed_mask;
+extern std::atomic<int> g_stub_heuristic_stages;
 extern std::atomic<int> g_stub_launches, g_stub_exact_searches, g_stub_speculative;
 
 #define CHECK(cond)                                                        \
@@ -53,6 +54,9 @@ int main(int argc, char** argv) {
         tot += n[(size_t)b];
       }
       g_stub_open_mask.store((rng() % 3 == 0) ? 0u : (unsigned)rng());  // every third batch: all closed by the peel
+      // runs of batches decided entirely by the degree closure (the heuristic stage is then not enqueued at all), broken
+      // by batches it leaves partly open (the finish half has to run the stage itself, once)
+      g_stub_closed_mask.store((rng() % 5 < 2) ? ~0u : (unsigned)(rng() & rng()));
       const bool host = (rng() & 1) != 0;
       int32_t t = -1;
       const int32_t rc = teaser_hip_submit_batch(h, src.data(), dst.data(), off.data(), n.data(), batch,
@@ -149,7 +153,7 @@ int main(int argc, char** argv) {
   const size_t left = pend.size();
   CHECK(teaser_hip_solver_destroy(h) == TEASER_HIP_OK);
   std::printf("submitted %d waited %d left_in_flight %zu busy %d staged_busy %d stub_launches %d exact_searches %d "
-              "speculative_bound_stages %d\n", submitted, waited, left, busy, staged_busy, g_stub_launches.load(),
-              g_stub_exact_searches.load(), g_stub_speculative.load());
+              "speculative_bound_stages %d heuristic_stages %d\n", submitted, waited, left, busy, staged_busy,
+              g_stub_launches.load(), g_stub_exact_searches.load(), g_stub_speculative.load(), g_stub_heuristic_stages.load());
   return 0;
 }

@@ -1318,6 +1318,62 @@ def test_async_batches_match_sync():
     mem.free()
 
 
+def test_async_headline_batch_64x10k_vs_oracle_fixture():
+    """The route bench.py times -- teaser_hip_submit_batch / teaser_hip_wait, two batches in flight, finisher threads on,
+    device and page-locked host inputs -- on a WHOLE headline batch (64 problems of N = 10 000, 95 % outliers), checked
+    problem by problem against the committed ORACLE fixture (tests/golden/make_config2_batch_golden.py): edge count,
+    maximum clique and both inlier lists (through their SHA-256; content only where the oracle found the maximum clique
+    unique -- one problem of the 64 has two), R and t to the north_star tolerances, and the 12.5 MB bitmap of four
+    problems bit for bit."""
+    import hashlib
+    import json
+    import os
+    from util import ROOT, HipBuffers
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "config2_batch_golden.json")))
+    B, n = fx["batch"], fx["n"]
+    probs = [tp.synth_problem(fx["seed0"] + b, n, fx["outlier_ratio"], fx["noise_bound"]) for b in range(B)]
+    other = [tp.synth_problem(fx["seed0"] + 500 + b, n, fx["outlier_ratio"], fx["noise_bound"]) for b in range(B)]
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(np.asarray(a, dtype=np.int32)).tobytes()).hexdigest()
+
+    def check(s, out, bitmaps):
+        assert sum(1 for f in fx["problems"] if not f["clique_unique"]) <= 2
+        for b, f in enumerate(fx["problems"]):
+            o = out[b]
+            assert bool(o.valid) == f["valid"] and o.num_edges == f["num_edges"] and o.clique_size == f["clique_size"], b
+            if f["clique_unique"]:
+                assert sha(s.getInlierMaxClique(b)) == f["max_clique_sha256"], b
+                assert sha(s.getRotationInliers(b)) == f["rotation_inliers_sha256"], b
+                assert sha(s.getTranslationInliers(b)) == f["translation_inliers_sha256"], b
+                assert np.linalg.norm(np.array(o.rotation[:]) - np.array(f["rotation"])) <= R_TOL, b
+                assert np.linalg.norm(np.array(o.translation[:]) - np.array(f["translation"])) <= T_TOL, b
+            else:  # a maximum clique, whichever: every pair adjacent
+                bm = s.getInlierGraphBitmap(b)
+                cl = np.asarray(s.getInlierMaxClique(b))
+                sub = np.unpackbits(np.ascontiguousarray(bm[cl]).view(np.uint8), axis=1, bitorder="little")[:, cl].astype(bool)
+                assert (sub | np.eye(len(cl), dtype=bool)).all(), b
+        for b in bitmaps:
+            bm = np.ascontiguousarray(s.getInlierGraphBitmap(b))
+            assert hashlib.sha256(bm.tobytes()).hexdigest() == fx["problems"][b]["bitmap_sha256"], b
+
+    mem = HipBuffers()
+    s = make_solver(**bench_params())
+    s.set_pipeline_depth(2)
+    for host in (False, True):
+        put = mem.pinned if host else mem.device
+        sa, da, off, nn = _packed(probs)
+        sb, db, _, _ = _packed(other)
+        A = (put(sa), put(da))
+        Bb = (put(sb), put(db))
+        t0 = s.submit_batch(A[0], A[1], off, nn, host=host)
+        t1 = s.submit_batch(Bb[0], Bb[1], off, nn, host=host)
+        check(s, s.wait(t0), (0, 30, 63))
+        t2 = s.submit_batch(A[0], A[1], off, nn, host=host)   # the same lane again, behind the other batch
+        s.wait(t1)
+        check(s, s.wait(t2), (17,))
+    del s
+    mem.free()
+
+
 def test_staged_batch_takes_the_first_free_lane():
     """Depth 2, host inputs: t0, t1 on the lanes, t2 staged.  After wait(t1) lane 1 is free although it is lane 0's
     turn: the staged batch must move there, and wait(t2) must succeed BEFORE t0 has been waited for (a caller that
@@ -1417,6 +1473,13 @@ def test_fused_estimators_match_the_separate_kernels():
     2 .. 512 vertices take the fast route, larger ones (and FGR / QUATRO / COMPLETE) the general route inside the kernel."""
     cases = [(300, 0.5, 31), (1200, 0.7, 32), (2500, 0.9, 33), (640, 0.1, 34), (9, 0.4, 35), (64, 0.0, 36), (513, 0.0, 37)]
     probs = [tp.synth_problem(9000 + seed, n, rho, 0.01) for n, rho, seed in cases]
+    try:
+        _fused_estimators_cases(cases, probs)
+    finally:
+        tp.set_option("fused_estimators", 1)
+
+
+def _fused_estimators_cases(cases, probs):
     res = {}
     for mode in ("0", "1"):
         tp.set_option("fused_estimators", int(mode))
@@ -1453,3 +1516,105 @@ def test_fused_estimators_match_the_separate_kernels():
         assert (got["0"][0] == got["1"][0]).all() and (got["0"][1] == got["1"][1]).all()
         assert got["0"][2] == got["1"][2] and got["0"][3] == got["1"][3]
     tp.set_option("fused_estimators", 1)
+
+
+# ---------------------------------------------------------------------------------------------
+# degree closure in front of the heuristic (kernels_heuristic.hip: degree_closure_kernel)
+# ---------------------------------------------------------------------------------------------
+def _solve_both_routes(probs, params):
+    """Every problem alone and the whole list as one batch, with and without the degree closure."""
+    got = {}
+    try:
+        for on in (1, 0):
+            tp.set_option("deg_closure", on)
+            s = make_solver(**params)
+            single = []
+            for pr in probs:
+                sol = s.solve(pr["src"], pr["dst"])
+                raw = s.raw_solution()
+                single.append((bool(sol.valid), sol.rotation.copy(), sol.translation.copy(), s.getInlierMaxClique(),
+                               s.getRotationInliers(), s.getTranslationInliers(), int(raw.colour_uncoloured),
+                               int(raw.num_edges), int(raw.heuristic_size)))
+            sols = s.solve_batch([p["src"] for p in probs], [p["dst"] for p in probs])
+            batch = [(bool(o.valid), o.rotation.copy(), o.translation.copy(), s.getInlierMaxClique(b),
+                      s.getRotationInliers(b), s.getTranslationInliers(b), int(s.raw_solution(b).colour_uncoloured),
+                      int(s.raw_solution(b).num_edges), int(s.raw_solution(b).heuristic_size))
+                     for b, o in enumerate(sols)]
+            got[on] = (single, batch)
+    finally:
+        tp.set_option("deg_closure", 1)
+    return got
+
+
+def test_degree_closure_matches_the_greedy_route_on_50_seeds():
+    """The closure (omega <= h1 = max{k : #{H >= k - 1} >= k} with H the h-index of a vertex's neighbours' degrees; a
+    (k - 1)-core of exactly k vertices IS the unique maximum clique: lb = ub as graph.cc:83-102) against the route without
+    it (greedy starts, selection, peel, colouring bound, exact search): identical cliques, inlier lists, R and t, bit for
+    bit -- on workloads it decides (marker colour_uncoloured = -2) and on workloads where it must decline: noise bounds
+    at which the outliers' degrees exceed the clique's size, random graphs whose maximum clique is not unique, graphs
+    without edges.  Where it decides, the oracle must agree that the maximum clique is unique, and on its content."""
+    cases = []
+    for k in range(30):   # the metric's regime at small sizes, several outlier rates
+        # (at 95 % outliers and these sizes the degree bound h0 is far above the clique: R, cut at 7/8 of h0, misses it)
+        cases.append((100 + 97 * k, [0.5, 0.8, 0.9, 0.95][k % 4], 0.01, True if k % 4 != 3 else None))
+    for k in range(12):   # declined: every outlier's degree is above the clique size (the clique is not inside R)
+        cases.append((1500 + 100 * k, 0.92, 0.05, False))
+    for k in range(8):    # tiny problems, all-outlier problems (cliques of 2 .. 4 among random edges: seldom unique)
+        cases.append(([2, 3, 5, 17, 64, 65, 128, 400][k], [0.0, 0.0, 0.4, 0.5, 1.0, 1.0, 1.0, 1.0][k], 0.01, None))
+    assert len(cases) == 50
+    probs = [tp.synth_problem(31000 + i, n, rho, nb) for i, (n, rho, nb, _) in enumerate(cases)]
+    decided = 0
+    for nb in (0.01, 0.05):
+        idx = [i for i, c in enumerate(cases) if c[2] == nb]
+        params = bench_params(noise_bound=nb)
+        got = _solve_both_routes([probs[i] for i in idx], params)
+        for j, i in enumerate(idx):
+            for kind in (0, 1):  # single, batched
+                a, b = got[1][kind][j], got[0][kind][j]
+                assert b[6] != -2  # switched off means off
+                assert a[0] == b[0] and len(a[3]) == len(b[3]) and a[7] == b[7], (cases[i], kind)
+                if cases[i][3] is True:
+                    assert a[6] == -2 and a[8] == len(a[3]), cases[i]
+                elif cases[i][3] is False:
+                    assert a[6] != -2, cases[i]
+                if a[6] == -2 or cases[i][3] is not None:  # (a maximum clique that is not unique is not pinned)
+                    assert a[3] == b[3], (cases[i], kind)
+                    if a[0]:
+                        assert (a[1] == b[1]).all() and (a[2] == b[2]).all() and a[4] == b[4] and a[5] == b[5], (cases[i], kind)
+                decided += int(a[6] == -2)
+            a = got[1][0][j]
+            if a[6] == -2 and cases[i][0] <= 1500:
+                o = oracle.solve(probs[i]["src"], probs[i]["dst"], **oracle_params(params))
+                assert o["clique_unique"] and o["max_clique"].tolist() == a[3], cases[i]
+    assert decided >= 44
+
+
+def test_degree_closure_switches_the_heuristic_launches_off_and_on():
+    """A handle whose previous batch was decided entirely by the closure does not enqueue greedy / select / peel for the
+    next one; a problem the closure then leaves open is served by the finish half (one more round trip) and switches
+    the launches back on.  Whatever the history, results equal those of a fresh handle."""
+    easy = [tp.synth_problem(32000 + i, 900 + 50 * i, 0.3, 0.05) for i in range(4)]
+    hard = [tp.synth_problem(32100 + i, 1800, 0.92, 0.05) for i in range(2)]
+    params = bench_params(noise_bound=0.05)
+
+    def solve(s, probs):
+        sols = s.solve_batch([p["src"] for p in probs], [p["dst"] for p in probs])
+        return [(o.rotation.copy(), o.translation.copy(), s.getInlierMaxClique(b), int(s.raw_solution(b).colour_uncoloured))
+                for b, o in enumerate(sols)]
+
+    def same(a, b):
+        return all((x[0] == y[0]).all() and (x[1] == y[1]).all() and x[2] == y[2] and x[3] == y[3] for x, y in zip(a, b))
+
+    want_easy = solve(make_solver(**params), easy)
+    want_mixed = solve(make_solver(**params), easy[:2] + hard)
+    assert all(w[3] == -2 for w in want_easy) and [w[3] == -2 for w in want_mixed] == [True, True, False, False]
+    s = make_solver(**params)
+    s.set_profiling(1)
+    assert same(solve(s, easy), want_easy)             # first batch: launches enqueued (nothing known yet), all skipped
+    assert same(solve(s, easy), want_easy)             # second: not enqueued at all
+    t_skip = s.get_profile()["peel_ms"]
+    assert t_skip == 0.0
+    assert same(solve(s, easy[:2] + hard), want_mixed)  # open problems: the finish half runs the stage
+    assert s.get_profile()["peel_ms"] > 0.0
+    assert same(solve(s, easy[:2] + hard), want_mixed)  # enqueued up front again
+    assert same(solve(s, easy), want_easy)

@@ -48,3 +48,5 @@ def test_async_host_side_is_clean_under_sanitizers(tmp_path, sanitizers, tag):
             words = p.stdout.split()
             assert int(words[1]) > 100 and int(words[3]) > 100  # submitted, waited
             assert int(words[13]) > 10 and int(words[15]) > 10  # exact searches, speculative bound stages: both paths ran
+            # the heuristic stage ran for some batches only (the others were decided by the degree closure)
+            assert 10 < int(words[17]) < int(words[1]) + 3 * int(words[3])
