@@ -130,6 +130,7 @@ enum Setting {
   S_K4_WAVES,          // 0: built-in; persistent waves of the exact search's phases     TEASER_K4_WAVES
   S_K4_LB_BONUS,       // diagnostics: the exact search starts with incumbent lb + this (what a better heuristic would buy) TEASER_K4_LB_BONUS
   S_DEG_CLOSURE,       // 0: no degree closure in front of the greedy heuristic          TEASER_HIP_DEG_CLOSURE
+  S_GREEDY_SMALL,      // 0: no all-starts greedy for small graphs                        TEASER_HIP_GREEDY_SMALL
   S_DEG_CLOSURE_WGS,   // 0: built-in; workgroups per problem of the closure's row launch TEASER_HIP_DEG_CLOSURE_WGS
   S_COUNT
 };
@@ -163,6 +164,11 @@ void launch_heuristic(hipStream_t s, const ProbDesc* d_desc, int batch, int max_
                       const uint64_t* d_bitmap, const int32_t* d_deg, ProbState* d_state,
                       int32_t* d_start_cliques /* [kMaxStarts][sum n] */, int64_t total_n,
                       int32_t* d_cand /* [kMaxStarts][sum n] */, int32_t* d_clique /* [sum n] */);
+// all-starts greedy for small graphs (n <= 1024), between the 16-start greedy and the selection: returns the slots per
+// problem to hand to launch_select_best (0: nothing launched).  d_best_seen: batch ints, zero on entry
+int64_t greedy_small_scratch_bytes(int batch);
+int launch_greedy_small(hipStream_t s, const ProbDesc* d_desc, int batch, int max_small_n, const uint64_t* d_bitmap,
+                        const int32_t* d_deg, ProbState* d_state, void* d_slots, int32_t* d_best_seen);
 // degree closure in front of the heuristic (kernels_heuristic.hip): problems whose maximum clique follows from the
 // degrees and the rows of the ~10^3 vertices of largest degree are closed (clique written, state proven,
 // deg_closed = 1); the others are left untouched.  d_scratch: degree_closure_scratch_bytes(batch);

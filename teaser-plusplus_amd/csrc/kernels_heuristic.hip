@@ -979,12 +979,304 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Small graphs (n <= kSmallCap: descriptor correspondences, a few hundred vertices, dense): a greedy clique from EVERY
+// vertex that could still beat the 16 starts -- what pmc_heu does (a clique grown from every vertex in core order,
+// reference graph.cc:88-91) and what the 16 high-degree starts only approximate: at BASELINE config 5 (629
+// correspondences, omega = 92) they end at 91, 40 of the 399 admissible starts reach 92, and every node of the exact
+// search's tree existed only because the incumbent was one short.
+// Grid (G, batch), four waves per workgroup, the problem's adjacency staged in LDS (odd row stride), ONE start per wave
+// at a time:  P = N(s);  repeat { d(u) = |N(u) & P| for u in P;  every u with d(u) = |P| - 1 joins at once;  the u with
+// the largest d (ties: lowest index) joins and P shrinks to its neighbours };  a start is dropped as soon as
+// |C| + |P| cannot exceed what the 16 starts found, or falls BELOW the best this launch has found so far -- strictly
+// below: a start that would tie the final best is never dropped, so the selection (largest clique, lowest start) does
+// not depend on the order in which the waves finish.  Every workgroup leaves its best (size, start, members) in its own
+// slot; select_best_kernel takes the best slot when it beats the 16 starts (and only then: equal size keeps them).
+// ------------------------------------------------------------------------------------------
+constexpr int kSmallCap = 768;
+constexpr int kSmallMaxW = kSmallCap / 64;
+constexpr int kSmallSlotWords = 2 + kSmallMaxW;  // 64-bit words: key (size << 32 | ~start), spare, the clique as a bit set
+
+__device__ __forceinline__ uint64_t wave_uniform_u64(uint64_t v) {  // a value every lane holds -> scalar registers
+  const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)v);
+  const unsigned int hi = __builtin_amdgcn_readfirstlane((unsigned int)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// The starts of one workgroup on a COMPACT graph of m vertices (rows of WB words at stride WB | 1 in LDS, rows
+// m .. 64 ceil(m / 64) - 1 zero).  Everything but the adjacency lives in registers: P as WB wave-uniform words, d(u) =
+// |N(u) & P| for the lane's vertex u = 64 x + lane of every word x, kept up to date INCREMENTALLY -- when P loses the
+// set R (the vertices not adjacent to the one that joined: a handful in the dense neighbourhoods that matter) every
+// remaining u loses the members of R it is adjacent to, read off R's rows (the adjacency is symmetric).
+// Leaves this wave's best (size, start, clique bits: lane x holds word x).
+template <int WB>
+__device__ __forceinline__ void small_all_starts(const uint64_t* A, int m, int lb0, int first, int stride, int* wg_best,
+                                                 int32_t* best_seen, int lane, int* mybest_out, int* mystart_out,
+                                                 uint64_t* bestw_out) {
+  constexpr int S = WB | 1;
+  int mybest = 0, mystart = -1;
+  uint64_t bestw = 0ull;
+  for (int s0 = first; s0 < m; s0 += stride) {
+    int bound = max(lb0 + 1, max(*wg_best, __hip_atomic_load(best_seen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+    uint64_t Pr[WB];
+    int dv[WB];
+    int pc = 0;
+#pragma unroll
+    for (int x = 0; x < WB; ++x) {
+      Pr[x] = wave_uniform_u64(A[s0 * S + x]);
+      pc += __popcll(Pr[x]);
+    }
+    if (pc + 1 < bound) continue;
+#pragma unroll
+    for (int x = 0; x < WB; ++x) {
+      dv[x] = 0;
+      if (Pr[x]) {  // (wave-uniform)
+        const uint64_t* row = A + (64 * x + lane) * S;
+#pragma unroll
+        for (int y = 0; y < WB; ++y) dv[x] += __popcll(row[y] & Pr[y]);
+      }
+    }
+    uint64_t cw = (lane == (s0 >> 6)) ? (1ull << (s0 & 63)) : 0ull;  // lane x: word x of the clique
+    int csize = 1;
+    while (pc > 0) {
+      bound = max(bound, *wg_best);
+      if (csize + pc < bound) {
+        csize = 0;  // dropped
+        break;
+      }
+      // members adjacent to every other member join at once (each of the others loses them all as neighbours)
+      int nU = 0;
+      unsigned int bestk = 0;
+#pragma unroll
+      for (int x = 0; x < WB; ++x) {
+        if (!Pr[x]) continue;
+        const bool inP = (Pr[x] >> lane) & 1ull;
+        const uint64_t mU = __ballot(inP && dv[x] == pc - 1);
+        if (mU) {
+          nU += __popcll(mU);
+          Pr[x] &= ~mU;
+          if (lane == x) cw |= mU;
+        }
+      }
+      csize += nU;
+      pc -= nU;
+      if (pc <= 0) break;
+#pragma unroll
+      for (int x = 0; x < WB; ++x) {
+        dv[x] -= nU;
+        if (Pr[x] && ((Pr[x] >> lane) & 1ull))
+          bestk = max(bestk, ((unsigned int)(dv[x] + 1) << 16) | (0xffffu - (unsigned int)(64 * x + lane)));
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) bestk = max(bestk, (unsigned int)__shfl_xor((int)bestk, o, 64));
+      const int u = (int)(0xffffu - (bestk & 0xffffu));
+      if (lane == (u >> 6)) cw |= 1ull << (u & 63);
+      ++csize;
+      // P shrinks to the neighbours of u; R = what leaves (u itself included)
+      uint64_t Rr[WB];
+      int rc = 0;
+      pc = 0;
+#pragma unroll
+      for (int x = 0; x < WB; ++x) {
+        const uint64_t nb = wave_uniform_u64(A[u * S + x]);
+        Rr[x] = Pr[x] & ~nb;
+        Pr[x] &= nb;
+        pc += __popcll(Pr[x]);
+        rc += __popcll(Rr[x]);
+      }
+      if (rc <= WB) {
+#pragma unroll
+        for (int y = 0; y < WB; ++y) {
+          uint64_t rb = Rr[y];
+          while (rb) {  // (wave-uniform)
+            const int r = 64 * y + __builtin_ctzll(rb);
+            rb &= rb - 1;
+            const uint64_t* rrow = A + r * S;
+#pragma unroll
+            for (int x = 0; x < WB; ++x) dv[x] -= (int)((rrow[x] >> lane) & 1ull);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int x = 0; x < WB; ++x) {
+          dv[x] = 0;
+          if (Pr[x]) {
+            const uint64_t* row = A + (64 * x + lane) * S;
+#pragma unroll
+            for (int y = 0; y < WB; ++y) dv[x] += __popcll(row[y] & Pr[y]);
+          }
+        }
+      }
+    }
+    if (csize > mybest) {  // (a later start of this wave has a higher index: strict improvement only)
+      mybest = csize;
+      mystart = s0;
+      bestw = cw;
+      if (lane == 0) {
+        atomicMax(wg_best, csize);
+        atomicMax(best_seen, csize);
+      }
+    }
+  }
+  *mybest_out = mybest;
+  *mystart_out = mystart;
+  *bestw_out = bestw;
+}
+
+// Per workgroup: (1) the peel at threshold lb0 (a clique of lb0 + 1 vertices survives it), rows read from L2;
+// (2) the survivors renumbered in ascending order and their induced adjacency gathered into LDS (lane = compact
+// column, one ballot per 64 columns); (3) this workgroup's share of the starts on the compact graph; (4) the best
+// clique back in original vertex numbers.  At BASELINE config 5: 629 vertices -> 197 survivors, rows of 4 words.
+__global__ __launch_bounds__(256) void greedy_small_kernel(const ProbDesc* __restrict__ descs,
+                                                           const uint64_t* __restrict__ bitmap,
+                                                           const int32_t* __restrict__ deg, ProbState* __restrict__ states,
+                                                           unsigned long long* __restrict__ slots /* [batch][G][kSmallSlotWords] */,
+                                                           int32_t* __restrict__ best_seen /* [batch], zero on entry */) {
+  TAIL_WAVE_PRIO();
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // the compact adjacency
+  __shared__ uint64_t alive[kSmallMaxW], nxt[kSmallMaxW], outb[kSmallMaxW];
+  __shared__ unsigned short alist[kSmallCap];
+  __shared__ int csum[256];
+  __shared__ unsigned long long wkey[4];
+  __shared__ uint64_t wbits[4][kSmallMaxW];
+  __shared__ int wg_best, changed;
+  const int p = blockIdx.y, G = gridDim.x;
+  const ProbDesc d = descs[p];
+  ProbState* st = states + p;
+  unsigned long long* slot = slots + ((size_t)p * G + blockIdx.x) * kSmallSlotWords;
+  const int n = d.n, W = d.W, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (n < 2 || n > kSmallCap || st->deg_closed) {
+    if (tid == 0) slot[0] = 0ull;
+    return;
+  }
+  const uint64_t* bm = bitmap + d.bm_off;
+  const int32_t* dg = deg + d.pt_off;
+  int lb0 = 0;
+  for (int k = 0; k < kMaxStarts; ++k) lb0 = max(lb0, st->start_size[k]);
+  // ---- (1) peel: alive = { deg >= lb0 }, then keep the vertices with >= lb0 alive neighbours, to the fixpoint
+  for (int w = wave; w < kSmallMaxW; w += 4) {
+    const int v = 64 * w + lane;
+    const uint64_t bits = __ballot(v < n && dg[v] >= lb0);
+    if (lane == 0) alive[w] = w < W ? bits : 0ull;
+  }
+  if (tid == 0) wg_best = 0;
+  __syncthreads();
+  for (int round = 0; round < 64; ++round) {
+    if (tid < kSmallMaxW) nxt[tid] = alive[tid];
+    if (tid == 0) changed = 0;
+    __syncthreads();
+    for (int v = tid; v < n; v += 256) {
+      if (!((alive[v >> 6] >> (v & 63)) & 1ull)) continue;
+      const uint64_t* row = bm + (int64_t)v * W;
+      uint64_t rw[kSmallMaxW];
+#pragma unroll
+      for (int x = 0; x < kSmallMaxW; ++x) rw[x] = x < W ? row[x] : 0ull;
+      int c = 0;
+#pragma unroll
+      for (int x = 0; x < kSmallMaxW; ++x) c += __popcll(rw[x] & alive[x]);
+      if (c < lb0) {
+        atomicAnd(reinterpret_cast<unsigned long long*>(&nxt[v >> 6]), ~(1ull << (v & 63)));
+        changed = 1;
+      }
+    }
+    __syncthreads();
+    const int ch = changed;
+    if (tid < kSmallMaxW) alive[tid] = nxt[tid];
+    __syncthreads();
+    if (!ch) break;
+  }
+  // ---- (2) survivors in ascending order; compact adjacency
+  int m = 0;
+  for (int w = 0; w < W; ++w) m += __popcll(alive[w]);
+  if (m <= lb0) {  // no clique of lb0 + 1 vertices
+    if (tid == 0) slot[0] = 0ull;
+    return;
+  }
+  list_bits_ascending(alive, W, alist, csum, tid);
+  const int Wc = (m + 63) >> 6;
+  const int WBc = Wc <= 4 ? 4 : (Wc <= 8 ? 8 : 12);
+  const int Sc = WBc | 1;
+  uint64_t* A = reinterpret_cast<uint64_t*>(smem);
+  for (int i = tid; i < 64 * Wc * Sc; i += 256) A[i] = 0ull;
+  __syncthreads();
+  for (int i0 = wave * 4; i0 < m; i0 += 16) {  // four rows in flight per wave
+    uint64_t words[4][kSmallMaxW];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = min(i0 + r, m - 1);
+      const uint64_t* row = bm + (int64_t)alist[i] * W;
+#pragma unroll
+      for (int g = 0; g < kSmallMaxW; ++g) {
+        const int c = 64 * g + lane;
+        const int vc = (g < Wc && c < m) ? alist[c] : -1;
+        words[r][g] = vc >= 0 ? ((row[vc >> 6] >> (vc & 63)) & 1ull) : 0ull;
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int g = 0; g < kSmallMaxW; ++g)
+        if (i0 + r < m && g < Wc) {  // (wave-uniform)
+          const uint64_t mask = __ballot(words[r][g] != 0ull);
+          if (lane == 0) A[(i0 + r) * Sc + g] = mask;
+        }
+  }
+  __syncthreads();
+  // ---- (3) this workgroup's starts
+  int mybest = 0, mystart = -1;
+  uint64_t bestw = 0ull;
+  const int first = blockIdx.x * 4 + wave, stride = G * 4;
+  if (WBc == 4) small_all_starts<4>(A, m, lb0, first, stride, &wg_best, best_seen + p, lane, &mybest, &mystart, &bestw);
+  else if (WBc == 8) small_all_starts<8>(A, m, lb0, first, stride, &wg_best, best_seen + p, lane, &mybest, &mystart, &bestw);
+  else small_all_starts<12>(A, m, lb0, first, stride, &wg_best, best_seen + p, lane, &mybest, &mystart, &bestw);
+  // ---- (4) the workgroup's best (largest, then lowest compact start = lowest vertex), in original numbering
+  if (lane == 0) wkey[wave] = mybest > 0 ? (((unsigned long long)mybest << 32) | (0xffffffffu - (unsigned int)alist[max(mystart, 0)])) : 0ull;
+  if (lane < kSmallMaxW) wbits[wave][lane] = bestw;
+  if (tid < kSmallMaxW) outb[tid] = 0ull;
+  __syncthreads();
+  unsigned long long kbest = 0;
+  int wbest = 0;
+  for (int k = 0; k < 4; ++k)
+    if (wkey[k] > kbest) {
+      kbest = wkey[k];
+      wbest = k;
+    }
+  for (int c = tid; c < m; c += 256)
+    if ((wbits[wbest][c >> 6] >> (c & 63)) & 1ull) {
+      const int v = alist[c];
+      atomicOr(reinterpret_cast<unsigned long long*>(&outb[v >> 6]), 1ull << (v & 63));
+    }
+  __syncthreads();
+  if (tid == 0) slot[0] = kbest;
+  if (tid < kSmallMaxW) slot[2 + tid] = kbest ? outb[tid] : 0ull;
+}
+
+int64_t greedy_small_scratch_bytes(int batch) { return (int64_t)std::max(batch, 1) * 64 * kSmallSlotWords * 8; }
+
+// returns the workgroups per problem (slots) of the launch; 0: nothing launched (no problem is small enough)
+int launch_greedy_small(hipStream_t s, const ProbDesc* d_desc, int batch, int max_small_n, const uint64_t* d_bitmap,
+                        const int32_t* d_deg, ProbState* d_state, void* d_slots, int32_t* d_best_seen) {
+  if (batch <= 0 || max_small_n < 2 || max_small_n > kSmallCap) return 0;
+  const int W = (max_small_n + 63) / 64;
+  const int WB = W <= 4 ? 4 : (W <= 8 ? 8 : 12);
+  const size_t lds = (size_t)(64 * W) * (WB | 1) * 8;  // (the compact graph at its largest: nothing peeled)
+  // workgroups per problem: every workgroup peels and gathers the compact graph itself, so few of them for large
+  // batches; a single problem gets a wave per start or so (the starts that matter run ~omega dependent steps each)
+  const int G = std::max(1, std::min(64, std::min((max_small_n + 3) / 4, std::max(2, 2048 / batch))));
+  static DynLdsOptIn optin;
+  if (lds > 32 * 1024) optin.ensure(reinterpret_cast<const void*>(greedy_small_kernel), (int)lds);
+  hipLaunchKernelGGL(greedy_small_kernel, dim3(G, batch), dim3(256), lds, s, d_desc, d_bitmap, d_deg, d_state,
+                     reinterpret_cast<unsigned long long*>(d_slots), d_best_seen);
+  return G;
+}
+
 // Per problem: choose the best start (largest clique, ties to the lowest start), emit it SORTED
 // into d_clique via an LDS membership bitset, set lb, and initialise the peel: alive = deg >= lb.
 __global__ __launch_bounds__(256) void select_best_kernel(
     const ProbDesc* __restrict__ descs, const int32_t* __restrict__ deg,
     ProbState* __restrict__ states, const int32_t* __restrict__ start_cliques, int64_t total_n,
-    int32_t* __restrict__ clique, uint64_t* __restrict__ alive_a, int do_peel) {
+    int32_t* __restrict__ clique, uint64_t* __restrict__ alive_a, int do_peel,
+    const unsigned long long* __restrict__ small_slots, int small_G) {
   TAIL_WAVE_PRIO();
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const ProbDesc d = descs[blockIdx.x];
@@ -1003,6 +1295,25 @@ __global__ __launch_bounds__(256) void select_best_kernel(
       bs = s;
     }
   }
+  // the all-starts greedy of small graphs (greedy_small_kernel): its best slot replaces the 16 starts' best only when
+  // it is strictly larger (largest clique, then lowest start -- the key's order)
+  const unsigned long long* small = nullptr;
+  if (small_G > 0 && n <= kSmallCap) {
+    unsigned long long kb = 0;
+    for (int g = 0; g < small_G; ++g) {
+      const unsigned long long* sl = small_slots + ((size_t)blockIdx.x * small_G + g) * kSmallSlotWords;
+      if (sl[0] > kb) {
+        kb = sl[0];
+        small = sl;
+      }
+    }
+    if ((int)(kb >> 32) > best) {
+      best = (int)(kb >> 32);
+      bs = -2;
+    } else {
+      small = nullptr;
+    }
+  }
   if (n == 1 && best == 0) {  // single vertex: the clique is that vertex
     if (tid == 0) {
       clique[d.pt_off] = 0;
@@ -1015,7 +1326,9 @@ __global__ __launch_bounds__(256) void select_best_kernel(
   }
   for (int w = tid; w < W; w += 256) memb[w] = 0;
   __syncthreads();
-  if (bs >= 0) {
+  if (small) {
+    for (int w = tid; w < W && w < kSmallMaxW; w += 256) memb[w] = small[2 + w];
+  } else if (bs >= 0) {
     const int32_t* C = start_cliques + (int64_t)bs * total_n + d.pt_off;
     for (int k = tid; k < best; k += 256) {
       const int u = C[k];
@@ -1201,11 +1514,13 @@ __global__ __launch_bounds__(256) void peel_round_kernel(const ProbDesc* __restr
 
 void launch_select_best(hipStream_t s, const ProbDesc* d_desc, int batch, int max_W,
                         const int32_t* d_deg, ProbState* d_state, const int32_t* d_start_cliques,
-                        int64_t total_n, int32_t* d_clique, uint64_t* d_alive_a, int do_peel) {
+                        int64_t total_n, int32_t* d_clique, uint64_t* d_alive_a, int do_peel,
+                        const void* d_small_slots, int small_G) {
   if (batch <= 0) return;
   const size_t lds = (size_t)((max_W + 1) & ~1) * 8 + 256 * 4 + 4 * 4;
   hipLaunchKernelGGL(select_best_kernel, dim3(batch), dim3(256), lds, s, d_desc, d_deg, d_state,
-                     d_start_cliques, total_n, d_clique, d_alive_a, do_peel);
+                     d_start_cliques, total_n, d_clique, d_alive_a, do_peel,
+                     reinterpret_cast<const unsigned long long*>(d_small_slots), small_G);
 }
 
 void launch_peel_rounds(hipStream_t s, const ProbDesc* d_desc, int batch, int max_W,

@@ -24,7 +24,8 @@ namespace thip {
 // launchers defined in the kernel files but not declared in internal.h
 void launch_select_best(hipStream_t s, const ProbDesc* d_desc, int batch, int max_W,
                         const int32_t* d_deg, ProbState* d_state, const int32_t* d_start_cliques,
-                        int64_t total_n, int32_t* d_clique, uint64_t* d_alive_a, int do_peel);
+                        int64_t total_n, int32_t* d_clique, uint64_t* d_alive_a, int do_peel,
+                        const void* d_small_slots = nullptr, int small_G = 0);
 void launch_peel_rounds(hipStream_t s, const ProbDesc* d_desc, int batch, int max_W,
                         const uint64_t* d_bitmap, ProbState* d_state, uint64_t* d_alive_a,
                         uint64_t* d_alive_b, int32_t* d_next_count, int rounds);
@@ -75,6 +76,7 @@ const SettingRow kSettingRows[S_COUNT] = {
     {"k4_waves", "TEASER_K4_WAVES", 0},
     {"k4_lb_bonus", "TEASER_K4_LB_BONUS", 0},
     {"deg_closure", "TEASER_HIP_DEG_CLOSURE", 1},
+    {"greedy_small", "TEASER_HIP_GREEDY_SMALL", 1},
     {"deg_closure_wgs", "TEASER_HIP_DEG_CLOSURE_WGS", 0},
 };
 struct SettingTable {
@@ -285,7 +287,7 @@ struct teaser_hip_solver {
 
   DevBuf d_desc, d_state, d_src, d_dst, d_bitmap, d_deg, d_clique, d_start_cliques, d_alive_a,
       d_alive_b, d_next_count, d_weights, d_rot_inl, d_trans_inl, d_tls_scratch, d_tim_off,
-      d_pk, d_prep, d_work, d_core;
+      d_pk, d_prep, d_work, d_core, d_small;
   // colouring bound
   DevBuf c_sel, c_colour, c_tent, c_xlist, c_list_a, c_list_b, c_counts, c_bits, c_class;
   std::vector<int32_t> colour_x;  // |X| per problem of the last solve (-1: stage not run)
@@ -1019,9 +1021,21 @@ int32_t enqueue_heuristic_stage(teaser_hip_solver* h, int batch, int mode, bool 
       HIPCHK(h, hipEventRecord(h->k1_done, s));
       h->k1_recorded = true;
     }
+    // small graphs: a greedy clique from every admissible vertex (the 16 starts' best is the bar to beat)
+    int small_G = 0;
+    if (setting(S_GREEDY_SMALL) != 0) {
+      int max_small = 0;
+      for (int b = 0; b < batch; ++b)
+        if (h->descs[(size_t)b].n <= 768) max_small = std::max(max_small, h->descs[(size_t)b].n);
+      if (max_small >= 2) {
+        HIPCHK(h, h->d_small.ensure((size_t)greedy_small_scratch_bytes(batch)));
+        small_G = launch_greedy_small(s, dd, batch, max_small, h->d_bitmap.as<uint64_t>(), h->d_deg.as<int32_t>(), ds,
+                                      h->d_small.p, h->d_next_count.as<int32_t>() + 4 * (size_t)batch);
+      }
+    }
     launch_select_best(s, dd, batch, h->max_W, h->d_deg.as<int32_t>(), ds,
                        h->d_start_cliques.as<int32_t>(), total_n, h->d_clique.as<int32_t>(),
-                       h->d_alive_a.as<uint64_t>(), mode == TEASER_INLIER_PMC_EXACT ? 1 : 0);
+                       h->d_alive_a.as<uint64_t>(), mode == TEASER_INLIER_PMC_EXACT ? 1 : 0, h->d_small.p, small_G);
   }
   if (mode == TEASER_INLIER_PMC_EXACT) {
     StageScope sc(h, ST_PEEL);
@@ -1105,7 +1119,7 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
   // ONE device block, filled by ONE H2D copy per solve (no memsets, no per-array copies)
   const size_t b_desc = sizeof(ProbDesc) * (size_t)batch, b_state = sizeof(ProbState) * (size_t)batch,
                b_off = 8 * (size_t)batch,
-               b_next = 16 * (size_t)batch /* peel: survivor counts, arrivals; degree closure: failures, arrivals */,
+               b_next = 20 * (size_t)batch /* peel: survivor counts, arrivals; degree closure: |R|, t; small greedy: best */,
                b_prep = (size_t)tim_prep_bytes(batch);
   auto al256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
   const size_t o_desc = 0, o_state = al256(o_desc + b_desc), o_off = al256(o_state + b_state),
@@ -1526,7 +1540,7 @@ void release_handle_resources(teaser_hip_solver* h) {
   DevBuf* bufs[] = {&h->d_desc, &h->d_state, &h->d_src, &h->d_dst, &h->d_bitmap, &h->d_deg,
                     &h->d_clique, &h->d_start_cliques, &h->d_alive_a, &h->d_alive_b,
                     &h->d_next_count, &h->d_weights, &h->d_rot_inl, &h->d_trans_inl,
-                    &h->d_tls_scratch, &h->d_tim_off, &h->d_pk, &h->d_prep, &h->d_work, &h->d_core, &h->hdr, &h->x_order,
+                    &h->d_tls_scratch, &h->d_tim_off, &h->d_pk, &h->d_prep, &h->d_work, &h->d_core, &h->d_small, &h->hdr, &h->x_order,
                     &h->x_src, &h->x_dst, &h->x_bitmap, &h->x_desc, &h->x_state, &h->x_ctrl,
                     &h->x_clique, &h->x_arena, &h->x_probs, &h->x_probs2, &h->x_keys, &h->x_xbits, &h->x_tasks, &h->c_sel, &h->c_colour, &h->c_tent, &h->c_xlist, &h->c_list_a, &h->c_list_b,
                     &h->c_counts, &h->c_bits, &h->c_class,
@@ -2366,19 +2380,25 @@ int32_t teaser_hip_max_clique(teaser_hip_solver* h, const uint64_t* bitmap, int3
   HIPCHK(h, h->d_start_cliques.ensure((size_t)n * 4 * kMaxStarts));
   HIPCHK(h, h->d_alive_a.ensure((size_t)W * 8));
   HIPCHK(h, h->d_alive_b.ensure((size_t)W * 8));
-  HIPCHK(h, h->d_next_count.ensure(8));
+  HIPCHK(h, h->d_next_count.ensure(32));
   HIPCHK(h, hipMemcpyAsync(h->d_desc.p, &d, sizeof(d), hipMemcpyHostToDevice, s));
   HIPCHK(h, hipMemcpyAsync(h->d_state.p, &st, sizeof(st), hipMemcpyHostToDevice, s));
   HIPCHK(h, hipMemcpyAsync(h->d_bitmap.p, bitmap, (size_t)n * W * 8, hipMemcpyHostToDevice, s));
-  HIPCHK(h, hipMemsetAsync(h->d_next_count.p, 0, 8, s));
+  HIPCHK(h, hipMemsetAsync(h->d_next_count.p, 0, 32, s));
   const ProbDesc* dd = h->d_desc.as<ProbDesc>();
   ProbState* ds = h->d_state.as<ProbState>();
   const bool exact = (mode == TEASER_INLIER_PMC_EXACT);
   launch_degrees(s, dd, 1, n, h->d_bitmap.as<uint64_t>(), h->d_deg.as<int32_t>(), ds);
   launch_heuristic(s, dd, 1, W, h->d_bitmap.as<uint64_t>(), h->d_deg.as<int32_t>(), ds,
                    h->d_start_cliques.as<int32_t>(), n, nullptr, h->d_clique.as<int32_t>());
+  int small_G = 0;
+  if (setting(S_GREEDY_SMALL) != 0 && n <= 768) {
+    HIPCHK(h, h->d_small.ensure((size_t)greedy_small_scratch_bytes(1)));
+    small_G = launch_greedy_small(s, dd, 1, n, h->d_bitmap.as<uint64_t>(), h->d_deg.as<int32_t>(), ds, h->d_small.p,
+                                  h->d_next_count.as<int32_t>() + 4);
+  }
   launch_select_best(s, dd, 1, W, h->d_deg.as<int32_t>(), ds, h->d_start_cliques.as<int32_t>(), n,
-                     h->d_clique.as<int32_t>(), h->d_alive_a.as<uint64_t>(), exact ? 1 : 0);
+                     h->d_clique.as<int32_t>(), h->d_alive_a.as<uint64_t>(), exact ? 1 : 0, h->d_small.p, small_G);
   if (mode == TEASER_INLIER_KCORE_HEU) {  // graph.cc:58-81
     if (n > 65536) {
       h->err = "KCORE_HEU supports at most 65536 vertices";

@@ -47,7 +47,12 @@ void launch_degree_closure(hipStream_t, const ProbDesc* dd, int batch, const uin
   }
 }
 void launch_select_best(hipStream_t, const ProbDesc*, int, int, const int32_t*, ProbState*, const int32_t*, int64_t,
-                        int32_t*, uint64_t*, int) { ++g_stub_launches; }
+                        int32_t*, uint64_t*, int, const void*, int) { ++g_stub_launches; }
+int64_t greedy_small_scratch_bytes(int batch) { return (int64_t)batch * 64; }
+int launch_greedy_small(hipStream_t, const ProbDesc*, int, int, const uint64_t*, const int32_t*, ProbState*, void*, int32_t*) {
+  ++g_stub_launches;
+  return 2;
+}
 void launch_peel_rounds(hipStream_t, const ProbDesc* dd, int batch, int, const uint64_t*, ProbState* ds, uint64_t*,
                         uint64_t*, int32_t*, int) {
   ++g_stub_launches;

@@ -175,7 +175,10 @@ def test_config5_3dmatch_pair():
     o = oracle.solve(A[c[:, 0]].astype(np.float64).T, B[c[:, 1]].astype(np.float64).T, **dict(p, estimate_scaling=0))
     assert sol.valid and o["valid"] and o["clique_exact_run"]
     clique = s.getInlierMaxClique()
-    assert len(clique) == len(o["max_clique"]) and s.raw_solution().clique_exact_run == 1
+    # max_core + 1 = 104 > omega = 92: the bound does not close by itself.  Either the exact search ran, or the
+    # heuristic already held a maximum clique and the colouring bound proved it (colour_uncoloured = 0)
+    raw = s.raw_solution()
+    assert len(clique) == len(o["max_clique"]) and (raw.clique_exact_run == 1 or raw.colour_uncoloured == 0)
     assert s.raw_solution().num_edges == o["num_edges"]
     _, bm = oracle.inlier_bitmap(A[c[:, 0]].astype(np.float64).T, B[c[:, 1]].astype(np.float64).T, vox, 1.0, False)
     dense = np.unpackbits(bm.view(np.uint8), axis=1, bitorder="little")[:, :len(c)].astype(bool)
