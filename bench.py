@@ -104,6 +104,9 @@ def parse(argv=None):
     ap.add_argument("--no-latency", action="store_true",
                     help="skip the single-problem latency probe (rocprofv3 runs: keeps every K1 launch the same size)")
     ap.add_argument("--cpu-solves", type=int, default=16)
+    ap.add_argument("--gather", choices=("auto", "rccl", "host"), default="auto",
+                    help="N > 1: how the result records are gathered and the ranks synchronised.  auto = RCCL when a probe "
+                         "all-reduce works on every rank, else the host path (gloo); rccl = RCCL or fail; host = gloo")
     ap.add_argument("--share-gpu", action="store_true",
                     help="testing on a 1-GPU box: ranks beyond the visible devices share them (record gather "
                          "over gloo, since RCCL refuses two ranks on one device)")
@@ -496,8 +499,8 @@ class Runner:
 
     def sync_all(self):
         self.torch.cuda.synchronize()
-        if self.dist is not None:
-            self.dist.barrier()
+        if self.dist is not None:  # barrier = an all-reduce on the gather device (RCCL, or gloo on the host path)
+            self.dist.all_reduce(self.torch.zeros(1, device=self.gather_dev))
         self.torch.cuda.synchronize()
 
     def max_over_ranks(self, seconds):
@@ -837,17 +840,46 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     dist = None
+    rccl_failed = False
     if world > 1:
         import torch.distributed as dist_mod
 
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if shared:
-            dist.init_process_group(backend="gloo")
+        # ONE process group with both backends: CPU tensors travel over gloo (the control plane: it always works),
+        # CUDA tensors over RCCL.  RCCL is PROBED with one all-reduce; the ranks then agree over gloo whether every one
+        # of them got through, and if not (or with --gather host) the record gather and the barriers use the host path
+        # -- a first multi-GPU run must not die on an RCCL bring-up problem.  --gather rccl makes a failure fatal.
+        import datetime
+        if shared or args.gather == "host":
+            dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=600))
+            gather_info = {"gather_backend": "gloo (host records; %s)" % ("ranks share a GPU: test mode" if shared else "--gather host"),
+                           "rccl_ranks": 0, "rccl_error": None}
         else:
-            dist.init_process_group(backend="nccl", device_id=dev)
-    gather_dev = torch.device("cpu") if shared else dev
+            dist.init_process_group(backend="cpu:gloo,cuda:nccl", timeout=datetime.timedelta(seconds=600))
+            ok, err = 1, None
+            try:
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                ok = 1 if int(probe.item()) == world else 0
+                err = None if ok else "probe all-reduce returned %r for %d ranks" % (probe.item(), world)
+            except Exception as e:  # noqa: BLE001 -- whatever RCCL raises, the host path takes over
+                ok, err = 0, repr(e)[:400]
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)  # (CPU tensor: gloo)
+            if int(flag.item()) == 1:
+                gather_info = {"gather_backend": "rccl", "rccl_ranks": world, "rccl_error": None}
+            elif args.gather == "rccl":
+                raise SystemExit("bench.py --gather rccl: RCCL is not usable on every rank (%s)" % err)
+            else:
+                rccl_failed = True
+                gather_info = {"gather_backend": "gloo (host records; automatic fallback: RCCL probe failed)",
+                               "rccl_ranks": 0, "rccl_error": err or "another rank's probe failed"}
+    else:
+        gather_info = {"gather_backend": "none (one rank)", "rccl_ranks": 0, "rccl_error": None}
+    gather_dev = torch.device("cpu") if (shared or args.gather == "host" or rccl_failed) else dev
 
     tp = importlib.import_module("teaser-plusplus_amd")
     B, n = args.batch, args.n
@@ -968,6 +1000,8 @@ def main():
             "host_resident_over_hbm_resident": (host_line["value"] / value) if host_line else None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": DTYPE,
             "data": "synthetic",
+            "gather_backend": gather_info["gather_backend"], "rccl_ranks": gather_info["rccl_ranks"],
+            "rccl_error": gather_info["rccl_error"],
             "config": {"workload": "synthetic N=%d correspondences, %.0f%% outliers, single-MI355X config "
                                    "(BASELINE configs[1]); noise_bound=%g, estimate_scaling=false, GNC-TLS, "
                                    "PMC_EXACT, CHAIN" % (n, 100 * args.outlier_ratio, args.noise_bound),
@@ -988,8 +1022,9 @@ def main():
                        "arithmetic": "FP64 estimators and FP64 reference expression for every pruning decision the "
                                      "K1 filter (exact bf16 split on MFMA + f32 epilogue with a rigorous error band) "
                                      "cannot make; bitmap bit-identical to the FP64 oracle",
-                       "parallelism": "independent problems per GPU, %s all_gather of result records"
-                                      % ("gloo (ranks share a GPU: test mode)" if shared else "RCCL")},
+                       "gather_backend": gather_info["gather_backend"], "rccl_ranks": gather_info["rccl_ranks"],
+                       "parallelism": "independent problems per GPU, one all_gather of result records (%s)"
+                                      % gather_info["gather_backend"]},
             "roofline": roofline_object(acc["ms"], acc["launches"], acc["bytes"], acc["pairs"], acc["aux"],
                                         traffic, traffic_src, k1_issue()),
             "configs": cfg_lines,

@@ -180,8 +180,11 @@ TEASER_HIP_API int32_t teaser_hip_solve_batch_device(teaser_hip_solver* h, const
  * colouring bound / exact search with their own syncs) runs on an INTERNAL finisher thread of the lane as soon
  * as the batch is enqueued; wait collects its result.  The caller's contract is unchanged: ONE calling thread,
  * tickets in any order; the threads are joined by teaser_hip_solver_destroy / teaser_hip_set_pipeline_depth.
- * Lanes want one hardware queue each: the library exports GPU_MAX_HW_QUEUES=8 when it is loaded (never over a
- * value already set); a process that initialised the HIP runtime before loading it should export that itself.
+ * Lanes want one hardware queue each.  HIP multiplexes its streams onto GPU_MAX_HW_QUEUES hardware queues (default
+ * 4) and reads that variable ONCE, at the process's first HIP call: a C / C++ caller that wants more than four
+ * batches in flight exports GPU_MAX_HW_QUEUES (8 is enough for depth <= 7) before that call -- the library never
+ * modifies the environment (the Python package sets it as a default before it loads the library).  With fewer
+ * queues than lanes the results are the same; lanes then share queues and overlap less (a one-time note on stderr).
  *   flags = TEASER_HIP_INPUT_DEVICE: src/dst are packed DEVICE arrays (as solve_batch_device), which
  *           must stay valid and unmodified until the matching wait;
  *   flags = TEASER_HIP_INPUT_HOST:   src/dst are packed HOST arrays of the same layout (problem b =

@@ -370,6 +370,10 @@ class RobustRegistrationSolver:
             if args or len(kw) > 1:
                 raise TypeError("RobustRegistrationSolver(params=...) takes no other solver argument")
             args, kw = (kw["params"],), {}
+        if len(args) > 1 and isinstance(args[0], RobustRegistrationSolver.Params):
+            # (the round-4 signature was (params, device): the device is keyword-only now)
+            raise TypeError("RobustRegistrationSolver(Params, ...) takes no further positional argument: "
+                            "pass the device as the keyword-only argument `device=`")
         if len(args) == 1 and (args[0] is None or isinstance(args[0], RobustRegistrationSolver.Params)):
             if kw:
                 raise TypeError("RobustRegistrationSolver(Params) takes no keyword arguments besides device")

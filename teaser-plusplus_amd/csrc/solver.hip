@@ -48,43 +48,55 @@ struct SettingRow {
   const char* name;  // teaser_hip_set_option name
   const char* env;   // read once, at the first use of the table
   int64_t def;
+  int64_t lo, hi;    // admissible values (teaser_hip_set_option answers BAD_ARG outside; an environment value outside
+                     // is ignored with a note on stderr)
 };
 const SettingRow kSettingRows[S_COUNT] = {
-    {"k1_fp64", "TEASER_HIP_K1_FP64", 0},
-    {"fused_estimators", "TEASER_HIP_FUSED_EST", 1},
-    {"scale_sort64", "TEASER_SCALE_SORT64", 0},
-    {"scale_batch", "TEASER_SCALE_BATCH", 1},
-    {"scale_mid_batch", "TEASER_SCALE_MID_BATCH", 1},
-    {"spec_bounds", "TEASER_HIP_SPEC_BOUNDS", 1},
-    {"finisher", "TEASER_HIP_FINISHER", 1},
-    {"copy_stream", "TEASER_HIP_COPY_STREAM", 0},
-    {"h2d_kernel", "TEASER_HIP_H2D_KERNEL", 0},
-    {"depth", "TEASER_HIP_DEPTH", 2},
-    {"stagger", "TEASER_HIP_STAGGER", 1},
-    {"k1_stream", "TEASER_HIP_K1_STREAM", 0},
-    {"tail_cus", "TEASER_HIP_TAIL_CUS", 0},
-    {"tail_cu_block", "TEASER_HIP_TAIL_CU_BLOCK", 0},
-    {"k4_lds_stack", "TEASER_K4_LDS_STACK", 16384},
-    {"k4_donate", "TEASER_K4_DONATE", 1},
-    {"k4_donate_after", "TEASER_K4_DONATE_AFTER", -1},
-    {"k4_hungry", "TEASER_K4_HUNGRY", -1},
-    {"k4_expand", "TEASER_K4_EXPAND", -1},
-    {"k4_debug", "TEASER_K4_DEBUG", 0},
-    {"heu_blocks", "TEASER_HEU_BLOCKS", 0},
-    {"greedy_threads", "TEASER_GREEDY_THREADS", 0},
-    {"fixup_wgs", "TEASER_K1_FIXUP_WGS", 0},
-    {"k4_waves", "TEASER_K4_WAVES", 0},
-    {"k4_lb_bonus", "TEASER_K4_LB_BONUS", 0},
-    {"deg_closure", "TEASER_HIP_DEG_CLOSURE", 1},
-    {"greedy_small", "TEASER_HIP_GREEDY_SMALL", 1},
-    {"deg_closure_wgs", "TEASER_HIP_DEG_CLOSURE_WGS", 0},
+    {"k1_fp64", "TEASER_HIP_K1_FP64", 0, 0, 1},
+    {"fused_estimators", "TEASER_HIP_FUSED_EST", 1, 0, 1},
+    {"scale_sort64", "TEASER_SCALE_SORT64", 0, 0, 1},
+    {"scale_batch", "TEASER_SCALE_BATCH", 1, 0, 1},
+    {"scale_mid_batch", "TEASER_SCALE_MID_BATCH", 1, 0, 1},
+    {"spec_bounds", "TEASER_HIP_SPEC_BOUNDS", 1, 0, 1},
+    {"finisher", "TEASER_HIP_FINISHER", 1, 0, 1},
+    {"copy_stream", "TEASER_HIP_COPY_STREAM", 0, 0, 2},
+    {"h2d_kernel", "TEASER_HIP_H2D_KERNEL", 0, 0, 1},
+    {"depth", "TEASER_HIP_DEPTH", 2, 1, 16},
+    {"stagger", "TEASER_HIP_STAGGER", 1, 0, 3},
+    {"k1_stream", "TEASER_HIP_K1_STREAM", 0, 0, 2},
+    {"tail_cus", "TEASER_HIP_TAIL_CUS", 0, 0, 255},
+    {"tail_cu_block", "TEASER_HIP_TAIL_CU_BLOCK", 0, 0, 1},
+    {"k4_lds_stack", "TEASER_K4_LDS_STACK", 16384, 0, 65536},
+    {"k4_donate", "TEASER_K4_DONATE", 1, 0, 1},
+    {"k4_donate_after", "TEASER_K4_DONATE_AFTER", -1, -1, 1048576},
+    {"k4_hungry", "TEASER_K4_HUNGRY", -1, -1, 1048576},
+    {"k4_expand", "TEASER_K4_EXPAND", -1, -1, 8},
+    {"k4_debug", "TEASER_K4_DEBUG", 0, 0, 1},
+    {"heu_blocks", "TEASER_HEU_BLOCKS", 0, 0, 16},
+    {"greedy_threads", "TEASER_GREEDY_THREADS", 0, 0, 512},
+    {"fixup_wgs", "TEASER_K1_FIXUP_WGS", 0, 0, 65536},
+    {"k4_waves", "TEASER_K4_WAVES", 0, 0, 1048576},
+    {"k4_lb_bonus", "TEASER_K4_LB_BONUS", 0, 0, 64},
+    {"deg_closure", "TEASER_HIP_DEG_CLOSURE", 1, 0, 1},
+    {"greedy_small", "TEASER_HIP_GREEDY_SMALL", 1, 0, 1},
+    {"deg_closure_wgs", "TEASER_HIP_DEG_CLOSURE_WGS", 0, 0, 64},
 };
 struct SettingTable {
   std::atomic<int64_t> v[S_COUNT];
   SettingTable() {
     for (int i = 0; i < S_COUNT; ++i) {
       const char* e = getenv(kSettingRows[i].env);
-      v[i].store((e && *e) ? (int64_t)atoll(e) : kSettingRows[i].def);
+      int64_t val = kSettingRows[i].def;
+      if (e && *e) {
+        char* end = nullptr;
+        const long long got = strtoll(e, &end, 10);
+        if (end == e || *end != '\0' || got < kSettingRows[i].lo || got > kSettingRows[i].hi)
+          fprintf(stderr, "[teaser_hip] %s=%s ignored: an integer in [%lld, %lld] is expected\n", kSettingRows[i].env, e,
+                  (long long)kSettingRows[i].lo, (long long)kSettingRows[i].hi);
+        else
+          val = got;
+      }
+      v[i].store(val);
     }
   }
 };
@@ -98,6 +110,7 @@ bool set_setting(const char* name, int64_t value) {
   if (!name) return false;
   for (int i = 0; i < S_COUNT; ++i)
     if (strcmp(name, kSettingRows[i].name) == 0) {
+      if (value < kSettingRows[i].lo || value > kSettingRows[i].hi) return false;
       setting_table().v[i].store(value, std::memory_order_relaxed);
       return true;
     }

@@ -5,6 +5,8 @@ import importlib
 import os
 import re
 
+import pytest
+
 from util import ROOT
 
 tp = importlib.import_module("teaser-plusplus_amd")
@@ -96,3 +98,41 @@ def test_bench_roofline_object():
     assert r0["pipes"]["valu"]["valu_insts_per_1024_pairs"] == bench.K1_VALU_PER_1024_STATIC
     z = bench.roofline_object(0.0, 0, 0, 0, 0.0, None, None)  # no launches: no division by zero
     assert z["achieved"] == 0.0 and z["traffic"] is None
+
+
+def test_roofline_flat_copies_and_measured_valu_peak():
+    """A record that keeps scalars only must still carry the pipe fractions, the traffic ratio and BOTH VALU peaks:
+    the assumed one (4 cycles per wave64 instruction at 2.4 GHz) and the one measured for K1's instruction mix
+    (scripts/probe/valu_rate weighted by scripts/k1_isa_stats.py, both committed under profiles/)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    pairs = 64 * 10000 * 9999 // 2
+    byts = 64 * (48 * 10000 + 8 * 10000 * 157)
+    r = bench.roofline_object(20 * 0.75, 20, 20 * byts, 20 * pairs, 0.0, 1.7e9, "profiles/x",
+                              issue=dict(valu_insts_per_1024_pairs=69.4, vmem_insts_per_1024_pairs=2.5, source="profiles/x"))
+    for k in ("frac_valu", "frac_mfma", "frac_hbm", "frac_l1"):
+        assert r[k] == r["pipes"][k[5:]]["frac"]
+    assert abs(r["traffic_over_algorithmic"] - 1.7e9 / byts) < 1e-9
+    m = r["valu_peak_measurement"]
+    assert m is not None and m["timed_share_of_mix"] > 0.8 and 2.0 < m["cycles_per_valu_inst_at_assumed_ghz"] < 6.0
+    assert r["valu_peak_assumed"] == 1024 * 2.4 / 4 and abs(r["valu_peak_measured"] - 1024 * m["assumed_ghz"] / m["cycles_per_valu_inst_at_assumed_ghz"]) < 0.1
+    assert abs(r["frac_valu_at_measured_peak"] - r["pipes"]["valu"]["achieved"] / r["valu_peak_measured"]) < 1e-12
+
+
+def test_set_option_validates_names_and_ranges():
+    """teaser_hip_set_option needs no device: unknown names and values outside an option's range answer BAD_ARG and
+    leave the table untouched (round-5 advice: a negative k4_lds_stack used to be masked and used)."""
+    L = tp.lib()
+    assert L.teaser_hip_set_option(None, b"no_such_option", 1) != 0
+    assert L.teaser_hip_set_option(None, b"k4_lds_stack", -16) != 0
+    assert L.teaser_hip_set_option(None, b"depth", 0) != 0 and L.teaser_hip_set_option(None, b"depth", 17) != 0
+    assert L.teaser_hip_set_option(None, b"deg_closure", 2) != 0
+    for name, v in ((b"depth", 2), (b"deg_closure", 1), (b"greedy_small", 1), (b"k4_lds_stack", 16384)):
+        assert L.teaser_hip_set_option(None, name, v) == 0
+    with pytest.raises(tp.TeaserHipError):
+        tp.set_option("fused_estimators", 7)
+    # the keyword-only device: Params followed by a positional argument is refused loudly (round-5 advice)
+    with pytest.raises(TypeError, match="device"):
+        tp.RobustRegistrationSolver._params_from_ctor_args((tp.RobustRegistrationSolver.Params(), 0), {})

@@ -113,4 +113,11 @@ def test_bench_two_ranks_on_one_gpu():
         r = d["roofline"]
         assert r["bound"] in r["pipes"] and 0 < r["frac"] <= 1.0 and all(0 <= p["frac"] <= 1.0 for p in r["pipes"].values())
     assert "gloo" in two["config"]["parallelism"]
+    # the fields a multi-GPU run is read by: which backend gathered the records, how many ranks RCCL connected
+    assert one["gather_backend"].startswith("none") and one["rccl_ranks"] == 0
+    assert two["gather_backend"].startswith("gloo") and two["rccl_ranks"] == 0 and two["rccl_error"] is None
+    assert two["config"]["gather_backend"] == two["gather_backend"]
+    # --gather host: the fallback a failed RCCL probe selects by itself
+    three = run(["--gpus", "2", "--share-gpu", "--gather", "host"])
+    assert three["gather_backend"].startswith("gloo") and three["n_gpus"] == 2
     assert 0.5 * one["value"] < two["value"] < 1.6 * one["value"], (one["value"], two["value"])
