@@ -97,7 +97,8 @@ typedef struct teaser_solution_c {
                                     heuristic_size colours (0: greedy clique proven maximum without
                                     search; > 0: they were the only B&B roots; -1: stage not run;
                                     -2: the degree closure decided the problem -- lb = ub from the vertex
-                                    degrees, graph.cc:83-102 -- before any heuristic ran) */
+                                    degrees, graph.cc:83-102 -- before any heuristic ran; -3: the same, and
+                                    the maximum clique it returns is proven maximum but not the only one) */
   int64_t num_edges;             /* edges of the inlier graph */
 } teaser_solution_c;
 

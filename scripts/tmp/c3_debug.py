@@ -4,7 +4,8 @@ sys.path.insert(0, '.')
 tp = importlib.import_module("teaser-plusplus_amd")
 kw = dict(noise_bound=0.01, cbar2=1.0, estimate_scaling=False, rotation_gnc_factor=1.4,
           rotation_max_iterations=100, rotation_cost_threshold=0.005)
-pr = tp.synth_problem(20250523 + 3, 50000, 0.99, 0.01)
+import os
+pr = tp.synth_problem(20250523 + int(os.environ.get("SEEDOFF", "0")), 50000, 0.99, 0.01)
 tp.set_option("spec_bounds", 0)
 for hb in (0, 1, 2, 4, 8):
     tp.set_option("heu_blocks", hb)

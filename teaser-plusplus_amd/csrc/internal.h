@@ -57,7 +57,8 @@ struct ProbState {
   int32_t next_start;    // heuristic: next start of the problem's queue (host: workgroups per problem)
   int32_t scale_overflow;  // 1: the scale stage's float-key sort met a run it could not fix (host reruns with the 64-bit sort)
   int32_t deg_closed;    // 1: the degree closure decided the problem (lb = ub from the degrees: no heuristic, no peel)
-  int32_t reserved0;
+  int32_t heu_best;      // heuristic: largest clique any start of the problem has finished with (atomicMax; starts that
+                         // can no longer reach it stop)
   int32_t start_vertex[kMaxStarts];
   int32_t start_size[kMaxStarts];
   unsigned long long deg_sum;  // sum of degrees = 2 * edges
@@ -132,6 +133,7 @@ enum Setting {
   S_DEG_CLOSURE,       // 0: no degree closure in front of the greedy heuristic          TEASER_HIP_DEG_CLOSURE
   S_GREEDY_SMALL,      // 0: no all-starts greedy for small graphs                        TEASER_HIP_GREEDY_SMALL
   S_DEG_CLOSURE_WGS,   // 0: built-in; workgroups per problem of the closure's row launch TEASER_HIP_DEG_CLOSURE_WGS
+  S_HEU_SKIP_CLOSED,   // 1: no greedy / select / peel launches behind a batch the closure decided entirely TEASER_HIP_HEU_SKIP_CLOSED
   S_COUNT
 };
 int64_t setting(Setting id);
@@ -159,11 +161,13 @@ void launch_degrees(hipStream_t s, const ProbDesc* d_desc, int batch, int max_n,
                     const uint64_t* d_bitmap, int32_t* d_deg, ProbState* d_state);
 // greedy multi-start clique heuristic (each workgroup picks its own start vertex; the problem states
 // must arrive zeroed); writes per-start cliques, then the per-problem best
-int heuristic_blocks_per_problem(int batch, int max_W);
+int heuristic_blocks_per_problem(int batch, int max_W, int expected_open = -1 /* problems the degree closure is expected to leave open; -1: no closure */);
 void launch_heuristic(hipStream_t s, const ProbDesc* d_desc, int batch, int max_W,
                       const uint64_t* d_bitmap, const int32_t* d_deg, ProbState* d_state,
                       int32_t* d_start_cliques /* [kMaxStarts][sum n] */, int64_t total_n,
-                      int32_t* d_cand /* [kMaxStarts][sum n] */, int32_t* d_clique /* [sum n] */);
+                      int32_t* d_trace /* diagnostics or null */, int32_t* d_clique /* [sum n] */,
+                      int nblk = 0 /* workgroups per problem = ProbState.next_start of the batch; 0: the built-in count */,
+                      int rows = 0 /* grid rows: 0 = one per problem; fewer = shared by the problems the degree closure left open */);
 // all-starts greedy for small graphs (n <= 1024), between the 16-start greedy and the selection: returns the slots per
 // problem to hand to launch_select_best (0: nothing launched).  d_best_seen: batch ints, zero on entry
 int64_t greedy_small_scratch_bytes(int batch);

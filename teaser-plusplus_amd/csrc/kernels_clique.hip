@@ -1346,6 +1346,13 @@ static_assert(kColourRounds > kColourClasses, "rounds = one per class + the all-
 // them (one ~500-cycle trip per neighbour and lane: at N = 50 000 a vertex has up to 1 400 coloured neighbours, 22 per
 // lane -- that chain, not the row's bytes, was the colouring rounds' time).  `words` holds the lane's masked words of
 // the row (word index = base + 64 * k + lane), `look(u)` returns the looked-up value, `use(u, value)` consumes it.
+#ifndef TEASER_COLOUR_LOOKUPS
+#define TEASER_COLOUR_LOOKUPS 4
+#endif
+#ifndef TEASER_COLOUR_ROW_WORDS
+#define TEASER_COLOUR_ROW_WORDS 8
+#endif
+constexpr int kLookupsInFlight = TEASER_COLOUR_LOOKUPS;
 template <int kWords, typename Look, typename Use>
 __device__ __forceinline__ void visit_bits_batched(const uint64_t (&words)[kWords], int base_word, int lane, Look look, Use use) {
 #pragma unroll
@@ -1353,21 +1360,21 @@ __device__ __forceinline__ void visit_bits_batched(const uint64_t (&words)[kWord
     uint64_t bits = words[k];
     const int u_base = (base_word + 64 * k + lane) * 64;
     while (bits) {
-      int u[4], val[4];
+      int u[kLookupsInFlight], val[kLookupsInFlight];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < kLookupsInFlight; ++j) {
         u[j] = bits ? u_base + __builtin_ctzll(bits) : -1;
         bits &= bits - (bits ? 1ull : 0ull);
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) val[j] = u[j] >= 0 ? look(u[j]) : -1;
+      for (int j = 0; j < kLookupsInFlight; ++j) val[j] = u[j] >= 0 ? look(u[j]) : -1;
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < kLookupsInFlight; ++j)
         if (u[j] >= 0) use(u[j], val[j]);
     }
   }
 }
-constexpr int kRowWordsPerLane = 8;  // words of a bitmap row a lane holds at once: 512 words = 32 768 vertices per pass
+constexpr int kRowWordsPerLane = TEASER_COLOUR_ROW_WORDS;  // words of a bitmap row a lane holds at once: 512 words = 32 768 vertices per pass
 
 __device__ __forceinline__ int colour_class(int v) { return (int)(mix32((unsigned int)v * 0x9E3779B9u + 0x51ed27u) & (kColourClasses - 1)); }
 

@@ -65,9 +65,20 @@ template <int kGreedyThreads>
 __device__ __forceinline__ int greedy_one_start(
     const ProbDesc* __restrict__ descs, const uint64_t* __restrict__ bitmap,
     const int32_t* __restrict__ deg, ProbState* __restrict__ states,
-    int32_t* __restrict__ start_cliques, int64_t total_n, char* smem, const int sidx) {
+    int32_t* __restrict__ start_cliques, int64_t total_n, char* smem, const int sidx, long long* trace, const int prob) {
   constexpr int kGreedyWaves = kGreedyThreads / 64;
-  const ProbDesc d = descs[blockIdx.y];
+  // diagnostics (k4_debug; trace == nullptr in the product): 100 MHz clock at the phase boundaries of this start,
+  // slots 6 / 7 = static picks / streaming vote rounds
+  long long* tr = trace ? trace + ((size_t)prob * kMaxStarts + sidx) * 8 : nullptr;
+  auto stamp = [&](int k) {
+    if (tr && threadIdx.x == 0) tr[k] = (long long)wall_clock64();
+  };
+  auto bump = [&](int k) {
+    if (tr && threadIdx.x == 0) tr[k] += 1;
+  };
+  if (tr && threadIdx.x == 0) tr[6] = tr[7] = 0;
+  stamp(0);
+  const ProbDesc d = descs[prob];
   const int n = d.n, W = d.W;
   const int Wpad = (W + 1) & ~1;
   uint64_t* P = reinterpret_cast<uint64_t*>(smem);                      // Wpad
@@ -80,7 +91,7 @@ __device__ __forceinline__ int greedy_one_start(
   int* red = wcnt + kGreedyMaxThreads;                                  // kGreedyMaxThreads / 64
   int* misc = red + kGreedyMaxThreads / 64;                             // 8
 
-  ProbState* st = states + blockIdx.y;
+  ProbState* st = states + prob;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const uint64_t* bm = bitmap + d.bm_off;
   const int32_t* dg = deg + d.pt_off;
@@ -129,9 +140,27 @@ __device__ __forceinline__ int greedy_one_start(
   }
   pc = blockN_sum_i<kGreedyWaves>(pc, red);
 
+  // A start that can no longer reach the largest clique another start of this problem has FINISHED with stops where it
+  // is (|C| + |P| strictly below it: it could not even tie, so the selection -- largest clique, lowest start -- is the
+  // same with or without it; at N = 50 000 one start in sixteen wanders through outliers for 0.6 ms while the others
+  // are done after 0.2).  The look is taken by one thread and shared: the loops below are full of block barriers.
+  auto cannot_win = [&](int reach) {
+    __syncthreads();
+    if (tid == 0) misc[1] = __hip_atomic_load(&st->heu_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    return reach < misc[1];
+  };
+  bool gave_up = false;
+  stamp(1);
   // ---- phase 1: shrink P to at most kCap candidates --------------------------------------
   bool prefer_vote = false;
   while (pc > kCap) {
+    if (cannot_win(csize + pc)) {
+      gave_up = true;
+      pc = 0;
+      break;
+    }
+    bump(prefer_vote ? 7 : 6);
     if (!prefer_vote) {
       // static pick: largest global degree, ties to the smallest index
       unsigned long long key = 0;
@@ -164,28 +193,70 @@ __device__ __forceinline__ int greedy_one_start(
     // streaming vote round over the set bits of P: wave `wave` owns words wave, wave+8, ...
     if (tid == 0) misc[0] = csize;
     unsigned long long bestk = 0;
-    for (int w = wave; w < W; w += kGreedyWaves) {
+    // (a round streams |P| rows -- 0.4 ms for the one start in sixteen that wanders through outliers at N = 50 000 --
+    // so every wave looks at the problem's best finished clique between rows and leaves the round when the start
+    // cannot reach it any more; the look after the round, which every thread takes, then sees at least that value:
+    // the give-up decision is uniform, and whatever this round computed is discarded)
+    const int reach = csize + pc;
+    bool hopeless = false;
+    for (int w = wave; w < W && !hopeless; w += kGreedyWaves) {
       uint64_t bits = P[w];
       uint64_t uni = 0;
+      // TWO candidates' rows at a time, eight words of each in flight per lane before the first use (a plain
+      // `for (x = lane; x < W; x += 64)` loop is one dependent round trip per word: 13 per row at N = 50 000, where
+      // the one start in sixteen that needs this round spent 0.41 ms in it and the whole stage waited for it)
       while (bits) {
-        const int b = __builtin_ctzll(bits);
+        if (__hip_atomic_load(&st->heu_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > reach) {
+          hopeless = true;
+          break;
+        }
+        const int b0 = __builtin_ctzll(bits);
         bits &= bits - 1;
-        const int u = w * 64 + b;
-        const uint64_t* ru = bm + (int64_t)u * W;
-        int c = 0;
-        for (int x = lane; x < W; x += 64) c += __popcll(ru[x] & P[x]);
-        c = wave_sum_i(c);
-        if (c == pc - 1) {
-          uni |= 1ull << b;
-        } else {
-          const unsigned long long kk =
-              ((unsigned long long)(unsigned int)(c + 1) << 32) | (0xffffffffu - (unsigned int)u);
-          bestk = kk > bestk ? kk : bestk;
+        const bool two = bits != 0ull;
+        const int b1 = two ? __builtin_ctzll(bits) : b0;
+        bits &= bits - (two ? 1ull : 0ull);
+        const uint64_t* r0 = bm + (int64_t)(w * 64 + b0) * W;
+        const uint64_t* r1 = bm + (int64_t)(w * 64 + b1) * W;
+        int c0 = 0, c1 = 0;
+        for (int x0 = 0; x0 < W; x0 += 64 * 8) {
+          uint64_t ra[8], rb[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int x = x0 + 64 * j + lane;
+            ra[j] = x < W ? r0[x] : 0ull;
+            rb[j] = (two && x < W) ? r1[x] : 0ull;
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int x = x0 + 64 * j + lane;
+            const uint64_t m = x < W ? P[x] : 0ull;
+            c0 += __popcll(ra[j] & m);
+            c1 += __popcll(rb[j] & m);
+          }
+        }
+        c0 = wave_sum_i(c0);
+        c1 = wave_sum_i(c1);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          if (k == 1 && !two) break;
+          const int b = k ? b1 : b0, c = k ? c1 : c0;
+          if (c == pc - 1) {
+            uni |= 1ull << b;
+          } else {
+            const unsigned long long kk =
+                ((unsigned long long)(unsigned int)(c + 1) << 32) | (0xffffffffu - (unsigned int)(w * 64 + b));
+            bestk = kk > bestk ? kk : bestk;
+          }
         }
       }
       if (lane == 0) U[w] = uni;
     }
     bestk = blockN_max_u64<kGreedyWaves>(bestk, red64);  // (barriers inside: U and misc[0] are visible after)
+    if (cannot_win(reach)) {  // (a wave may have left the round early: U / bestk are then incomplete)
+      gave_up = true;
+      pc = 0;
+      break;
+    }
     // append the universal candidates (any order: the final clique is re-sorted) and drop them
     int nU = 0;
     for (int w = tid; w < W; w += kGreedyThreads) {
@@ -222,6 +293,7 @@ __device__ __forceinline__ int greedy_one_start(
       __syncthreads();
     }
   }
+  stamp(2);
   if (pc > 0) {
     // ---- phase 2: candidate list in index order (contiguous word chunks per thread) -------
     const int wpt = (W + kGreedyThreads - 1) / kGreedyThreads;
@@ -317,9 +389,14 @@ __device__ __forceinline__ int greedy_one_start(
     }
     if (tid == 0) misc[0] = csize;
     __syncthreads();
+    stamp(3);
     // ---- phase 4: vote rounds on the compact matrix (all in LDS) ---------------------------
     int pcnt = pc;
     while (pcnt > 0) {
+      if (cannot_win(csize + pcnt)) {
+        gave_up = true;
+        break;
+      }
       constexpr int kVote = (kCap + kGreedyThreads - 1) / kGreedyThreads;
       int dv[kVote];
       bool in[kVote];
@@ -376,7 +453,12 @@ __device__ __forceinline__ int greedy_one_start(
       }
     }
   }
-  if (tid == 0) st->start_size[sidx] = csize;
+  (void)gave_up;  // (the clique so far is a clique: it is recorded like any other)
+  stamp(4);
+  if (tid == 0) {
+    st->start_size[sidx] = csize;
+    atomicMax(&st->heu_best, csize);
+  }
   return csize;
 }
 
@@ -753,6 +835,8 @@ __global__ __launch_bounds__(kDegThreads) void degree_closure_rows_kernel(
   }
 }
 
+constexpr int kCoverMax = 4;   // a core of up to k + kCoverMax vertices is still decided (vertex cover of its missing edges)
+constexpr int kMissCap = 64;   // ... when it misses at most this many edges
 // Launch 2 of the closure, one workgroup per problem: h1 from the H values, the core peel inside the compact graph
 // (its rows come from launch 1: plain loads behind a kernel boundary), the clique in ascending order, the state.
 __global__ __launch_bounds__(kDegThreads) void degree_closure_verdict_kernel(
@@ -766,6 +850,8 @@ __global__ __launch_bounds__(kDegThreads) void degree_closure_verdict_kernel(
   __shared__ uint64_t Sa[kCoreWords], Sb[kCoreWords];
   __shared__ int csum[kDegThreads];
   __shared__ unsigned long long red64[4];
+  __shared__ int miss_n, miss_verdict;
+  __shared__ unsigned short miss_a[kMissCap], miss_b[kMissCap];
   const int m = counters[blockIdx.x], t = counters[batch + blockIdx.x];
   if (m < 2) return;
   const ProbDesc d = descs[blockIdx.x];
@@ -839,7 +925,118 @@ __global__ __launch_bounds__(kDegThreads) void degree_closure_verdict_kernel(
       __syncthreads();
     }
     if (cnt >= k && !fix) return;  // (64 rounds without a fixpoint: give up)
-    if (cnt > k) return;           // a (k - 1)-core larger than k: undecided
+    int tie = 0;
+    if (cnt > k) {
+      // A (k - 1)-core T of k + x vertices, x small: every member misses at most x of the others, every k-clique of
+      // the graph lies inside T, and T minus a vertex cover of its MISSING edges is a clique.  No clique has more
+      // than k vertices, so a cover has at least x of them; one of exactly x leaves a maximum clique -- one of several
+      // (the headline's workload: an outlier consistent with all inliers but one, in one problem out of ~200, which
+      // used to send its whole batch through greedy, selection, peel and a second estimator launch).  Which one:
+      // the cover found first by a search that drops the endpoint of the smaller degree first (ties: the larger vertex
+      // index) -- deterministic, and what a degree-greedy heuristic tends to keep.  No cover of x vertices: no
+      // k-clique, the next feasible size.  More than kCoverMax extra vertices or kMissCap missing edges: undecided.
+      const int extra = cnt - k;
+      if (extra > kCoverMax) return;
+      if (tid == 0) miss_n = 0;
+      __syncthreads();
+      for (int r = tid; r < m; r += kDegThreads) {
+        if (!((Sa[r >> 6] >> (r & 63)) & 1ull)) continue;
+        const uint64_t* rowp = comp + (size_t)r * kCoreWords;
+        for (int g = r >> 6; g < ng; ++g) {
+          uint64_t bits = Sa[g] & ~rowp[g];
+          if (g == (r >> 6)) bits &= ~((2ull << (r & 63)) - 1ull);  // partners above r only (and not r itself)
+          while (bits) {
+            const int q = 64 * g + __builtin_ctzll(bits);
+            bits &= bits - 1;
+            const int pos = atomicAdd(&miss_n, 1);
+            if (pos < kMissCap) {
+              miss_a[pos] = (unsigned short)r;
+              miss_b[pos] = (unsigned short)q;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      const int nm = miss_n;
+      if (nm > kMissCap) return;
+      if (tid == 0) {
+        // (the list's order depends on the atomics: sort it -- at most kMissCap entries -- so that the search does not)
+        for (int i = 1; i < nm; ++i) {
+          const unsigned short a = miss_a[i], b = miss_b[i];
+          int j = i - 1;
+          while (j >= 0 && (miss_a[j] > a || (miss_a[j] == a && miss_b[j] > b))) {
+            miss_a[j + 1] = miss_a[j];
+            miss_b[j + 1] = miss_b[j];
+            --j;
+          }
+          miss_a[j + 1] = a;
+          miss_b[j + 1] = b;
+        }
+        // depth-first over "which endpoint of the first uncovered edge goes": drop[] = the cover so far
+        int drop[kCoverMax], edge_at[kCoverMax], choice[kCoverMax];
+        int depth = 0, found = 0;
+        auto covered = [&](int e, int dpt) {
+          for (int i = 0; i < dpt; ++i)
+            if (drop[i] == miss_a[e] || drop[i] == miss_b[e]) return true;
+          return false;
+        };
+        auto first_uncovered = [&](int dpt) {
+          for (int e = 0; e < nm; ++e)
+            if (!covered(e, dpt)) return e;
+          return -1;
+        };
+        auto pick = [&](int e, int c) {  // c = 0: the endpoint of the smaller degree (ties: the larger vertex), 1: the other
+          const int a = miss_a[e], b = miss_b[e];
+          const unsigned int ka = keys[a], kb2 = keys[b];
+          const bool a_first = (ka >> 16) < (kb2 >> 16) || ((ka >> 16) == (kb2 >> 16) && (ka & 0xffffu) > (kb2 & 0xffffu));
+          return (c == 0) == a_first ? a : b;
+        };
+        int e = first_uncovered(0);
+        if (e < 0) {
+          found = 0;  // (no missing edge inside a core larger than k: impossible while omega <= k; undecided)
+        } else {
+          edge_at[0] = e;
+          choice[0] = 0;
+          for (int guard = 0; guard < 4096; ++guard) {
+            if (choice[depth] > 1) {  // both endpoints tried at this level: back up
+              if (--depth < 0) break;
+              ++choice[depth];
+              continue;
+            }
+            drop[depth] = pick(edge_at[depth], choice[depth]);
+            const int e2 = first_uncovered(depth + 1);
+            if (e2 < 0) {  // (a cover smaller than `extra` would leave a clique above the bound: cannot be; undecided)
+              found = depth + 1 == extra ? 1 : -1;
+              break;
+            }
+            if (depth + 1 == extra) {  // budget spent, edges left
+              ++choice[depth];
+              continue;
+            }
+            ++depth;
+            edge_at[depth] = e2;
+            choice[depth] = 0;
+          }
+        }
+        miss_verdict = found == 1 ? 1 : (found == 0 && depth < 0 ? 2 : 0);  // 1: cover in drop[0 .. extra), 2: none exists, 0: undecided
+        if (found == 1)
+          for (int i = 0; i < extra; ++i) miss_a[i] = (unsigned short)drop[i];
+      }
+      __syncthreads();
+      const int verdict = miss_verdict;
+      if (verdict == 0) return;
+      if (verdict == 2) {
+        kmax = k - 1;
+        continue;
+      }
+      if (tid < extra) {
+        const int r = miss_a[tid];
+        atomicAnd(reinterpret_cast<unsigned long long*>(&Sa[r >> 6]), ~(1ull << (r & 63)));
+      }
+      __syncthreads();
+      cnt = k;
+      tie = 1;
+    }
     if (cnt < k) {                 // no k-clique: the next feasible size
       kmax = k - 1;
       continue;
@@ -862,7 +1059,7 @@ __global__ __launch_bounds__(kDegThreads) void degree_closure_verdict_kernel(
       st->proven = 1;
       st->peel_done = 1;
       st->heu_closed = 1;
-      st->deg_closed = 1;
+      st->deg_closed = tie ? 2 : 1;  // 2: a maximum clique, proven, but not the only one
     }
     return;
   }
@@ -901,18 +1098,51 @@ template <int kGreedyThreads>
 __global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
     const ProbDesc* __restrict__ descs, const uint64_t* __restrict__ bitmap,
     const int32_t* __restrict__ deg, ProbState* __restrict__ states,
-    int32_t* __restrict__ start_cliques, int64_t total_n) {
+    int32_t* __restrict__ start_cliques, int64_t total_n, long long* __restrict__ trace, int batch) {
   TAIL_WAVE_PRIO();
   constexpr int kGreedyWaves = kGreedyThreads / 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int next_s;
   __shared__ int red_c[kGreedyWaves];
-  ProbState* st = states + blockIdx.y;
-  if (st->deg_closed) return;  // decided by the degree closure (written by an EARLIER launch: uniform for the problem)
-  const ProbDesc d = descs[blockIdx.y];
+  // Grid rows: one per problem (gridDim.y = batch), or -- behind the degree closure, which leaves few problems open --
+  // FEWER rows than problems: row y then serves the open problems of rank y, y + gridDim.y, ... in problem order.  A
+  // launch that finds nothing to do is then 16 x 4 workgroups looking at the states instead of 16 x 64 that each
+  // wait for 60 KB of LDS beside K1 only to return (0.2 - 0.4 ms per batch on the path of the next-but-one K1).
+  for (int rank = blockIdx.y;; rank += gridDim.y) {
+  int prob = rank;
+  if ((int)gridDim.y < batch) {
+    __syncthreads();  // (next_s / red_c of the previous problem are no longer read)
+    int seen = 0, hit = -1;
+    for (int p0 = 0; p0 < batch && hit < 0; p0 += kGreedyThreads) {
+      const int p = p0 + (int)threadIdx.x;
+      const bool open = p < batch && !states[p].deg_closed;
+      const uint64_t m = __ballot(open);
+      if ((threadIdx.x & 63) == 0) red_c[threadIdx.x >> 6] = __builtin_popcountll(m);
+      __syncthreads();
+      int before = seen;
+      for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) before += red_c[w];
+      if (open && before + __builtin_popcountll(m & ((1ull << (threadIdx.x & 63)) - 1ull)) == rank) next_s = p;
+      int tot = 0;
+      for (int w = 0; w < kGreedyWaves; ++w) tot += red_c[w];
+      __syncthreads();
+      if (seen + tot > rank) hit = next_s;  // (uniform: every thread sees the same counts)
+      seen += tot;
+      __syncthreads();
+    }
+    if (hit < 0) return;  // fewer open problems than this rank
+    prob = hit;
+  } else if (rank >= batch) {
+    return;
+  }
+  ProbState* st = states + prob;
+  if (st->deg_closed) {  // decided by the degree closure (written by an EARLIER launch: uniform for the problem)
+    if ((int)gridDim.y < batch) continue;
+    return;
+  }
+  const ProbDesc d = descs[prob];
   int sidx = blockIdx.x;
   while (sidx < kMaxStarts) {
-    const int csize = greedy_one_start<kGreedyThreads>(descs, bitmap, deg, states, start_cliques, total_n, smem, sidx);
+    const int csize = greedy_one_start<kGreedyThreads>(descs, bitmap, deg, states, start_cliques, total_n, smem, sidx, trace, prob);
     if (gridDim.x >= kMaxStarts) break;  // every start has its own workgroup: nothing left to skip
     // closure test: the peel at threshold csize, in LDS (the start's P / U bitsets are free again)
     const int W = d.W, tid = threadIdx.x;
@@ -976,6 +1206,8 @@ __global__ __launch_bounds__(kGreedyThreads) void greedy_clique_kernel(
     __syncthreads();
     sidx = next_s;
     __syncthreads();
+  }
+  if ((int)gridDim.y >= batch) return;
   }
 }
 
@@ -1406,9 +1638,14 @@ size_t greedy_lds_bytes(int max_W) {
 }
 
 // workgroups per problem of the heuristic (the host initialises ProbState.next_start with it)
-int heuristic_blocks_per_problem(int batch, int max_W) {
+int heuristic_blocks_per_problem(int batch, int max_W, int expected_open) {
   const int forced = (int)setting(S_HEU_BLOCKS);  // diagnostics
   if (forced >= 1 && forced <= kMaxStarts) return forced;
+  // behind the degree closure only the problems it left open do anything (the workgroups of a decided problem return
+  // at once), and such a problem is not closed by a start's own peel either (two maximum cliques, typically): with one
+  // workgroup it runs its 16 starts one after the other -- 0.43 ms on the critical path of the batch's tail, which
+  // the next-but-one K1 waits for.  `expected_open` = what the closure left open in the handle's previous batch.
+  if (expected_open >= 0 && expected_open * kMaxStarts <= 256) return kMaxStarts;
   // about 128 workgroups in flight: every start in parallel for small batches (lowest latency, the GPU is
   // otherwise idle), ONE workgroup per problem from 64 problems on (they run beside the next batch's K1, whose
   // time they inflate: 1 measured 3-5 % faster than 2, 2 6 % faster than 4; profiles/r4l, r4m)
@@ -1420,10 +1657,12 @@ int heuristic_blocks_per_problem(int batch, int max_W) {
 
 void launch_heuristic(hipStream_t s, const ProbDesc* d_desc, int batch, int max_W,
                       const uint64_t* d_bitmap, const int32_t* d_deg, ProbState* d_state,
-                      int32_t* d_start_cliques, int64_t total_n, int32_t* d_cand,
-                      int32_t* d_clique) {
+                      int32_t* d_start_cliques, int64_t total_n, int32_t* d_trace /* diagnostics: batch x 16 x 8 int64, or null */,
+                      int32_t* d_clique, int nblk /* = ProbState.next_start of the batch; 0: the built-in count */,
+                      int rows /* grid rows; 0 or >= batch: one per problem; fewer: the open problems share them */) {
   if (batch <= 0) return;
-  const int nblk = heuristic_blocks_per_problem(batch, max_W);
+  if (nblk <= 0) nblk = heuristic_blocks_per_problem(batch, max_W);
+  if (rows <= 0 || rows > batch) rows = batch;
   const size_t lds = greedy_lds_bytes(max_W);
   // Small batches (<= 16 problems = at most one workgroup per CU) run 512-thread workgroups: nothing
   // competes for the CUs and the gather loops finish sooner (N = 1889: 0.51 vs 0.90 ms).  Larger batches
@@ -1434,12 +1673,12 @@ void launch_heuristic(hipStream_t s, const ProbDesc* d_desc, int batch, int max_
   static DynLdsOptIn optin256, optin512;  // beyond the 64 KB default dynamic-LDS limit once W >= ~300
   if (wide) {
     if (lds > 48 * 1024) optin512.ensure(reinterpret_cast<const void*>(greedy_clique_kernel<512>), (int)lds);
-    hipLaunchKernelGGL(greedy_clique_kernel<512>, dim3(nblk, batch), dim3(512), lds, s, d_desc, d_bitmap,
-                       d_deg, d_state, d_start_cliques, total_n);
+    hipLaunchKernelGGL(greedy_clique_kernel<512>, dim3(nblk, rows), dim3(512), lds, s, d_desc, d_bitmap,
+                       d_deg, d_state, d_start_cliques, total_n, reinterpret_cast<long long*>(d_trace), batch);
   } else {
     if (lds > 48 * 1024) optin256.ensure(reinterpret_cast<const void*>(greedy_clique_kernel<256>), (int)lds);
-    hipLaunchKernelGGL(greedy_clique_kernel<256>, dim3(nblk, batch), dim3(256), lds, s, d_desc, d_bitmap,
-                       d_deg, d_state, d_start_cliques, total_n);
+    hipLaunchKernelGGL(greedy_clique_kernel<256>, dim3(nblk, rows), dim3(256), lds, s, d_desc, d_bitmap,
+                       d_deg, d_state, d_start_cliques, total_n, reinterpret_cast<long long*>(d_trace), batch);
   }
 }
 

@@ -80,6 +80,7 @@ const SettingRow kSettingRows[S_COUNT] = {
     {"deg_closure", "TEASER_HIP_DEG_CLOSURE", 1, 0, 1},
     {"greedy_small", "TEASER_HIP_GREEDY_SMALL", 1, 0, 1},
     {"deg_closure_wgs", "TEASER_HIP_DEG_CLOSURE_WGS", 0, 0, 64},
+    {"heu_skip_closed", "TEASER_HIP_HEU_SKIP_CLOSED", 0, 0, 1},
 };
 struct SettingTable {
   std::atomic<int64_t> v[S_COUNT];
@@ -323,11 +324,17 @@ struct teaser_hip_solver {
   // 40-60 us per launch, profiles/r5e).  TEASER_HIP_SPEC_BOUNDS=0 disables.
   bool spec_bounds_next = false;
   int last_unproven = 0;
-  // The degree closure (kernels_heuristic.hip) decides the metric's workloads from the degrees alone.  Once a whole
-  // batch of this handle has been closed that way, the next batch does not enqueue greedy / select / peel at all (they
-  // would run beside the next K1 only to find every problem decided); a problem the closure then leaves open costs
-  // one more host round trip (solve_packed_finish) and switches the launches back on.
+  // The degree closure (kernels_heuristic.hip) decides the metric's workloads from the degrees alone; greedy / select /
+  // peel are enqueued behind it all the same (their workgroups return at once for a decided problem: five launches of
+  // ~5 us), with every start of an open problem in its own workgroup as long as the previous batch had few of them
+  // (closure_open_prev).  Setting heu_skip_closed = 1: once a whole batch of this handle has been closed, the next one
+  // does not enqueue them at all; a problem the closure then leaves open costs one more host round trip
+  // (solve_packed_finish), a second estimator launch, and switches the launches back on (round 6: 1.15 ms of tail on
+  // the path of the next-but-one K1 in one batch out of two of the headline, profiles/r6a/timeline).
   bool skip_heuristic_next = false;
+  int closure_open_prev = 0;   // problems the closure left open in this handle's previous batch
+  int heu_blocks = 0;          // workgroups per problem of the current batch's greedy launch (= ProbState.next_start)
+  int heu_rows = 0;            // its grid rows: 0 = one per problem; behind the closure a few, shared by the open problems
 
   // ---- state carried from the enqueue half of a solve to its finish half -----------------
   struct Pending {
@@ -1028,8 +1035,14 @@ int32_t enqueue_heuristic_stage(teaser_hip_solver* h, int batch, int mode, bool 
   const int64_t total_n = std::max<int64_t>(h->total_n, 1);
   {
     StageScope sc(h, ST_HEU);
+    int32_t* heu_trace = nullptr;
+    if (setting(S_K4_DEBUG) && batch <= 4) {  // diagnostics only: per-start phase clocks of the greedy kernel
+      HIPCHK(h, h->s_e.ensure(sizeof(long long) * 8 * kMaxStarts * (size_t)batch));
+      HIPCHK(h, hipMemsetAsync(h->s_e.p, 0, sizeof(long long) * 8 * kMaxStarts * (size_t)batch, s));
+      heu_trace = h->s_e.as<int32_t>();
+    }
     launch_heuristic(s, dd, batch, h->max_W, h->d_bitmap.as<uint64_t>(), h->d_deg.as<int32_t>(), ds,
-                     h->d_start_cliques.as<int32_t>(), total_n, nullptr, h->d_clique.as<int32_t>());
+                     h->d_start_cliques.as<int32_t>(), total_n, heu_trace, h->d_clique.as<int32_t>(), h->heu_blocks, h->heu_rows);
     if (record_stagger && h->k1_done && h->stagger_point == 2) {
       HIPCHK(h, hipEventRecord(h->k1_done, s));
       h->k1_recorded = true;
@@ -1090,7 +1103,10 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
   {
     int mx = 0;
     for (int b = 0; b < batch; ++b) mx = std::max(mx, n[b]);
-    heu_blocks = heuristic_blocks_per_problem(batch, (mx + 63) / 64);
+    const bool closure_ahead = effective_mode(P) == TEASER_INLIER_PMC_EXACT && mx <= 65536 && setting(S_DEG_CLOSURE) != 0;
+    heu_blocks = heuristic_blocks_per_problem(batch, (mx + 63) / 64, closure_ahead ? h->closure_open_prev : -1);
+    h->heu_blocks = heu_blocks;
+    h->heu_rows = closure_ahead && h->closure_open_prev * 4 <= batch ? std::min(batch, std::max(4, 2 * h->closure_open_prev)) : 0;
   }
   for (int b = 0; b < batch; ++b) {
     if (n[b] < 0) return TEASER_HIP_ERR_BAD_ARG;
@@ -1252,9 +1268,9 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
       launch_degrees(s, dd, batch, max_n, h->d_bitmap.as<uint64_t>(), h->d_deg.as<int32_t>(), ds);
     }
     // Degree closure (PMC_EXACT: the answer must be THE maximum clique, which is what the closure proves): problems
-    // whose clique follows from the degrees are closed before any heuristic runs.  When the previous batch of this
-    // handle was closed entirely, the greedy / select / peel launches are not even enqueued: the finish half runs
-    // them (heuristic_stage) for the problems the closure left open, should there be any.
+    // whose clique follows from the degrees are closed before any heuristic runs.  (heu_skip_closed = 1: when the
+    // previous batch of this handle was closed entirely, the greedy / select / peel launches are not even enqueued:
+    // the finish half runs them for the problems the closure left open, should there be any.)
     const bool closure = mode == TEASER_INLIER_PMC_EXACT && max_n <= 65536 && setting(S_DEG_CLOSURE) != 0;
     if (closure) {
       StageScope sc(h, ST_HEU);
@@ -1263,7 +1279,7 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
                             h->d_clique.as<int32_t>(), h->d_core.p, h->d_next_count.as<int32_t>() + 2 * (size_t)batch);
     }
     h->pend.closure = closure;
-    h->pend.heuristic_enqueued = !(closure && h->skip_heuristic_next);
+    h->pend.heuristic_enqueued = !(closure && h->skip_heuristic_next && setting(S_HEU_SKIP_CLOSED) != 0);
     if (h->pend.heuristic_enqueued) {
       int32_t rc = enqueue_heuristic_stage(h, batch, mode, mfma_k1);
       if (rc != TEASER_HIP_OK) return rc;
@@ -1334,6 +1350,7 @@ int32_t solve_packed_finish(teaser_hip_solver* h, teaser_solution_c* out, bool* 
       memcpy(h->states.data(), h->pin_states.p, sizeof(ProbState) * (size_t)batch);
     }
     h->skip_heuristic_next = open == 0;
+    h->closure_open_prev = open;
   }
   for (int b = 0; b < batch; ++b) h->heu_size[(size_t)b] = h->states[(size_t)b].lb;
   if (setting(S_K4_DEBUG) && batch <= 4)  // diagnostics only: what the greedy starts found
@@ -1343,6 +1360,14 @@ int32_t solve_packed_finish(teaser_hip_solver* h, teaser_solution_c* out, bool* 
               b, st.lb, st.best_start, st.deg_closed, st.proven, st.alive_count);
       for (int k = 0; k < kMaxStarts; ++k) fprintf(stderr, " %d:%d", st.start_vertex[k], st.start_size[k]);
       fprintf(stderr, "\n");
+      long long tr[kMaxStarts][8];
+      if (h->s_e.p && hipMemcpy(tr, h->s_e.as<long long>() + (size_t)b * kMaxStarts * 8, sizeof(tr), hipMemcpyDeviceToHost) == hipSuccess) {
+        fprintf(stderr, "[teaser_hip]   per start, us: select | shrink (static picks, vote rounds) | gather | vote | total:");
+        for (int k = 0; k < kMaxStarts; ++k)
+          fprintf(stderr, " [%.0f %.0f (%lld,%lld) %.0f %.0f = %.0f]", (tr[k][1] - tr[k][0]) * 0.01, (tr[k][2] - tr[k][1]) * 0.01, tr[k][6],
+                  tr[k][7], (tr[k][3] - tr[k][2]) * 0.01, (tr[k][4] - tr[k][3]) * 0.01, (tr[k][4] - tr[k][0]) * 0.01);
+        fprintf(stderr, "\n");
+      }
     }
   h->last_unproven = 0;
   if (h->pend.need_graph && h->pend.mode == TEASER_INLIER_PMC_EXACT) {
@@ -1367,7 +1392,7 @@ int32_t solve_packed_finish(teaser_hip_solver* h, teaser_solution_c* out, bool* 
     o.clique_size = st.clique_size;
     o.heuristic_size = h->heu_size[(size_t)b];
     o.clique_exact_run = h->exact_run[(size_t)b];
-    o.colour_uncoloured = st.deg_closed ? -2 : (b < (int)h->colour_x.size() ? h->colour_x[(size_t)b] : -1);
+    o.colour_uncoloured = st.deg_closed ? (st.deg_closed == 2 ? -3 : -2) : (b < (int)h->colour_x.size() ? h->colour_x[(size_t)b] : -1);
     o.num_edges = (int64_t)(st.deg_sum / 2);
     if (st.clique_size <= 1) {  // registration.cc:643-647
       o.valid = 0;

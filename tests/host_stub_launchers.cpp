@@ -23,7 +23,7 @@ int64_t tim_prep_bytes(int batch) { return (int64_t)batch * 64 + 64; }
 int64_t tim_operand_bytes(int64_t total_tiles) { return total_tiles * 64; }
 int64_t tim_work_items(const int32_t*, int batch) { return (int64_t)batch * 1024; }
 int64_t tim_prep_fill_segments(void*, const int32_t*, int batch) { return (int64_t)batch * 512; }
-int heuristic_blocks_per_problem(int, int) { return 1; }
+int heuristic_blocks_per_problem(int, int, int) { return 1; }
 
 void launch_tim_graph_mfma(hipStream_t, int, const ProbDesc*, int, int, int64_t, const double*, const double*, void*, void*,
                            void*, int64_t, uint64_t*, ProbState*, int32_t*, double, double) { ++g_stub_launches; }
@@ -31,7 +31,7 @@ void launch_tim_graph(hipStream_t, const ProbDesc*, int, int, const double*, con
                       const ProbState*) { ++g_stub_launches; }
 void launch_degrees(hipStream_t, const ProbDesc*, int, int, const uint64_t*, int32_t*, ProbState*) { ++g_stub_launches; }
 void launch_heuristic(hipStream_t, const ProbDesc*, int, int, const uint64_t*, const int32_t*, ProbState*, int32_t*, int64_t,
-                      int32_t*, int32_t*) {
+                      int32_t*, int32_t*, int, int) {
   ++g_stub_launches;
   ++g_stub_heuristic_stages;
 }

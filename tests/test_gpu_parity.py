@@ -1577,22 +1577,57 @@ def test_degree_closure_matches_the_greedy_route_on_50_seeds():
                     assert a[6] == -2 and a[8] == len(a[3]), cases[i]
                 elif cases[i][3] is False:
                     assert a[6] != -2, cases[i]
-                if a[6] == -2 or cases[i][3] is not None:  # (a maximum clique that is not unique is not pinned)
+                if a[6] == -3:  # decided among several maximum cliques: the size is pinned (above), the content is not
+                    assert cases[i][3] is not True and a[8] == len(a[3]), cases[i]
+                elif a[6] == -2 or cases[i][3] is not None:  # (a maximum clique that is not unique is not pinned)
                     assert a[3] == b[3], (cases[i], kind)
                     if a[0]:
                         assert (a[1] == b[1]).all() and (a[2] == b[2]).all() and a[4] == b[4] and a[5] == b[5], (cases[i], kind)
                 decided += int(a[6] == -2)
             a = got[1][0][j]
-            if a[6] == -2 and cases[i][0] <= 1500:
+            if a[6] in (-2, -3) and cases[i][0] <= 1500:
                 o = oracle.solve(probs[i]["src"], probs[i]["dst"], **oracle_params(params))
-                assert o["clique_unique"] and o["max_clique"].tolist() == a[3], cases[i]
+                if a[6] == -2:
+                    assert o["clique_unique"] and o["max_clique"].tolist() == a[3], cases[i]
+                else:
+                    assert not o["clique_unique"] and len(o["max_clique"]) == len(a[3]), cases[i]
     assert decided >= 44
 
 
-def test_degree_closure_switches_the_heuristic_launches_off_and_on():
-    """A handle whose previous batch was decided entirely by the closure does not enqueue greedy / select / peel for the
-    next one; a problem the closure then leaves open is served by the finish half (one more round trip) and switches
-    the launches back on.  Whatever the history, results equal those of a fresh handle."""
+def test_degree_closure_decides_a_tie_between_maximum_cliques():
+    """Headline shape, the one problem in ~200 the closure used to leave open: the (k - 1)-core has k + 1 vertices (an
+    outlier consistent with every inlier but one), so there are two maximum cliques.  The closure now drops a minimum
+    vertex cover of the core's missing edges (marker colour_uncoloured = -3): a maximum clique of the oracle's size,
+    every pair of it an edge of the graph, the other route (closure off) agreeing on the size, and the oracle on the
+    clique not being unique."""
+    pr = tp.synth_problem(20250523 + 30, 10000, 0.95, 0.01)
+    params = bench_params()
+    got = _solve_both_routes([pr], params)
+    a, b = got[1][0][0], got[0][0][0]
+    assert a[6] == -3 and b[6] != -3 and b[6] != -2
+    assert a[0] and b[0] and len(a[3]) == len(b[3]) == a[8] and a[7] == b[7]
+    assert got[1][1][0][3] == a[3]  # batched = single
+    s = make_solver(**params)
+    s.solve(pr["src"], pr["dst"])
+    bm = s.getInlierGraphBitmap()  # every pair of the clique is an edge of the graph
+    members = np.array(a[3])
+    for v in a[3]:
+        bits = (bm[v, members >> 6] >> (members & 63).astype(np.uint64)) & np.uint64(1)
+        assert int(bits.sum()) == len(a[3]) - 1
+    o = oracle.solve(pr["src"], pr["dst"], **oracle_params(params))
+    assert len(o["max_clique"]) == len(a[3]) and not o["clique_unique"]
+    # the estimate is as good as the other route's: both cliques hold 499 of the same inliers
+    assert np.linalg.norm(a[1] - b[1]) < 1e-3 and np.linalg.norm(a[2] - b[2]) < 1e-3
+
+
+@pytest.mark.parametrize("skip_closed", [0, 1])
+def test_degree_closure_switches_the_heuristic_launches_off_and_on(skip_closed):
+    """Default (heu_skip_closed = 0): greedy / select / peel are always enqueued behind the closure (their workgroups
+    return at once for a decided problem), with every start of an open problem in a workgroup of its own once the
+    previous batch had few open problems.  heu_skip_closed = 1: a handle whose previous batch was decided entirely by
+    the closure does not enqueue them for the next one; a problem the closure then leaves open is served by the finish
+    half (one more round trip) and switches the launches back on.  Whatever the history and the setting, results equal
+    those of a fresh handle."""
     easy = [tp.synth_problem(32000 + i, 900 + 50 * i, 0.3, 0.05) for i in range(4)]
     hard = [tp.synth_problem(32100 + i, 1800, 0.92, 0.05) for i in range(2)]
     params = bench_params(noise_bound=0.05)
@@ -1608,13 +1643,17 @@ def test_degree_closure_switches_the_heuristic_launches_off_and_on():
     want_easy = solve(make_solver(**params), easy)
     want_mixed = solve(make_solver(**params), easy[:2] + hard)
     assert all(w[3] == -2 for w in want_easy) and [w[3] == -2 for w in want_mixed] == [True, True, False, False]
-    s = make_solver(**params)
-    s.set_profiling(1)
-    assert same(solve(s, easy), want_easy)             # first batch: launches enqueued (nothing known yet), all skipped
-    assert same(solve(s, easy), want_easy)             # second: not enqueued at all
-    t_skip = s.get_profile()["peel_ms"]
-    assert t_skip == 0.0
-    assert same(solve(s, easy[:2] + hard), want_mixed)  # open problems: the finish half runs the stage
-    assert s.get_profile()["peel_ms"] > 0.0
-    assert same(solve(s, easy[:2] + hard), want_mixed)  # enqueued up front again
-    assert same(solve(s, easy), want_easy)
+    tp.set_option("heu_skip_closed", skip_closed)
+    try:
+        s = make_solver(**params)
+        s.set_profiling(1)
+        assert same(solve(s, easy), want_easy)             # first batch: launches enqueued (nothing known yet), all skipped
+        assert same(solve(s, easy), want_easy)             # second: not enqueued at all when skip_closed
+        t_skip = s.get_profile()["peel_ms"]
+        assert (t_skip == 0.0) == bool(skip_closed)
+        assert same(solve(s, easy[:2] + hard), want_mixed)  # open problems (skip_closed: the finish half runs the stage)
+        assert s.get_profile()["peel_ms"] > 0.0
+        assert same(solve(s, easy[:2] + hard), want_mixed)  # enqueued up front again
+        assert same(solve(s, easy), want_easy)
+    finally:
+        tp.set_option("heu_skip_closed", 0)
