@@ -241,6 +241,32 @@ def k1_issue():
     return dict(keep, source=src) if keep else None
 
 
+def clique_lds_counters(label):
+    """LDS evidence for the clique-stage kernels of a `configs` line (north_star: "LDS hit-rate on the clique search"):
+    the newest committed profiles/<round>/clique_lds_counters.json (separate rocprofv3 --pmc passes of
+    scripts/gpu.sh cliquepmc; counters cannot be collected inside a timed run).  Per kernel: the share of its data
+    reads served from LDS (SQ_INSTS_LDS / (SQ_INSTS_LDS + SQ_INSTS_VMEM_RD)) and the LDS bank-conflict fraction
+    (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE cycles).  label: c3 (config 3), c5 (config 5 single), c5b (batched)."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "clique_lds_counters.json"))):
+        try:
+            doc = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if label in doc:
+            best = (doc[label], os.path.relpath(path, ROOT))
+    if not best:
+        return None
+    out = {}
+    for k, v in best[0].items():
+        out[k] = {"lds_share_of_reads": round(v.get("lds_share_of_reads", 0.0), 4),
+                  "lds_bank_conflict_frac": round(v.get("lds_bank_conflict_frac", 0.0), 4),
+                  "valu_insts_per_launch": round(v.get("SQ_INSTS_VALU", 0.0) / max(v.get("_launches", 1), 1)),
+                  "launches_in_pass": v.get("_launches")}
+    return {"source": best[1], "kernels": out}
+
+
 def k1_measured_valu_peak():
     """VALU issue peak for K1's ACTUAL instruction mix: the per-opcode cost of scripts/probe/valu_rate (newest committed
     profiles/<round>/valu_rate.jsonl: independent streams, three waves per SIMD, one MFMA per 14 instructions -- the
@@ -661,6 +687,8 @@ def run_config(tag, tp, torch, runner, args, dev, world, rank, make_workload, st
     line.update(wl.get("extra", {}))
     if "extra_fn" in wl:
         line.update(wl["extra_fn"]())
+    if wl.get("lds_label"):
+        line["clique_lds"] = clique_lds_counters(wl["lds_label"])
     if want_cpu and rank == 0:
         line["cpu_baseline"] = wl["cpu"]()
     del bufs
@@ -746,7 +774,7 @@ def config5_workload(tp, args, rank, B, n_batches):
 
     sizes_all = np.concatenate(szs)
     return solver, dict(
-        pool=pool, offsets=offs, sizes=szs, problems_per_step=B, check=check,
+        pool=pool, offsets=offs, sizes=szs, problems_per_step=B, check=check, lds_label="c5b",
         workload="BASELINE configs[4]: 3DMatch pair of examples/teaser_python_fpfh_icp (voxel 0.05), %d perturbed "
                  "copies per step, real FPFH correspondences (%d-%d per problem), noise_bound=%g, GNC-TLS 10000 "
                  "iterations / 1e-16, PMC_EXACT" % (B, sizes_all.min(), sizes_all.max(), vox),
@@ -809,7 +837,7 @@ def synth_workload(tp, args, rank, tag, B, n, rho, n_batches, cpu_solves, cpu_bu
             "config3": "BASELINE configs[2]: N=%d, one problem per step" % n}[tag]
     return solver, dict(
         pool=pool, offsets=np.arange(B, dtype=np.int64) * n, sizes=np.full(B, n, dtype=np.int32), n=n,
-        problems_per_step=B, check=check,
+        problems_per_step=B, check=check, lds_label={"config3": "c3"}.get(tag),
         workload="%s, %.0f%% outliers; noise_bound=%g, estimate_scaling=false, GNC-TLS, PMC_EXACT, CHAIN"
                  % (name, 100 * rho, nb),
         cpu=lambda: cpu_baseline(tp, n, rho, nb, args.seed + 31, cpu_solves, cpu_budget))

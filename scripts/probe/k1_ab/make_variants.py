@@ -11,6 +11,10 @@ behind an opaque use (empty graph, no worklist overflow, no fallback: the events
   load32    buffer_load_dword instead of dwordx4 (same instruction count, a quarter of the bytes)
   ldsload   the loop's operands come from LDS (ds_read_b128 of a constant buffer) instead of global memory
   touch     (correct results) one extra dword load per 64-byte line of the half tile after the next, as a prefetch
+  seq3/seq4 (correct results) ONE accumulator set live at a time (row half 0: 4 MFMAs + epilogue, then row half 1 with the
+            next half tile's loads behind its MFMAs) at 3 / 4 waves per SIMD: 151 VGPRs / 128 with no scratch access in
+            the steady-state loop.  Round 6: 0.606 - 0.612 ms alone against 0.596 - 0.611 for the product (two sets,
+            168 VGPRs, 3 waves): the fourth wave buys nothing (profiles/r6b/k1_sequential_accumulators.txt)
 usage: make_variants.py [name ...]   then  bash scripts/probe/k1_ab/build.sh <name> ...   (see README.md)"""
 import os
 import sys
@@ -60,7 +64,67 @@ def no_mfma(bd, keep=lambda l: False):
     return "\n".join(out)
 
 
+
+SEQ_BODY = '''  auto body_flat = [&](const int J, auto diag_tag) {
+    constexpr bool DIAG = decltype(diag_tag)::value;
+    unsigned int tr[2][2];  // [ct][rt]: this lane's 16 column bits
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+      const bf16x8 b0 = __builtin_bit_cast(bf16x8, bX[0]), b1 = __builtin_bit_cast(bf16x8, bX[1]);
+      const bf16x8 b2 = __builtin_bit_cast(bf16x8, bX[2]);
+      const int Jn = (ct == 0 || J + 1 >= Jend) ? J : J + 1, gn = ct ^ 1;
+      f32x16 z;
+      for (int k = 0; k < 16; ++k) z[k] = 0.f;
+      {
+        Acc acc;
+        __builtin_amdgcn_s_setprio(2);
+        acc.U = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[0][0], b0, z, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        acc.W = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[0][3], b0, z, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        acc.U = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[0][1], b1, acc.U, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        acc.U = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[0][2], b2, acc.U, 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        tr[ct][0] = epi(acc, DIAG && ct == 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        Acc acc;
+        __builtin_amdgcn_s_setprio(2);
+        acc.U = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[1][0], b0, z, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        acc.W = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[1][3], b0, z, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        bX[0] = load_op(Jn, 1, gn, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        acc.U = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[1][1], b1, acc.U, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        bX[1] = load_op(Jn, 1, gn, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        acc.U = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[1][2], b2, acc.U, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        bX[2] = load_op(Jn, 1, gn, 2);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        tr[ct][1] = epi(acc, DIAG && ct == 1);
+      }
+    }
+    finish_tile(J, DIAG, tr);
+  };
+
+'''
+
+
+def sequential(occ):
+    a, b = flat_body(SRC)
+    return once(SRC[:a] + SEQ_BODY + SRC[b:], "constexpr int kK1Chunks = 1, kK1Occ = 3;", "constexpr int kK1Chunks = 1, kK1Occ = %d;" % occ)
+
+
 VARIANTS = {
+    "seq3": lambda: sequential(3),
+    "seq4": lambda: sequential(4),
     "zero": lambda: zeroed(SRC),
     "nomfma": lambda: in_body(zeroed(SRC), lambda bd: once(no_mfma(bd), LOADS[0],
         '      asm volatile("" : "=v"(acc[0].U), "=v"(acc[0].W), "=v"(acc[1].U), "=v"(acc[1].W) : "v"(b0), "v"(b1), "v"(b2));\n' + LOADS[0])),

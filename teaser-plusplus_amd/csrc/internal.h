@@ -133,6 +133,7 @@ enum Setting {
   S_DEG_CLOSURE,       // 0: no degree closure in front of the greedy heuristic          TEASER_HIP_DEG_CLOSURE
   S_GREEDY_SMALL,      // 0: no all-starts greedy for small graphs                        TEASER_HIP_GREEDY_SMALL
   S_DEG_CLOSURE_WGS,   // 0: built-in; workgroups per problem of the closure's row launch TEASER_HIP_DEG_CLOSURE_WGS
+  S_COLOUR_PERSISTENT, // > 0: problems of at least this many vertices run all colouring rounds in one launch (0: never) TEASER_HIP_COLOUR_PERSISTENT
   S_HEU_SKIP_CLOSED,   // 1: no greedy / select / peel launches behind a batch the closure decided entirely TEASER_HIP_HEU_SKIP_CLOSED
   S_COUNT
 };
@@ -241,6 +242,9 @@ int certify_on_device(hipStream_t s, const double* R, const double* src, const d
 // global colouring bound on the peel survivors of the selected problems (kernels_clique.hip)
 constexpr int kColourMaxLb = 4096;  // palette limit (64 LDS words per wave)
 constexpr int kColourRounds = 16;  // one per vertex class (8) + the all-in rounds
+// d_counts of launch_colour_bound: per problem kColourRounds + 2 list counters, then per problem 16 words of barrier state
+// (colour_persistent_kernel)
+inline int64_t colour_counts_bytes(int nsel) { return 4 * (int64_t)nsel * (kColourRounds + 2 + 16); }
 constexpr int kRootPruneCap = 512;   // leftover roots tested by root_prune_kernel (counts in d_tent)
 constexpr int kRootPruneSlices = 32; // workgroups per root
 constexpr int kRootPruneRows = 16;   // grid rows walking the roots (512 workgroups per problem in flight)

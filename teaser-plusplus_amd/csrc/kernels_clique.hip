@@ -14,6 +14,8 @@
 #include <algorithm>
 #include <utility>
 
+#include <mutex>
+
 #include "internal.h"
 
 namespace thip {
@@ -1341,13 +1343,17 @@ __device__ __forceinline__ unsigned int colour_hash(int v, int round, unsigned i
 constexpr int kColourClasses = 8;
 static_assert(kColourRounds > kColourClasses, "rounds = one per class + the all-in rounds");
 
-// Visit the set bits of a lane's masked row words FOUR at a time: the per-neighbour lookups (colour / tentative colour
-// of vertex u) are independent L2 round trips, and a `while (bits)` loop that loads inside every iteration serialises
-// them (one ~500-cycle trip per neighbour and lane: at N = 50 000 a vertex has up to 1 400 coloured neighbours, 22 per
-// lane -- that chain, not the row's bytes, was the colouring rounds' time).  `words` holds the lane's masked words of
-// the row (word index = base + 64 * k + lane), `look(u)` returns the looked-up value, `use(u, value)` consumes it.
+// Visit the set bits of a lane's masked row words kLookupsInFlight at a time: the per-neighbour lookups (colour /
+// tentative colour of vertex u) are independent L2 round trips, and a `while (bits)` loop that loads inside every
+// iteration serialises them (one ~500-cycle trip per neighbour and lane: at N = 50 000 a vertex has up to 1 400 coloured
+// neighbours, 22 per lane).  Every slot of a pass costs its ~25 vector instructions whether its lane has a bit left or
+// not, and the masked words are sparse (one or two bits): the rounds are as much instruction-bound as latency-bound
+// (profiles/r6b/clique_lds_counters.json: 1 500 VALU instructions per assigned vertex).  Measured at N = 50 000, colouring
+// stage: 1 in flight 0.80 ms, 2: 0.735, 4: 0.77, 8: 0.90 (profiles/r6b/colour_lookups_in_flight.txt).
+// `words` holds the lane's masked words of the row (word index = base + 64 * k + lane), `look(u)` returns the looked-up
+// value, `use(u, value)` consumes it.
 #ifndef TEASER_COLOUR_LOOKUPS
-#define TEASER_COLOUR_LOOKUPS 4
+#define TEASER_COLOUR_LOOKUPS 2
 #endif
 #ifndef TEASER_COLOUR_ROW_WORDS
 #define TEASER_COLOUR_ROW_WORDS 8
@@ -1618,6 +1624,321 @@ __global__ __launch_bounds__(64 * kColourWaves) void colour_resolve_kernel(const
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// ALL colouring rounds in ONE launch (large single problems: BASELINE config 3, N = 50 000, where the 16 x (assign,
+// resolve) launches were 0.78 ms of a 1.9 ms solve -- every launch a wave per listed vertex chasing one chain of
+// dependent L2 gathers, 28 + 17 us a round whatever the bytes).  Same algorithm, same hashes, same result as the two
+// kernels above; what changes is where the state lives and what separates the rounds:
+//   * one 16-wave workgroup per CU, resident for the whole stage; rounds are separated by a grid barrier (one
+//     monotonic arrival counter, relaxed polls, one release fence before arriving and one acquire fence after);
+//   * every workgroup keeps the WHOLE colour table in LDS -- 16 bits per vertex: 0xffff = no colour, bit 15 set = this
+//     round's bid, else the committed colour -- so the ~1 600 per-neighbour lookups of a vertex are LDS reads, not L2
+//     round trips.  The table is brought up to date from two small logs in global memory: after the assign step every
+//     workgroup reads all bids of the round (one 4-byte entry per listed vertex), after the resolve step the same
+//     entries with the winners marked;
+//   * the loop ends with the first empty list (the launch-per-round version runs its 16 rounds blind).
+// The workgroups of one problem must all be resident: the grid is one workgroup per CU and a workgroup takes a CU's
+// whole register file, so other work drains first and queues behind; launches of this kernel are serialised per
+// process (colour_persistent_gate) -- two of them half resident would wait for each other.  Every spin is bounded: a
+// barrier that does not complete within kPcTimeoutTicks raises the problem's abort flag, everybody leaves, and
+// colour_abort_kernel sends the survivors still without a colour to X (a partial colouring is a proper one: a colour
+// is only ever committed by a vertex that beat every rival, so the bound's logic holds with a larger X).
+// ------------------------------------------------------------------------------------------
+constexpr int kPcWaves = 16, kPcThreads = 64 * kPcWaves;
+constexpr int kPcSyncInts = 16;                  // per problem: [0] arrivals, [1] abort
+constexpr long long kPcTimeoutTicks = 200000000;  // 2 s of the 100 MHz wall clock
+constexpr unsigned short kPcNone = 0xffffu;
+
+// returns false when the stage was aborted (by this workgroup's timeout or somebody else's)
+__device__ __forceinline__ bool pc_grid_sync(unsigned int* sync, unsigned int nwg, unsigned int& target, int* sh_flag) {
+  __syncthreads();  // (workgroup-scope release: every wave's stores have reached L2)
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    target += nwg;
+    __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long t0 = (long long)wall_clock64();
+    int ok = 1;
+    unsigned int polls = 0;
+    while (__hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if ((++polls & 63u) == 0u) {
+        if (__hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+          ok = 0;
+          break;
+        }
+        if ((long long)wall_clock64() - t0 > kPcTimeoutTicks) {
+          __hip_atomic_store(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          ok = 0;
+          break;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    *sh_flag = ok;
+  }
+  __syncthreads();
+  return *sh_flag != 0;
+}
+
+// the set bits of a lane's masked row words, kFly LDS lookups at a time (same shape as visit_bits_batched; the table
+// is a few hundred cycles closer than L2, so fewer lookups in flight -- i.e. fewer empty slots per pass -- are enough)
+template <int kFly, int kWords, typename Use>
+__device__ __forceinline__ void pc_visit(const uint64_t (&words)[kWords], int base_word, int lane, const unsigned short* tab,
+                                         Use use) {
+#pragma unroll
+  for (int k = 0; k < kWords; ++k) {
+    uint64_t bits = words[k];
+    const int u_base = (base_word + 64 * k + lane) * 64;
+    while (bits) {
+      int u[kFly];
+      unsigned int val[kFly];
+#pragma unroll
+      for (int j = 0; j < kFly; ++j) {
+        u[j] = bits ? u_base + __builtin_ctzll(bits) : -1;
+        bits &= bits - (bits ? 1ull : 0ull);
+      }
+#pragma unroll
+      for (int j = 0; j < kFly; ++j) val[j] = u[j] >= 0 ? (unsigned int)tab[u[j]] : (unsigned int)kPcNone;
+#pragma unroll
+      for (int j = 0; j < kFly; ++j)
+        if (u[j] >= 0) use(u[j], val[j]);
+    }
+  }
+}
+constexpr int kPcFly = 2;
+
+__global__ __launch_bounds__(kPcThreads) void colour_persistent_kernel(
+    const ProbDesc* __restrict__ descs, const int32_t* __restrict__ sel, const uint64_t* __restrict__ bitmap,
+    ProbState* __restrict__ states, int32_t* __restrict__ colour, int32_t* __restrict__ log /* = tent: [sum n] */,
+    const int32_t* __restrict__ class_lists, int32_t* __restrict__ list_a, int32_t* __restrict__ list_b,
+    int32_t* __restrict__ counts, int32_t* __restrict__ xlist, uint64_t* __restrict__ colbits,
+    unsigned int* __restrict__ sync_all, int64_t total_n, int rounds, long long* __restrict__ dbg /* diagnostics or null */) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short tab[];  // 64 W entries, then two bit sets of W words
+  __shared__ unsigned long long Fs[kPcWaves][kColourMaxWords];
+  __shared__ int lostv[kPcWaves];
+  __shared__ int sh_flag;
+  const int p = sel ? sel[blockIdx.y] : (int)blockIdx.y;
+  const ProbDesc d = descs[p];
+  if (!sel && colour_not_needed(states[p], d.n)) return;  // (uniform over the problem's workgroups)
+  unsigned int* sync = sync_all + (size_t)blockIdx.y * kPcSyncInts;
+  if (__hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;  // aborted before this workgroup started
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, tid = threadIdx.x;
+  const unsigned int nwg = gridDim.x;
+  unsigned int target = 0;
+  int32_t* cnt = counts + (int64_t)blockIdx.y * (kColourRounds + 2);
+  int32_t* col = colour + d.pt_off;
+  int32_t* lg = log + d.pt_off;
+  const int lb = states[p].lb;
+  const int nw = (lb + 63) >> 6;
+  const int npad = d.W * 64;
+  unsigned long long* F = Fs[wave];
+  // `cbm` = vertices holding a colour, `bdm` = this round's bidders: a vertex ANDs its bitmap row with them and looks
+  // up only the neighbours that matter (the coloured ones when it picks a colour, the bidders when it defends its bid)
+  unsigned long long* cbm = reinterpret_cast<unsigned long long*>(tab + npad);
+  unsigned long long* bdm = cbm + d.W;
+  // the table from colour_init_kernel's colours (clique members hold 0 .. lb - 1, everybody else none)
+  for (int v = tid; v < npad; v += kPcThreads) {
+    const int c = v < d.n ? col[v] : -3;
+    tab[v] = c >= 0 ? (unsigned short)c : kPcNone;
+  }
+  for (int w = tid; w < d.W; w += kPcThreads) {
+    cbm[w] = colbits[d.w_off + w];
+    bdm[w] = 0ull;
+  }
+  __syncthreads();
+  // diagnostics (k4_debug): workgroup 0's wall clock at the phase boundaries of every round, 8 stamps a round
+  auto stamp = [&](int r, int k) {
+    if (dbg && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) dbg[r * 16 + k] = (long long)wall_clock64();
+  };
+  for (int r = 0; r < rounds; ++r) {
+    const bool cls = r < kColourClasses;
+    const int j = r - kColourClasses;
+    const int32_t* cur = (cls ? class_lists + (int64_t)r * total_n : ((j & 1) ? list_b : list_a)) + d.pt_off;
+    int32_t* nxt = (cls ? list_a : ((j & 1) ? list_a : list_b)) + d.pt_off;
+    const int count_idx = cls ? r : kColourClasses + j;
+    const int next_idx = cls ? kColourClasses : kColourClasses + j + 1;
+    const bool last = r == rounds - 1;
+    const int count = cnt[count_idx];  // (complete: its writers arrived at the previous barrier)
+    if (count == 0) {
+      if (cls) continue;  // an empty class: nothing to bid for, nothing to wait for (every workgroup sees the same count)
+      break;              // nobody is left
+    }
+    // ---- assign: the hash(v, r)-th colour no coloured neighbour holds -------------------------------------------
+    stamp(r, 0);
+    for (int it = blockIdx.x * kPcWaves + wave; it < count; it += nwg * kPcWaves) {
+      const int v = cur[it];
+      const bool probe = dbg && it == 0;
+      if (probe) {
+        asm volatile("" :: "v"(v));
+        stamp(r, 8);
+      }
+      F[lane] = 0ull;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      const uint64_t* row = bitmap + d.bm_off + (int64_t)v * d.W;
+      for (int w0 = 0; w0 < d.W; w0 += 64 * kRowWordsPerLane) {
+        uint64_t words[kRowWordsPerLane];
+#pragma unroll
+        for (int k = 0; k < kRowWordsPerLane; ++k) {
+          const int w = w0 + 64 * k + lane;
+          words[k] = w < d.W ? (row[w] & cbm[w]) : 0ull;
+        }
+        if (probe && w0 == 0) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          stamp(r, 9);
+        }
+        pc_visit<kPcFly>(words, w0, lane, tab, [&](int, unsigned int t) {
+          if (t < 0x8000u) atomicOr(&F[t >> 6], 1ull << (t & 63));
+        });
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      if (probe) stamp(r, 10);
+      unsigned long long freeb = 0ull;
+      if (lane < nw) {
+        freeb = ~F[lane];
+        const int rem = lb - lane * 64;
+        if (rem < 64) freeb &= (1ull << rem) - 1ull;
+      }
+      const int fc = __popcll(freeb);
+      int incl = fc;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+      }
+      const int total = __shfl(incl, 63, 64);
+      if (total == 0) {  // palette exhausted: v belongs to X for good
+        if (lane == 0) {
+          col[v] = -2;
+          lg[it] = -1;
+          xlist[d.pt_off + atomicAdd(&states[p].x_count, 1)] = v;
+        }
+        continue;
+      }
+      const int tgt = (int)(colour_hash(v, r, 0x1234567u) % (unsigned int)total);
+      const int excl = incl - fc;
+      if (tgt >= excl && tgt < incl) {
+        int k = tgt - excl;
+        unsigned long long b = freeb;
+        while (k-- > 0) b &= b - 1;
+        lg[it] = lane * 64 + __builtin_ctzll(b);
+      }
+      if (probe) stamp(r, 11);
+    }
+    __syncthreads();
+    stamp(r, 1);
+    if (!pc_grid_sync(sync, nwg, target, &sh_flag)) return;
+    stamp(r, 2);
+    // ---- everybody learns the round's bids ----------------------------------------------------------------------
+    for (int it0 = 0; it0 < count; it0 += 8 * kPcThreads) {  // (eight entries' loads in flight per thread)
+      int c[8], v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int it = it0 + q * kPcThreads + tid;
+        c[q] = it < count ? lg[it] : -1;
+        v[q] = it < count ? cur[it] : 0;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (c[q] >= 0) {
+          tab[v[q]] = (unsigned short)(0x8000 | c[q]);
+          atomicOr(&bdm[v[q] >> 6], 1ull << (v[q] & 63));
+        }
+    }
+    __syncthreads();
+    stamp(r, 3);
+    // ---- resolve: among adjacent bidders of one colour the highest hash priority keeps it -------------------------
+    for (int it0 = blockIdx.x * kPcWaves; it0 < count; it0 += nwg * kPcWaves) {  // (block-uniform trip count)
+      const int it = it0 + wave;
+      const int v = it < count ? cur[it] : -1;
+      const int tv = v >= 0 ? lg[it] : -1;
+      bool lose = false;
+      if (tv >= 0) {
+        const unsigned int mine = 0x8000u | (unsigned int)tv;
+        const unsigned int pv = colour_hash(v, r, 0xabcdef1u);
+        const uint64_t* row = bitmap + d.bm_off + (int64_t)v * d.W;
+        for (int w0 = 0; w0 < d.W; w0 += 64 * kRowWordsPerLane) {
+          uint64_t words[kRowWordsPerLane];
+#pragma unroll
+          for (int k = 0; k < kRowWordsPerLane; ++k) {
+            const int w = w0 + 64 * k + lane;
+            words[k] = w < d.W ? (row[w] & bdm[w]) : 0ull;
+          }
+          pc_visit<kPcFly>(words, w0, lane, tab, [&](int u, unsigned int t) {
+            if (t == mine) {
+              const unsigned int pu = colour_hash(u, r, 0xabcdef1u);
+              lose |= (pu > pv) | ((pu == pv) & (u > v));
+            }
+          });
+        }
+        const bool lost = __ballot(lose) != 0ull;
+        if (lane == 0) {
+          if (!lost) {  // the winner commits its colour
+            col[v] = tv;
+            lg[it] = tv | 0x40000000;
+            atomicOr(reinterpret_cast<unsigned long long*>(colbits + d.w_off + (v >> 6)), 1ull << (v & 63));
+          }
+          lostv[wave] = lost ? v : -1;
+        }
+      } else if (lane == 0) {
+        lostv[wave] = -1;
+      }
+      __syncthreads();
+      if (wave == 0) {  // the losers go to the next round's list (after the last round: to X)
+        const int x = lane < kPcWaves ? lostv[lane] : -1;
+        const uint64_t m = __ballot(x >= 0);
+        if (m) {
+          int base = 0;
+          if (lane == 0) base = atomicAdd(last ? &states[p].x_count : &cnt[next_idx], __builtin_popcountll(m));
+          base = __shfl(base, 0, 64);
+          if (x >= 0) (last ? xlist + d.pt_off : nxt)[base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = x;
+        }
+      }
+      __syncthreads();
+    }
+    if (last) break;
+    stamp(r, 4);
+    if (!pc_grid_sync(sync, nwg, target, &sh_flag)) return;
+    stamp(r, 5);
+    // ---- everybody learns who won: the winner's colour stays, a loser's bid goes ---------------------------------
+    for (int w = tid; w < d.W; w += kPcThreads) bdm[w] = 0ull;
+    for (int it0 = 0; it0 < count; it0 += 8 * kPcThreads) {
+      int c[8], v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int it = it0 + q * kPcThreads + tid;
+        c[q] = it < count ? lg[it] : -1;
+        v[q] = it < count ? cur[it] : 0;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (c[q] >= 0) {
+          const bool won = (c[q] & 0x40000000) != 0;
+          tab[v[q]] = won ? (unsigned short)(c[q] & 0xffff) : kPcNone;
+          if (won) atomicOr(&cbm[v[q] >> 6], 1ull << (v[q] & 63));
+        }
+    }
+    __syncthreads();
+    stamp(r, 6);
+  }
+}
+
+// behind colour_persistent_kernel: an aborted problem's survivors still without a colour all go to X
+__global__ __launch_bounds__(256) void colour_abort_kernel(const ProbDesc* __restrict__ descs, const int32_t* __restrict__ sel,
+                                                           const uint64_t* __restrict__ alive, ProbState* __restrict__ states,
+                                                           int32_t* __restrict__ colour, int32_t* __restrict__ xlist,
+                                                           const unsigned int* __restrict__ sync_all) {
+  if (__hip_atomic_load(&sync_all[(size_t)blockIdx.y * kPcSyncInts + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+  const int p = sel ? sel[blockIdx.y] : (int)blockIdx.y;
+  const ProbDesc d = descs[p];
+  if (!sel && colour_not_needed(states[p], d.n)) return;
+  for (int v = blockIdx.x * 256 + threadIdx.x; v < d.n; v += gridDim.x * 256) {
+    if (!((alive[d.w_off + (v >> 6)] >> (v & 63)) & 1ull)) continue;
+    if (colour[d.pt_off + v] != -1) continue;
+    colour[d.pt_off + v] = -2;
+    xlist[d.pt_off + atomicAdd(&states[p].x_count, 1)] = v;
+  }
+}
+
 // the per-root counters of root_prune_kernel (indexed by position in X)
 __global__ __launch_bounds__(256) void colour_finish_kernel(const ProbDesc* __restrict__ descs,
                                                             const int32_t* __restrict__ sel,
@@ -1710,6 +2031,36 @@ __global__ __launch_bounds__(256) void root_prune_kernel(const ProbDesc* __restr
   }
 }
 
+// Serialises the launches of colour_persistent_kernel of this process on a device: the stream about to launch one
+// waits for the previous one's completion event, and leaves its own.  (An event wait captures the record it sees, so
+// ONE event per device is enough.)
+namespace {
+struct ColourPersistentGate {
+  static std::mutex& mu() {
+    static std::mutex m;
+    return m;
+  }
+  static hipEvent_t& event_of(int dev) {
+    static hipEvent_t ev[64] = {};
+    return ev[dev & 63];
+  }
+  hipStream_t s;
+  int dev = 0;
+  explicit ColourPersistentGate(hipStream_t stream) : s(stream) {
+    mu().lock();
+    (void)hipGetDevice(&dev);
+    hipEvent_t& e = event_of(dev);
+    if (e) (void)hipStreamWaitEvent(s, e, 0);
+  }
+  ~ColourPersistentGate() {
+    hipEvent_t& e = event_of(dev);
+    if (!e) (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    if (e) (void)hipEventRecord(e, s);
+    mu().unlock();
+  }
+};
+}  // namespace
+
 void launch_colour_bound(hipStream_t s, const ProbDesc* d_desc, const int32_t* d_sel, int nsel,
                          int max_n, const uint64_t* d_bitmap, const uint64_t* d_alive,
                          const int32_t* d_clique, ProbState* d_state, int32_t* d_colour,
@@ -1720,12 +2071,60 @@ void launch_colour_bound(hipStream_t s, const ProbDesc* d_desc, const int32_t* d
                          int64_t total_n, int rounds) {
   if (nsel <= 0 || max_n <= 0) return;
   rounds = std::max(kColourClasses + 1, std::min(rounds, kColourRounds));
-  (void)hipMemsetAsync(d_counts, 0, sizeof(int32_t) * (size_t)nsel * (kColourRounds + 2), s);
+  (void)hipMemsetAsync(d_counts, 0, (size_t)colour_counts_bytes(nsel), s);
   uint64_t* colbits = d_bits;
   uint64_t* classbits = d_bits + total_w;
   const int gi = std::min((max_n + 255) / 256, 1024);
   hipLaunchKernelGGL(colour_init_kernel, dim3(gi, nsel), dim3(256), 0, s, d_desc, d_sel, d_alive, d_clique,
                      d_state, d_colour, d_tent, d_class_lists, d_counts, colbits, classbits, total_w, total_n);
+  // one or two large problems: every round inside ONE launch (colour_persistent_kernel)
+  const int pc_min_n = (int)setting(S_COLOUR_PERSISTENT);
+  if (pc_min_n > 0 && nsel <= 2 && max_n >= pc_min_n && max_n <= 65536) {
+    static int cus = 0;
+    if (cus == 0) {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+      if (cus <= 0) cus = 256;
+    }
+    const size_t lds = (size_t)((max_n + 63) / 64) * (64 * sizeof(unsigned short) + 16);
+    static DynLdsOptIn optin;
+    optin.ensure(reinterpret_cast<const void*>(colour_persistent_kernel), (int)lds);
+    unsigned int* sync = reinterpret_cast<unsigned int*>(d_counts + (size_t)nsel * (kColourRounds + 2));
+    long long* dbg = nullptr;
+    if (setting(S_K4_DEBUG)) {  // diagnostics only: phase clocks of workgroup 0
+      static long long* d_dbg = nullptr;
+      if (!d_dbg) (void)hipMalloc(&d_dbg, sizeof(long long) * 16 * kColourRounds);
+      dbg = d_dbg;
+      if (dbg) (void)hipMemsetAsync(dbg, 0, sizeof(long long) * 16 * kColourRounds, s);
+    }
+    {
+      ColourPersistentGate gate(s);  // one such kernel at a time per process and device: they need every CU
+      hipLaunchKernelGGL(colour_persistent_kernel, dim3(std::max(8, cus / nsel), nsel), dim3(kPcThreads), lds, s, d_desc, d_sel,
+                         d_bitmap, d_state, d_colour, d_tent, d_class_lists, d_list_a, d_list_b, d_counts, d_xlist, colbits,
+                         sync, total_n, rounds, dbg);
+    }
+    if (dbg) {
+      long long t[16 * kColourRounds];
+      (void)hipStreamSynchronize(s);
+      if (hipMemcpy(t, dbg, sizeof(t), hipMemcpyDeviceToHost) == hipSuccess) {
+        fprintf(stderr, "[teaser_hip] persistent colouring, workgroup 0, us per round: assign | barrier | bids | resolve | barrier | winners\n");
+        for (int r = 0; r < rounds && t[16 * r]; ++r)
+          fprintf(stderr, "[teaser_hip]   round %2d: %6.1f %6.1f %6.1f %6.1f %6.1f %6.1f   first vertex of wave 0: list %5.1f row %5.1f lookups %5.1f pick %5.1f\n", r, (t[16 * r + 1] - t[16 * r]) * 0.01,
+                  (t[16 * r + 2] - t[16 * r + 1]) * 0.01, (t[16 * r + 3] - t[16 * r + 2]) * 0.01, (t[16 * r + 4] - t[16 * r + 3]) * 0.01,
+                  (t[16 * r + 5] - t[16 * r + 4]) * 0.01, (t[16 * r + 6] - t[16 * r + 5]) * 0.01,
+                  (t[16 * r + 8] - t[16 * r]) * 0.01, (t[16 * r + 9] - t[16 * r + 8]) * 0.01, (t[16 * r + 10] - t[16 * r + 9]) * 0.01,
+                  (t[16 * r + 11] - t[16 * r + 10]) * 0.01);
+      }
+    }
+    hipLaunchKernelGGL(colour_abort_kernel, dim3(std::min((max_n + 255) / 256, 64), nsel), dim3(256), 0, s, d_desc, d_sel,
+                       d_alive, d_state, d_colour, d_xlist, sync);
+    hipLaunchKernelGGL(colour_finish_kernel, dim3(2, nsel), dim3(256), 0, s, d_desc, d_sel, d_state, d_tent);
+    const int max_W = (max_n + 63) / 64;
+    hipLaunchKernelGGL(root_prune_kernel, dim3(kRootPruneSlices, kRootPruneRows, nsel), dim3(256),
+                       (size_t)max_W * 8, s, d_desc, d_sel, d_bitmap, d_alive, d_state, d_xlist, d_tent);
+    return;
+  }
   // counters: [k] = class list k (k < kColourClasses), [kColourClasses + j] = leftover list of all-in round j.
   // Class round r walks class list r (an eighth of the survivors); its losers go to leftover list 0; all-in
   // round j walks leftover list j (A / B alternating) and sends its losers to list j + 1, the last one to X.

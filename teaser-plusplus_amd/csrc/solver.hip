@@ -80,6 +80,7 @@ const SettingRow kSettingRows[S_COUNT] = {
     {"deg_closure", "TEASER_HIP_DEG_CLOSURE", 1, 0, 1},
     {"greedy_small", "TEASER_HIP_GREEDY_SMALL", 1, 0, 1},
     {"deg_closure_wgs", "TEASER_HIP_DEG_CLOSURE_WGS", 0, 0, 64},
+    {"colour_persistent", "TEASER_HIP_COLOUR_PERSISTENT", 0, 0, 65536},
     {"heu_skip_closed", "TEASER_HIP_HEU_SKIP_CLOSED", 0, 0, 1},
 };
 struct SettingTable {
@@ -734,7 +735,7 @@ int32_t close_clique_bounds(teaser_hip_solver* h, int batch, int64_t total_n, bo
       HIPCHK(h, h->c_sel.ensure(4 * csel.size()));
       HIPCHK(h, h->c_list_a.ensure(4 * (size_t)total_n));
       HIPCHK(h, h->c_list_b.ensure(4 * (size_t)total_n));
-      HIPCHK(h, h->c_counts.ensure(4 * csel.size() * (size_t)(kColourRounds + 2)));
+      HIPCHK(h, h->c_counts.ensure((size_t)colour_counts_bytes((int)csel.size())));
       HIPCHK(h, h->c_bits.ensure(8 * 10 * (size_t)std::max<int64_t>(h->total_w, 1)));
       HIPCHK(h, h->c_class.ensure(4 * 8 * (size_t)total_n));
       HIPCHK(h, hipMemcpyAsync(h->c_sel.p, csel.data(), 4 * csel.size(), hipMemcpyHostToDevice, s));
@@ -961,7 +962,7 @@ int32_t enqueue_bounds_speculative(teaser_hip_solver* h, int batch, int64_t tota
   HIPCHK(h, h->c_xlist.ensure(4 * (size_t)total_n));
   HIPCHK(h, h->c_list_a.ensure(4 * (size_t)total_n));
   HIPCHK(h, h->c_list_b.ensure(4 * (size_t)total_n));
-  HIPCHK(h, h->c_counts.ensure(4 * (size_t)batch * (size_t)(kColourRounds + 2)));
+  HIPCHK(h, h->c_counts.ensure((size_t)colour_counts_bytes(batch)));
   HIPCHK(h, h->c_bits.ensure(8 * 10 * tw));
   HIPCHK(h, h->c_class.ensure(4 * 8 * (size_t)total_n));
   HIPCHK(h, h->x_probs.ensure(sizeof(ExactProb) * (size_t)batch));

@@ -686,6 +686,31 @@ def test_colouring_bound_and_restricted_roots_vs_oracle():
     assert n_exact > 0
 
 
+@pytest.mark.parametrize("n,rho,seed", [(20000, 0.985, 41), (30000, 0.99, 42), (50000, 0.99, 43)])
+def test_colouring_rounds_in_one_launch_match_the_launch_per_round_route(n, rho, seed):
+    """colour_persistent_kernel (option colour_persistent = n0 > 0: problems of at least n0 vertices; off by default --
+    measured slower) runs every colouring round inside one launch, rounds separated by a grid barrier, the
+    colour table in LDS.  Same hashes, same rule: the uncoloured set, the clique and the estimate must be those of the
+    launch-per-round kernels, bit for bit.  (Outlier degrees far above the clique size: the peel closes nothing and the
+    colouring bound is what proves the greedy clique.)"""
+    pr = tp.synth_problem(20250523 + seed, n, rho, 0.01)
+    got = {}
+    try:
+        for mode in (0, 8192):
+            tp.set_option("colour_persistent", mode)
+            s = make_solver(**bench_params())
+            sol = s.solve(pr["src"], pr["dst"])
+            raw = s.raw_solution()
+            got[mode] = (bool(sol.valid), sol.rotation.copy(), sol.translation.copy(), s.getInlierMaxClique(),
+                         int(raw.colour_uncoloured), int(raw.clique_exact_run), int(raw.heuristic_size))
+    finally:
+        tp.set_option("colour_persistent", 0)
+    a, b = got[0], got[8192]
+    assert a[0] and b[0] and a[4] >= 0, a[4:]  # the colouring stage ran
+    assert a[3] == b[3] and a[4:] == b[4:] and (a[1] == b[1]).all() and (a[2] == b[2]).all()
+    assert set(np.flatnonzero(pr["inliers"]).tolist()) <= set(a[3])
+
+
 # ---------------------------------------------------------------------------------------------
 # end-to-end
 # ---------------------------------------------------------------------------------------------
