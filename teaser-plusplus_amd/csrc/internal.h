@@ -133,6 +133,8 @@ enum Setting {
   S_DEG_CLOSURE,       // 0: no degree closure in front of the greedy heuristic          TEASER_HIP_DEG_CLOSURE
   S_GREEDY_SMALL,      // 0: no all-starts greedy for small graphs                        TEASER_HIP_GREEDY_SMALL
   S_DEG_CLOSURE_WGS,   // 0: built-in; workgroups per problem of the closure's row launch TEASER_HIP_DEG_CLOSURE_WGS
+  S_SCALE_HULL,        // > 0: the scale stage of a large problem sorts only the hull of the arg-min, up to this many % of the endpoints (0: everything) TEASER_HIP_SCALE_HULL
+  S_SCALE_HULL_SYNC,   // 1: the host reads the hull's size before the compaction (one more sync per large scale stage) TEASER_HIP_SCALE_HULL_SYNC
   S_COLOUR_PERSISTENT, // > 0: problems of at least this many vertices run all colouring rounds in one launch (0: never) TEASER_HIP_COLOUR_PERSISTENT
   S_HEU_SKIP_CLOSED,   // 1: no greedy / select / peel launches behind a batch the closure decided entirely TEASER_HIP_HEU_SKIP_CLOSED
   S_COUNT

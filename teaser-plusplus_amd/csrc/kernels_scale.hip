@@ -13,6 +13,8 @@
 //      first minimum wins, NaN never wins (registration.cc:77-78).
 // The running sums are therefore associated differently from the reference's sequential loop
 // (~1e-16 relative); the estimate is compared against the oracle at 1e-9.
+#include <algorithm>
+#include <cstdio>
 #include <cstring>
 #include <cstdint>
 
@@ -104,6 +106,10 @@ __device__ __forceinline__ unsigned int float_order_bits(float v) {
 // reaches more than kFxHalo items beyond a chunk (degenerate data: thousands of equal measurements) raises the
 // overflow flag; the host then repeats the stage with the 64-bit sort.
 constexpr int kFxHalo = 64;
+// BY_ID (the hull path: the endpoints arrive compacted in arbitrary order, and the arrays are padded with tag-0 entries up
+// to a fixed capacity): equal FP64 keys are ranked by endpoint id 2 k + (closing ? 1 : 0) -- the insertion order of the
+// reference's loop -- instead of by position.
+template <bool BY_ID>
 __global__ __launch_bounds__(kSwThreads) void tls_order_fix_kernel(
     const uint32_t* __restrict__ fk, int fk_stride, const int32_t* __restrict__ tags, const double* __restrict__ x,
     const double* __restrict__ r, int64_t m, int64_t nblk, int32_t* __restrict__ out_tags,
@@ -112,6 +118,8 @@ __global__ __launch_bounds__(kSwThreads) void tls_order_fix_kernel(
     double beta) {
   __shared__ uint32_t s_fk[kSwChunk + 2 * kFxHalo];
   __shared__ double s_kd[kSwChunk + 2 * kFxHalo];
+  __shared__ uint32_t s_id[BY_ID ? kSwChunk + 2 * kFxHalo : 1];
+  auto id_of = [](int tag) -> uint32_t { return tag > 0 ? 2u * (uint32_t)(tag - 1) : 2u * (uint32_t)(-tag - 1) + 1u; };
   int64_t trim0 = 0;  // first TRIM of this problem (tags are global in a batch)
   if (segs) {
     const ScaleSeg sg = segs[blockIdx.y];
@@ -157,6 +165,9 @@ __global__ __launch_bounds__(kSwThreads) void tls_order_fix_kernel(
     if (tg[e] != 0) {
       s_fk[li] = fk[pos * fk_stride];
       s_kd[li] = tg[e] > 0 ? xr[e].x - xr[e].y : xr[e].x + xr[e].y;  // the endpoint kernels' s - a / s + a
+      if (BY_ID) s_id[li] = id_of(tg[e]);
+    } else if (BY_ID && pos < m) {
+      s_fk[li] = 0xffffffffu;  // padding: no key of a real endpoint (the pad keys are 0x7f7f7f7f)
     }
   }
   if (threadIdx.x < 2 * kFxHalo) {  // the halos
@@ -164,15 +175,26 @@ __global__ __launch_bounds__(kSwThreads) void tls_order_fix_kernel(
     const int64_t pos = lo + li;
     if (pos >= 0 && pos < m) {
       const int t = tags[pos];
-      const double2 v = measure(t);
-      s_fk[li] = fk[pos * fk_stride];
-      s_kd[li] = t > 0 ? v.x - v.y : v.x + v.y;
+      if (!BY_ID || t != 0) {
+        const double2 v = measure(t);
+        s_fk[li] = fk[pos * fk_stride];
+        s_kd[li] = t > 0 ? v.x - v.y : v.x + v.y;
+        if (BY_ID) s_id[li] = id_of(t);
+      } else {
+        s_fk[li] = 0xffffffffu;
+      }
     }
   }
   __syncthreads();
   bool over = false;
   for (int e = 0; e < kSwPer; ++e) {
-    if (tg[e] == 0) continue;
+    if (tg[e] == 0) {
+      if (BY_ID) {  // padding stays padding (the sweep skips tag 0)
+        const int64_t ppos = c0 + threadIdx.x + (int64_t)e * kSwThreads;
+        if (ppos < m) out_tags[ppos] = 0;
+      }
+      continue;
+    }
     const int li = kFxHalo + threadIdx.x + e * kSwThreads;
     const int64_t pos = lo + li;
     const uint32_t f = s_fk[li];
@@ -180,16 +202,442 @@ __global__ __launch_bounds__(kSwThreads) void tls_order_fix_kernel(
     int shift = 0;
     // items of the run in front of this one that must end up behind it (strictly larger key) ...
     int j = li - 1;
-    for (; j >= 0 && lo + j >= 0 && s_fk[j] == f; --j) shift -= s_kd[j] > kd ? 1 : 0;
+    const uint32_t my_id = BY_ID ? s_id[li] : 0u;
+    for (; j >= 0 && lo + j >= 0 && s_fk[j] == f; --j)
+      shift -= (s_kd[j] > kd || (BY_ID && s_kd[j] == kd && s_id[j] > my_id)) ? 1 : 0;
     if (j < 0 && lo + j >= 0) over = true;  // the run continues beyond the halo
     // ... and behind it that must end up in front (strictly smaller key)
     j = li + 1;
-    for (; j < kSwChunk + 2 * kFxHalo && lo + j < m && s_fk[j] == f; ++j) shift += s_kd[j] < kd ? 1 : 0;
+    for (; j < kSwChunk + 2 * kFxHalo && lo + j < m && s_fk[j] == f; ++j)
+      shift += (s_kd[j] < kd || (BY_ID && s_kd[j] == kd && s_id[j] < my_id)) ? 1 : 0;
     if (j >= kSwChunk + 2 * kFxHalo && lo + j < m) over = true;
     out_tags[pos + shift] = tg[e];
     out_xr[pos + shift] = xr[e];
   }
   if (over) *overflow = 1;
+}
+
+// ------------------------------------------------------------------------------------------
+// Hull of the arg-min (setting scale_hull, large single problems): the sweep of registration.cc:58-78 needs the
+// endpoints in exact order only where the minimum can be.  cost(e) = SS(I_e) + R_total - S(e), S(e) = the summed ranges
+// of the consensus set I_e, SS its sum of squares about x_hat, so inside a value bin b
+//     cost >= R_total - (S at the bin's start + the ranges of the openers inside b) + SS_mean(members at the start that
+//             do not close inside b)
+// (the consensus set only grows by the bin's openers; the sum of squares about the mean never falls when members are
+// added, and it is below the sum about any other point).  Bins whose bound exceeds ONE achieved cost cannot hold the
+// minimum; the rest, first to last, is the hull [t_lo, t_hi): only its endpoints are sorted, order-fixed and swept, from
+// the exact state in front of t_lo.  Four passes regenerate the TRIMs from the points (nothing is stored per TRIM):
+//   hull_hist_kernel   per bin, openers and closers apart: ranges (openers rounded up, closers down), counts, and --
+//                      for the measurements within kHullSpan of the centre -- count, sum, sum of squares; 64-bit
+//                      FIXED-POINT integers in LDS, merged by integer atomics: sums that do not depend on any order
+//   hull_eval_kernel   the achieved cost: the consensus set in front of the boundary of the largest S, summed in FP64 in
+//                      a fixed order (rows, then a fixed tree)
+//   hull_plan_kernel   bounds, hull, its size against the capacity of the compacted arrays
+//   hull_emit_kernel   the hull's endpoints (float key, tag) compacted in arbitrary order -- the order-fix pass then ranks
+//                      equal keys by ENDPOINT ID, i.e. insertion order, instead of by position -- and, per row, the state
+//                      contribution of everything in front of the hull
+// Anything unusual (a range beyond kHullRangeCap, a non-finite measurement, a hull larger than the capacity, no finite
+// cost) raises the problem's overflow flag and the host repeats the stage on the full 64-bit sort, like a float-key run
+// too long to fix.  Sized before it was built: scripts/probe/scale_hull_model.py (profiles/r6b/scale_hull_model.txt).
+// ------------------------------------------------------------------------------------------
+constexpr int kHullBins = 2048;
+constexpr int kHullTail = 256;               // geometric bins above 4 c (c = ratio of the clouds' RMS sizes)
+constexpr double kHullRangeCap = 1024.0;     // ranges are accumulated with 20 fractional bits
+constexpr double kHullSpan = 64.0;           // |x - c| <= kHullSpan c takes part in the sums of squares
+constexpr int kHullThreads = 1024;
+struct HullPlan {
+  double c;            // centre of the measurements (ratio of the RMS sizes of dst and src)
+  double t0;           // boundary whose consensus set gives the achieved cost
+  double ub;           // that cost
+  double r_total;      // sum of all ranges
+  double t_lo, t_hi;   // the hull
+  long long hull_items;
+  int first_bin, last_bin;
+  int anomalies;       // measurements the histograms cannot take
+  int failed;          // 1: no hull (the caller's overflow flag is raised as well)
+  unsigned int emitted;  // (filled by hull_init_kernel: the sum of the shard counters)
+  int pad;
+};
+// The compacted arrays are cut into kHullShards equal shards, row i appends to shard i mod kHullShards: one atomic
+// per wave and 256 rows of pairs on ONE counter serialised in L2 (7.8e5 returning atomics: 8.9 ms for a pass whose
+// arithmetic takes 0.2); a shard that fills up fails the hull (the rows are spread evenly: it takes a hull within a few
+// per cent of the capacity).  Unused slots keep their padding (tag 0), which the sort moves behind every real key.
+constexpr int kHullShards = 256;  // (a power of two)
+// histograms, [kind][bin]: 0 / 1 ranges of openers (rounded up) / closers (rounded down); 2 / 3 counts, 4 / 5 sums, 6 / 7
+// sums of squares of the openers / closers within the span (8 x 16 KB + the 16 KB table: one workgroup per CU)
+constexpr int kHullKinds = 8;
+
+__device__ __forceinline__ int hull_bin(const double* __restrict__ T, double v) {  // largest b with T[b] <= v (T[0] = -inf)
+  int lo = 0, hi = kHullBins;  // invariant: T[lo] <= v < T[hi] (T[kHullBins] = +inf); NaN ends in the last bin
+  if (!(v == v)) return kHullBins - 1;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (T[mid] <= v) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(256) void hull_table_kernel(const double* __restrict__ src, const double* __restrict__ dst, int n,
+                                                         double* __restrict__ T, HullPlan* __restrict__ plan) {
+  __shared__ double red[4][8];
+  // centre: sqrt(sum |d - mean d|^2 / sum |s - mean s|^2) from one-pass sums (only a location for the bins: any positive
+  // value gives a correct result)
+  double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int p = threadIdx.x; p < n; p += 256) {
+    for (int k = 0; k < 3; ++k) {
+      const double sv = src[3 * p + k], dv = dst[3 * p + k];
+      a[k] += sv;
+      a[3 + k] += dv;
+      a[6] += sv * sv;
+      a[7] += dv * dv;
+    }
+  }
+  for (int q = 0; q < 8; ++q) {
+    double v = a[q];
+    for (int off = 32; off > 0; off >>= 1) v += shfl_down_d(v, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][q] = v;
+  }
+  __syncthreads();
+  __shared__ double c_sh;
+  if (threadIdx.x == 0) {
+    double t[8];
+    for (int q = 0; q < 8; ++q) t[q] = red[0][q] + red[1][q] + red[2][q] + red[3][q];
+    const double vs = t[6] - (t[0] * t[0] + t[1] * t[1] + t[2] * t[2]) / n;
+    const double vd = t[7] - (t[3] * t[3] + t[4] * t[4] + t[5] * t[5]) / n;
+    double c = __builtin_sqrt(vd / vs);
+    if (!(c > 1e-300 && c < 1e300)) c = 1.0;
+    c_sh = c;
+    plan->c = c;
+    plan->anomalies = 0;
+    plan->failed = 0;
+    plan->emitted = 0u;
+    plan->hull_items = 0;
+  }
+  __syncthreads();
+  const double c = c_sh;
+  constexpr int kLin = kHullBins - kHullTail;
+  for (int b = threadIdx.x; b <= kHullBins; b += 256) {
+    double v;
+    if (b == 0) v = -INFINITY;
+    else if (b == kHullBins) v = INFINITY;
+    else if (b <= kLin) v = (4.0 * c) * ((double)b / kLin);
+    else v = (4.0 * c) * exp(log(2500.0) * ((double)(b - kLin) / kHullTail));
+    T[b] = v;
+  }
+}
+
+__global__ __launch_bounds__(kHullThreads) void hull_hist_kernel(const double* __restrict__ src, const double* __restrict__ dst,
+                                                                 int n, double beta, const double* __restrict__ T_g,
+                                                                 HullPlan* __restrict__ plan,
+                                                                 unsigned long long* __restrict__ hist /* [kHullKinds][kHullBins] */) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long lh[];  // [kHullKinds][kHullBins], then the table
+  double* T = reinterpret_cast<double*>(lh + kHullKinds * kHullBins);
+  for (int k = threadIdx.x; k < kHullKinds * kHullBins; k += kHullThreads) lh[k] = 0ull;
+  for (int k = threadIdx.x; k <= kHullBins; k += kHullThreads) T[k] = T_g[k];
+  __syncthreads();
+  const double c = plan->c;
+  int bad = 0;
+  for (int i = blockIdx.x; i < n - 1; i += gridDim.x) {
+    for (int j = i + 1 + threadIdx.x; j < n; j += kHullThreads) {
+      double sv, av;
+      trim_terms(src, dst, i, j, beta, &sv, &av);
+      if (!(av >= 0.0 && av <= kHullRangeCap) || !(sv == sv) || !(sv < INFINITY && sv > -INFINITY)) {
+        ++bad;
+        continue;
+      }
+      const double lo = sv - av, hi = sv + av;  // (the endpoint kernels' keys)
+      const int bo = hull_bin(T, lo), bc = hull_bin(T, hi);
+      const double rq = av * 1048576.0;  // 2^20
+      const unsigned long long r_up = (unsigned long long)__builtin_ceil(rq), r_dn = (unsigned long long)__builtin_floor(rq);
+      atomicAdd(&lh[0 * kHullBins + bo], r_up);
+      atomicAdd(&lh[1 * kHullBins + bc], r_dn);
+      const double xc = sv - c;
+      if (__builtin_fabs(xc) <= kHullSpan * c) {
+        // centred, scaled by c: |xs| <= 64; 2^40 and 2^30 steps: sums of 5e7 terms stay below 2^63
+        const double xs = xc / c;
+        const long long xq = (long long)__builtin_rint(xs * 1099511627776.0);         // 2^40
+        const long long xxq = (long long)__builtin_rint(xs * xs * 1073741824.0);      // 2^30
+        atomicAdd(&lh[2 * kHullBins + bo], 1ull);
+        atomicAdd(&lh[3 * kHullBins + bc], 1ull);
+        atomicAdd(&lh[4 * kHullBins + bo], (unsigned long long)xq);
+        atomicAdd(&lh[5 * kHullBins + bc], (unsigned long long)xq);
+        atomicAdd(&lh[6 * kHullBins + bo], (unsigned long long)xxq);
+        atomicAdd(&lh[7 * kHullBins + bc], (unsigned long long)xxq);
+      }
+    }
+  }
+  __syncthreads();
+  for (int k = threadIdx.x; k < kHullKinds * kHullBins; k += kHullThreads) {
+    const unsigned long long v = lh[k];
+    if (v) atomicAdd(&hist[k], v);
+  }
+  if (bad) atomicAdd(&plan->anomalies, bad);
+}
+
+// Partial state sums of one row of pairs, reduced over the workgroup in a fixed shape (thread order inside a wave by a
+// shuffle tree, then the waves in order): kind = which endpoints take part
+//   hull_eval_kernel: the consensus set in front of t0 (opened before t0, not closed before t0), + the sum of all ranges
+//   hull_emit_kernel: every endpoint in front of t_lo, with its sign
+template <int kThreads>
+__device__ __forceinline__ void hull_block_reduce(double (&a)[7], double (*red)[7], double* out) {
+  for (int q = 0; q < 7; ++q) {
+    double v = a[q];
+    for (int off = 32; off > 0; off >>= 1) v += shfl_down_d(v, off);
+    a[q] = v;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0)
+    for (int q = 0; q < 7; ++q) red[wave][q] = a[q];
+  __syncthreads();
+  if (threadIdx.x < 7) {
+    double v = 0;
+    for (int w = 0; w < kThreads / 64; ++w) v += red[w][threadIdx.x];
+    out[threadIdx.x] = v;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void hull_eval_kernel(const double* __restrict__ src, const double* __restrict__ dst, int n,
+                                                        double beta, const HullPlan* __restrict__ plan,
+                                                        double* __restrict__ rows /* [n - 1][7] */) {
+  __shared__ double red[4][7];
+  const int i = blockIdx.x;
+  const double t0 = plan->t0;
+  double a[7] = {0, 0, 0, 0, 0, 0, 0};
+  for (int j = i + 1 + threadIdx.x; j < n; j += 256) {
+    double sv, av;
+    trim_terms(src, dst, i, j, beta, &sv, &av);
+    a[6] += av;
+    if (sv - av < t0 && !(sv + av < t0)) {
+      const double w = 1.0 / (av * av);
+      a[0] += 1.0;
+      a[1] += w;
+      a[2] += w * sv;
+      a[3] += av;
+      a[4] += sv;
+      a[5] += sv * sv;
+    }
+  }
+  hull_block_reduce<256>(a, red, rows + (size_t)i * 7);
+}
+
+// rows[r][7] summed over r in a fixed order (the first 256 threads: contiguous row ranges in thread order, then the threads in order)
+constexpr int kHullRowThreads = 256;
+__device__ __forceinline__ void hull_rows_total(const double* __restrict__ rows, int nrows, double (*tot)[7], double* out7) {
+  const int t = threadIdx.x;
+  const int L = (nrows + kHullRowThreads - 1) / kHullRowThreads;
+  if (t < kHullRowThreads) {
+    double a[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int r = t * L; r < nrows && r < (t + 1) * L; ++r)
+      for (int q = 0; q < 7; ++q) a[q] += rows[(size_t)r * 7 + q];
+    for (int q = 0; q < 7; ++q) tot[t][q] = a[q];
+  }
+  __syncthreads();
+  if (t < 7) {
+    double v = 0;
+    for (int k = 0; k < kHullRowThreads; ++k) v += tot[k][t];
+    out7[t] = v;
+  }
+  __syncthreads();
+}
+
+// phase 0: the boundary in front of which the summed ranges of the consensus set are largest (-> t0);
+// phase 1: the achieved cost, the bounds, the hull
+__global__ __launch_bounds__(kHullThreads) void hull_plan_kernel(int phase, const unsigned long long* __restrict__ hist,
+                                                                 long long* __restrict__ pre /* [4][kHullBins] */,
+                                                                 const double* __restrict__ T, const double* __restrict__ rows,
+                                                                 int nrows, HullPlan* __restrict__ plan,
+                                                                 int32_t* __restrict__ overflow) {
+  // pre: exclusive prefix of (openers - closers) per bin: ranges, and -- within the span -- count, sum, sum of squares
+  __shared__ double tot[kHullRowThreads][7];
+  __shared__ double acc7[7];
+  __shared__ int cand_first, cand_last;
+  __shared__ unsigned long long red64[kHullThreads / 64];
+  const int t = threadIdx.x;
+  if (plan->anomalies != 0 || plan->failed) {
+    if (t == 0) {
+      plan->failed = 1;
+      *overflow = 1;
+    }
+    return;
+  }
+  if (phase == 0) {
+    if (t < 4) {  // one thread per kind: 2048 integer adds
+      const int ko = 2 * t, kc = ko + 1;
+      long long acc = 0;
+      for (int b = 0; b < kHullBins; ++b) {
+        pre[t * kHullBins + b] = acc;
+        acc += (long long)hist[ko * kHullBins + b] - (long long)hist[kc * kHullBins + b];
+      }
+    }
+    __syncthreads();
+    // first bin with the largest start value
+    unsigned long long best = 0;
+    for (int b = t; b < kHullBins; b += kHullThreads) {
+      const long long v = pre[b] < 0 ? 0 : pre[b];
+      const unsigned long long key = ((unsigned long long)v << 11) | (unsigned long long)(kHullBins - 1 - b);
+      best = key > best ? key : best;
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      const unsigned long long o = __shfl_down(best, off, 64);
+      best = o > best ? o : best;
+    }
+    if ((t & 63) == 0) red64[t >> 6] = best;
+    __syncthreads();
+    if (t == 0) {
+      for (int w = 1; w < kHullThreads / 64; ++w) best = red64[w] > best ? red64[w] : best;
+      int b0 = kHullBins - 1 - (int)(best & 2047ull);
+      if (b0 < 1) b0 = 1;  // (T[0] = -inf: nothing in front of it)
+      plan->t0 = T[b0];
+    }
+    return;
+  }
+  hull_rows_total(rows, nrows, tot, acc7);
+  if (t == 0) {
+    cand_first = kHullBins;
+    cand_last = -1;
+    const double cnt = acc7[0], w = acc7[1], wx = acc7[2], rin = acc7[3], sx = acc7[4], sxx = acc7[5], rtot = acc7[6];
+    const double xh = wx / w;
+    const double ub = (cnt * xh * xh + sxx - 2 * sx * xh) + (rtot - rin);  // registration.cc:69-72
+    plan->ub = ub;
+    plan->r_total = rtot;
+  }
+  __syncthreads();
+  const double ub = plan->ub, rtot = plan->r_total, c = plan->c;
+  if (!(ub < INFINITY) || !(ub == ub) || !(acc7[0] > 0.0)) {
+    if (t == 0) {
+      plan->failed = 1;
+      *overflow = 1;
+    }
+    return;
+  }
+  // every sum below errs on the safe side: ranges of openers were rounded up and of closers down, the squares carry
+  // their worst-case rounding, and the comparison a relative margin far above FP64's own noise in the sweep
+  const double margin = 1e-9 * __builtin_fabs(ub) + 1e-9 * rtot + 1e-6;
+  for (int b = t; b < kHullBins; b += kHullThreads) {
+    const double s_hat = ((double)pre[b] + (double)hist[0 * kHullBins + b]) * (1.0 / 1048576.0);
+    const long long nc = pre[1 * kHullBins + b] - (long long)hist[3 * kHullBins + b];
+    double ss = 0.0;
+    if (nc > 1) {
+      const double s1 = (double)(pre[2 * kHullBins + b] - (long long)hist[5 * kHullBins + b]) * (1.0 / 1099511627776.0);
+      const double s2 = (double)(pre[3 * kHullBins + b] - (long long)hist[7 * kHullBins + b]) * (1.0 / 1073741824.0);
+      const double err = (double)nc * (1.0 / 1073741824.0) + 2.0 * __builtin_fabs(s1) * (1.0 / 1099511627776.0) + 1e-9 * s2;
+      ss = (s2 - s1 * s1 / (double)nc - err) * (c * c);  // (the sums are in units of c)
+      if (!(ss > 0.0)) ss = 0.0;
+    }
+    const double lb = rtot - s_hat + ss;
+    if (lb <= ub + margin) {
+      atomicMin(&cand_first, b);
+      atomicMax(&cand_last, b);
+    }
+  }
+  __syncthreads();
+  if (t == 0) {
+    const int f = cand_first, l = cand_last;
+    if (l < f) {  // cannot be (the bin in front of t0 is a candidate); be safe
+      plan->failed = 1;
+      *overflow = 1;
+      return;
+    }
+    plan->first_bin = f;
+    plan->last_bin = l;
+    plan->t_lo = T[f];
+    plan->t_hi = T[l + 1];
+    // how many endpoints the hull holds, to within the few whose measurement lies outside the span (the host sizes the
+    // compacted arrays from it, with slack; the shards' own check is what guards them)
+    long long est = 0;
+    for (int b = f; b <= l; ++b) est += (long long)hist[2 * kHullBins + b] + (long long)hist[3 * kHullBins + b];
+    plan->hull_items = est;
+  }
+}
+
+__global__ __launch_bounds__(256) void hull_emit_kernel(const double* __restrict__ src, const double* __restrict__ dst, int n,
+                                                        double beta, HullPlan* __restrict__ plan, float* __restrict__ fkeys,
+                                                        int32_t* __restrict__ tags, double* __restrict__ rows /* [n - 1][7] */,
+                                                        long long cap_items, unsigned int* __restrict__ shard_count) {
+  __shared__ double red[4][7];
+  const int i = blockIdx.x;
+  const long long shard_items = cap_items / kHullShards;
+  // rows get shorter with i: shards are assigned in snake order (0 .. 255, 255 .. 0, ...) so that every shard takes
+  // the same share of long and short rows (i mod 256 alone leaves the first shard 5 % fuller than the last)
+  const int shard = ((i / kHullShards) & 1) ? kHullShards - 1 - (i % kHullShards) : (i % kHullShards);
+  const long long shard_base = (long long)shard * shard_items;
+  unsigned int* counter = shard_count + shard;
+  const bool failed = plan->failed != 0;
+  const double t_lo = plan->t_lo, t_hi = plan->t_hi;
+  const int64_t seg = (int64_t)i * n - (int64_t)i * (i + 1) / 2;
+  double a[7] = {0, 0, 0, 0, 0, 0, 0};
+  const int lane = threadIdx.x & 63;
+  for (int j0 = i + 1; j0 < n && !failed; j0 += 256) {  // (block-uniform trip count: ballots inside)
+    const int j = j0 + threadIdx.x;
+    double sv = 0, av = 1, lo = 0, hi = 0;
+    bool in_lo = false, in_hi = false;
+    if (j < n) {
+      trim_terms(src, dst, i, j, beta, &sv, &av);
+      lo = sv - av;
+      hi = sv + av;
+      in_lo = lo >= t_lo && lo < t_hi;
+      in_hi = hi >= t_lo && hi < t_hi;
+      const double w = 1.0 / (av * av);
+      if (lo < t_lo) {  // an opener in front of the hull
+        a[0] += 1.0; a[1] += w; a[2] += w * sv; a[3] += av; a[4] += sv; a[5] += sv * sv;
+      }
+      if (hi < t_lo) {  // ... and a closer
+        a[0] -= 1.0; a[1] -= w; a[2] -= w * sv; a[3] -= av; a[4] -= sv; a[5] -= sv * sv;
+      }
+    }
+    const int mine = (in_lo ? 1 : 0) + (in_hi ? 1 : 0);
+    // one reservation per wave
+    int incl = mine;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += up;
+    }
+    const int wtot = __shfl(incl, 63, 64);
+    unsigned int base = 0;
+    if (lane == 0 && wtot) base = atomicAdd(counter, (unsigned int)wtot);
+    base = (unsigned int)__shfl((int)base, 0, 64);
+    long long pos = (long long)base + (incl - mine);
+    const int64_t k = seg + (j - i - 1);
+    if (in_lo && pos < shard_items) {
+      fkeys[shard_base + pos] = (float)lo;
+      tags[shard_base + pos] = (int)(k + 1);
+    }
+    pos += in_lo ? 1 : 0;
+    if (in_hi && pos < shard_items) {
+      fkeys[shard_base + pos] = (float)hi;
+      tags[shard_base + pos] = -(int)(k + 1);
+    }
+  }
+  hull_block_reduce<256>(a, red, rows + (size_t)i * 7);
+}
+
+// the state in front of the hull: the rows' contributions in a fixed order -> init[0..5]; init[6] = the sum of all ranges;
+// more endpoints in the hull than the compacted arrays hold: the stage is repeated on the full sort
+__global__ __launch_bounds__(kHullThreads) void hull_init_kernel(const double* __restrict__ rows, int nrows,
+                                                                 HullPlan* __restrict__ plan, double* __restrict__ init,
+                                                                 long long cap_items, const unsigned int* __restrict__ shard_count,
+                                                                 int32_t* __restrict__ overflow) {
+  __shared__ double tot[kHullRowThreads][7];
+  __shared__ double acc7[7];
+  hull_rows_total(rows, nrows, tot, acc7);
+  if (threadIdx.x < 6) init[threadIdx.x] = acc7[threadIdx.x];
+  if (threadIdx.x == 6) init[6] = plan->r_total;
+  if (threadIdx.x == 0) {
+    const long long shard_items = cap_items / kHullShards;
+    long long total = 0;
+    bool full = false;
+    for (int k = 0; k < kHullShards; ++k) {
+      total += shard_count[k];
+      full |= (long long)shard_count[k] > shard_items;
+    }
+    plan->hull_items = total;
+    plan->emitted = (unsigned int)total;
+    if (plan->failed || full || total == 0) {
+      plan->failed = 1;
+      *overflow = 1;
+    }
+  }
 }
 
 // One row of pairs per workgroup (row i, columns j > i), like trims_kernel, plus the endpoints.
@@ -335,7 +783,9 @@ __global__ __launch_bounds__(kSwThreads) void tls_sweep_totals_kernel(
 __global__ __launch_bounds__(1024) void tls_sweep_scan_kernel(double* __restrict__ partials,
                                                               int64_t nblk,
                                                               double* __restrict__ out,
-                                                              const ScaleSeg* __restrict__ segs) {
+                                                              const ScaleSeg* __restrict__ segs,
+                                                              const double* __restrict__ init = nullptr /* hull path: the
+                                                              state in front of the first endpoint [0..5], sum of all ranges [6] */) {
   __shared__ double tot[1024];
   const int t = threadIdx.x, q = blockIdx.y;
   if (segs) {  // batch: blockIdx.x = problem slot
@@ -354,13 +804,13 @@ __global__ __launch_bounds__(1024) void tls_sweep_scan_kernel(double* __restrict
   }
   __syncthreads();
   if (t == 0) {
-    double acc = 0;
+    double acc = (init && q < 6) ? init[q] : 0;
     for (int k = 0; k < 1024; ++k) {
       const double v = tot[k];
       tot[k] = acc;
       acc += v;
     }
-    if (q == 6) out[0] = acc;
+    if (q == 6) out[0] = init ? init[6] : acc;
   }
   __syncthreads();
   double acc = tot[t];
@@ -500,7 +950,8 @@ __global__ __launch_bounds__(kSwThreads) void tls_sweep_cost_kernel(
 __global__ __launch_bounds__(1024) void tls_sweep_argmin_kernel(
     const double* __restrict__ best_cost, const double* __restrict__ best_hat,
     const int64_t* __restrict__ best_pos, int64_t nblk, const double* __restrict__ first_hat,
-    double* __restrict__ est, const ScaleSeg* __restrict__ segs, int64_t est_stride) {
+    double* __restrict__ est, const ScaleSeg* __restrict__ segs, int64_t est_stride,
+    int32_t* __restrict__ hull_overflow = nullptr /* hull path: raised when no endpoint of the hull has a finite cost */) {
   __shared__ double bc[16], bh[16];
   __shared__ int64_t bp[16];
   if (segs) {  // batch: one workgroup per problem slot; est = the scale field of problem 0's record
@@ -548,6 +999,7 @@ __global__ __launch_bounds__(1024) void tls_sweep_argmin_kernel(
       }
     // no finite cost anywhere: the reference's minCoeff lands on index 0
     est[0] = (c < INFINITY) ? h : first_hat[0];
+    if (hull_overflow && !(c < INFINITY)) *hull_overflow = 1;
   }
 }
 
@@ -643,25 +1095,38 @@ Work carve(char* ws, int64_t n) {
 inline float* fkeys0(const Work& w) { return reinterpret_cast<float*>(w.keys[0]); }
 inline float* fkeys1(const Work& w, int64_t m) { return reinterpret_cast<float*>(w.keys[0]) + ((m + 63) & ~(int64_t)63); }
 
+// hull path: the endpoint arrays hold `items` (capacity, padded with tag 0) compacted endpoints of the hull, `init` the
+// state in front of it and the sum of all ranges
+struct HullRun {
+  int64_t items;
+  const double* init;
+};
 hipError_t sort_and_sweep(hipStream_t s, const Work& w, const double* d_x, const double* d_r,
                           int64_t n, double* d_est, int32_t* d_overflow, const double* d_src = nullptr,
-                          const double* d_dst = nullptr, int n_pts = 0, double beta = 0.0) {
-  const int64_t m = 2 * n;
+                          const double* d_dst = nullptr, int n_pts = 0, double beta = 0.0, const HullRun* hull = nullptr) {
+  const int64_t m_full = 2 * n;
+  const int64_t m = hull ? hull->items : m_full;
+  const int64_t nblk = hull ? (m + kSwChunk - 1) / kSwChunk : w.nblk;
   const int32_t* tags = nullptr;
   const double2* sorted_xr = nullptr;
   size_t tmp = w.sort_tmp_bytes;
   if (d_overflow) {
-    rocprim::double_buffer<float> kb(fkeys0(w), fkeys1(w, m));
+    rocprim::double_buffer<float> kb(fkeys0(w), fkeys1(w, m_full));
     rocprim::double_buffer<int32_t> vb(w.tags[0], w.tags[1]);
     hipError_t e = rocprim::radix_sort_pairs(w.sort_tmp, tmp, kb, vb, (size_t)m, 0, 32, s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(tls_order_fix_kernel, dim3((unsigned)w.nblk), dim3(kSwThreads), 0, s,
-                       reinterpret_cast<const uint32_t*>(kb.current()), 1, vb.current(), d_x, d_r, m, w.nblk, vb.alternate(),
-                       w.xr_sorted, d_overflow, (int64_t)0, static_cast<const ScaleSeg*>(nullptr), d_src, d_dst, n_pts, beta);
+    if (hull)
+      hipLaunchKernelGGL(tls_order_fix_kernel<true>, dim3((unsigned)nblk), dim3(kSwThreads), 0, s,
+                         reinterpret_cast<const uint32_t*>(kb.current()), 1, vb.current(), d_x, d_r, m, nblk, vb.alternate(),
+                         w.xr_sorted, d_overflow, (int64_t)0, static_cast<const ScaleSeg*>(nullptr), d_src, d_dst, n_pts, beta);
+    else
+      hipLaunchKernelGGL(tls_order_fix_kernel<false>, dim3((unsigned)nblk), dim3(kSwThreads), 0, s,
+                         reinterpret_cast<const uint32_t*>(kb.current()), 1, vb.current(), d_x, d_r, m, nblk, vb.alternate(),
+                         w.xr_sorted, d_overflow, (int64_t)0, static_cast<const ScaleSeg*>(nullptr), d_src, d_dst, n_pts, beta);
     tags = vb.alternate();
     sorted_xr = w.xr_sorted;
-    hipLaunchKernelGGL(tls_sweep_totals_kernel, dim3((unsigned)w.nblk), dim3(kSwThreads), 0, s, tags,
-                       static_cast<const double*>(nullptr), static_cast<const double*>(nullptr), m, w.nblk, w.partials,
+    hipLaunchKernelGGL(tls_sweep_totals_kernel, dim3((unsigned)nblk), dim3(kSwThreads), 0, s, tags,
+                       static_cast<const double*>(nullptr), static_cast<const double*>(nullptr), m, nblk, w.partials,
                        w.xr_sorted, static_cast<const ScaleSeg*>(nullptr));
   } else {
     rocprim::double_buffer<double> kb(w.keys[0], w.keys[1]);
@@ -673,16 +1138,17 @@ hipError_t sort_and_sweep(hipStream_t s, const Work& w, const double* d_x, const
     // measurements in sorted order (2 x 8 -> 16 bytes per endpoint)
     double2* out_xr = reinterpret_cast<double2*>(w.keys[0]);
     sorted_xr = out_xr;
-    hipLaunchKernelGGL(tls_sweep_totals_kernel, dim3((unsigned)w.nblk), dim3(kSwThreads), 0, s, tags,
-                       d_x, d_r, m, w.nblk, w.partials, out_xr, static_cast<const ScaleSeg*>(nullptr));
+    hipLaunchKernelGGL(tls_sweep_totals_kernel, dim3((unsigned)nblk), dim3(kSwThreads), 0, s, tags,
+                       d_x, d_r, m, nblk, w.partials, out_xr, static_cast<const ScaleSeg*>(nullptr));
   }
-  hipLaunchKernelGGL(tls_sweep_scan_kernel, dim3(1, kNumAcc), dim3(1024), 0, s, w.partials, w.nblk,
-                     w.scalars, static_cast<const ScaleSeg*>(nullptr));
-  hipLaunchKernelGGL(tls_sweep_cost_kernel, dim3((unsigned)w.nblk), dim3(kSwThreads), 0, s, tags,
-                     sorted_xr, m, w.nblk, w.partials, w.scalars, w.best_cost, w.best_hat,
+  hipLaunchKernelGGL(tls_sweep_scan_kernel, dim3(1, kNumAcc), dim3(1024), 0, s, w.partials, nblk,
+                     w.scalars, static_cast<const ScaleSeg*>(nullptr), hull ? hull->init : static_cast<const double*>(nullptr));
+  hipLaunchKernelGGL(tls_sweep_cost_kernel, dim3((unsigned)nblk), dim3(kSwThreads), 0, s, tags,
+                     sorted_xr, m, nblk, w.partials, w.scalars, w.best_cost, w.best_hat,
                      w.best_pos, w.scalars + 1, static_cast<const ScaleSeg*>(nullptr));
   hipLaunchKernelGGL(tls_sweep_argmin_kernel, dim3(1), dim3(1024), 0, s, w.best_cost, w.best_hat,
-                     w.best_pos, w.nblk, w.scalars + 1, d_est, static_cast<const ScaleSeg*>(nullptr), (int64_t)0);
+                     w.best_pos, nblk, w.scalars + 1, d_est, static_cast<const ScaleSeg*>(nullptr), (int64_t)0,
+                     hull ? d_overflow : static_cast<int32_t*>(nullptr));
   return hipGetLastError();
 }
 }  // namespace
@@ -801,7 +1267,7 @@ hipError_t launch_tls_scale_batch(hipStream_t s, const double* d_src, const doub
     rocprim::double_buffer<int32_t> vb(w.tags[0], w.tags[1]);
     e = rocprim::radix_sort_pairs(w.sort_tmp, tmp, kb, vb, (size_t)m, 0, (unsigned)(32 + bits), s);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(tls_order_fix_kernel, dim3((unsigned)max_nblk, (unsigned)count), dim3(kSwThreads), 0, s,
+    hipLaunchKernelGGL(tls_order_fix_kernel<false>, dim3((unsigned)max_nblk, (unsigned)count), dim3(kSwThreads), 0, s,
                        reinterpret_cast<const uint32_t*>(kb.current()), 2, vb.current(), d_raw,
                        static_cast<const double*>(nullptr), (int64_t)0, (int64_t)0, vb.alternate(), w.xr_sorted, d_overflow0,
                        scale_stride, w.segs, d_src, d_dst, 0, beta);
@@ -868,6 +1334,85 @@ hipError_t launch_tls_scale_large(hipStream_t s, const double* d_src, const doub
   if (force_sort64()) d_overflow = nullptr;
   const int64_t M = (int64_t)n * (n - 1) / 2;
   const Work w = carve(d_workspace, M);
+  const int64_t hull_pct = setting(S_SCALE_HULL);
+  // (problems of up to 4096 points share one sort per batch -- solver.hip, kMidScaledN -- and a problem must give the
+  // same bits alone and in a batch: the hull path is for the sizes above)
+  if (d_overflow && hull_pct > 0 && n > 4096) {
+    // the hull of the arg-min (above): compacted endpoints up to hull_pct % of all (a multiple of the sweep's chunk)
+    const int64_t m = 2 * M;
+    int64_t cap = (m / 100) * hull_pct;
+    constexpr int64_t kCapUnit = (int64_t)kSwChunk * kHullShards;  // whole sweep chunks, equal shards
+    cap = (cap / kCapUnit) * kCapUnit;
+    // small state in keys[1] (free on the float-key path): table | histograms | prefixes | plan | rows | init
+    char* q = reinterpret_cast<char*>(w.keys[1]);
+    auto take = [&](size_t bytes) {
+      char* r = q;
+      q += align_up(bytes);
+      return r;
+    };
+    double* T = reinterpret_cast<double*>(take(sizeof(double) * (kHullBins + 1)));
+    unsigned long long* hist = reinterpret_cast<unsigned long long*>(take(8 * (size_t)kHullKinds * kHullBins));
+    long long* pre = reinterpret_cast<long long*>(take(8 * 4 * (size_t)kHullBins));
+    HullPlan* plan = reinterpret_cast<HullPlan*>(take(sizeof(HullPlan)));
+    double* rows = reinterpret_cast<double*>(take(sizeof(double) * 7 * (size_t)n));
+    double* init = reinterpret_cast<double*>(take(sizeof(double) * 8));
+    unsigned int* shard_count = reinterpret_cast<unsigned int*>(take(sizeof(unsigned int) * kHullShards));
+    if ((size_t)(q - reinterpret_cast<char*>(w.keys[1])) <= (size_t)m * 8 && cap >= kCapUnit) {
+      static int cus = 0;
+      if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+      }
+      const size_t lds = 8 * (size_t)kHullKinds * kHullBins + sizeof(double) * (kHullBins + 1);
+      static DynLdsOptIn optin;
+      optin.ensure(reinterpret_cast<const void*>(hull_hist_kernel), (int)lds);
+      (void)hipMemsetAsync(hist, 0, 8 * (size_t)kHullKinds * kHullBins, s);
+      (void)hipMemsetAsync(shard_count, 0, sizeof(unsigned int) * kHullShards, s);
+      hipLaunchKernelGGL(hull_table_kernel, dim3(1), dim3(256), 0, s, d_src, d_dst, n, T, plan);
+      hipLaunchKernelGGL(hull_hist_kernel, dim3((unsigned)std::min(n - 1, cus)), dim3(kHullThreads), lds, s, d_src, d_dst, n, beta,
+                         T, plan, hist);
+      hipLaunchKernelGGL(hull_plan_kernel, dim3(1), dim3(kHullThreads), 0, s, 0, hist, pre, T, rows, n - 1, plan, d_overflow);
+      hipLaunchKernelGGL(hull_eval_kernel, dim3((unsigned)(n - 1)), dim3(256), 0, s, d_src, d_dst, n, beta, plan, rows);
+      hipLaunchKernelGGL(hull_plan_kernel, dim3(1), dim3(kHullThreads), 0, s, 1, hist, pre, T, rows, n - 1, plan, d_overflow);
+      bool use_hull = true;
+      if (setting(S_SCALE_HULL_SYNC) != 0) {
+        // ONE host look at the plan: the compacted arrays (and with them the sort, the order-fix pass and the sweep) are
+        // sized by the hull itself instead of by the worst case the setting allows -- 1.6 % of the endpoints when the
+        // inliers form a peak, a third on a flat top -- and a hull that failed or is too large to pay goes straight to the
+        // full sort instead of through the overflow flag and a repeated solve
+        HullPlan hp;
+        if (hipMemcpyAsync(&hp, plan, sizeof(hp), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+          return hipErrorUnknown;
+        const int64_t want = hp.hull_items + hp.hull_items / 25 + kCapUnit;
+        if (hp.failed || hp.anomalies || want > cap) {
+          use_hull = false;
+          (void)hipMemsetAsync(d_overflow, 0, sizeof(int32_t), s);
+        } else {
+          cap = ((want + kCapUnit - 1) / kCapUnit) * kCapUnit;
+        }
+      }
+      if (use_hull) {
+      (void)hipMemsetAsync(fkeys0(w), 0x7f, (size_t)cap * 4, s);
+      (void)hipMemsetAsync(w.tags[0], 0, (size_t)cap * 4, s);
+      hipLaunchKernelGGL(hull_emit_kernel, dim3((unsigned)(n - 1)), dim3(256), 0, s, d_src, d_dst, n, beta, plan, fkeys0(w),
+                         w.tags[0], rows, (long long)cap, shard_count);
+      hipLaunchKernelGGL(hull_init_kernel, dim3(1), dim3(kHullThreads), 0, s, rows, n - 1, plan, init, (long long)cap,
+                         shard_count, d_overflow);
+      if (setting(S_K4_DEBUG)) {  // diagnostics only
+        HullPlan hp;
+        (void)hipStreamSynchronize(s);
+        if (hipMemcpy(&hp, plan, sizeof(hp), hipMemcpyDeviceToHost) == hipSuccess)
+          fprintf(stderr, "[teaser_hip] scale hull: centre %.4f, t0 %.6f, achieved cost %.6f of %.6f, bins %d..%d = [%.6f, %.6f), "
+                  "%lld of %lld endpoints (capacity %lld), anomalies %d, failed %d\n", hp.c, hp.t0, hp.ub, hp.r_total,
+                  hp.first_bin, hp.last_bin, hp.t_lo, hp.t_hi, hp.hull_items, (long long)m, (long long)cap, hp.anomalies, hp.failed);
+      }
+      const HullRun run{cap, init};
+      return sort_and_sweep(s, w, d_raw, nullptr, M, d_scale, d_overflow, d_src, d_dst, n, beta, &run);
+      }
+    }
+  }
   hipLaunchKernelGGL(trim_endpoints_kernel, dim3(n - 1), dim3(256), 0, s, d_src, d_dst, n, beta,
                      d_raw, d_alpha, w.keys[0], w.tags[0], d_overflow ? fkeys0(w) : static_cast<float*>(nullptr));
   // (64-bit path: (raw, alpha) interleaved in d_raw; float-key path: recomputed from the points)

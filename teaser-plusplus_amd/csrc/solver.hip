@@ -80,6 +80,8 @@ const SettingRow kSettingRows[S_COUNT] = {
     {"deg_closure", "TEASER_HIP_DEG_CLOSURE", 1, 0, 1},
     {"greedy_small", "TEASER_HIP_GREEDY_SMALL", 1, 0, 1},
     {"deg_closure_wgs", "TEASER_HIP_DEG_CLOSURE_WGS", 0, 0, 64},
+    {"scale_hull", "TEASER_HIP_SCALE_HULL", 60, 0, 100},
+    {"scale_hull_sync", "TEASER_HIP_SCALE_HULL_SYNC", 1, 0, 1},
     {"colour_persistent", "TEASER_HIP_COLOUR_PERSISTENT", 0, 0, 65536},
     {"heu_skip_closed", "TEASER_HIP_HEU_SKIP_CLOSED", 0, 0, 1},
 };

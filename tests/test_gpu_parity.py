@@ -4,6 +4,7 @@ golden vectors.  Run on a real MI355X with `pytest -m gpu`.
 Parity bar (BASELINE.json north_star): bit-exact adjacency bitmap / clique / inlier index sets,
 rotation within 1e-4 Frobenius, translation within 1e-4 m.
 """
+import hashlib
 import importlib
 
 import numpy as np
@@ -270,16 +271,60 @@ def test_scale_float_key_sort_matches_the_64_bit_sort():
         assert (ma == mb).all()
         oe, om = oracle.scalar_tls(x, r)
         assert abs(ea - oe) < 1e-9 and (ma == om).all()
-    # whole solves: one large problem, one mid-size batch
+    # whole solves: one large problem, one mid-size batch (the hull path off: it sums the state in front of the hull
+    # in its own order, see test_scale_hull_matches_the_full_sort)
     p = bench_params(estimate_scaling=True, noise_bound=0.02)
     pr = tp.synth_problem(4242, 3000, 0.8, 0.01)
     sv = make_solver(**p)
-    a, b = both(lambda: sv.solve(pr["src"], pr["dst"] * 1.5).scale)
-    assert np.float64(a).tobytes() == np.float64(b).tobytes() and abs(a - 1.5) < 0.05
-    probs = [tp.synth_problem(4300 + i, m, 0.7, 0.01) for i, m in enumerate([900, 1500, 800, 2000])]
-    srcs, dsts = [q["src"] for q in probs], [q["dst"] * (1.0 + 0.2 * i) for i, q in enumerate(probs)]
-    a, b = both(lambda: [o.scale for o in sv.solve_batch(srcs, dsts)])
-    assert [np.float64(v).tobytes() for v in a] == [np.float64(v).tobytes() for v in b]
+    tp.set_option("scale_hull", 0)
+    try:
+        a, b = both(lambda: sv.solve(pr["src"], pr["dst"] * 1.5).scale)
+        assert np.float64(a).tobytes() == np.float64(b).tobytes() and abs(a - 1.5) < 0.05
+        probs = [tp.synth_problem(4300 + i, m, 0.7, 0.01) for i, m in enumerate([900, 1500, 800, 2000])]
+        srcs, dsts = [q["src"] for q in probs], [q["dst"] * (1.0 + 0.2 * i) for i, q in enumerate(probs)]
+        a, b = both(lambda: [o.scale for o in sv.solve_batch(srcs, dsts)])
+        assert [np.float64(v).tobytes() for v in a] == [np.float64(v).tobytes() for v in b]
+    finally:
+        tp.set_option("scale_hull", 60)
+
+
+@pytest.mark.parametrize("n,rho,k,nb,seed", [(4500, 0.8, 1.5, 0.02, 4242), (4200, 0.95, 1.3, 0.013, 4243),
+                                             (6000, 0.6, 0.8, 0.008, 4244), (5000, 0.99, 1.0, 0.01, 4245)])
+def test_scale_hull_matches_the_full_sort(n, rho, k, nb, seed):
+    """Large problems sort only the HULL of the arg-min (kernels_scale.hip: value bins with exact prefix sums, a lower
+    bound of the cost per bin against one achieved cost; the endpoints outside the hull enter as an exactly summed
+    state).  Same arg-min as the sweep over everything: the estimate agrees to the last few ulps (the state in front
+    of the hull is summed in another order), the consensus graph is the same graph -- with the host sizing the
+    compacted arrays (one more sync) and with the fixed capacity of the option -- and the oracle agrees with both.
+    Cases: an inlier peak (a hull of a per cent of the endpoints), almost no inliers (a flat top: a third of them)."""
+    pr = tp.synth_problem(seed, n, rho, 0.01)
+    src, dst = pr["src"], pr["dst"] * k
+    p = bench_params(estimate_scaling=True, noise_bound=nb)
+    got = {}
+    try:
+        for name, hull, sync in (("full", 0, 1), ("hull", 60, 1), ("hull_fixed", 60, 0), ("hull_tiny", 1, 1)):
+            tp.set_option("scale_hull", hull)
+            tp.set_option("scale_hull_sync", sync)
+            s = make_solver(**p)
+            sol = s.solve(src, dst)
+            raw = s.raw_solution()
+            # (the clique's SIZE: with almost no inliers there are many maximum cliques, and which one the parallel
+            # search meets first is not pinned)
+            got[name] = (sol.scale, int(raw.num_edges), len(s.getInlierMaxClique()),
+                         hashlib.sha256(s.getInlierGraphBitmap().tobytes()).hexdigest())
+    finally:
+        tp.set_option("scale_hull", 60)
+        tp.set_option("scale_hull_sync", 1)
+    full = got["full"]
+    for name in ("hull", "hull_fixed", "hull_tiny"):
+        g = got[name]
+        assert abs(g[0] - full[0]) <= 1e-13 * abs(full[0]), (name, g[0], full[0])
+        assert g[1:] == full[1:], name
+    if n <= 4500:  # (the oracle's sort of 2 x 1e7 endpoints: seconds)
+        o = oracle.solve(src, dst, **oracle_params(p))
+        assert abs(full[0] - o["scale"]) <= 1e-9
+
+
 
 
 def test_estimate_scaling_degenerate_ties_fall_back_to_the_64_bit_sort():
