@@ -245,8 +245,10 @@ constexpr int kHullTail = 256;               // geometric bins above 4 c (c = ra
 constexpr double kHullRangeCap = 1024.0;     // ranges are accumulated with 20 fractional bits
 constexpr double kHullSpan = 64.0;           // |x - c| <= kHullSpan c takes part in the sums of squares
 constexpr int kHullThreads = 1024;
+static_assert(kHullBins == 2048 && kHullThreads == 1024, "hull_plan_kernel's prefix sums: 4 kinds x 256 threads x 8 bins");
 struct HullPlan {
   double c;            // centre of the measurements (ratio of the RMS sizes of dst and src)
+  double v0, inv_w;    // the table's linear part: T[b] ~ v0 + b / inv_w for 1 <= b <= n_lin
   double t0;           // boundary whose consensus set gives the achieved cost
   double ub;           // that cost
   double r_total;      // sum of all ranges
@@ -256,20 +258,39 @@ struct HullPlan {
   int anomalies;       // measurements the histograms cannot take
   int failed;          // 1: no hull (the caller's overflow flag is raised as well)
   unsigned int emitted;  // (filled by hull_init_kernel: the sum of the shard counters)
-  int pad;
+  int n_lin;
+  int levels, pad;     // 1 / 2: which level's hull t_lo, t_hi describe
 };
 // The compacted arrays are cut into kHullShards equal shards, row i appends to shard i mod kHullShards: one atomic
 // per wave and 256 rows of pairs on ONE counter serialised in L2 (7.8e5 returning atomics: 8.9 ms for a pass whose
 // arithmetic takes 0.2); a shard that fills up fails the hull (the rows are spread evenly: it takes a hull within a few
 // per cent of the capacity).  Unused slots keep their padding (tag 0), which the sort moves behind every real key.
 constexpr int kHullShards = 256;  // (a power of two)
+constexpr int kHullEmitSplit = 4;
+constexpr int kHullCountStride = 64;  // uint32 per shard counter: one 256-byte line each (neighbours in one line serialise in L2)
 // histograms, [kind][bin]: 0 / 1 ranges of openers (rounded up) / closers (rounded down); 2 / 3 counts, 4 / 5 sums, 6 / 7
 // sums of squares of the openers / closers within the span (8 x 16 KB + the 16 KB table: one workgroup per CU)
 constexpr int kHullKinds = 8;
 
-__device__ __forceinline__ int hull_bin(const double* __restrict__ T, double v) {  // largest b with T[b] <= v (T[0] = -inf)
-  int lo = 0, hi = kHullBins;  // invariant: T[lo] <= v < T[hi] (T[kHullBins] = +inf); NaN ends in the last bin
+// largest b with T[b] <= v (T[0] = -inf, T[kHullBins] = +inf; NaN ends in the last bin).  The table IS the definition of the
+// bins (every kernel asks it, so they agree to the bit); `inv_w` = bins per unit of the table's linear part, `v0` its
+// origin, give a first guess that is off by at most a step there, the geometric tail is searched
+__device__ __forceinline__ int hull_bin(const double* __restrict__ T, double v, double v0, double inv_w, int n_lin) {
   if (!(v == v)) return kHullBins - 1;
+  int lo = 0, hi = kHullBins;  // invariant: T[lo] <= v < T[hi]
+  const double g = (v - v0) * inv_w;
+  if (g >= 1.0 && g < (double)n_lin) {
+    int b = (int)g;
+    b = b < 1 ? 1 : (b > n_lin ? n_lin : b);
+    if (T[b] <= v) {
+      if (v < T[b + 1]) return b;
+      if (v < T[b + 2]) return b + 1;
+      lo = b + 1;
+    } else {
+      if (T[b - 1] <= v) return b - 1;
+      hi = b - 1;
+    }
+  }
   while (hi - lo > 1) {
     const int mid = (lo + hi) >> 1;
     if (T[mid] <= v) lo = mid; else hi = mid;
@@ -308,6 +329,9 @@ __global__ __launch_bounds__(256) void hull_table_kernel(const double* __restric
     if (!(c > 1e-300 && c < 1e300)) c = 1.0;
     c_sh = c;
     plan->c = c;
+    plan->v0 = 0.0;
+    plan->inv_w = (double)(kHullBins - kHullTail) / (4.0 * c);
+    plan->n_lin = kHullBins - kHullTail;
     plan->anomalies = 0;
     plan->failed = 0;
     plan->emitted = 0u;
@@ -329,13 +353,16 @@ __global__ __launch_bounds__(256) void hull_table_kernel(const double* __restric
 __global__ __launch_bounds__(kHullThreads) void hull_hist_kernel(const double* __restrict__ src, const double* __restrict__ dst,
                                                                  int n, double beta, const double* __restrict__ T_g,
                                                                  HullPlan* __restrict__ plan,
-                                                                 unsigned long long* __restrict__ hist /* [kHullKinds][kHullBins] */) {
+                                                                 unsigned long long* __restrict__ hist /* [kHullKinds][kHullBins] */,
+                                                                 int inner_only /* level 2: bins 0 and kHullBins - 1 (outside the
+                                                                 first hull: two thirds of the endpoints on two counters) are left out */) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long lh[];  // [kHullKinds][kHullBins], then the table
   double* T = reinterpret_cast<double*>(lh + kHullKinds * kHullBins);
   for (int k = threadIdx.x; k < kHullKinds * kHullBins; k += kHullThreads) lh[k] = 0ull;
   for (int k = threadIdx.x; k <= kHullBins; k += kHullThreads) T[k] = T_g[k];
   __syncthreads();
-  const double c = plan->c;
+  const double c = plan->c, v0 = plan->v0, inv_w = plan->inv_w;
+  const int n_lin = plan->n_lin;
   int bad = 0;
   for (int i = blockIdx.x; i < n - 1; i += gridDim.x) {
     for (int j = i + 1 + threadIdx.x; j < n; j += kHullThreads) {
@@ -346,23 +373,28 @@ __global__ __launch_bounds__(kHullThreads) void hull_hist_kernel(const double* _
         continue;
       }
       const double lo = sv - av, hi = sv + av;  // (the endpoint kernels' keys)
-      const int bo = hull_bin(T, lo), bc = hull_bin(T, hi);
+      const int bo = hull_bin(T, lo, v0, inv_w, n_lin), bc = hull_bin(T, hi, v0, inv_w, n_lin);
       const double rq = av * 1048576.0;  // 2^20
       const unsigned long long r_up = (unsigned long long)__builtin_ceil(rq), r_dn = (unsigned long long)__builtin_floor(rq);
-      atomicAdd(&lh[0 * kHullBins + bo], r_up);
-      atomicAdd(&lh[1 * kHullBins + bc], r_dn);
+      const bool use_o = !inner_only || (bo >= 1 && bo <= kHullBins - 2), use_c = !inner_only || (bc >= 1 && bc <= kHullBins - 2);
+      if (use_o) atomicAdd(&lh[0 * kHullBins + bo], r_up);
+      if (use_c) atomicAdd(&lh[1 * kHullBins + bc], r_dn);
       const double xc = sv - c;
       if (__builtin_fabs(xc) <= kHullSpan * c) {
         // centred, scaled by c: |xs| <= 64; 2^40 and 2^30 steps: sums of 5e7 terms stay below 2^63
         const double xs = xc / c;
         const long long xq = (long long)__builtin_rint(xs * 1099511627776.0);         // 2^40
         const long long xxq = (long long)__builtin_rint(xs * xs * 1073741824.0);      // 2^30
-        atomicAdd(&lh[2 * kHullBins + bo], 1ull);
-        atomicAdd(&lh[3 * kHullBins + bc], 1ull);
-        atomicAdd(&lh[4 * kHullBins + bo], (unsigned long long)xq);
-        atomicAdd(&lh[5 * kHullBins + bc], (unsigned long long)xq);
-        atomicAdd(&lh[6 * kHullBins + bo], (unsigned long long)xxq);
-        atomicAdd(&lh[7 * kHullBins + bc], (unsigned long long)xxq);
+        if (use_o) {
+          atomicAdd(&lh[2 * kHullBins + bo], 1ull);
+          atomicAdd(&lh[4 * kHullBins + bo], (unsigned long long)xq);
+          atomicAdd(&lh[6 * kHullBins + bo], (unsigned long long)xxq);
+        }
+        if (use_c) {
+          atomicAdd(&lh[3 * kHullBins + bc], 1ull);
+          atomicAdd(&lh[5 * kHullBins + bc], (unsigned long long)xq);
+          atomicAdd(&lh[7 * kHullBins + bc], (unsigned long long)xxq);
+        }
       }
     }
   }
@@ -371,7 +403,7 @@ __global__ __launch_bounds__(kHullThreads) void hull_hist_kernel(const double* _
     const unsigned long long v = lh[k];
     if (v) atomicAdd(&hist[k], v);
   }
-  if (bad) atomicAdd(&plan->anomalies, bad);
+  if (bad && !inner_only) atomicAdd(&plan->anomalies, bad);
 }
 
 // Partial state sums of one row of pairs, reduced over the workgroup in a fixed shape (thread order inside a wave by a
@@ -441,8 +473,12 @@ __device__ __forceinline__ void hull_rows_total(const double* __restrict__ rows,
   __syncthreads();
 }
 
-// phase 0: the boundary in front of which the summed ranges of the consensus set are largest (-> t0);
-// phase 1: the achieved cost, the bounds, the hull
+// phase 0: the four prefix sums, the boundary in front of which the summed ranges of the consensus set are largest (-> t0);
+// phase 1: the achieved cost, the bounds, the hull;
+// phase 2 (second level: `hist` holds the endpoints INSIDE the first hull, binned by a table that cuts it into
+//          kHullBins - 2 equal bins -- bin 0 is everything in front of it, the last bin everything behind): prefix sums
+//          continued from the first level's state in front of the hull (pre[.][first_bin]: exact integers), the same
+//          bounds against the same achieved cost, a hull inside the hull
 __global__ __launch_bounds__(kHullThreads) void hull_plan_kernel(int phase, const unsigned long long* __restrict__ hist,
                                                                  long long* __restrict__ pre /* [4][kHullBins] */,
                                                                  const double* __restrict__ T, const double* __restrict__ rows,
@@ -453,6 +489,8 @@ __global__ __launch_bounds__(kHullThreads) void hull_plan_kernel(int phase, cons
   __shared__ double acc7[7];
   __shared__ int cand_first, cand_last;
   __shared__ unsigned long long red64[kHullThreads / 64];
+  __shared__ long long part[4][256];
+  __shared__ long long base4[4];
   const int t = threadIdx.x;
   if (plan->anomalies != 0 || plan->failed) {
     if (t == 0) {
@@ -461,16 +499,36 @@ __global__ __launch_bounds__(kHullThreads) void hull_plan_kernel(int phase, cons
     }
     return;
   }
-  if (phase == 0) {
-    if (t < 4) {  // one thread per kind: 2048 integer adds
-      const int ko = 2 * t, kc = ko + 1;
-      long long acc = 0;
-      for (int b = 0; b < kHullBins; ++b) {
-        pre[t * kHullBins + b] = acc;
-        acc += (long long)hist[ko * kHullBins + b] - (long long)hist[kc * kHullBins + b];
+  if (phase == 0 || phase == 2) {
+    // four exclusive prefix sums over the bins (integers: any order gives the same sums): 256 threads per kind, 8 bins each
+    if (t < 4) base4[t] = phase == 2 ? pre[t * kHullBins + plan->first_bin] : 0;
+    __syncthreads();
+    const int kind = t >> 8, u = t & 255, ko = 2 * kind, kc = ko + 1;
+    long long v[8], sum = 0;
+    for (int e = 0; e < 8; ++e) {
+      const int b = u * 8 + e;
+      v[e] = (long long)hist[ko * kHullBins + b] - (long long)hist[kc * kHullBins + b];
+      sum += v[e];
+    }
+    part[kind][u] = sum;
+    __syncthreads();
+    if (u == 0) {
+      long long acc = base4[kind];
+      for (int k = 0; k < 256; ++k) {
+        const long long x = part[kind][k];
+        part[kind][k] = acc;
+        acc += x;
       }
     }
     __syncthreads();
+    long long acc = part[kind][u];
+    for (int e = 0; e < 8; ++e) {
+      pre[kind * kHullBins + u * 8 + e] = acc;
+      acc += v[e];
+    }
+    __syncthreads();
+  }
+  if (phase == 0) {
     // first bin with the largest start value
     unsigned long long best = 0;
     for (int b = t; b < kHullBins; b += kHullThreads) {
@@ -492,19 +550,23 @@ __global__ __launch_bounds__(kHullThreads) void hull_plan_kernel(int phase, cons
     }
     return;
   }
-  hull_rows_total(rows, nrows, tot, acc7);
+  if (phase == 1) {
+    hull_rows_total(rows, nrows, tot, acc7);
+    if (t == 0) {
+      const double cnt = acc7[0], w = acc7[1], wx = acc7[2], rin = acc7[3], sx = acc7[4], sxx = acc7[5], rtot = acc7[6];
+      const double xh = wx / w;
+      const double ub = (cnt * xh * xh + sxx - 2 * sx * xh) + (rtot - rin);  // registration.cc:69-72
+      plan->ub = (cnt > 0.0) ? ub : INFINITY;
+      plan->r_total = rtot;
+    }
+  }
   if (t == 0) {
     cand_first = kHullBins;
     cand_last = -1;
-    const double cnt = acc7[0], w = acc7[1], wx = acc7[2], rin = acc7[3], sx = acc7[4], sxx = acc7[5], rtot = acc7[6];
-    const double xh = wx / w;
-    const double ub = (cnt * xh * xh + sxx - 2 * sx * xh) + (rtot - rin);  // registration.cc:69-72
-    plan->ub = ub;
-    plan->r_total = rtot;
   }
   __syncthreads();
   const double ub = plan->ub, rtot = plan->r_total, c = plan->c;
-  if (!(ub < INFINITY) || !(ub == ub) || !(acc7[0] > 0.0)) {
+  if (!(ub < INFINITY) || !(ub == ub)) {
     if (t == 0) {
       plan->failed = 1;
       *overflow = 1;
@@ -514,7 +576,8 @@ __global__ __launch_bounds__(kHullThreads) void hull_plan_kernel(int phase, cons
   // every sum below errs on the safe side: ranges of openers were rounded up and of closers down, the squares carry
   // their worst-case rounding, and the comparison a relative margin far above FP64's own noise in the sweep
   const double margin = 1e-9 * __builtin_fabs(ub) + 1e-9 * rtot + 1e-6;
-  for (int b = t; b < kHullBins; b += kHullThreads) {
+  const int b_lo = phase == 2 ? 1 : 0, b_hi = phase == 2 ? kHullBins - 2 : kHullBins - 1;  // (level 2: the interior bins)
+  for (int b = b_lo + t; b <= b_hi; b += kHullThreads) {
     const double s_hat = ((double)pre[b] + (double)hist[0 * kHullBins + b]) * (1.0 / 1048576.0);
     const long long nc = pre[1 * kHullBins + b] - (long long)hist[3 * kHullBins + b];
     double ss = 0.0;
@@ -548,6 +611,28 @@ __global__ __launch_bounds__(kHullThreads) void hull_plan_kernel(int phase, cons
     long long est = 0;
     for (int b = f; b <= l; ++b) est += (long long)hist[2 * kHullBins + b] + (long long)hist[3 * kHullBins + b];
     plan->hull_items = est;
+    plan->levels = phase == 2 ? 2 : 1;
+  }
+}
+
+// second-level table: bin 0 = (-inf, t_lo), bins 1 .. kHullBins - 2 cut [t_lo, t_hi) into equal parts, the last bin = [t_hi, inf)
+__global__ __launch_bounds__(256) void hull_table2_kernel(double* __restrict__ T, HullPlan* __restrict__ plan) {
+  const double lo = plan->t_lo, hi = plan->t_hi;
+  constexpr int kIn = kHullBins - 2;
+  const double w = (hi - lo) / kIn;
+  for (int b = threadIdx.x; b <= kHullBins; b += 256) {
+    double v;
+    if (b == 0) v = -INFINITY;
+    else if (b == kHullBins) v = INFINITY;
+    else if (b == kHullBins - 1) v = hi;
+    else v = lo + w * (double)(b - 1);
+    if (b >= 1 && b < kHullBins - 1 && !(v < hi)) v = hi;  // (rounding: never beyond the hull's end)
+    T[b] = v;
+  }
+  if (threadIdx.x == 0) {
+    plan->v0 = lo - w;
+    plan->inv_w = 1.0 / w;
+    plan->n_lin = kIn;
   }
 }
 
@@ -556,19 +641,21 @@ __global__ __launch_bounds__(256) void hull_emit_kernel(const double* __restrict
                                                         int32_t* __restrict__ tags, double* __restrict__ rows /* [n - 1][7] */,
                                                         long long cap_items, unsigned int* __restrict__ shard_count) {
   __shared__ double red[4][7];
+  // kHullEmitSplit workgroups per row, each taking every kHullEmitSplit-th chunk of 256 pairs: a workgroup's reservations
+  // (one returning atomic per wave and chunk) form a dependent chain, 40 links long for a whole row at N = 10 000
   const int i = blockIdx.x;
   const long long shard_items = cap_items / kHullShards;
   // rows get shorter with i: shards are assigned in snake order (0 .. 255, 255 .. 0, ...) so that every shard takes
   // the same share of long and short rows (i mod 256 alone leaves the first shard 5 % fuller than the last)
   const int shard = ((i / kHullShards) & 1) ? kHullShards - 1 - (i % kHullShards) : (i % kHullShards);
   const long long shard_base = (long long)shard * shard_items;
-  unsigned int* counter = shard_count + shard;
+  unsigned int* counter = shard_count + (size_t)shard * kHullCountStride;
   const bool failed = plan->failed != 0;
   const double t_lo = plan->t_lo, t_hi = plan->t_hi;
   const int64_t seg = (int64_t)i * n - (int64_t)i * (i + 1) / 2;
   double a[7] = {0, 0, 0, 0, 0, 0, 0};
   const int lane = threadIdx.x & 63;
-  for (int j0 = i + 1; j0 < n && !failed; j0 += 256) {  // (block-uniform trip count: ballots inside)
+  for (int j0 = i + 1 + 256 * (int)blockIdx.y; j0 < n && !failed; j0 += 256 * kHullEmitSplit) {  // (block-uniform trip count)
     const int j = j0 + threadIdx.x;
     double sv = 0, av = 1, lo = 0, hi = 0;
     bool in_lo = false, in_hi = false;
@@ -609,7 +696,7 @@ __global__ __launch_bounds__(256) void hull_emit_kernel(const double* __restrict
       tags[shard_base + pos] = -(int)(k + 1);
     }
   }
-  hull_block_reduce<256>(a, red, rows + (size_t)i * 7);
+  hull_block_reduce<256>(a, red, rows + ((size_t)i * kHullEmitSplit + blockIdx.y) * 7);
 }
 
 // the state in front of the hull: the rows' contributions in a fixed order -> init[0..5]; init[6] = the sum of all ranges;
@@ -628,8 +715,9 @@ __global__ __launch_bounds__(kHullThreads) void hull_init_kernel(const double* _
     long long total = 0;
     bool full = false;
     for (int k = 0; k < kHullShards; ++k) {
-      total += shard_count[k];
-      full |= (long long)shard_count[k] > shard_items;
+      const unsigned int c = shard_count[(size_t)k * kHullCountStride];
+      total += c;
+      full |= (long long)c > shard_items;
     }
     plan->hull_items = total;
     plan->emitted = (unsigned int)total;
@@ -1354,9 +1442,9 @@ hipError_t launch_tls_scale_large(hipStream_t s, const double* d_src, const doub
     unsigned long long* hist = reinterpret_cast<unsigned long long*>(take(8 * (size_t)kHullKinds * kHullBins));
     long long* pre = reinterpret_cast<long long*>(take(8 * 4 * (size_t)kHullBins));
     HullPlan* plan = reinterpret_cast<HullPlan*>(take(sizeof(HullPlan)));
-    double* rows = reinterpret_cast<double*>(take(sizeof(double) * 7 * (size_t)n));
+    double* rows = reinterpret_cast<double*>(take(sizeof(double) * 7 * (size_t)n * kHullEmitSplit));
     double* init = reinterpret_cast<double*>(take(sizeof(double) * 8));
-    unsigned int* shard_count = reinterpret_cast<unsigned int*>(take(sizeof(unsigned int) * kHullShards));
+    unsigned int* shard_count = reinterpret_cast<unsigned int*>(take(sizeof(unsigned int) * kHullShards * kHullCountStride));
     if ((size_t)(q - reinterpret_cast<char*>(w.keys[1])) <= (size_t)m * 8 && cap >= kCapUnit) {
       static int cus = 0;
       if (cus == 0) {
@@ -1369,10 +1457,10 @@ hipError_t launch_tls_scale_large(hipStream_t s, const double* d_src, const doub
       static DynLdsOptIn optin;
       optin.ensure(reinterpret_cast<const void*>(hull_hist_kernel), (int)lds);
       (void)hipMemsetAsync(hist, 0, 8 * (size_t)kHullKinds * kHullBins, s);
-      (void)hipMemsetAsync(shard_count, 0, sizeof(unsigned int) * kHullShards, s);
+      (void)hipMemsetAsync(shard_count, 0, sizeof(unsigned int) * kHullShards * kHullCountStride, s);
       hipLaunchKernelGGL(hull_table_kernel, dim3(1), dim3(256), 0, s, d_src, d_dst, n, T, plan);
       hipLaunchKernelGGL(hull_hist_kernel, dim3((unsigned)std::min(n - 1, cus)), dim3(kHullThreads), lds, s, d_src, d_dst, n, beta,
-                         T, plan, hist);
+                         T, plan, hist, 0);
       hipLaunchKernelGGL(hull_plan_kernel, dim3(1), dim3(kHullThreads), 0, s, 0, hist, pre, T, rows, n - 1, plan, d_overflow);
       hipLaunchKernelGGL(hull_eval_kernel, dim3((unsigned)(n - 1)), dim3(256), 0, s, d_src, d_dst, n, beta, plan, rows);
       hipLaunchKernelGGL(hull_plan_kernel, dim3(1), dim3(kHullThreads), 0, s, 1, hist, pre, T, rows, n - 1, plan, d_overflow);
@@ -1385,6 +1473,17 @@ hipError_t launch_tls_scale_large(hipStream_t s, const double* d_src, const doub
         HullPlan hp;
         if (hipMemcpyAsync(&hp, plan, sizeof(hp), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
           return hipErrorUnknown;
+        if (!hp.failed && !hp.anomalies && hp.hull_items > m / 12 && hp.t_lo > -INFINITY && hp.t_hi < INFINITY) {
+          // a wide hull (a flat top: no inlier peak): a second level of bins inside it, ten times finer, before anything
+          // is sorted -- one more pass over the TRIMs for a hull a few times smaller
+          (void)hipMemsetAsync(hist, 0, 8 * (size_t)kHullKinds * kHullBins, s);
+          hipLaunchKernelGGL(hull_table2_kernel, dim3(1), dim3(256), 0, s, T, plan);
+          hipLaunchKernelGGL(hull_hist_kernel, dim3((unsigned)std::min(n - 1, cus)), dim3(kHullThreads), lds, s, d_src, d_dst, n,
+                             beta, T, plan, hist, 1);
+          hipLaunchKernelGGL(hull_plan_kernel, dim3(1), dim3(kHullThreads), 0, s, 2, hist, pre, T, rows, n - 1, plan, d_overflow);
+          if (hipMemcpyAsync(&hp, plan, sizeof(hp), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
+            return hipErrorUnknown;
+        }
         const int64_t want = hp.hull_items + hp.hull_items / 25 + kCapUnit;
         if (hp.failed || hp.anomalies || want > cap) {
           use_hull = false;
@@ -1396,16 +1495,16 @@ hipError_t launch_tls_scale_large(hipStream_t s, const double* d_src, const doub
       if (use_hull) {
       (void)hipMemsetAsync(fkeys0(w), 0x7f, (size_t)cap * 4, s);
       (void)hipMemsetAsync(w.tags[0], 0, (size_t)cap * 4, s);
-      hipLaunchKernelGGL(hull_emit_kernel, dim3((unsigned)(n - 1)), dim3(256), 0, s, d_src, d_dst, n, beta, plan, fkeys0(w),
-                         w.tags[0], rows, (long long)cap, shard_count);
-      hipLaunchKernelGGL(hull_init_kernel, dim3(1), dim3(kHullThreads), 0, s, rows, n - 1, plan, init, (long long)cap,
-                         shard_count, d_overflow);
+      hipLaunchKernelGGL(hull_emit_kernel, dim3((unsigned)(n - 1), kHullEmitSplit), dim3(256), 0, s, d_src, d_dst, n, beta, plan,
+                         fkeys0(w), w.tags[0], rows, (long long)cap, shard_count);
+      hipLaunchKernelGGL(hull_init_kernel, dim3(1), dim3(kHullThreads), 0, s, rows, (n - 1) * kHullEmitSplit, plan, init,
+                         (long long)cap, shard_count, d_overflow);
       if (setting(S_K4_DEBUG)) {  // diagnostics only
         HullPlan hp;
         (void)hipStreamSynchronize(s);
         if (hipMemcpy(&hp, plan, sizeof(hp), hipMemcpyDeviceToHost) == hipSuccess)
-          fprintf(stderr, "[teaser_hip] scale hull: centre %.4f, t0 %.6f, achieved cost %.6f of %.6f, bins %d..%d = [%.6f, %.6f), "
-                  "%lld of %lld endpoints (capacity %lld), anomalies %d, failed %d\n", hp.c, hp.t0, hp.ub, hp.r_total,
+          fprintf(stderr, "[teaser_hip] scale hull: centre %.4f, t0 %.6f, achieved cost %.6f of %.6f, level %d bins %d..%d = [%.6f, %.6f), "
+                  "%lld of %lld endpoints (capacity %lld), anomalies %d, failed %d\n", hp.c, hp.t0, hp.ub, hp.r_total, hp.levels,
                   hp.first_bin, hp.last_bin, hp.t_lo, hp.t_hi, hp.hull_items, (long long)m, (long long)cap, hp.anomalies, hp.failed);
       }
       const HullRun run{cap, init};
