@@ -101,6 +101,8 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-resident", action="store_true",
                     help="skip the second timed loop fed from page-locked host memory")
+    ap.add_argument("--no-power", action="store_true",
+                    help="skip the >= 1.5 s power region (board power / clock from the GPU's hwmon node)")
     ap.add_argument("--no-latency", action="store_true",
                     help="skip the single-problem latency probe (rocprofv3 runs: keeps every K1 launch the same size)")
     ap.add_argument("--cpu-solves", type=int, default=16)
@@ -118,6 +120,65 @@ def solver_params(tp, nb, **kw):
              rotation_max_iterations=100, rotation_cost_threshold=0.005)
     p.update(kw)
     return tp.RobustRegistrationSolver.Params(**p)
+
+
+class PowerSampler:
+    """Board power and shader clock of ONE GPU from its amdgpu hwmon node (sysfs: power1_input / power1_average in uW,
+    freq1_input in Hz, power1_cap), sampled every ~10 ms by a thread while a region runs.  The node is found through the
+    device's PCI address, so a box that exposes several cards reads the right one.  Reading sysfs costs the GPU nothing."""
+
+    def __init__(self, torch, dev):
+        import glob
+        self.node = None
+        try:
+            pr = torch.cuda.get_device_properties(dev)
+            bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            nodes = glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*" % bdf)
+            self.node = nodes[0] if nodes else None
+            self.bdf = bdf
+        except Exception:  # noqa: BLE001 -- no sysfs, no such attribute: the line then carries power = null
+            self.node = None
+        self.rows = []
+        self._stop = False
+        self._th = None
+
+    def _read(self, name):
+        try:
+            with open(os.path.join(self.node, name)) as f:
+                return int(f.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def available(self):
+        return self.node is not None and (self._read("power1_input") or self._read("power1_average")) is not None
+
+    def __enter__(self):
+        import threading
+        self.rows, self._stop = [], False
+
+        def loop():
+            while not self._stop:
+                pw = self._read("power1_input") or self._read("power1_average")
+                ck = self._read("freq1_input")
+                self.rows.append((time.perf_counter(), (pw or 0) * 1e-6, (ck or 0) * 1e-6))
+                time.sleep(0.01)
+        self._th = threading.Thread(target=loop, daemon=True)
+        self._th.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop = True
+        self._th.join()
+
+    def summary(self, t0, t1):
+        """mean over the samples of [t0 + 40 % , t1]: the first part of a region is the board's power filter settling"""
+        rows = [r for r in self.rows if t0 + 0.4 * (t1 - t0) <= r[0] <= t1 and r[1] > 0]
+        if not rows:
+            return None
+        cap = self._read("power1_cap")
+        return {"avg_w": round(float(np.mean([r[1] for r in rows])), 1), "max_w": round(max(r[1] for r in rows), 1),
+                "sclk_mhz": round(float(np.mean([r[2] for r in rows])), 0), "cap_w": round(cap * 1e-6, 1) if cap else None,
+                "samples": len(rows), "hwmon": self.node, "pci": self.bdf}
 
 
 def roofline_object(k1_ms, k1_launches, k1_bytes, k1_pairs, k1_aux_ms, traffic, traffic_src, issue=None):
@@ -973,6 +1034,30 @@ def main():
                              "SURVEY.md 8(d)'s timer scope; never `value`"}
         del pinned
 
+    # ---- board power over a LONG run of the same steps (rank 0; untimed extra) ---------------------
+    # The two-lane pipeline of this workload runs at the board's power cap: energy per step is the same whatever the
+    # schedule (profiles/r6c), so the step time is energy / cap and K1 takes longer inside the pipeline than alone
+    # because its clock is what the power controller gives.  hwmon samples are ~10 ms apart and the controller's
+    # filter is slower still, so the region here is >= 1.5 s of steps, not the 20-step timed regions above.
+    power = None
+    if not args.no_power and rank == 0:
+        ps = PowerSampler(torch, dev)
+        if ps.available():
+            steps_p = max(args.steps, int(1.5 / max(elapsed / args.steps, 1e-5)))
+            with ps:
+                tp0 = time.perf_counter()
+                el_p = runner.timed(args.warmup + 1, steps_p, pool, offsets, sizes, False)[0]
+                tp1 = time.perf_counter()
+            power = ps.summary(tp0, tp1)
+            if power is not None:
+                power.update({"steps": steps_p, "ms_per_step": round(1e3 * el_p / steps_p, 4),
+                              "joule_per_step": round(power["avg_w"] * el_p / steps_p, 4),
+                              "millijoule_per_registration": round(1e3 * power["avg_w"] * el_p / (steps_p * B), 3),
+                              "frac_of_cap": round(power["avg_w"] / power["cap_w"], 3) if power.get("cap_w") else None,
+                              "note": "board power (hwmon) over %d consecutive steps of the headline loop; at frac_of_cap "
+                                      ">= 0.97 the step is bound by the power limit: time = energy per step / cap "
+                                      "(profiles/r6c: energy per step is invariant under the schedule)" % steps_p})
+
     # single-problem latency (not the headline value; reported for the ms/solve half of the metric)
     lat = []
     s_t, d_t = pool[0]
@@ -1053,8 +1138,8 @@ def main():
                        "gather_backend": gather_info["gather_backend"], "rccl_ranks": gather_info["rccl_ranks"],
                        "parallelism": "independent problems per GPU, one all_gather of result records (%s)"
                                       % gather_info["gather_backend"]},
-            "roofline": roofline_object(acc["ms"], acc["launches"], acc["bytes"], acc["pairs"], acc["aux"],
-                                        traffic, traffic_src, k1_issue()),
+            "roofline": dict(roofline_object(acc["ms"], acc["launches"], acc["bytes"], acc["pairs"], acc["aux"],
+                                             traffic, traffic_src, k1_issue()), power=power),
             "configs": cfg_lines,
         }
         if top_cpu is not None:

@@ -7,7 +7,13 @@
 //                   events), step ms (synchronous API), FNV hash of two bitmaps (must agree across variants)
 //     mode "pipe" : registrations/s through teaser_hip_submit_batch / teaser_hip_wait for depth 1..4,
 //                   K1 staggering on and off
+//     (K1_PROBE_TAIL_SKIP=<mask> in the environment: the library's tail_skip setting -- stages not enqueued -- switched
+//      on behind the warm-up of modes k1 / one / pipe: timing only, the results are wrong)
 //     mode "one"  : only the variant in the environment, `iters` synchronous steps (for rocprofv3)
+//     mode "storm": K1 (synchronous steps, HIP events around K1) while a second host thread keeps a SIDE stream busy with
+//                   (a) nothing, (b) empty one-wave kernels back to back (kernel boundaries only), (c) the same, each
+//                   dirtying one cache line, (d) ONE long sleeping kernel of 64 workgroups per 2 ms (occupancy, no
+//                   boundaries), (e) 30-us sleeping kernels of 64 workgroups back to back (a latency-bound tail's shape)
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -16,7 +22,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "teaser_hip.h"
@@ -41,6 +49,33 @@ static uint64_t fnv(const uint64_t* p, size_t n) {
     h *= 1099511628211ull;
   }
   return h;
+}
+
+__global__ void side_empty_kernel() {}
+__global__ void side_dirty_kernel(unsigned* p) { p[(blockIdx.x * 64 + threadIdx.x) * 32] = threadIdx.x; }
+__global__ void side_sleep_kernel(long long cycles) {  // (s_memtime: 100 MHz)
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < cycles) __builtin_amdgcn_s_sleep(32);
+}
+
+__global__ void side_lds_kernel(long long cycles, int words) {  // big workgroups holding LDS and registers
+  extern __shared__ unsigned lds[];
+  for (int i = threadIdx.x; i < words; i += blockDim.x) lds[i] = i;
+  __syncthreads();
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < cycles) __builtin_amdgcn_s_sleep(32);
+  if (lds[threadIdx.x] == 0xffffffffu) printf("x");
+}
+__global__ void side_stream_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    uint4 v = in[i];
+    v.x += 1;
+    out[i] = v;
+  }
+}
+__global__ void side_atomic_kernel(unsigned* p, int span) {
+  const unsigned i = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u;
+  atomicXor(p + (i % (unsigned)span), 1u << (i & 31));
 }
 
 struct Pool {
@@ -85,6 +120,10 @@ int main(int argc, char** argv) {
   const int iters = argc > 3 ? atoi(argv[3]) : 10;
   const std::string mode = argc > 4 ? argv[4] : "k1";
   const double rho = argc > 5 ? atof(argv[5]) : 0.95;
+  {
+    char pci[64] = {0};
+    if (hipDeviceGetPCIBusId(pci, sizeof(pci), 0) == hipSuccess) printf("{\"probe\":\"device\",\"pci\":\"%s\"}\n", pci);
+  }
   Pool P = make_pool(4, B, n, rho);
   teaser_params_c prm = bench_params();
   std::vector<teaser_solution_c> out((size_t)B);
@@ -113,6 +152,7 @@ int main(int argc, char** argv) {
       for (int w = 0; w < 2; ++w)
         CK(teaser_hip_solve_batch_device(h, P.d_src[w % 4], P.d_dst[w % 4], P.off.data(), P.n.data(), B, out.data()));
       CK(teaser_hip_set_profiling(h, 2));
+      if (getenv("K1_PROBE_TAIL_SKIP")) CK(teaser_hip_set_option(nullptr, "tail_skip", atoi(getenv("K1_PROBE_TAIL_SKIP"))));
       double k1 = 0, aux = 0;
       int launches = 0;
       CK(hipDeviceSynchronize());
@@ -127,6 +167,7 @@ int main(int argc, char** argv) {
       }
       const double t1 = now_ms();
       CK(teaser_hip_set_profiling(h, 0));
+      (void)teaser_hip_set_option(nullptr, "tail_skip", 0);  // (an older library build has no such option)
       CK(teaser_hip_solve_batch_device(h, P.d_src[0], P.d_dst[0], P.off.data(), P.n.data(), B, out.data()));
       uint64_t hsh = 0;
       for (int pb : {0, B - 1}) {
@@ -141,6 +182,72 @@ int main(int argc, char** argv) {
       fflush(stdout);
       teaser_hip_solver_destroy(h);
     }
+  }
+  if (mode == "storm") {
+    teaser_hip_solver* h = nullptr;
+    CK(teaser_hip_solver_create(&prm, 0, &h));
+    for (int w = 0; w < 2; ++w)
+      CK(teaser_hip_solve_batch_device(h, P.d_src[w % 4], P.d_dst[w % 4], P.off.data(), P.n.data(), B, out.data()));
+    CK(teaser_hip_set_profiling(h, 2));
+    unsigned* dirt = nullptr;
+    CK(hipMalloc(&dirt, 1 << 20));
+    uint4 *sa = nullptr, *sb = nullptr;
+    const size_t sn = (size_t)(64 << 20) / 16;
+    CK(hipMalloc(&sa, sn * 16));
+    CK(hipMalloc(&sb, sn * 16));
+    unsigned* at = nullptr;
+    CK(hipMalloc(&at, 256u << 20));
+    CK(hipMemset(at, 0, 256u << 20));
+    const char* names[] = {"none", "empty", "dirty", "long_sleep", "short_sleep", "empty_2streams", "many_wg_empty",
+                           "many_wg_30us", "big_wg_lds_30us", "stream_64MB", "atomics_1M_over_256MB", "atomics_1M_over_1MB"};
+    for (int kind = 0; kind < 12; ++kind) {
+      std::atomic<int> stop{0};
+      std::atomic<long> launched{0};
+      auto side = [&](int) {
+        CK(hipSetDevice(0));
+        hipStream_t s;
+        CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        long nl = 0;
+        while (!stop.load()) {
+          for (int r = 0; r < 16; ++r) {
+            if (kind == 1 || kind == 5) hipLaunchKernelGGL(side_empty_kernel, dim3(1), dim3(64), 0, s);
+            if (kind == 2) hipLaunchKernelGGL(side_dirty_kernel, dim3(1), dim3(64), 0, s, dirt);
+            if (kind == 3) hipLaunchKernelGGL(side_sleep_kernel, dim3(64), dim3(256), 0, s, 200000ll);
+            if (kind == 4) hipLaunchKernelGGL(side_sleep_kernel, dim3(64), dim3(256), 0, s, 3000ll);
+            if (kind == 6) hipLaunchKernelGGL(side_empty_kernel, dim3(16384), dim3(256), 0, s);
+            if (kind == 7) hipLaunchKernelGGL(side_sleep_kernel, dim3(2048), dim3(256), 0, s, 3000ll);
+            if (kind == 8) hipLaunchKernelGGL(side_lds_kernel, dim3(64), dim3(1024), 48 << 10, s, 3000ll, 12 << 10);
+            if (kind == 9) hipLaunchKernelGGL(side_stream_kernel, dim3(1024), dim3(256), 0, s, sa, sb, sn);
+            if (kind == 10) hipLaunchKernelGGL(side_atomic_kernel, dim3(4096), dim3(256), 0, s, at, 64 << 20);
+            if (kind == 11) hipLaunchKernelGGL(side_atomic_kernel, dim3(4096), dim3(256), 0, s, at, 256 << 10);
+            ++nl;
+          }
+          CK(hipStreamSynchronize(s));
+        }
+        launched += nl;
+        CK(hipStreamDestroy(s));
+      };
+      std::vector<std::thread> th;
+      if (kind) th.emplace_back(side, 0);
+      if (kind == 5) th.emplace_back(side, 1);
+      double k1 = 0;
+      int launches = 0;
+      const double t0 = now_ms();
+      for (int it = 0; it < iters; ++it) {
+        CK(teaser_hip_solve_batch_device(h, P.d_src[it % 4], P.d_dst[it % 4], P.off.data(), P.n.data(), B, out.data()));
+        teaser_profile_c pf;
+        teaser_hip_get_profile(h, &pf);
+        k1 += pf.tim_graph_ms;
+        launches += pf.tim_graph_launches;
+      }
+      const double t1 = now_ms();
+      stop = 1;
+      for (auto& t : th) t.join();
+      printf("{\"probe\":\"storm\",\"side\":\"%s\",\"k1_ms\":%.4f,\"step_ms_sync\":%.4f,\"side_launches_per_ms\":%.1f}\n",
+             names[kind], launches ? k1 / launches : 0.0, (t1 - t0) / iters, launched.load() / (t1 - t0));
+      fflush(stdout);
+    }
+    teaser_hip_solver_destroy(h);
   }
   if (mode == "pipe") {
     struct Cfg { int k1stream, depth, greedy; };
@@ -168,6 +275,7 @@ int main(int argc, char** argv) {
             tk.pop_front();
           }
           CK(hipDeviceSynchronize());
+          if (getenv("K1_PROBE_TAIL_SKIP")) CK(teaser_hip_set_option(nullptr, "tail_skip", atoi(getenv("K1_PROBE_TAIL_SKIP"))));
           k1 = 0;
           launches = 0;
           t0 = now_ms();
@@ -195,6 +303,7 @@ int main(int argc, char** argv) {
       }
       CK(hipDeviceSynchronize());
       const double t1 = now_ms();
+      (void)teaser_hip_set_option(nullptr, "tail_skip", 0);  // (an older library build has no such option)
       printf("{\"probe\":\"pipe\",\"variant\":\"%s\",\"k1_stream\":%d,\"depth\":%d,\"greedy_threads\":%d,\"batch\":%d,\"n\":%d,"
              "\"step_ms\":%.4f,\"reg_per_s\":%.0f,\"k1_ms\":%.4f,\"clique0\":%d}\n",
              v.c_str(), cf.k1stream, depth, cf.greedy, B, n, (t1 - t0) / iters, 1e3 * B * iters / (t1 - t0),

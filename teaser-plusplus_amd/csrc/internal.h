@@ -137,6 +137,7 @@ enum Setting {
   S_SCALE_HULL_SYNC,   // 1: the host reads the hull's size before the compaction (one more sync per large scale stage) TEASER_HIP_SCALE_HULL_SYNC
   S_COLOUR_PERSISTENT, // > 0: problems of at least this many vertices run all colouring rounds in one launch (0: never) TEASER_HIP_COLOUR_PERSISTENT
   S_HEU_SKIP_CLOSED,   // 1: no greedy / select / peel launches behind a batch the closure decided entirely TEASER_HIP_HEU_SKIP_CLOSED
+  S_TAIL_SKIP,         // TIMING PROBES ONLY (results are wrong): bit mask of stages NOT enqueued behind K1 -- 1 fix-up, 2 degree closure, 4 greedy / select / peel, 8 estimators, 16 K1 pre-pass (stale operands) TEASER_HIP_TAIL_SKIP
   S_COUNT
 };
 int64_t setting(Setting id);

@@ -1217,29 +1217,40 @@ __global__ __launch_bounds__(256) void tim_fixup_group_kernel(const ProbDesc* __
   // one broadcast fetch of the column point and one word, instead of 17 points and 16 words on 16 different bitmap
   // rows (1.8 KB of sectors per item: that traffic, not the arithmetic, was the kernel's 0.175 ms per 64 x 10 k launch).
   __shared__ double row_pts[4][64][6];
+  // ... and so are the COLUMN sides of a region's items (round 6): lane k fetches the column point of item k and the
+  // transposed word that holds its 16 provisional bits -- seven load instructions per region, whatever its item count --
+  // and the 16 lanes of an item read them back from the wave's LDS slice.  (Fetched inside the item loop they were
+  // seven instructions per FOUR items, each for four distinct addresses: ~5 M vector-memory instructions per
+  // 64 x 10 k batch, two thirds of what K1 itself issues, and on a step bound by the board's power limit the fix-up's
+  // energy -- 0.1 J of 1.1 -- is paid for in K1's clock: profiles/r6v, r6w.)
+  __shared__ __attribute__((aligned(16))) double col_pts[4][64][8];  // [6]: the word's bits, [7]: unused
   const uint64_t* bm64 = bitmap + d.bm_off;
-  auto resolve = [&](unsigned long long it, bool valid, auto staged, int tile) {
+  auto resolve = [&](unsigned long long it, bool valid, auto staged, int tile, int slot) {
     constexpr bool STAGED = decltype(staged)::value;
     int r = (int)((it >> 16) & 0xffff) + rq, col = (int)(it & 0xffff);
     valid = valid && r < n && col < n && r != col;
     r = valid ? r : (STAGED ? tile * 64 : 0);
     col = valid ? col : 0;
     // every load up front: the two points and the word that holds the provisional bit
-    double sx, sy, sz, dx, dy, dz;
+    double sx, sy, sz, dx, dy, dz, cx, cy, cz, ex, ey, ez;
+    unsigned long long tword = 0ull;
     if (STAGED) {
       const double* rp = row_pts[wave][r & 63];
       sx = rp[0]; sy = rp[1]; sz = rp[2]; dx = rp[3]; dy = rp[4]; dz = rp[5];
+      const double* cp = col_pts[wave][slot];
+      cx = cp[0]; cy = cp[1]; cz = cp[2]; ex = cp[3]; ey = cp[4]; ez = cp[5];
+      tword = (unsigned long long)__double_as_longlong(cp[6]);
     } else {
       sx = ps[3 * r]; sy = ps[3 * r + 1]; sz = ps[3 * r + 2];
       dx = pd[3 * r]; dy = pd[3 * r + 1]; dz = pd[3 * r + 2];
+      cx = ps[3 * col]; cy = ps[3 * col + 1]; cz = ps[3 * col + 2];
+      ex = pd[3 * col]; ey = pd[3 * col + 1]; ez = pd[3 * col + 2];
     }
-    const double cx = ps[3 * col], cy = ps[3 * col + 1], cz = ps[3 * col + 2];
-    const double ex = pd[3 * col], ey = pd[3 * col + 1], ez = pd[3 * col + 2];
     unsigned int* wp = bm32 + 2 * ((int64_t)r * W + (col >> 6)) + ((col >> 5) & 1);
     const unsigned int bit = 1u << (col & 31);
     bool prov;
     if (STAGED && (r >> 6) != (col >> 6)) {  // (uniform over the 16 lanes of an item)
-      prov = ((bm64[(int64_t)col * W + (r >> 6)] >> (r & 63)) & 1ull) != 0ull;
+      prov = ((tword >> (r & 63)) & 1ull) != 0ull;
     } else {
       prov = (*wp & bit) != 0u;
     }
@@ -1271,19 +1282,28 @@ __global__ __launch_bounds__(256) void tim_fixup_group_kernel(const ProbDesc* __
       rp[0] = ps[3 * pr]; rp[1] = ps[3 * pr + 1]; rp[2] = ps[3 * pr + 2];
       rp[3] = pd[3 * pr]; rp[4] = pd[3 * pr + 1]; rp[5] = pd[3 * pr + 2];
     }
+    if (lane >= 1 && lane <= cnt) {  // item `lane`: its column point and (off the diagonal tile) its transposed word
+      const int col = min((int)(mine & 0xffffull), n - 1);
+      double* cp = col_pts[wave][lane];
+      const double c0 = ps[3 * col], c1 = ps[3 * col + 1], c2 = ps[3 * col + 2];
+      const double e0 = pd[3 * col], e1 = pd[3 * col + 1], e2 = pd[3 * col + 2];
+      const unsigned long long tw = (col >> 6) != tile ? bm64[(int64_t)col * W + tile] : 0ull;
+      cp[0] = c0; cp[1] = c1; cp[2] = c2; cp[3] = e0; cp[4] = e1; cp[5] = e2;
+      cp[6] = __longlong_as_double((long long)tw);
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // wave-private LDS slice: same-wave ordering suffices
 #pragma nounroll
     for (int base = 1; base <= cnt; base += 4) {
       const int k = base + sub;
       const unsigned int lo = (unsigned int)__shfl((int)(unsigned int)mine, k & 63, 64);
       const unsigned int hi = (unsigned int)__shfl((int)(unsigned int)(mine >> 32), k & 63, 64);
-      resolve(((unsigned long long)hi << 32) | lo, k <= cnt, std::true_type(), tile);
+      resolve(((unsigned long long)hi << 32) | lo, k <= cnt, std::true_type(), tile, k & 63);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the next region overwrites the slice)
   }
   const unsigned long long* seg = work + (((size_t)tpr.seg_off_hi << 32) | (size_t)tpr.seg_off_lo);
   const unsigned int ngrp = gridDim.x * 16;
-  for (unsigned int w = (blockIdx.x * 256 + threadIdx.x) >> 4; w < total; w += ngrp) resolve(seg[w], true, std::false_type(), 0);
+  for (unsigned int w = (blockIdx.x * 256 + threadIdx.x) >> 4; w < total; w += ngrp) resolve(seg[w], true, std::false_type(), 0, 0);
 }
 void launch_tim_graph(hipStream_t s, const ProbDesc* d_desc, int batch, int max_n,
                       const double* d_src, const double* d_dst, uint64_t* d_bitmap,

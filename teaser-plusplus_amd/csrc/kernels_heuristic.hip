@@ -622,11 +622,14 @@ __device__ __forceinline__ void suffix_counts(const int* hist, int* above, int t
   __syncthreads();
 }
 
-// Launch 1 of the closure, grid (G, batch): R, its order, H and the compact rows of this workgroup's slice of R.
-__global__ __launch_bounds__(kDegThreads) void degree_closure_rows_kernel(
-    const ProbDesc* __restrict__ descs, const uint64_t* __restrict__ bitmap, const int32_t* __restrict__ deg,
-    ProbState* __restrict__ states, uint64_t* __restrict__ comp_pool /* [batch][kCoreCap][kCoreWords] */,
-    int32_t* __restrict__ h_pool /* [batch][kCoreCap] */, uint32_t* __restrict__ key_pool /* [batch][kCoreCap] */,
+// Launch 1 of the closure, ONE workgroup per problem (grid (1, batch)): R = { deg >= t } and its order (degree
+// descending, vertex ascending) as keys (degree << 16 | vertex), |R| and t.  (Round 6: this preamble used to run in every
+// one of the G workgroups per problem of the rows launch -- 16 x 64 histograms over all n degrees per batch; on a step
+// that is bound by the board's power limit, not by time, the tail's redundant work is paid for in K1's clock:
+// profiles/r6v.)
+__global__ __launch_bounds__(kDegThreads) void degree_closure_order_kernel(
+    const ProbDesc* __restrict__ descs, const int32_t* __restrict__ deg, ProbState* __restrict__ states,
+    uint32_t* __restrict__ key_pool /* [batch][kCoreCap] */,
     int32_t* __restrict__ counters /* [batch] |R|, [batch] t; zero on entry (|R| = 0: the closure declined) */, int batch) {
   TAIL_WAVE_PRIO();
   __shared__ uint64_t Pa[kDegMaxW];          // { deg >= t } over the vertices
@@ -640,7 +643,6 @@ __global__ __launch_bounds__(kDegThreads) void degree_closure_rows_kernel(
   const int n = d.n, W = d.W, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (n < 2 || W > kDegMaxW) return;  // (uniform per problem: every workgroup of it leaves)
   const int32_t* dg = deg + d.pt_off;
-  const uint64_t* bm = bitmap + d.bm_off;
   // ---- degree histogram: the degree-only bound h0, the threshold t of R, the slot cursors ---
   for (int i = tid; i <= kDegBins; i += kDegThreads) hist[i] = 0;
   __syncthreads();
@@ -763,16 +765,50 @@ __global__ __launch_bounds__(kDegThreads) void degree_closure_rows_kernel(
   for (int q = 0; q < kCoreCap / kDegThreads; ++q)
     if (fin_pos[q] >= 0) keys[fin_pos[q]] = fin_key[q];
   __syncthreads();
+  {  // what the rows and verdict launches need
+    uint32_t* kout = key_pool + (size_t)blockIdx.y * kCoreCap;
+    for (int r = tid; r < m; r += kDegThreads) kout[r] = keys[r];
+    if (tid == 0) {
+      counters[blockIdx.y] = m;
+      counters[batch + blockIdx.y] = t;
+    }
+  }
+}
+
+// Launch 2 of the closure, grid (G, batch): H and the compact rows of this workgroup's slice of R.  A wave takes four
+// rows at a time: the bitmap rows are read ONCE, whole, with coalesced loads into the wave's LDS slice, and the bits of
+// the |R| candidate columns are picked out of LDS (round 6; it was one global gather instruction per row and 64 columns
+// -- ~9 per row at N = 10 k, each touching most of the row's 20 cache lines: seven times the row's lines through the
+// address units, 0.13 J of the headline step's 1.13 J).  Rows longer than kRowStageWords words keep the gather.
+constexpr int kRowStageWords = 256;  // n <= 16384
+__global__ __launch_bounds__(kDegThreads) void degree_closure_rows_kernel(
+    const ProbDesc* __restrict__ descs, const uint64_t* __restrict__ bitmap,
+    uint64_t* __restrict__ comp_pool /* [batch][kCoreCap][kCoreWords] */,
+    int32_t* __restrict__ h_pool /* [batch][kCoreCap] */, const uint32_t* __restrict__ key_pool /* [batch][kCoreCap] */,
+    const int32_t* __restrict__ counters, int batch) {
+  TAIL_WAVE_PRIO();
+  constexpr int kRows = 4, kGrp = 8;
+  __shared__ unsigned int keys[kCoreCap];
+  __shared__ __attribute__((aligned(16))) uint64_t rowbuf[kDegThreads / 64][kRows][kRowStageWords];
+  const int m = counters[blockIdx.y];
+  if (m < 2) return;
+  const ProbDesc d = descs[blockIdx.y];
+  const int W = d.W, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const uint64_t* bm = bitmap + d.bm_off;
+  {
+    const uint32_t* kin = key_pool + (size_t)blockIdx.y * kCoreCap;
+    for (int r = tid; r < m; r += kDegThreads) keys[r] = kin[r];
+  }
+  __syncthreads();
   const int ng = (m + 63) >> 6;
   uint64_t* comp = comp_pool + (size_t)blockIdx.y * kCoreCap * kCoreWords;
   int32_t* hout = h_pool + (size_t)blockIdx.y * kCoreCap;
-  // ---- this workgroup's slice of the rows: H and the compact row ------------------------------
+  const bool staged = W <= kRowStageWords;
   {
     const int G = gridDim.x;
     const int per = (((m + G - 1) / G) + 15) & ~15;
     const int k0 = min(m, (int)blockIdx.x * per), k1 = min(m, k0 + per);
     const unsigned int* bm32 = reinterpret_cast<const unsigned int*>(bm);
-    constexpr int kRows = 4, kGrp = 8;
     const uint64_t le_mask = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
     for (int rb = k0 + wave * kRows; rb < k1; rb += 4 * kRows) {
       const unsigned int* rp[kRows];
@@ -786,33 +822,56 @@ __global__ __launch_bounds__(kDegThreads) void degree_closure_rows_kernel(
         base[r] = 0;
         myword[r] = 0;
       }
-      for (int g0 = 0; g0 < ng; g0 += kGrp) {
-        unsigned int x[kRows][kGrp];
-        int cbit[kGrp], cdeg[kGrp];
+      if (staged) {  // (uniform per problem) every load of the four rows first, then the LDS stores
+        uint64_t wv[kRows][kRowStageWords / 64];
 #pragma unroll
-        for (int q = 0; q < kGrp; ++q) {
-          const int idx = 64 * (g0 + q) + lane;
-          const unsigned int key = idx < m ? keys[idx] : 0u;
-          const int c = (int)(key & 0xffffu);
-          cdeg[q] = idx < m ? (int)(key >> 16) : -1;  // (-1: no such column)
-          cbit[q] = c & 31;
+        for (int r = 0; r < kRows; ++r)
 #pragma unroll
-          for (int r = 0; r < kRows; ++r) x[r][q] = (cdeg[q] >= 0) ? rp[r][c >> 5] : 0u;
-        }
+          for (int u = 0; u < kRowStageWords / 64; ++u)
+            wv[r][u] = 64 * u + lane < W ? reinterpret_cast<const uint64_t*>(rp[r])[64 * u + lane] : 0ull;
 #pragma unroll
-        for (int q = 0; q < kGrp; ++q) {
-          if (g0 + q >= ng) break;
+        for (int r = 0; r < kRows; ++r)
 #pragma unroll
-          for (int r = 0; r < kRows; ++r) {
-            const bool bit = cdeg[q] >= 0 && ((x[r][q] >> cbit[q]) & 1u);
-            const uint64_t mask = __ballot(bit);
-            const int P = base[r] + __popcll(mask & le_mask);
-            if (bit) hmax[r] = max(hmax[r], min(P, cdeg[q]));
-            base[r] += __popcll(mask);
-            if (lane == g0 + q) myword[r] = mask;
+          for (int u = 0; u < kRowStageWords / 64; ++u)
+            if (64 * u < W) rowbuf[wave][r][64 * u + lane] = wv[r][u];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // wave-private slice: same-wave ordering suffices
+      }
+      const unsigned int* rowlds = reinterpret_cast<const unsigned int*>(&rowbuf[wave][0][0]);  // (LDS address space)
+      auto groups = [&](auto staged_tag) {
+        constexpr bool STAGED = decltype(staged_tag)::value;
+        for (int g0 = 0; g0 < ng; g0 += kGrp) {
+          unsigned int x[kRows][kGrp];
+          int cbit[kGrp], cdeg[kGrp];
+#pragma unroll
+          for (int q = 0; q < kGrp; ++q) {
+            const int idx = 64 * (g0 + q) + lane;
+            const unsigned int key = idx < m ? keys[idx] : 0u;
+            const int c = (int)(key & 0xffffu);
+            cdeg[q] = idx < m ? (int)(key >> 16) : -1;  // (-1: no such column)
+            cbit[q] = c & 31;
+#pragma unroll
+            for (int r = 0; r < kRows; ++r)
+              x[r][q] = (cdeg[q] >= 0) ? (STAGED ? rowlds[r * 2 * kRowStageWords + (c >> 5)] : rp[r][c >> 5]) : 0u;
+          }
+#pragma unroll
+          for (int q = 0; q < kGrp; ++q) {
+            if (g0 + q >= ng) break;
+#pragma unroll
+            for (int r = 0; r < kRows; ++r) {
+              const bool bit = cdeg[q] >= 0 && ((x[r][q] >> cbit[q]) & 1u);
+              const uint64_t mask = __ballot(bit);
+              const int P = base[r] + __popcll(mask & le_mask);
+              if (bit) hmax[r] = max(hmax[r], min(P, cdeg[q]));
+              base[r] += __popcll(mask);
+              if (lane == g0 + q) myword[r] = mask;
+            }
           }
         }
-      }
+      };
+      if (staged)
+        groups(std::true_type());
+      else
+        groups(std::false_type());
 #pragma unroll
       for (int r = 0; r < kRows; ++r) {
         int hv = hmax[r];
@@ -823,14 +882,7 @@ __global__ __launch_bounds__(kDegThreads) void degree_closure_rows_kernel(
           if (lane == 0) hout[rb + r] = hv;
         }
       }
-    }
-  }
-  if (blockIdx.x == 0) {  // what the verdict launch needs besides H and the compact rows
-    uint32_t* kout = key_pool + (size_t)blockIdx.y * kCoreCap;
-    for (int r = tid; r < m; r += kDegThreads) kout[r] = keys[r];
-    if (tid == 0) {
-      counters[blockIdx.y] = m;
-      counters[batch + blockIdx.y] = t;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (the next pass overwrites the slice)
     }
   }
 }
@@ -1078,8 +1130,10 @@ void launch_degree_closure(hipStream_t s, const ProbDesc* d_desc, int batch, con
   uint64_t* comp = reinterpret_cast<uint64_t*>(d_scratch);
   int32_t* hp = reinterpret_cast<int32_t*>(comp + (size_t)batch * kCoreCap * kCoreWords);
   uint32_t* kp = reinterpret_cast<uint32_t*>(hp + (size_t)batch * kCoreCap);
-  hipLaunchKernelGGL(degree_closure_rows_kernel, dim3(G, batch), dim3(kDegThreads), 0, s, d_desc, d_bitmap, d_deg, d_state,
-                     comp, hp, kp, d_counters, batch);
+  hipLaunchKernelGGL(degree_closure_order_kernel, dim3(1, batch), dim3(kDegThreads), 0, s, d_desc, d_deg, d_state, kp,
+                     d_counters, batch);
+  hipLaunchKernelGGL(degree_closure_rows_kernel, dim3(G, batch), dim3(kDegThreads), 0, s, d_desc, d_bitmap, comp, hp, kp,
+                     d_counters, batch);
   hipLaunchKernelGGL(degree_closure_verdict_kernel, dim3(batch), dim3(kDegThreads), 0, s, d_desc, d_state, d_clique, comp, hp,
                      kp, d_counters, batch);
 }

@@ -84,6 +84,7 @@ const SettingRow kSettingRows[S_COUNT] = {
     {"scale_hull_sync", "TEASER_HIP_SCALE_HULL_SYNC", 1, 0, 1},
     {"colour_persistent", "TEASER_HIP_COLOUR_PERSISTENT", 0, 0, 65536},
     {"heu_skip_closed", "TEASER_HIP_HEU_SKIP_CLOSED", 0, 0, 1},
+    {"tail_skip", "TEASER_HIP_TAIL_SKIP", 0, 0, 31},
 };
 struct SettingTable {
   std::atomic<int64_t> v[S_COUNT];
@@ -1226,7 +1227,9 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
                        P.cbar2, P.estimate_scaling ? 1 : 0, ds);
     } else {
       const int64_t cap = tim_work_items(n, batch);
+      const int64_t tail_skip = setting(S_TAIL_SKIP);  // (timing probes only)
       for (int phase = 0; phase < 3; ++phase) {
+        if ((phase == 2 && (tail_skip & 1)) || (phase == 0 && (tail_skip & 16))) continue;
         // lanes (asynchronous batches in flight) run their K1 kernels one after the other: this
         // lane's starts when the previously submitted lane's has finished, so that a K1 shares the
         // GPU only with the latency-bound tail stages of the batches before it
@@ -1274,7 +1277,8 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
     // whose clique follows from the degrees are closed before any heuristic runs.  (heu_skip_closed = 1: when the
     // previous batch of this handle was closed entirely, the greedy / select / peel launches are not even enqueued:
     // the finish half runs them for the problems the closure left open, should there be any.)
-    const bool closure = mode == TEASER_INLIER_PMC_EXACT && max_n <= 65536 && setting(S_DEG_CLOSURE) != 0;
+    const bool closure = mode == TEASER_INLIER_PMC_EXACT && max_n <= 65536 && setting(S_DEG_CLOSURE) != 0 &&
+                         !(setting(S_TAIL_SKIP) & 2);
     if (closure) {
       StageScope sc(h, ST_HEU);
       HIPCHK(h, h->d_core.ensure((size_t)degree_closure_scratch_bytes(batch)));
@@ -1283,7 +1287,7 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
     }
     h->pend.closure = closure;
     h->pend.heuristic_enqueued = !(closure && h->skip_heuristic_next && setting(S_HEU_SKIP_CLOSED) != 0);
-    if (h->pend.heuristic_enqueued) {
+    if (h->pend.heuristic_enqueued && !(setting(S_TAIL_SKIP) & 4)) {
       int32_t rc = enqueue_heuristic_stage(h, batch, mode, mfma_k1);
       if (rc != TEASER_HIP_OK) return rc;
     }
@@ -1319,7 +1323,7 @@ int32_t solve_packed_enqueue(teaser_hip_solver* h, const double* d_src, const do
   // speculative: the greedy clique is almost always the maximum one, so the estimators are
   // enqueued before the host learns whether the peel closed the bound (one sync per solve)
   h->pend.spec_bounds = false;
-  int32_t rc = enqueue_estimators(h);
+  int32_t rc = (setting(S_TAIL_SKIP) & 8) ? TEASER_HIP_OK : enqueue_estimators(h);
   if (rc == TEASER_HIP_OK && need_graph && mode == TEASER_INLIER_PMC_EXACT && h->spec_bounds_next && spec_bounds_enabled() &&
       h->pend.heuristic_enqueued) {
     rc = enqueue_bounds_speculative(h, batch, total_n);

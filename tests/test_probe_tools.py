@@ -14,5 +14,5 @@ def test_k1_knockout_variants_still_apply(tmp_path):
     for name, make in mod.VARIANTS.items():
         text = make()
         assert text != mod.SRC and "tim_graph_mfma3_kernel" in text, name
-        if name != "touch":  # every variant with wrong bits forces its outputs to zero and drops its flags
+        if name not in ("touch", "seq3", "seq4"):  # every variant with wrong bits forces its outputs to zero and drops its flags
             assert "ownw = 0;" in text and "unsigned int vf = 0;" in text, name
