@@ -1034,15 +1034,20 @@ def main():
                              "SURVEY.md 8(d)'s timer scope; never `value`"}
         del pinned
 
-    # ---- board power over a LONG run of the same steps (rank 0; untimed extra) ---------------------
+    # ---- board power over a LONG run of the same steps (untimed extra) ---------------------
     # The two-lane pipeline of this workload runs at the board's power cap: energy per step is the same whatever the
     # schedule (profiles/r6c), so the step time is energy / cap and K1 takes longer inside the pipeline than alone
     # because its clock is what the power controller gives.  hwmon samples are ~10 ms apart and the controller's
     # filter is slower still, so the region here is >= 1.5 s of steps, not the 20-step timed regions above.
     power = None
-    if not args.no_power and rank == 0:
+    if not args.no_power:  # (every rank runs the region -- its barriers are collective --, rank 0's GPU is the one reported)
         ps = PowerSampler(torch, dev)
-        if ps.available():
+        have = ps.available()
+        if world > 1:  # the ranks must agree on whether the region runs
+            flag = torch.tensor([1 if have else 0], device=runner.gather_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            have = bool(int(flag.item()))
+        if have:
             steps_p = max(args.steps, int(1.5 / max(elapsed / args.steps, 1e-5)))
             with ps:
                 tp0 = time.perf_counter()

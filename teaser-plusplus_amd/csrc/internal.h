@@ -137,6 +137,7 @@ enum Setting {
   S_SCALE_HULL_SYNC,   // 1: the host reads the hull's size before the compaction (one more sync per large scale stage) TEASER_HIP_SCALE_HULL_SYNC
   S_COLOUR_PERSISTENT, // > 0: problems of at least this many vertices run all colouring rounds in one launch (0: never) TEASER_HIP_COLOUR_PERSISTENT
   S_HEU_SKIP_CLOSED,   // 1: no greedy / select / peel launches behind a batch the closure decided entirely TEASER_HIP_HEU_SKIP_CLOSED
+  S_REFERENCE_SNAPSHOT, // 1: a handle behaves like the reference SNAPSHOT's binary, whose solve() never sees the caller's clique / graph fields (params_ is not stored: registration.h:830-908, registration.cc:574-583): PMC_EXACT + CHAIN + the default k-core threshold and time limit whatever was passed; read when a handle is created or reset TEASER_HIP_REFERENCE_SNAPSHOT
   S_TAIL_SKIP,         // TIMING PROBES ONLY (results are wrong): bit mask of stages NOT enqueued behind K1 -- 1 fix-up, 2 degree closure, 4 greedy / select / peel, 8 estimators, 16 K1 pre-pass (stale operands) TEASER_HIP_TAIL_SKIP
   S_COUNT
 };

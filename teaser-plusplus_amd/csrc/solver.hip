@@ -84,6 +84,7 @@ const SettingRow kSettingRows[S_COUNT] = {
     {"scale_hull_sync", "TEASER_HIP_SCALE_HULL_SYNC", 1, 0, 1},
     {"colour_persistent", "TEASER_HIP_COLOUR_PERSISTENT", 0, 0, 65536},
     {"heu_skip_closed", "TEASER_HIP_HEU_SKIP_CLOSED", 0, 0, 1},
+    {"reference_snapshot_semantics", "TEASER_HIP_REFERENCE_SNAPSHOT", 0, 0, 1},
     {"tail_skip", "TEASER_HIP_TAIL_SKIP", 0, 0, 31},
 };
 struct SettingTable {
@@ -278,7 +279,8 @@ struct LaneFinisher {
 };
 
 struct teaser_hip_solver {
-  teaser_params_c params;
+  teaser_params_c params;        // what the solve paths read (reference_snapshot_semantics applied)
+  teaser_params_c params_given;  // what the caller passed (teaser_hip_solver_get_params)
   int device = 0;
   hipStream_t stream = nullptr;
   std::string err;
@@ -490,6 +492,26 @@ void profile_end(teaser_hip_solver* h) {
 bool params_supported(const teaser_params_c& p) {
   return p.rotation_estimation_algorithm >= TEASER_ROT_GNC_TLS &&
          p.rotation_estimation_algorithm <= TEASER_ROT_QUATRO;
+}
+
+// reference_snapshot_semantics = 1: the fields the reference snapshot's solve() reads from its never-assigned params_
+// (registration.h:830-908: neither reset overload stores them; registration.cc:574-583, 609, 623-632, 657 read them)
+// take the defaults of registration.h:419-514, as they do in the reference binary; the fields reset() bakes into the
+// sub-solvers (noise bound, cbar2, estimate_scaling, the rotation algorithm and its GNC settings) stay the caller's.
+teaser_params_c snapshot_params(const teaser_params_c& given) {
+  teaser_params_c p = given;
+  if (setting(S_REFERENCE_SNAPSHOT) != 0) {
+    teaser_params_c def;
+    teaser_hip_params_default(&def);
+    p.inlier_selection_mode = def.inlier_selection_mode;        // PMC_EXACT
+    p.rotation_tim_graph = def.rotation_tim_graph;              // CHAIN
+    p.kcore_heuristic_threshold = def.kcore_heuristic_threshold;
+    p.use_max_clique = def.use_max_clique;
+    p.max_clique_exact_solution = def.max_clique_exact_solution;
+    p.max_clique_time_limit = def.max_clique_time_limit;
+    p.max_clique_num_threads = def.max_clique_num_threads;
+  }
+  return p;
 }
 
 int effective_mode(const teaser_params_c& p) {
@@ -2033,9 +2055,10 @@ int32_t teaser_hip_solver_create(const teaser_params_c* params, int32_t device,
   teaser_hip_solver* h = new teaser_hip_solver();
   h->device = device;
   if (params)
-    h->params = *params;
+    h->params_given = *params;
   else
-    teaser_hip_params_default(&h->params);
+    teaser_hip_params_default(&h->params_given);
+  h->params = snapshot_params(h->params_given);
   memset(&h->prof, 0, sizeof(h->prof));
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
     delete h;
@@ -2071,7 +2094,8 @@ int32_t teaser_hip_solver_destroy(teaser_hip_solver* h) {
 
 int32_t teaser_hip_solver_reset(teaser_hip_solver* h, const teaser_params_c* params) {
   if (!h || !params) return TEASER_HIP_ERR_BAD_ARG;
-  h->params = *params;
+  h->params_given = *params;
+  h->params = snapshot_params(h->params_given);
   h->batch = 0;  // reset() clears max_clique_/inliers/graph, registration.h:881-885
   h->have_graph = false;
   h->route.clear();
@@ -2080,7 +2104,7 @@ int32_t teaser_hip_solver_reset(teaser_hip_solver* h, const teaser_params_c* par
 
 int32_t teaser_hip_solver_get_params(const teaser_hip_solver* h, teaser_params_c* params) {
   if (!h || !params) return TEASER_HIP_ERR_BAD_ARG;
-  *params = h->params;
+  *params = h->params_given;
   return TEASER_HIP_OK;
 }
 

@@ -1104,6 +1104,39 @@ def test_inlier_selection_modes():
         s.solve(pr["src"], pr["dst"])
 
 
+def test_reference_snapshot_semantics_option():
+    """reference_snapshot_semantics = 1: a handle behaves like the reference SNAPSHOT's binary, whose solve() reads a
+    params_ that neither constructor nor reset() ever assigns (registration.h:830-908, registration.cc:574-583; SURVEY
+    F3): inlier_selection_mode NONE / use_max_clique = false / COMPLETE graph are ignored -- PMC_EXACT + CHAIN run --
+    while noise bound, scaling and the rotation estimator stay the caller's.  Default 0: the documented modes."""
+    pr = tp.synth_problem(31, 400, 0.8, 0.01)
+    truth = np.flatnonzero(pr["inliers"]).tolist()
+    kw = bench_params(inlier_selection_mode=tp.InlierSelectionMode.NONE, use_max_clique=False,
+                      rotation_tim_graph=tp.InlierGraphFormulation.COMPLETE)
+    s = make_solver(**kw)
+    s.solve(pr["src"], pr["dst"])
+    assert s.getInlierMaxClique() == list(range(400))  # documented semantics: no clique selection
+    ref = make_solver(**bench_params())
+    want = ref.solve(pr["src"], pr["dst"])
+    tp.set_option("reference_snapshot_semantics", 1)
+    try:
+        s2 = make_solver(**kw)  # (the option is read when a handle is created or reset)
+        got = s2.solve(pr["src"], pr["dst"])
+        assert s2.getInlierMaxClique() == truth == ref.getInlierMaxClique()
+        assert np.array_equal(got.rotation, want.rotation) and np.array_equal(got.translation, want.translation)
+        assert s2.getRotationInliers() == ref.getRotationInliers()
+        # the caller's Params are still what the getter returns
+        assert int(s2.getParams().inlier_selection_mode) == int(tp.InlierSelectionMode.NONE)
+        s.reset(tp.RobustRegistrationSolver.Params(**kw))  # an existing handle picks the option up at reset()
+        s.solve(pr["src"], pr["dst"])
+        assert s.getInlierMaxClique() == truth
+    finally:
+        tp.set_option("reference_snapshot_semantics", 0)
+    s.reset(tp.RobustRegistrationSolver.Params(**kw))
+    s.solve(pr["src"], pr["dst"])
+    assert s.getInlierMaxClique() == list(range(400))
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
 def test_reference_no_max_clique_and_clique_finder_modes(seed):
     """The reference's own NoMaxClique / CliqueFinderModes tests (registration-test.cc:469-680; inputs restated in
