@@ -363,6 +363,7 @@ __global__ __launch_bounds__(kHullThreads) void hull_hist_kernel(const double* _
   __syncthreads();
   const double c = plan->c, v0 = plan->v0, inv_w = plan->inv_w;
   const int n_lin = plan->n_lin;
+  const double t_in_lo = T[1], t_in_hi = T[kHullBins - 1];
   int bad = 0;
   for (int i = blockIdx.x; i < n - 1; i += gridDim.x) {
     for (int j = i + 1 + threadIdx.x; j < n; j += kHullThreads) {
@@ -373,6 +374,14 @@ __global__ __launch_bounds__(kHullThreads) void hull_hist_kernel(const double* _
         continue;
       }
       const double lo = sv - av, hi = sv + av;  // (the endpoint kernels' keys)
+      // level 2: nine endpoints in ten lie outside the first hull, i.e. in the two bins that are left out -- two
+      // compares against the hull's ends (T[1], T[kHullBins - 1]: exactly hull_bin's own criterion for those bins; a
+      // NaN fails both and takes the long way) instead of two table searches: 0.76 -> 0.70 ms.  What the pass costs is
+      // the binning code itself -- table search, FP64 -> int64 conversions, eight 64-bit LDS atomics -- which a wave
+      // executes whenever ONE of its lanes needs it (99 % of the steps); measured and not adopted (profiles/r6c):
+      // four pairs per thread side by side (not latency), per-workgroup slabs instead of global atomics for the flush
+      // (not contention).  hull_eval_kernel does the same measurements alone in 0.205 ms = the FP64 issue rate.
+      if (inner_only && (lo < t_in_lo || lo >= t_in_hi) && (hi < t_in_lo || hi >= t_in_hi)) continue;
       const int bo = hull_bin(T, lo, v0, inv_w, n_lin), bc = hull_bin(T, hi, v0, inv_w, n_lin);
       const double rq = av * 1048576.0;  // 2^20
       const unsigned long long r_up = (unsigned long long)__builtin_ceil(rq), r_dn = (unsigned long long)__builtin_floor(rq);

@@ -2,7 +2,7 @@
 """Generates tests/golden/config_golden.json: ORACLE results for the full-size BASELINE configs the
 GPU test-suite cannot afford to re-run on the CPU each time:
 
-  * config 3 -- N = 50 000, 99 % outliers (seed 20250523 + 3): maximum clique, rotation /
+  * config 3 -- N = 50 000, 99 % outliers (seeds 20250523 + 3 and + 2003): maximum clique, rotation /
     translation inlier index lists, R, t, GNC cost / iterations, edge count, and the SHA-256 of the
     whole 313 MB adjacency bitmap (so the GPU bitmap is compared bit for bit through its digest);
   * config 4 -- three elements (0, 57, 127) of the 128 x N = 5 000, 90 % outliers batch
@@ -35,13 +35,19 @@ KW = dict(noise_bound=0.01, cbar2=1.0, estimate_scaling=0, rotation_gnc_factor=1
 CASES = [
     ("config2", 20250523, 10000, 0.95),
     ("config3", 20250523 + 3, 50000, 0.99),
+    ("config3_seed2", 20250523 + 3 + 2000, 50000, 0.99),   # (a second full-size case: round 6)
     ("config4_b0", 20250523 + 4000 + 0, 5000, 0.9),
     ("config4_b57", 20250523 + 4000 + 57, 5000, 0.9),
     ("config4_b127", 20250523 + 4000 + 127, 5000, 0.9),
 ]
 
-out = {}
+# `make_config_golden.py name ...`: only those cases are recomputed, the others keep their committed entries
+PATH = os.path.join(ROOT, "tests", "golden", "config_golden.json")
+only = set(sys.argv[1:])
+out = json.load(open(PATH)) if only and os.path.exists(PATH) else {}
 for name, seed, n, rho in CASES:
+    if only and name not in only:
+        continue
     pr = tp.synth_problem(seed, n, rho, 0.01)
     t0 = time.time()
     o = oracle.solve(pr["src"], pr["dst"], **KW)
@@ -66,4 +72,4 @@ for name, seed, n, rho in CASES:
     }
     print(name, {k: v for k, v in out[name].items()
                  if k not in ("max_clique", "rotation_inliers", "translation_inliers")}, flush=True)
-json.dump(out, open(os.path.join(ROOT, "tests", "golden", "config_golden.json"), "w"), indent=0)
+json.dump(out, open(PATH, "w"), indent=0)

@@ -860,12 +860,13 @@ def check_against_fixture(s, sol, fx, problem=0):
         assert np.linalg.norm(np.asarray(sol.translation) - np.array(fx["translation"])) <= T_TOL
 
 
-def test_solve_config3_50k_vs_oracle_fixture():
-    """BASELINE config 3 against the ORACLE (committed fixture: the oracle needs minutes at this size):
+@pytest.mark.parametrize("case", ["config3", "config3_seed2"])
+def test_solve_config3_50k_vs_oracle_fixture(case):
+    """BASELINE config 3 against the ORACLE (committed fixtures, two seeds: the oracle needs minutes at this size):
     identical clique / inlier index sets, R and t within 1e-4, identical edge count, and the WHOLE 313 MB
     adjacency bitmap bit for bit through its SHA-256."""
     import hashlib
-    fx = config_golden()["config3"]
+    fx = config_golden()[case]
     pr = tp.synth_problem(fx["seed"], fx["n"], fx["outlier_ratio"], fx["noise_bound"])
     s = make_solver(**bench_params())
     sol = s.solve(pr["src"], pr["dst"])
