@@ -350,69 +350,118 @@ __global__ __launch_bounds__(256) void hull_table_kernel(const double* __restric
   }
 }
 
+// round-to-nearest-even of |x| < 2^51 as an integer: one addition and one integer subtraction (the compiler's own
+// FP64 -> int64 conversion is a ~20-instruction sequence, and the histogram pass converts five values per pair)
+__device__ __forceinline__ long long rint_small_ll(double x, double* rounded) {
+  const double y = x + 6755399441055744.0;  // 2^52 + 2^51
+  *rounded = y - 6755399441055744.0;
+  return __double_as_longlong(y) - 0x4338000000000000ll;
+}
+
+// INNER = level 2: bins 0 and kHullBins - 1 (outside the first hull: nine endpoints in ten) are left out.
+// What a pass costs beyond the measurements themselves (hull_eval_kernel makes the same ones alone in 0.205 ms = the FP64
+// issue rate) is the binning code -- table searches, conversions, eight 64-bit LDS atomics -- and a wave runs it whenever
+// ONE of its lanes needs it.  Level 2 therefore COMPACTS: the pairs with an endpoint inside the hull (two compares
+// against the hull's ends: exactly hull_bin's own criterion for the two outer bins; a NaN fails both and is kept) are
+// queued in the wave's 1 KB of LDS and binned up to 63 at a time (0.76 -> 0.48 ms; level 1: 0.65 -> 0.61 with the cheaper conversions).  Measured and not adopted (profiles/r6c): four
+// pairs per thread side by side (not latency), per-workgroup slabs instead of global atomics for the flush (not contention).
+constexpr int kHullQueue = 63;
+template <bool INNER>
 __global__ __launch_bounds__(kHullThreads) void hull_hist_kernel(const double* __restrict__ src, const double* __restrict__ dst,
                                                                  int n, double beta, const double* __restrict__ T_g,
                                                                  HullPlan* __restrict__ plan,
-                                                                 unsigned long long* __restrict__ hist /* [kHullKinds][kHullBins] */,
-                                                                 int inner_only /* level 2: bins 0 and kHullBins - 1 (outside the
-                                                                 first hull: two thirds of the endpoints on two counters) are left out */) {
-  extern __shared__ __attribute__((aligned(16))) unsigned long long lh[];  // [kHullKinds][kHullBins], then the table
+                                                                 unsigned long long* __restrict__ hist /* [kHullKinds][kHullBins] */) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long lh[];  // [kHullKinds][kHullBins], the table, the waves' queues
   double* T = reinterpret_cast<double*>(lh + kHullKinds * kHullBins);
+  // (INNER only) kHullQueue pairs per wave: what the 160 KB leave (a step in which all 64 lanes need the code bins them directly)
+  double2* queue = reinterpret_cast<double2*>(T + kHullBins + 2) + (threadIdx.x >> 6) * kHullQueue;
   for (int k = threadIdx.x; k < kHullKinds * kHullBins; k += kHullThreads) lh[k] = 0ull;
   for (int k = threadIdx.x; k <= kHullBins; k += kHullThreads) T[k] = T_g[k];
   __syncthreads();
   const double c = plan->c, v0 = plan->v0, inv_w = plan->inv_w;
+  const double inv_c = 1.0 / c;
   const int n_lin = plan->n_lin;
   const double t_in_lo = T[1], t_in_hi = T[kHullBins - 1];
+  const int lane = threadIdx.x & 63;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
   int bad = 0;
-  for (int i = blockIdx.x; i < n - 1; i += gridDim.x) {
-    for (int j = i + 1 + threadIdx.x; j < n; j += kHullThreads) {
-      double sv, av;
-      trim_terms(src, dst, i, j, beta, &sv, &av);
-      if (!(av >= 0.0 && av <= kHullRangeCap) || !(sv == sv) || !(sv < INFINITY && sv > -INFINITY)) {
-        ++bad;
-        continue;
+  auto bin_pair = [&](double sv, double av) {
+    const double lo = sv - av, hi = sv + av;  // (the endpoint kernels' keys)
+    const int bo = hull_bin(T, lo, v0, inv_w, n_lin), bc = hull_bin(T, hi, v0, inv_w, n_lin);
+    const double rq = av * 1048576.0;  // 2^20; 0 <= rq <= 2^30
+    double rr;
+    const long long ri = rint_small_ll(rq, &rr);
+    const unsigned long long r_up = (unsigned long long)(ri + (rr < rq ? 1 : 0)), r_dn = (unsigned long long)(ri - (rr > rq ? 1 : 0));  // ceil, floor
+    const bool use_o = !INNER || (bo >= 1 && bo <= kHullBins - 2), use_c = !INNER || (bc >= 1 && bc <= kHullBins - 2);
+    if (use_o) atomicAdd(&lh[0 * kHullBins + bo], r_up);
+    if (use_c) atomicAdd(&lh[1 * kHullBins + bc], r_dn);
+    const double xc = sv - c;
+    if (__builtin_fabs(xc) <= kHullSpan * c) {
+      // centred, scaled by c: |xs| <= 64 (to an ulp: the product with 1 / c instead of a division moves a quantised value
+      // by one step in 2^40 at most once in ~1e4 pairs, far inside the bounds' own rounding allowance); 2^40 and 2^30
+      // steps: sums of 5e7 terms stay below 2^63
+      const double xs = xc * inv_c;
+      double unused;
+      const long long xq = rint_small_ll(xs * 1099511627776.0, &unused);         // 2^40
+      const long long xxq = rint_small_ll(xs * xs * 1073741824.0, &unused);      // 2^30
+      if (use_o) {
+        atomicAdd(&lh[2 * kHullBins + bo], 1ull);
+        atomicAdd(&lh[4 * kHullBins + bo], (unsigned long long)xq);
+        atomicAdd(&lh[6 * kHullBins + bo], (unsigned long long)xxq);
       }
-      const double lo = sv - av, hi = sv + av;  // (the endpoint kernels' keys)
-      // level 2: nine endpoints in ten lie outside the first hull, i.e. in the two bins that are left out -- two
-      // compares against the hull's ends (T[1], T[kHullBins - 1]: exactly hull_bin's own criterion for those bins; a
-      // NaN fails both and takes the long way) instead of two table searches: 0.76 -> 0.70 ms.  What the pass costs is
-      // the binning code itself -- table search, FP64 -> int64 conversions, eight 64-bit LDS atomics -- which a wave
-      // executes whenever ONE of its lanes needs it (99 % of the steps); measured and not adopted (profiles/r6c):
-      // four pairs per thread side by side (not latency), per-workgroup slabs instead of global atomics for the flush
-      // (not contention).  hull_eval_kernel does the same measurements alone in 0.205 ms = the FP64 issue rate.
-      if (inner_only && (lo < t_in_lo || lo >= t_in_hi) && (hi < t_in_lo || hi >= t_in_hi)) continue;
-      const int bo = hull_bin(T, lo, v0, inv_w, n_lin), bc = hull_bin(T, hi, v0, inv_w, n_lin);
-      const double rq = av * 1048576.0;  // 2^20
-      const unsigned long long r_up = (unsigned long long)__builtin_ceil(rq), r_dn = (unsigned long long)__builtin_floor(rq);
-      const bool use_o = !inner_only || (bo >= 1 && bo <= kHullBins - 2), use_c = !inner_only || (bc >= 1 && bc <= kHullBins - 2);
-      if (use_o) atomicAdd(&lh[0 * kHullBins + bo], r_up);
-      if (use_c) atomicAdd(&lh[1 * kHullBins + bc], r_dn);
-      const double xc = sv - c;
-      if (__builtin_fabs(xc) <= kHullSpan * c) {
-        // centred, scaled by c: |xs| <= 64; 2^40 and 2^30 steps: sums of 5e7 terms stay below 2^63
-        const double xs = xc / c;
-        const long long xq = (long long)__builtin_rint(xs * 1099511627776.0);         // 2^40
-        const long long xxq = (long long)__builtin_rint(xs * xs * 1073741824.0);      // 2^30
-        if (use_o) {
-          atomicAdd(&lh[2 * kHullBins + bo], 1ull);
-          atomicAdd(&lh[4 * kHullBins + bo], (unsigned long long)xq);
-          atomicAdd(&lh[6 * kHullBins + bo], (unsigned long long)xxq);
+      if (use_c) {
+        atomicAdd(&lh[3 * kHullBins + bc], 1ull);
+        atomicAdd(&lh[5 * kHullBins + bc], (unsigned long long)xq);
+        atomicAdd(&lh[7 * kHullBins + bc], (unsigned long long)xxq);
+      }
+    }
+  };
+  int queued = 0;  // (wave-uniform)
+  auto flush = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // wave-private queue: same-wave ordering suffices
+    if (lane < queued) {
+      const double2 e = queue[lane];
+      bin_pair(e.x, e.y);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    queued = 0;
+  };
+  for (int i = blockIdx.x; i < n - 1; i += gridDim.x) {
+    for (int j0 = i + 1; j0 < n; j0 += kHullThreads) {  // (a wave steps through the row together: its queue is uniform)
+      const int j = j0 + (int)threadIdx.x;
+      bool need = false;
+      double sv = 0.0, av = 0.0;
+      if (j < n) {
+        trim_terms(src, dst, i, j, beta, &sv, &av);
+        if (!(av >= 0.0 && av <= kHullRangeCap) || !(sv == sv) || !(sv < INFINITY && sv > -INFINITY)) {
+          ++bad;
+        } else if (!INNER) {
+          bin_pair(sv, av);
+        } else {
+          const double lo = sv - av, hi = sv + av;
+          need = !((lo < t_in_lo || lo >= t_in_hi) && (hi < t_in_lo || hi >= t_in_hi));
         }
-        if (use_c) {
-          atomicAdd(&lh[3 * kHullBins + bc], 1ull);
-          atomicAdd(&lh[5 * kHullBins + bc], (unsigned long long)xq);
-          atomicAdd(&lh[7 * kHullBins + bc], (unsigned long long)xxq);
+      }
+      if (INNER) {
+        const uint64_t m = __ballot(need);
+        const int cnt = __popcll(m);
+        if (queued + cnt > kHullQueue) flush();
+        if (cnt > kHullQueue) {
+          bin_pair(sv, av);  // (all 64 lanes)
+        } else {
+          if (need) queue[queued + __popcll(m & lt_mask)] = make_double2(sv, av);
+          queued += cnt;
         }
       }
     }
   }
+  if (INNER) flush();
   __syncthreads();
   for (int k = threadIdx.x; k < kHullKinds * kHullBins; k += kHullThreads) {
     const unsigned long long v = lh[k];
     if (v) atomicAdd(&hist[k], v);
   }
-  if (bad && !inner_only) atomicAdd(&plan->anomalies, bad);
+  if (bad && !INNER) atomicAdd(&plan->anomalies, bad);
 }
 
 // Partial state sums of one row of pairs, reduced over the workgroup in a fixed shape (thread order inside a wave by a
@@ -1462,14 +1511,16 @@ hipError_t launch_tls_scale_large(hipStream_t s, const double* d_src, const doub
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
         if (cus <= 0) cus = 256;
       }
-      const size_t lds = 8 * (size_t)kHullKinds * kHullBins + sizeof(double) * (kHullBins + 1);
-      static DynLdsOptIn optin;
-      optin.ensure(reinterpret_cast<const void*>(hull_hist_kernel), (int)lds);
+      // histograms | table (kHullBins + 1 doubles, padded to + 2) | one 64-pair queue per wave (level 2)
+      const size_t lds = 8 * (size_t)kHullKinds * kHullBins + sizeof(double) * (kHullBins + 2) + sizeof(double2) * kHullQueue * (kHullThreads / 64);
+      static DynLdsOptIn optin, optin2;
+      optin.ensure(reinterpret_cast<const void*>(hull_hist_kernel<false>), (int)lds);
+      optin2.ensure(reinterpret_cast<const void*>(hull_hist_kernel<true>), (int)lds);
       (void)hipMemsetAsync(hist, 0, 8 * (size_t)kHullKinds * kHullBins, s);
       (void)hipMemsetAsync(shard_count, 0, sizeof(unsigned int) * kHullShards * kHullCountStride, s);
       hipLaunchKernelGGL(hull_table_kernel, dim3(1), dim3(256), 0, s, d_src, d_dst, n, T, plan);
-      hipLaunchKernelGGL(hull_hist_kernel, dim3((unsigned)std::min(n - 1, cus)), dim3(kHullThreads), lds, s, d_src, d_dst, n, beta,
-                         T, plan, hist, 0);
+      hipLaunchKernelGGL(hull_hist_kernel<false>, dim3((unsigned)std::min(n - 1, cus)), dim3(kHullThreads), lds, s, d_src, d_dst, n,
+                         beta, T, plan, hist);
       hipLaunchKernelGGL(hull_plan_kernel, dim3(1), dim3(kHullThreads), 0, s, 0, hist, pre, T, rows, n - 1, plan, d_overflow);
       hipLaunchKernelGGL(hull_eval_kernel, dim3((unsigned)(n - 1)), dim3(256), 0, s, d_src, d_dst, n, beta, plan, rows);
       hipLaunchKernelGGL(hull_plan_kernel, dim3(1), dim3(kHullThreads), 0, s, 1, hist, pre, T, rows, n - 1, plan, d_overflow);
@@ -1487,8 +1538,8 @@ hipError_t launch_tls_scale_large(hipStream_t s, const double* d_src, const doub
           // is sorted -- one more pass over the TRIMs for a hull a few times smaller
           (void)hipMemsetAsync(hist, 0, 8 * (size_t)kHullKinds * kHullBins, s);
           hipLaunchKernelGGL(hull_table2_kernel, dim3(1), dim3(256), 0, s, T, plan);
-          hipLaunchKernelGGL(hull_hist_kernel, dim3((unsigned)std::min(n - 1, cus)), dim3(kHullThreads), lds, s, d_src, d_dst, n,
-                             beta, T, plan, hist, 1);
+          hipLaunchKernelGGL(hull_hist_kernel<true>, dim3((unsigned)std::min(n - 1, cus)), dim3(kHullThreads), lds, s, d_src, d_dst, n,
+                             beta, T, plan, hist);
           hipLaunchKernelGGL(hull_plan_kernel, dim3(1), dim3(kHullThreads), 0, s, 2, hist, pre, T, rows, n - 1, plan, d_overflow);
           if (hipMemcpyAsync(&hp, plan, sizeof(hp), hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess)
             return hipErrorUnknown;
