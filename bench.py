@@ -1143,8 +1143,11 @@ def main():
                        "gather_backend": gather_info["gather_backend"], "rccl_ranks": gather_info["rccl_ranks"],
                        "parallelism": "independent problems per GPU, one all_gather of result records (%s)"
                                       % gather_info["gather_backend"]},
+            # `limiter`: what bounds the STEP -- the board's power cap when the long region ran at >= 97 % of it (then the
+            # executed-pipe fractions above describe a kernel whose clock is set by the power controller), else the pipe
             "roofline": dict(roofline_object(acc["ms"], acc["launches"], acc["bytes"], acc["pairs"], acc["aux"],
-                                             traffic, traffic_src, k1_issue()), power=power),
+                                             traffic, traffic_src, k1_issue()), power=power,
+                             limiter=("board power cap" if power and (power.get("frac_of_cap") or 0) >= 0.97 else "kernel pipes")),
             "configs": cfg_lines,
         }
         if top_cpu is not None:
