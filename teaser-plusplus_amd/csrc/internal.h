@@ -139,6 +139,7 @@ enum Setting {
   S_HEU_SKIP_CLOSED,   // 1: no greedy / select / peel launches behind a batch the closure decided entirely TEASER_HIP_HEU_SKIP_CLOSED
   S_REFERENCE_SNAPSHOT, // 1: a handle behaves like the reference SNAPSHOT's binary, whose solve() never sees the caller's clique / graph fields (params_ is not stored: registration.h:830-908, registration.cc:574-583): PMC_EXACT + CHAIN + the default k-core threshold and time limit whatever was passed; read when a handle is created or reset TEASER_HIP_REFERENCE_SNAPSHOT
   S_TAIL_SKIP,         // TIMING PROBES ONLY (results are wrong): bit mask of stages NOT enqueued behind K1 -- 1 fix-up, 2 degree closure, 4 greedy / select / peel, 8 estimators, 16 K1 pre-pass (stale operands) TEASER_HIP_TAIL_SKIP
+  S_COLOUR_MIS,        // > 0: problems of at least this many vertices run the colour-centric colouring bound (bit set per colour, independent-set rounds); 0: the vertex-centric rounds everywhere TEASER_HIP_COLOUR_MIS
   S_COUNT
 };
 int64_t setting(Setting id);
@@ -249,6 +250,10 @@ constexpr int kColourRounds = 16;  // one per vertex class (8) + the all-in roun
 // d_counts of launch_colour_bound: per problem kColourRounds + 2 list counters, then per problem 16 words of barrier state
 // (colour_persistent_kernel)
 inline int64_t colour_counts_bytes(int nsel) { return 4 * (int64_t)nsel * (kColourRounds + 2 + 16); }
+// colour-centric route (colour_mis): palette cap (a problem with a larger incumbent uses the first kMisMaxColours
+// colours only -- still a proper colouring) and the bytes of its arena for a launch of nsel problems of up to max_n vertices
+constexpr int kMisMaxColours = 1024;
+int64_t colour_mis_bytes(int nsel, int max_n);
 constexpr int kRootPruneCap = 512;   // leftover roots tested by root_prune_kernel (counts in d_tent)
 constexpr int kRootPruneSlices = 32; // workgroups per root
 constexpr int kRootPruneRows = 16;   // grid rows walking the roots (512 workgroups per problem in flight)
@@ -257,7 +262,8 @@ void launch_colour_bound(hipStream_t s, const ProbDesc* d_desc, const int32_t* d
                          const int32_t* d_clique, ProbState* d_state, int32_t* d_colour,
                          int32_t* d_tent, int32_t* d_xlist, int32_t* d_class_lists /* 8 * total_n */,
                          int32_t* d_list_a, int32_t* d_list_b, int32_t* d_counts /* nsel * (kColourRounds + 2) */,
-                         uint64_t* d_bits /* 10 * total_w words */, int64_t total_w, int64_t total_n, int rounds);
+                         uint64_t* d_bits /* 10 * total_w words */, int64_t total_w, int64_t total_n, int rounds,
+                         void* d_mis = nullptr /* colour_mis_bytes(nsel, max_n), or null: vertex-centric rounds only */);
 
 // KCORE_HEU (graph.cc:58-81): exact core numbers; when max_core > (int)(threshold * n) and
 // threshold != 1 the clique is replaced by every vertex of the maximum core (n <= 65536)

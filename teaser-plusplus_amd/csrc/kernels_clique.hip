@@ -2031,6 +2031,376 @@ __global__ __launch_bounds__(256) void root_prune_kernel(const ProbDesc* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Colouring bound, colour-centric form (large problems; option `colour_mis`).  Same bound, same palette of lb colours
+// as the vertex-centric rounds above; what changes is who does the work.  There a wave per vertex walks the ~1 600 set
+// bits of its bitmap row and looks every neighbour's colour up (~2 000 vector instructions per vertex and step, sparse
+// 64-bit words in lock step: instruction-bound, 0.74 ms at N = 50 000).  Here the state is one bit set per COLOUR,
+//   NC[c] = union of the bitmap rows of the vertices that hold colour c      (lb x W words; 3 MB at N = 50 000),
+// so "colour c is free for v" is ONE bit, and a round is
+//   bid    (a wave per 64-vertex bitmap word): load the word's column of NC, transpose it across the wave (64 x 64 bits,
+//          six butterfly stages), and every uncoloured vertex of the word picks the hash(v, round)-th free colour and
+//          joins that colour's bidder list;
+//   accept (a workgroup per colour): the colour's bidders in priority order; a bidder whose bit in NC[c] is clear is
+//          accepted and its row is OR-ed into NC[c] -- the lexicographically first maximal independent set of the
+//          bidders.  Candidates are taken sixteen at a time: their 16 x 16 mutual adjacency bits with one gather, the
+//          accepted ones' rows with one round of wide loads (a bitmap row is read ONCE in the whole stage: when its vertex
+//          is accepted).
+// About 45 % of the bidders are accepted per round: five or six rounds colour config 3 (the vertex-centric route: 16),
+// traffic = one sweep of the bitmap.  Every choice is a pure function of (v, round) and of the committed colours; a
+// colour with more than kMisBidders bidders in a round (the admission rate keeps the mean at 128) admits nobody in that
+// round, so the result does not depend on the order in which the lists were filled.
+// ------------------------------------------------------------------------------------------
+constexpr int kMisBidders = 256;  // per colour and round
+constexpr int kMisBatch = 16;     // candidates resolved per step of the accept kernel
+constexpr int kMisRounds = 8;
+
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t x, int o) {
+  const unsigned int lo = (unsigned int)__shfl_xor((int)(unsigned int)x, o, 64);
+  const unsigned int hi = (unsigned int)__shfl_xor((int)(unsigned int)(x >> 32), o, 64);
+  return ((uint64_t)hi << 32) | lo;
+}
+// 64 x 64 bit transpose across a wave: bit c of lane r  ->  bit r of lane c
+__device__ __forceinline__ uint64_t wave_transpose64(uint64_t x, int lane) {
+  constexpr uint64_t kM[6] = {0x00000000ffffffffull, 0x0000ffff0000ffffull, 0x00ff00ff00ff00ffull,
+                              0x0f0f0f0f0f0f0f0full, 0x3333333333333333ull, 0x5555555555555555ull};
+#pragma unroll
+  for (int st = 0; st < 6; ++st) {
+    const int s = 32 >> st;
+    const uint64_t m = kM[st];
+    const uint64_t y = shfl_xor_u64(x, s);
+    x = (lane & s) ? (((y >> s) & m) | (x & ~m)) : ((x & m) | ((y & m) << s));
+  }
+  return x;
+}
+// position of the k-th (0-based) set bit of m; k < popcount(m)
+__device__ __forceinline__ int select_bit64(uint64_t m, int k) {
+  int pos = 0;
+  unsigned int w = (unsigned int)m;
+  int c = __popc(w);
+  if (k >= c) { k -= c; pos = 32; w = (unsigned int)(m >> 32); }
+#pragma unroll
+  for (int s = 16; s >= 1; s >>= 1) {
+    const unsigned int lowm = (1u << s) - 1u;
+    c = __popc(w & lowm);
+    if (k >= c) { k -= c; pos += s; w >>= s; }
+    w &= lowm;
+  }
+  return pos;
+}
+
+struct MisBuf {  // one launch's slices of the d_mis arena
+  uint64_t* nc;      // [nsel][cap][max_W]
+  int32_t* bl;       // [nsel][cap][kMisBidders]
+  int32_t* bcount;   // [nsel][cap]
+  int32_t* ucount;   // [nsel][4]: [0] uncoloured survivors outside the clique
+  int cap, max_W;
+};
+__host__ __device__ inline MisBuf mis_layout(void* base, int nsel, int max_n) {
+  MisBuf b;
+  b.cap = max_n < kMisMaxColours ? max_n : kMisMaxColours;
+  b.max_W = (max_n + 63) / 64;
+  char* p = reinterpret_cast<char*>(base);
+  b.nc = reinterpret_cast<uint64_t*>(p);
+  p += (size_t)nsel * b.cap * b.max_W * 8;
+  b.bl = reinterpret_cast<int32_t*>(p);
+  p += (size_t)nsel * b.cap * kMisBidders * 4;
+  b.bcount = reinterpret_cast<int32_t*>(p);
+  p += (size_t)nsel * b.cap * 4;
+  b.ucount = reinterpret_cast<int32_t*>(p);
+  return b;
+}
+int64_t colour_mis_bytes(int nsel, int max_n) {
+  const int64_t cap = std::min(max_n, kMisMaxColours), W = (max_n + 63) / 64;
+  return (int64_t)nsel * (cap * W * 8 + cap * kMisBidders * 4 + cap * 4 + 16) + 256;
+}
+
+// the uncoloured set (survivors outside the clique), NC[c] = the row of clique member c
+__global__ __launch_bounds__(256) void mis_init_kernel(const ProbDesc* __restrict__ descs, const int32_t* __restrict__ sel,
+                                                       const uint64_t* __restrict__ bitmap, const uint64_t* __restrict__ alive,
+                                                       const int32_t* __restrict__ clique, ProbState* __restrict__ states,
+                                                       int32_t* __restrict__ colour, uint64_t* __restrict__ unc, MisBuf mb) {
+  const int p = sel ? sel[blockIdx.y] : (int)blockIdx.y;
+  const ProbDesc d = descs[p];
+  if (!sel && colour_not_needed(states[p], d.n)) return;
+  const int lb = states[p].lb, lbc = min(lb, mb.cap);
+  const int lane = threadIdx.x & 63;
+  if (blockIdx.x == 0 && threadIdx.x == 0) states[p].x_count = 0;
+  const int32_t* cl = clique + d.pt_off;
+  const int npad = d.W * 64;
+  int mine = 0;
+  for (int v0 = blockIdx.x * 256; v0 < npad; v0 += gridDim.x * 256) {
+    const int v = v0 + threadIdx.x;  // a wave = one 64-vertex word
+    const bool in = v < d.n;
+    const bool al = in && ((alive[d.w_off + (v >> 6)] >> (v & 63)) & 1ull);
+    int c = al ? -1 : -3;
+    if (al) {  // position of v in the sorted clique (binary search)
+      int lo = 0, hi = lb;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cl[mid] < v) lo = mid + 1; else hi = mid;
+      }
+      if (lo < lb && cl[lo] == v) c = lo;
+    }
+    if (in) colour[d.pt_off + v] = c;
+    const uint64_t m = __ballot(c == -1);
+    if (lane == 0 && v < npad) {
+      unc[d.w_off + (v >> 6)] = m;
+      mine += __builtin_popcountll(m);
+    }
+  }
+  if (mine) atomicAdd(&mb.ucount[4 * blockIdx.y], mine);
+  uint64_t* nc = mb.nc + (size_t)blockIdx.y * mb.cap * mb.max_W;
+  const uint64_t* bm = bitmap + d.bm_off;
+  for (int c = blockIdx.x; c < lbc; c += gridDim.x) {
+    const uint64_t* row = bm + (int64_t)cl[c] * d.W;
+    for (int w = threadIdx.x; w < d.W; w += 256) nc[(size_t)c * mb.max_W + w] = row[w];
+  }
+}
+
+// admission rate of a round: one vertex in K bids, so that a colour expects at most 128 bidders
+__device__ __forceinline__ int mis_admit_k(int uncoloured, int lbc) {
+  const int k = (uncoloured + 128 * lbc - 1) / (128 * lbc);
+  return k < 1 ? 1 : k;
+}
+
+__global__ __launch_bounds__(256) void mis_bid_kernel(const ProbDesc* __restrict__ descs, const int32_t* __restrict__ sel,
+                                                      const ProbState* __restrict__ states, const uint64_t* __restrict__ unc,
+                                                      MisBuf mb, int round) {
+  const int p = sel ? sel[blockIdx.y] : (int)blockIdx.y;
+  const ProbDesc d = descs[p];
+  if (!sel && colour_not_needed(states[p], d.n)) return;
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= d.W) return;
+  const uint64_t ub = unc[d.w_off + j];
+  if (ub == 0ull) return;
+  const int uc = mb.ucount[4 * blockIdx.y];
+  const int lbc = min(states[p].lb, mb.cap);
+  const int K = mis_admit_k(uc, lbc);
+  const int v = j * 64 + lane;
+  bool bidder = ((ub >> lane) & 1ull) != 0ull;
+  if (K > 1) bidder = bidder && (colour_hash(v, round, 0x77aa11u) % (unsigned int)K) == 0u;
+  if (__ballot(bidder) == 0ull) return;
+  const uint64_t* nc = mb.nc + (size_t)blockIdx.y * mb.cap * mb.max_W + j;
+  const int nch = (lbc + 63) >> 6;
+  // pass 1: free colours of every vertex of the word
+  int nfree = 0;
+  for (int k = 0; k < nch; ++k) {
+    const int c = 64 * k + lane;
+    const uint64_t blocked = c < lbc ? nc[(size_t)c * mb.max_W] : ~0ull;  // bit i: colour c is taken for vertex 64 j + i
+    nfree += __builtin_popcountll(~wave_transpose64(blocked, lane));      // lane i: bit l = colour 64 k + l
+  }
+  bidder = bidder && nfree > 0;  // (no free colour: the vertex stays uncoloured -- its neighbours only gain colours -- and ends in X)
+  const int target = bidder ? (int)(colour_hash(v, round, 0x1234567u) % (unsigned int)nfree) : 0;
+  // pass 2: the target-th free colour
+  int chosen = -1, run = 0;
+  for (int k = 0; k < nch; ++k) {
+    const int c = 64 * k + lane;
+    const uint64_t blocked = c < lbc ? nc[(size_t)c * mb.max_W] : ~0ull;
+    const uint64_t freeb = ~wave_transpose64(blocked, lane);
+    const int pc = __builtin_popcountll(freeb);
+    if (bidder && chosen < 0 && target < run + pc) chosen = 64 * k + select_bit64(freeb, target - run);
+    run += pc;
+  }
+  if (bidder && chosen >= 0) {
+    const int slot = atomicAdd(&mb.bcount[(size_t)blockIdx.y * mb.cap + chosen], 1);
+    if (slot < kMisBidders) mb.bl[((size_t)blockIdx.y * mb.cap + chosen) * kMisBidders + slot] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void mis_accept_kernel(const ProbDesc* __restrict__ descs, const int32_t* __restrict__ sel,
+                                                         const uint64_t* __restrict__ bitmap, const ProbState* __restrict__ states,
+                                                         int32_t* __restrict__ colour, uint64_t* __restrict__ unc, MisBuf mb,
+                                                         int round) {
+  __shared__ int su[kMisBidders];
+  __shared__ unsigned int sp[kMisBidders];
+  __shared__ int sorted[kMisBidders];
+  __shared__ uint64_t ncl[1024];
+  __shared__ uint64_t wmask[4];
+  __shared__ int cand[kMisBatch];
+  __shared__ unsigned int adjm[kMisBatch];
+  __shared__ int won_total;
+  const int p = sel ? sel[blockIdx.y] : (int)blockIdx.y;
+  const ProbDesc d = descs[p];
+  if (!sel && colour_not_needed(states[p], d.n)) return;
+  const int lbc = min(states[p].lb, mb.cap);
+  const int c = blockIdx.x;
+  if (c >= lbc) return;
+  int32_t* bc = mb.bcount + (size_t)blockIdx.y * mb.cap + c;
+  const int cnt = *bc;
+  if (cnt == 0) return;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (cnt > kMisBidders) {  // (the stored subset depends on timing: nobody is admitted, everybody bids again)
+    if (t == 0) *bc = 0;
+    return;
+  }
+  const int W = d.W;
+  const uint64_t* bm = bitmap + d.bm_off;
+  uint64_t* ncg = mb.nc + ((size_t)blockIdx.y * mb.cap + c) * mb.max_W;
+  const int32_t* bl = mb.bl + ((size_t)blockIdx.y * mb.cap + c) * kMisBidders;
+  // the bidders in priority order
+  const int u_in = t < cnt ? bl[t] : -1;
+  const unsigned int p_in = t < cnt ? colour_hash(u_in, round, 0xabcdef1u) : 0u;
+  su[t] = u_in;
+  sp[t] = p_in;
+  uint64_t nc[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int w = t + 256 * m;
+    nc[m] = w < W ? ncg[w] : 0ull;
+    if (w < W) ncl[w] = nc[m];
+  }
+  if (t == 0) won_total = 0;
+  __syncthreads();
+  if (t < cnt) {
+    int r = 0;
+    for (int jx = 0; jx < cnt; ++jx) {
+      const unsigned int pj = sp[jx];
+      const int uj = su[jx];
+      r += ((pj > p_in) || (pj == p_in && uj > u_in)) ? 1 : 0;
+    }
+    sorted[r] = u_in;
+  }
+  __syncthreads();
+  const int my_u = t < cnt ? sorted[t] : 0;
+  bool pending = t < cnt;
+  int nwon = 0;
+  for (;;) {
+    // still eligible: pending and not adjacent to anything accepted so far
+    const bool elig = pending && !((ncl[my_u >> 6] >> (my_u & 63)) & 1ull);
+    pending = elig;
+    const uint64_t bal = __ballot(elig);
+    if (lane == 0) wmask[wave] = bal;
+    if (t < kMisBatch) adjm[t] = 0u;
+    __syncthreads();
+    int before = __builtin_popcountll(bal & ((1ull << lane) - 1ull)), total = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < 4; ++w2) {
+      const int pc = __builtin_popcountll(wmask[w2]);
+      before += w2 < wave ? pc : 0;
+      total += pc;
+    }
+    if (total == 0) break;
+    const int ncand = total < kMisBatch ? total : kMisBatch;
+    int mycand = -1;
+    if (elig && before < kMisBatch) {
+      cand[before] = my_u;
+      mycand = before;
+      pending = false;
+    }
+    __syncthreads();
+    {  // the candidates' mutual adjacency: thread (a, b) reads bit (cand a, cand b)
+      const int a = t >> 4, b = t & 15;
+      if (a < ncand && b < ncand && a != b) {
+        const int ua = cand[a], ub = cand[b];
+        if ((bm[(int64_t)ua * W + (ub >> 6)] >> (ub & 63)) & 1ull) atomicOr(&adjm[a], 1u << b);
+      }
+    }
+    __syncthreads();
+    unsigned int acc = 0u;  // (every thread resolves the batch for itself: sixteen LDS reads)
+    for (int a = 0; a < ncand; ++a)
+      if ((adjm[a] & acc) == 0u) acc |= 1u << a;
+    // the accepted rows join NC[c]: four rows in flight
+    unsigned int todo = acc;
+    while (todo) {
+      const uint64_t* rows[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (todo) {
+          rows[q] = bm + (int64_t)cand[__builtin_ctz(todo)] * W;
+          todo &= todo - 1u;
+        } else {
+          rows[q] = nullptr;
+        }
+      }
+      uint64_t got[4][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const int w = t + 256 * m;
+          got[q][m] = (rows[q] && w < W) ? rows[q][w] : 0ull;
+        }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int m = 0; m < 4; ++m) nc[m] |= got[q][m];
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int w = t + 256 * m;
+      if (w < W) ncl[w] = nc[m];
+    }
+    if (mycand >= 0 && ((acc >> mycand) & 1u)) {
+      colour[d.pt_off + my_u] = c;
+      atomicAnd(reinterpret_cast<unsigned long long*>(unc + d.w_off + (my_u >> 6)), ~(1ull << (my_u & 63)));
+      ++nwon;
+    }
+    __syncthreads();
+  }
+  if (nwon) atomicAdd(&won_total, nwon);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int w = t + 256 * m;
+    if (w < W) ncg[w] = nc[m];
+  }
+  __syncthreads();
+  if (t == 0) {
+    *bc = 0;
+    if (won_total) atomicSub(&mb.ucount[4 * blockIdx.y], won_total);
+  }
+}
+
+// whoever is still without a colour forms X
+__global__ __launch_bounds__(256) void mis_finish_kernel(const ProbDesc* __restrict__ descs, const int32_t* __restrict__ sel,
+                                                         ProbState* __restrict__ states, const uint64_t* __restrict__ unc,
+                                                         int32_t* __restrict__ colour, int32_t* __restrict__ xlist) {
+  const int p = sel ? sel[blockIdx.y] : (int)blockIdx.y;
+  const ProbDesc d = descs[p];
+  if (!sel && colour_not_needed(states[p], d.n)) return;
+  for (int w = blockIdx.x * 256 + threadIdx.x; w < d.W; w += gridDim.x * 256) {
+    uint64_t bits = unc[d.w_off + w];
+    if (!bits) continue;
+    int base = atomicAdd(&states[p].x_count, __builtin_popcountll(bits));
+    while (bits) {
+      const int v = w * 64 + __builtin_ctzll(bits);
+      bits &= bits - 1;
+      colour[d.pt_off + v] = -2;
+      xlist[d.pt_off + base++] = v;
+    }
+  }
+}
+
+// diagnostics (k4_debug): pairs of adjacent vertices that hold the same colour (must be 0), wave per vertex
+__global__ __launch_bounds__(256) void mis_verify_kernel(const ProbDesc* __restrict__ descs, const int32_t* __restrict__ sel,
+                                                         const uint64_t* __restrict__ bitmap, const int32_t* __restrict__ colour,
+                                                         int* __restrict__ out /* [nsel][2]: violations, coloured */) {
+  const int p = sel ? sel[blockIdx.y] : (int)blockIdx.y;
+  const ProbDesc d = descs[p];
+  const int lane = threadIdx.x & 63;
+  const int32_t* col = colour + d.pt_off;
+  for (int v = blockIdx.x * 4 + (threadIdx.x >> 6); v < d.n; v += gridDim.x * 4) {
+    const int cv = col[v];
+    if (cv < 0) continue;
+    int bad = 0;
+    const uint64_t* row = bitmap + d.bm_off + (int64_t)v * d.W;
+    for (int w = lane; w < d.W; w += 64) {
+      uint64_t bits = row[w];
+      while (bits) {
+        const int u = w * 64 + __builtin_ctzll(bits);
+        bits &= bits - 1;
+        bad += (u < d.n && col[u] == cv) ? 1 : 0;
+      }
+    }
+    bad = wsum(bad);
+    if (lane == 0) {
+      if (bad) atomicAdd(&out[2 * blockIdx.y], bad);
+      atomicAdd(&out[2 * blockIdx.y + 1], 1);
+    }
+  }
+}
+
 // Serialises the launches of colour_persistent_kernel of this process on a device: the stream about to launch one
 // waits for the previous one's completion event, and leaves its own.  (An event wait captures the record it sees, so
 // ONE event per device is enough.)
@@ -2068,8 +2438,49 @@ void launch_colour_bound(hipStream_t s, const ProbDesc* d_desc, const int32_t* d
                          int32_t* d_list_a, int32_t* d_list_b,
                          int32_t* d_counts /* nsel * (kColourRounds + 2), zeroed here */,
                          uint64_t* d_bits /* (kColourClasses + 2) * total_w words */, int64_t total_w,
-                         int64_t total_n, int rounds) {
+                         int64_t total_n, int rounds, void* d_mis) {
   if (nsel <= 0 || max_n <= 0) return;
+  // large problems: the colour-centric rounds (bit set per colour, independent-set rounds)
+  const int mis_min_n = (int)setting(S_COLOUR_MIS);
+  if (d_mis && mis_min_n > 0 && max_n >= mis_min_n && max_n <= 65536) {
+    const MisBuf mb = mis_layout(d_mis, nsel, max_n);
+    (void)hipMemsetAsync(mb.bcount, 0, (size_t)nsel * ((size_t)mb.cap * 4 + 16), s);
+    uint64_t* unc = d_bits;
+    const int max_W = (max_n + 63) / 64;
+    hipLaunchKernelGGL(mis_init_kernel, dim3(512, nsel), dim3(256), 0, s, d_desc, d_sel, d_bitmap, d_alive, d_clique, d_state,
+                       d_colour, unc, mb);
+    const bool dbg = setting(S_K4_DEBUG) != 0;  // diagnostics only: survivors without a colour after every round, then a check of the colouring
+    for (int r = 0; r < kMisRounds; ++r) {
+      hipLaunchKernelGGL(mis_bid_kernel, dim3((max_W + 3) / 4, nsel), dim3(256), 0, s, d_desc, d_sel, d_state, unc, mb, r);
+      hipLaunchKernelGGL(mis_accept_kernel, dim3(mb.cap, nsel), dim3(256), 0, s, d_desc, d_sel, d_bitmap, d_state, d_colour,
+                         unc, mb, r);
+      if (dbg) {
+        int uc = -1;
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(&uc, mb.ucount, sizeof(int), hipMemcpyDeviceToHost);
+        fprintf(stderr, "[teaser_hip] colour_mis round %d: %d survivors of the first problem without a colour\n", r, uc);
+      }
+    }
+    if (dbg) {
+      int* d_out = nullptr;
+      std::vector<int> out(2 * (size_t)nsel, 0);
+      if (hipMalloc(&d_out, out.size() * sizeof(int)) == hipSuccess) {
+        (void)hipMemsetAsync(d_out, 0, out.size() * sizeof(int), s);
+        hipLaunchKernelGGL(mis_verify_kernel, dim3(1024, nsel), dim3(256), 0, s, d_desc, d_sel, d_bitmap, d_colour, d_out);
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpy(out.data(), d_out, out.size() * sizeof(int), hipMemcpyDeviceToHost);
+        (void)hipFree(d_out);
+        for (int k = 0; k < nsel; ++k)
+          fprintf(stderr, "[teaser_hip] colour_mis verify, slot %d: %d coloured vertices, %d same-colour adjacencies\n", k, out[2 * k + 1], out[2 * k]);
+      }
+    }
+    hipLaunchKernelGGL(mis_finish_kernel, dim3((max_W + 255) / 256, nsel), dim3(256), 0, s, d_desc, d_sel, d_state, unc, d_colour,
+                       d_xlist);
+    hipLaunchKernelGGL(colour_finish_kernel, dim3(2, nsel), dim3(256), 0, s, d_desc, d_sel, d_state, d_tent);
+    hipLaunchKernelGGL(root_prune_kernel, dim3(kRootPruneSlices, kRootPruneRows, nsel), dim3(256), (size_t)max_W * 8, s, d_desc,
+                       d_sel, d_bitmap, d_alive, d_state, d_xlist, d_tent);
+    return;
+  }
   rounds = std::max(kColourClasses + 1, std::min(rounds, kColourRounds));
   (void)hipMemsetAsync(d_counts, 0, (size_t)colour_counts_bytes(nsel), s);
   uint64_t* colbits = d_bits;

@@ -86,6 +86,7 @@ const SettingRow kSettingRows[S_COUNT] = {
     {"heu_skip_closed", "TEASER_HIP_HEU_SKIP_CLOSED", 0, 0, 1},
     {"reference_snapshot_semantics", "TEASER_HIP_REFERENCE_SNAPSHOT", 0, 0, 1},
     {"tail_skip", "TEASER_HIP_TAIL_SKIP", 0, 0, 31},
+    {"colour_mis", "TEASER_HIP_COLOUR_MIS", 8192, 0, 65536},
 };
 struct SettingTable {
   std::atomic<int64_t> v[S_COUNT];
@@ -309,7 +310,7 @@ struct teaser_hip_solver {
       d_alive_b, d_next_count, d_weights, d_rot_inl, d_trans_inl, d_tls_scratch, d_tim_off,
       d_pk, d_prep, d_work, d_core, d_small;
   // colouring bound
-  DevBuf c_sel, c_colour, c_tent, c_xlist, c_list_a, c_list_b, c_counts, c_bits, c_class;
+  DevBuf c_sel, c_colour, c_tent, c_xlist, c_list_a, c_list_b, c_counts, c_bits, c_class, c_mis;
   std::vector<int32_t> colour_x;  // |X| per problem of the last solve (-1: stage not run)
   // exact stage
   DevBuf x_order, x_src, x_dst, x_bitmap, x_desc, x_state, x_ctrl, x_clique, x_arena, x_probs, x_probs2, x_keys, x_xbits, x_tasks;
@@ -766,12 +767,14 @@ int32_t close_clique_bounds(teaser_hip_solver* h, int batch, int64_t total_n, bo
       HIPCHK(h, hipMemcpyAsync(h->c_sel.p, csel.data(), 4 * csel.size(), hipMemcpyHostToDevice, s));
       int cmax_n = 0;
       for (int32_t b : csel) cmax_n = std::max(cmax_n, h->descs[(size_t)b].n);
+      const bool mis = setting(S_COLOUR_MIS) > 0 && cmax_n >= setting(S_COLOUR_MIS) && cmax_n <= 65536;
+      if (mis) HIPCHK(h, h->c_mis.ensure((size_t)colour_mis_bytes((int)csel.size(), cmax_n)));
       launch_colour_bound(s, dd, h->c_sel.as<int32_t>(), (int)csel.size(), cmax_n,
                           h->d_bitmap.as<uint64_t>(), final_alive, h->d_clique.as<int32_t>(), ds,
                           h->c_colour.as<int32_t>(), h->c_tent.as<int32_t>(),
                           h->c_xlist.as<int32_t>(), h->c_class.as<int32_t>(), h->c_list_a.as<int32_t>(),
                           h->c_list_b.as<int32_t>(), h->c_counts.as<int32_t>(), h->c_bits.as<uint64_t>(),
-                          std::max<int64_t>(h->total_w, 1), total_n, kColourRounds);
+                          std::max<int64_t>(h->total_w, 1), total_n, kColourRounds, mis ? h->c_mis.p : nullptr);
       HIPCHK(h, hipGetLastError());
       if (setting(S_K4_DEBUG)) {  // diagnostics only: the work lists of the colouring rounds of the first selected problem
         int32_t cc[kColourRounds + 2] = {0};
@@ -993,13 +996,15 @@ int32_t enqueue_bounds_speculative(teaser_hip_solver* h, int batch, int64_t tota
   HIPCHK(h, h->x_probs.ensure(sizeof(ExactProb) * (size_t)batch));
   HIPCHK(h, h->x_xbits.ensure(8 * tw));
   HIPCHK(h, h->pin_ep.ensure(sizeof(ExactProb) * (size_t)batch));
+  const bool mis = setting(S_COLOUR_MIS) > 0 && h->max_n >= setting(S_COLOUR_MIS) && h->max_n <= 65536;
+  if (mis) HIPCHK(h, h->c_mis.ensure((size_t)colour_mis_bytes(batch, h->max_n)));
   {
     StageScope sc(h, ST_COLOUR);
     launch_colour_bound(s, dd, nullptr, batch, h->max_n, h->d_bitmap.as<uint64_t>(), final_alive,
                         h->d_clique.as<int32_t>(), ds, h->c_colour.as<int32_t>(), h->c_tent.as<int32_t>(),
                         h->c_xlist.as<int32_t>(), h->c_class.as<int32_t>(), h->c_list_a.as<int32_t>(),
                         h->c_list_b.as<int32_t>(), h->c_counts.as<int32_t>(), h->c_bits.as<uint64_t>(), (int64_t)tw, total_n,
-                        kColourRounds);
+                        kColourRounds, mis ? h->c_mis.p : nullptr);
   }
   {
     StageScope sc(h, ST_EXACT);
@@ -1610,7 +1615,7 @@ void release_handle_resources(teaser_hip_solver* h) {
                     &h->d_tls_scratch, &h->d_tim_off, &h->d_pk, &h->d_prep, &h->d_work, &h->d_core, &h->d_small, &h->hdr, &h->x_order,
                     &h->x_src, &h->x_dst, &h->x_bitmap, &h->x_desc, &h->x_state, &h->x_ctrl,
                     &h->x_clique, &h->x_arena, &h->x_probs, &h->x_probs2, &h->x_keys, &h->x_xbits, &h->x_tasks, &h->c_sel, &h->c_colour, &h->c_tent, &h->c_xlist, &h->c_list_a, &h->c_list_b,
-                    &h->c_counts, &h->c_bits, &h->c_class,
+                    &h->c_counts, &h->c_bits, &h->c_class, &h->c_mis,
                     &h->s_a, &h->s_b, &h->s_c, &h->s_d, &h->s_e, &h->f_pts, &h->f_counts, &h->f_cursor, &h->f_offsets, &h->f_list, &h->f_list2,
                     &h->f_normals, &h->f_spfh, &h->f_out, &h->f_meta, &h->f_feat_a, &h->f_feat_b, &h->f_part_d,
                     &h->f_part_i, &h->f_nn_a, &h->f_nn_b};

@@ -756,6 +756,37 @@ def test_colouring_rounds_in_one_launch_match_the_launch_per_round_route(n, rho,
     assert set(np.flatnonzero(pr["inliers"]).tolist()) <= set(a[3])
 
 
+@pytest.mark.parametrize("n,rho,seed", [(20000, 0.985, 41), (30000, 0.99, 42), (50000, 0.99, 43)])
+def test_colour_centric_bound_matches_the_vertex_centric_route(n, rho, seed, capfd):
+    """Option colour_mis = n0 (default 8192): problems of at least n0 vertices prove the greedy clique with the
+    colour-centric rounds (a bit set per colour = the union of its members' rows; bidders accepted in priority order as
+    the lexicographically first maximal independent set: kernels_clique.hip, mis_*).  Another proper colouring with the
+    same palette: the verdict, the clique and the estimate must be those of the vertex-centric rounds; the diagnostics
+    pass of k4_debug checks every coloured vertex against its whole row (no two adjacent vertices share a colour)."""
+    pr = tp.synth_problem(20250523 + seed, n, rho, 0.01)
+    got = {}
+    try:
+        for mode in (0, 4096):
+            tp.set_option("colour_mis", mode)
+            tp.set_option("k4_debug", 1 if mode else 0)
+            s = make_solver(**bench_params())
+            capfd.readouterr()
+            sol = s.solve(pr["src"], pr["dst"])
+            err = capfd.readouterr().err
+            raw = s.raw_solution()
+            got[mode] = (bool(sol.valid), sol.rotation.copy(), sol.translation.copy(), s.getInlierMaxClique(),
+                         int(raw.colour_uncoloured), int(raw.clique_exact_run), int(raw.heuristic_size), err)
+    finally:
+        tp.set_option("colour_mis", 8192)
+        tp.set_option("k4_debug", 0)
+    a, b = got[0], got[4096]
+    assert a[0] and b[0] and a[4] >= 0 and b[4] >= 0, (a[4:7], b[4:7])  # the colouring stage ran on both routes
+    assert a[3] == b[3] and a[5:7] == b[5:7] and (a[1] == b[1]).all() and (a[2] == b[2]).all()
+    assert "colour_mis verify" in b[7] and " 0 same-colour adjacencies" in b[7], b[7][-600:]
+    assert b[4] <= max(64, 4 * a[4]), (a[4], b[4])  # (as good a colouring: a handful of survivors without a colour)
+    assert set(np.flatnonzero(pr["inliers"]).tolist()) <= set(a[3])
+
+
 # ---------------------------------------------------------------------------------------------
 # end-to-end
 # ---------------------------------------------------------------------------------------------
