@@ -263,7 +263,8 @@ void launch_colour_bound(hipStream_t s, const ProbDesc* d_desc, const int32_t* d
                          int32_t* d_tent, int32_t* d_xlist, int32_t* d_class_lists /* 8 * total_n */,
                          int32_t* d_list_a, int32_t* d_list_b, int32_t* d_counts /* nsel * (kColourRounds + 2) */,
                          uint64_t* d_bits /* 10 * total_w words */, int64_t total_w, int64_t total_n, int rounds,
-                         void* d_mis = nullptr /* colour_mis_bytes(nsel, max_n), or null: vertex-centric rounds only */);
+                         void* d_mis = nullptr /* colour_mis_bytes(nsel, max_n), or null: vertex-centric rounds only */,
+                         const int32_t* d_deg = nullptr /* vertex degrees: the colour-centric route's priority */);
 
 // KCORE_HEU (graph.cc:58-81): exact core numbers; when max_core > (int)(threshold * n) and
 // threshold != 1 the clique is replaced by every vertex of the maximum core (n <= 65536)

@@ -2052,8 +2052,12 @@ __global__ __launch_bounds__(256) void root_prune_kernel(const ProbDesc* __restr
 // round, so the result does not depend on the order in which the lists were filled.
 // ------------------------------------------------------------------------------------------
 constexpr int kMisBidders = 256;  // per colour and round
-constexpr int kMisBatch = 16;     // candidates resolved per step of the accept kernel
-constexpr int kMisRounds = 8;
+#ifndef TEASER_MIS_BATCH
+#define TEASER_MIS_BATCH 32
+#endif
+constexpr int kMisBatch = TEASER_MIS_BATCH;  // candidates resolved per step of the accept kernel (<= 64)
+constexpr int kMisRounds = 6;
+constexpr int kMisMaxChunks = kMisMaxColours / 64;
 
 __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t x, int o) {
   const unsigned int lo = (unsigned int)__shfl_xor((int)(unsigned int)x, o, 64);
@@ -2164,62 +2168,134 @@ __device__ __forceinline__ int mis_admit_k(int uncoloured, int lbc) {
   return k < 1 ? 1 : k;
 }
 
+// A workgroup = kMisSlab consecutive bitmap words (256 vertices), a word per wave.  Its slab of NC -- lbc colours x kMisSlab words, 64 B per
+// colour -- is fetched once with full-width loads into LDS (a wave reading its word's column straight from NC took one
+// 128-B line per colour and word: 51 MB of lines per round for the 3 MB the round needs), then every wave reads the
+// column of its word back (row pitch kMisSlab + 1 words: conflict-free).
+constexpr int kMisSlab = 4;
+constexpr int kMisSlabPitch = kMisSlab + 1;
 __global__ __launch_bounds__(256) void mis_bid_kernel(const ProbDesc* __restrict__ descs, const int32_t* __restrict__ sel,
                                                       const ProbState* __restrict__ states, const uint64_t* __restrict__ unc,
                                                       MisBuf mb, int round) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  uint64_t* slab = reinterpret_cast<uint64_t*>(smem);  // [lbc][kMisSlabPitch]
+  __shared__ uint64_t ubs[kMisSlab];
   const int p = sel ? sel[blockIdx.y] : (int)blockIdx.y;
   const ProbDesc d = descs[p];
   if (!sel && colour_not_needed(states[p], d.n)) return;
-  const int lane = threadIdx.x & 63;
-  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (j >= d.W) return;
-  const uint64_t ub = unc[d.w_off + j];
-  if (ub == 0ull) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j0 = blockIdx.x * kMisSlab;
+  if (j0 >= d.W) return;
   const int uc = mb.ucount[4 * blockIdx.y];
   const int lbc = min(states[p].lb, mb.cap);
   const int K = mis_admit_k(uc, lbc);
-  const int v = j * 64 + lane;
-  bool bidder = ((ub >> lane) & 1ull) != 0ull;
-  if (K > 1) bidder = bidder && (colour_hash(v, round, 0x77aa11u) % (unsigned int)K) == 0u;
-  if (__ballot(bidder) == 0ull) return;
-  const uint64_t* nc = mb.nc + (size_t)blockIdx.y * mb.cap * mb.max_W + j;
+  // the slab's bidders (block-uniform exit when there is none)
+  if (threadIdx.x < kMisSlab) {
+    const int j = j0 + threadIdx.x;
+    ubs[threadIdx.x] = j < d.W ? unc[d.w_off + j] : 0ull;
+  }
+  __syncthreads();
+  uint64_t any = 0ull;
+#pragma unroll
+  for (int q = 0; q < kMisSlab; ++q) any |= ubs[q];
+  if (any == 0ull) return;
+  {
+    const uint64_t* nc = mb.nc + (size_t)blockIdx.y * mb.cap * mb.max_W;
+    const int wq = threadIdx.x & (kMisSlab - 1);
+    const bool won = j0 + wq < d.W;
+    for (int c0 = 0; c0 < lbc; c0 += 8 * (256 / kMisSlab)) {  // eight loads in flight per thread
+      uint64_t got[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = c0 + q * (256 / kMisSlab) + (threadIdx.x / kMisSlab);
+        got[q] = (c < lbc && won) ? nc[(size_t)c * mb.max_W + j0 + wq] : ~0ull;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int c = c0 + q * (256 / kMisSlab) + (threadIdx.x / kMisSlab);
+        if (c < lbc) slab[c * kMisSlabPitch + wq] = got[q];
+      }
+    }
+  }
+  __syncthreads();
   const int nch = (lbc + 63) >> 6;
-  // pass 1: free colours of every vertex of the word
-  int nfree = 0;
-  for (int k = 0; k < nch; ++k) {
-    const int c = 64 * k + lane;
-    const uint64_t blocked = c < lbc ? nc[(size_t)c * mb.max_W] : ~0ull;  // bit i: colour c is taken for vertex 64 j + i
-    nfree += __builtin_popcountll(~wave_transpose64(blocked, lane));      // lane i: bit l = colour 64 k + l
-  }
-  bidder = bidder && nfree > 0;  // (no free colour: the vertex stays uncoloured -- its neighbours only gain colours -- and ends in X)
-  const int target = bidder ? (int)(colour_hash(v, round, 0x1234567u) % (unsigned int)nfree) : 0;
-  // pass 2: the target-th free colour
-  int chosen = -1, run = 0;
-  for (int k = 0; k < nch; ++k) {
-    const int c = 64 * k + lane;
-    const uint64_t blocked = c < lbc ? nc[(size_t)c * mb.max_W] : ~0ull;
-    const uint64_t freeb = ~wave_transpose64(blocked, lane);
-    const int pc = __builtin_popcountll(freeb);
-    if (bidder && chosen < 0 && target < run + pc) chosen = 64 * k + select_bit64(freeb, target - run);
-    run += pc;
-  }
-  if (bidder && chosen >= 0) {
-    const int slot = atomicAdd(&mb.bcount[(size_t)blockIdx.y * mb.cap + chosen], 1);
-    if (slot < kMisBidders) mb.bl[((size_t)blockIdx.y * mb.cap + chosen) * kMisBidders + slot] = v;
+  for (int wq = wave; wq < kMisSlab; wq += 4) {
+    const int j = j0 + wq;
+    const uint64_t ub = ubs[wq];
+    if (j >= d.W || ub == 0ull) continue;
+    const int v = j * 64 + lane;
+    bool bidder = ((ub >> lane) & 1ull) != 0ull;
+    if (K > 1) bidder = bidder && (colour_hash(v, round, 0x77aa11u) % (unsigned int)K) == 0u;
+    if (__ballot(bidder) == 0ull) continue;
+    // lane l, chunk k: bit i = colour 64 k + l is taken for vertex 64 j + i; transposed: lane i, chunk k: bit l = colour
+    // 64 k + l is free for vertex 64 j + i
+    // (four chunks per uniform branch: their transposes -- six dependent cross-lane stages each -- interleave)
+    uint64_t freeb[kMisMaxChunks];
+    int nfree = 0;
+#pragma unroll
+    for (int k4 = 0; k4 < kMisMaxChunks; k4 += 4) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) freeb[k4 + q] = 0ull;
+      if (k4 < nch) {
+        uint64_t blocked[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c = 64 * (k4 + q) + lane;
+          blocked[q] = c < lbc ? slab[c * kMisSlabPitch + wq] : ~0ull;
+        }
+        constexpr uint64_t kM[6] = {0x00000000ffffffffull, 0x0000ffff0000ffffull, 0x00ff00ff00ff00ffull,
+                                    0x0f0f0f0f0f0f0f0full, 0x3333333333333333ull, 0x5555555555555555ull};
+#pragma unroll
+        for (int st = 0; st < 6; ++st) {
+          const int sh = 32 >> st;
+          uint64_t y[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) y[q] = shfl_xor_u64(blocked[q], sh);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            blocked[q] = (lane & sh) ? (((y[q] >> sh) & kM[st]) | (blocked[q] & ~kM[st])) : ((blocked[q] & kM[st]) | ((y[q] & kM[st]) << sh));
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          freeb[k4 + q] = ~blocked[q];
+          nfree += __builtin_popcountll(freeb[k4 + q]);
+        }
+      }
+    }
+    bidder = bidder && nfree > 0;  // (no free colour: the vertex stays uncoloured -- its neighbours only gain colours -- and ends in X)
+    const int target = bidder ? (int)(colour_hash(v, round, 0x1234567u) % (unsigned int)nfree) : 0;
+    // the target-th free colour
+    int run = 0, kk = -1, rem = 0;
+    uint64_t pick = 0ull;
+#pragma unroll
+    for (int k = 0; k < kMisMaxChunks; ++k) {
+      const int pc = __builtin_popcountll(freeb[k]);
+      if (kk < 0 && target < run + pc) {
+        kk = k;
+        rem = target - run;
+        pick = freeb[k];
+      }
+      run += pc;
+    }
+    const int chosen = (bidder && kk >= 0) ? 64 * kk + select_bit64(pick, rem) : -1;
+    if (bidder && chosen >= 0) {
+      const int slot = atomicAdd(&mb.bcount[(size_t)blockIdx.y * mb.cap + chosen], 1);
+      if (slot < kMisBidders) mb.bl[((size_t)blockIdx.y * mb.cap + chosen) * kMisBidders + slot] = v;
+    }
   }
 }
 
 __global__ __launch_bounds__(256) void mis_accept_kernel(const ProbDesc* __restrict__ descs, const int32_t* __restrict__ sel,
                                                          const uint64_t* __restrict__ bitmap, const ProbState* __restrict__ states,
                                                          int32_t* __restrict__ colour, uint64_t* __restrict__ unc, MisBuf mb,
-                                                         int round) {
+                                                         int round, const int32_t* __restrict__ deg) {
   __shared__ int su[kMisBidders];
-  __shared__ unsigned int sp[kMisBidders];
+  __shared__ unsigned long long sp[kMisBidders];
   __shared__ int sorted[kMisBidders];
   __shared__ uint64_t ncl[1024];
   __shared__ uint64_t wmask[4];
   __shared__ int cand[kMisBatch];
-  __shared__ unsigned int adjm[kMisBatch];
+  __shared__ unsigned long long adjm[kMisBatch];
   __shared__ int won_total;
   const int p = sel ? sel[blockIdx.y] : (int)blockIdx.y;
   const ProbDesc d = descs[p];
@@ -2241,7 +2317,10 @@ __global__ __launch_bounds__(256) void mis_accept_kernel(const ProbDesc* __restr
   const int32_t* bl = mb.bl + ((size_t)blockIdx.y * mb.cap + c) * kMisBidders;
   // the bidders in priority order
   const int u_in = t < cnt ? bl[t] : -1;
-  const unsigned int p_in = t < cnt ? colour_hash(u_in, round, 0xabcdef1u) : 0u;
+  // priority: largest degree first (the vertices that run out of colours are the high-degree ones: with them in front
+  // the palette of config 3 leaves nobody over, where hash order left 10 - 17), ties by hash
+  const unsigned long long p_in =
+      t < cnt ? (((unsigned long long)(unsigned int)(deg ? deg[d.pt_off + u_in] : 0)) << 32) | colour_hash(u_in, round, 0xabcdef1u) : 0ull;
   su[t] = u_in;
   sp[t] = p_in;
   uint64_t nc[4];
@@ -2256,7 +2335,7 @@ __global__ __launch_bounds__(256) void mis_accept_kernel(const ProbDesc* __restr
   if (t < cnt) {
     int r = 0;
     for (int jx = 0; jx < cnt; ++jx) {
-      const unsigned int pj = sp[jx];
+      const unsigned long long pj = sp[jx];
       const int uj = su[jx];
       r += ((pj > p_in) || (pj == p_in && uj > u_in)) ? 1 : 0;
     }
@@ -2272,7 +2351,7 @@ __global__ __launch_bounds__(256) void mis_accept_kernel(const ProbDesc* __restr
     pending = elig;
     const uint64_t bal = __ballot(elig);
     if (lane == 0) wmask[wave] = bal;
-    if (t < kMisBatch) adjm[t] = 0u;
+    if (t < kMisBatch) adjm[t] = 0ull;
     __syncthreads();
     int before = __builtin_popcountll(bal & ((1ull << lane) - 1ull)), total = 0;
 #pragma unroll
@@ -2290,40 +2369,67 @@ __global__ __launch_bounds__(256) void mis_accept_kernel(const ProbDesc* __restr
       pending = false;
     }
     __syncthreads();
-    {  // the candidates' mutual adjacency: thread (a, b) reads bit (cand a, cand b)
-      const int a = t >> 4, b = t & 15;
-      if (a < ncand && b < ncand && a != b) {
-        const int ua = cand[a], ub = cand[b];
-        if ((bm[(int64_t)ua * W + (ub >> 6)] >> (ub & 63)) & 1ull) atomicOr(&adjm[a], 1u << b);
+    {  // the candidates' mutual adjacency: kTpc threads per candidate a, each reads the bits (cand a, cand b) of kPpt partners, loads first
+      constexpr int kTpc = kMisBidders / kMisBatch, kPpt = kMisBatch / kTpc, kGrp = kPpt < 8 ? kPpt : 8;
+      static_assert(kMisBatch <= 64 && kTpc * kPpt == kMisBatch && kPpt % kGrp == 0, "thread mapping of the adjacency gather");
+      const int a = t / kTpc;
+      const int ua = a < ncand ? cand[a] : 0;
+      const uint64_t* rowa = bm + (int64_t)ua * W;
+      unsigned long long bits = 0ull;
+#pragma unroll
+      for (int g0 = 0; g0 < kPpt; g0 += kGrp) {
+        uint64_t wd[kGrp];
+        int ubv[kGrp];
+#pragma unroll
+        for (int q = 0; q < kGrp; ++q) {
+          const int b = (t % kTpc) * kPpt + g0 + q;
+          const bool on = a < ncand && b < ncand && a != b;
+          ubv[q] = on ? cand[b] : -1;
+          wd[q] = on ? rowa[ubv[q] >> 6] : 0ull;
+        }
+#pragma unroll
+        for (int q = 0; q < kGrp; ++q)
+          if (ubv[q] >= 0 && ((wd[q] >> (ubv[q] & 63)) & 1ull)) bits |= 1ull << ((t % kTpc) * kPpt + g0 + q);
       }
+      if (bits) atomicOr(&adjm[a], bits);
     }
     __syncthreads();
-    unsigned int acc = 0u;  // (every thread resolves the batch for itself: sixteen LDS reads)
-    for (int a = 0; a < ncand; ++a)
-      if ((adjm[a] & acc) == 0u) acc |= 1u << a;
-    // the accepted rows join NC[c]: four rows in flight
-    unsigned int todo = acc;
+    // every wave resolves the batch for itself, the masks in registers (lane a: candidate a's adjacency): candidate a
+    // is accepted when no accepted candidate in front of it is adjacent
+    unsigned long long acc = 0ull;
+    {
+      const unsigned long long mine = lane < kMisBatch ? adjm[lane] : 0ull;
+      const unsigned int mlo = (unsigned int)mine, mhi = (unsigned int)(mine >> 32);
+      for (int a = 0; a < ncand; ++a) {
+        const unsigned long long ma = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)mhi, a) << 32) |
+                                      (unsigned int)__builtin_amdgcn_readlane((int)mlo, a);
+        if ((ma & acc) == 0ull) acc |= 1ull << a;
+      }
+    }
+    // the accepted rows join NC[c]: eight rows in flight
+    unsigned long long todo = acc;
     while (todo) {
-      const uint64_t* rows[4];
+      constexpr int kFly = 8;
+      const uint64_t* rows[kFly];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < kFly; ++q) {
         if (todo) {
-          rows[q] = bm + (int64_t)cand[__builtin_ctz(todo)] * W;
-          todo &= todo - 1u;
+          rows[q] = bm + (int64_t)cand[__builtin_ctzll(todo)] * W;
+          todo &= todo - 1ull;
         } else {
           rows[q] = nullptr;
         }
       }
-      uint64_t got[4][4];
+      uint64_t got[kFly][4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < kFly; ++q)
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
           const int w = t + 256 * m;
           got[q][m] = (rows[q] && w < W) ? rows[q][w] : 0ull;
         }
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
+      for (int q = 0; q < kFly; ++q)
 #pragma unroll
         for (int m = 0; m < 4; ++m) nc[m] |= got[q][m];
     }
@@ -2332,7 +2438,7 @@ __global__ __launch_bounds__(256) void mis_accept_kernel(const ProbDesc* __restr
       const int w = t + 256 * m;
       if (w < W) ncl[w] = nc[m];
     }
-    if (mycand >= 0 && ((acc >> mycand) & 1u)) {
+    if (mycand >= 0 && ((acc >> mycand) & 1ull)) {
       colour[d.pt_off + my_u] = c;
       atomicAnd(reinterpret_cast<unsigned long long*>(unc + d.w_off + (my_u >> 6)), ~(1ull << (my_u & 63)));
       ++nwon;
@@ -2438,7 +2544,7 @@ void launch_colour_bound(hipStream_t s, const ProbDesc* d_desc, const int32_t* d
                          int32_t* d_list_a, int32_t* d_list_b,
                          int32_t* d_counts /* nsel * (kColourRounds + 2), zeroed here */,
                          uint64_t* d_bits /* (kColourClasses + 2) * total_w words */, int64_t total_w,
-                         int64_t total_n, int rounds, void* d_mis) {
+                         int64_t total_n, int rounds, void* d_mis, const int32_t* d_deg) {
   if (nsel <= 0 || max_n <= 0) return;
   // large problems: the colour-centric rounds (bit set per colour, independent-set rounds)
   const int mis_min_n = (int)setting(S_COLOUR_MIS);
@@ -2449,11 +2555,14 @@ void launch_colour_bound(hipStream_t s, const ProbDesc* d_desc, const int32_t* d
     const int max_W = (max_n + 63) / 64;
     hipLaunchKernelGGL(mis_init_kernel, dim3(512, nsel), dim3(256), 0, s, d_desc, d_sel, d_bitmap, d_alive, d_clique, d_state,
                        d_colour, unc, mb);
+    const size_t bid_lds = (size_t)mb.cap * kMisSlabPitch * 8;
+    static DynLdsOptIn bid_optin;
+    bid_optin.ensure(reinterpret_cast<const void*>(mis_bid_kernel), (int)bid_lds);
     const bool dbg = setting(S_K4_DEBUG) != 0;  // diagnostics only: survivors without a colour after every round, then a check of the colouring
     for (int r = 0; r < kMisRounds; ++r) {
-      hipLaunchKernelGGL(mis_bid_kernel, dim3((max_W + 3) / 4, nsel), dim3(256), 0, s, d_desc, d_sel, d_state, unc, mb, r);
+      hipLaunchKernelGGL(mis_bid_kernel, dim3((max_W + kMisSlab - 1) / kMisSlab, nsel), dim3(256), bid_lds, s, d_desc, d_sel, d_state, unc, mb, r);
       hipLaunchKernelGGL(mis_accept_kernel, dim3(mb.cap, nsel), dim3(256), 0, s, d_desc, d_sel, d_bitmap, d_state, d_colour,
-                         unc, mb, r);
+                         unc, mb, r, d_deg);
       if (dbg) {
         int uc = -1;
         (void)hipStreamSynchronize(s);

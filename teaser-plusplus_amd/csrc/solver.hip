@@ -774,7 +774,7 @@ int32_t close_clique_bounds(teaser_hip_solver* h, int batch, int64_t total_n, bo
                           h->c_colour.as<int32_t>(), h->c_tent.as<int32_t>(),
                           h->c_xlist.as<int32_t>(), h->c_class.as<int32_t>(), h->c_list_a.as<int32_t>(),
                           h->c_list_b.as<int32_t>(), h->c_counts.as<int32_t>(), h->c_bits.as<uint64_t>(),
-                          std::max<int64_t>(h->total_w, 1), total_n, kColourRounds, mis ? h->c_mis.p : nullptr);
+                          std::max<int64_t>(h->total_w, 1), total_n, kColourRounds, mis ? h->c_mis.p : nullptr, h->d_deg.as<int32_t>());
       HIPCHK(h, hipGetLastError());
       if (setting(S_K4_DEBUG)) {  // diagnostics only: the work lists of the colouring rounds of the first selected problem
         int32_t cc[kColourRounds + 2] = {0};
@@ -1004,7 +1004,7 @@ int32_t enqueue_bounds_speculative(teaser_hip_solver* h, int batch, int64_t tota
                         h->d_clique.as<int32_t>(), ds, h->c_colour.as<int32_t>(), h->c_tent.as<int32_t>(),
                         h->c_xlist.as<int32_t>(), h->c_class.as<int32_t>(), h->c_list_a.as<int32_t>(),
                         h->c_list_b.as<int32_t>(), h->c_counts.as<int32_t>(), h->c_bits.as<uint64_t>(), (int64_t)tw, total_n,
-                        kColourRounds, mis ? h->c_mis.p : nullptr);
+                        kColourRounds, mis ? h->c_mis.p : nullptr, h->d_deg.as<int32_t>());
   }
   {
     StageScope sc(h, ST_EXACT);
