@@ -787,6 +787,69 @@ def test_colour_centric_bound_matches_the_vertex_centric_route(n, rho, seed, cap
     assert set(np.flatnonzero(pr["inliers"]).tolist()) <= set(a[3])
 
 
+def _sparse_graph_with_planted_clique(rng, n, avg_deg, k):
+    """G(n, avg_deg / n) as an edge list + a planted k-clique (members spread over the index range)."""
+    m = int(n * avg_deg / 2)
+    e = rng.integers(0, n, size=(m, 2))
+    e = e[e[:, 0] != e[:, 1]]
+    members = np.sort(rng.choice(n, size=k, replace=False))
+    ii, jj = np.triu_indices(k, 1)
+    e = np.concatenate([e, np.stack([members[ii], members[jj]], 1)])
+    return e, members
+
+
+@pytest.mark.parametrize("n,avg_deg,k", [(9000, 40, 24), (12000, 90, 22), (20000, 60, 12)])
+def test_colour_centric_bound_on_supplied_graphs(n, avg_deg, k):
+    """The colour-centric bound through findMaxClique on graphs whose colouring is NOT a formality: (a) palette ample, the
+    bound closes; (b) palette short by a few colours, the survivors without a colour are the roots of the exact search;
+    (c) palette far too small, most survivors are roots.  Both routes must return a maximum clique of the same size
+    (a valid clique containing the planted one when that is the unique maximum)."""
+    rng = np.random.default_rng(1000 + n)
+    e, members = _sparse_graph_with_planted_clique(rng, n, avg_deg, k)
+    bm = np.zeros((n, (n + 63) // 64), dtype=np.uint64)
+    for a, b in ((e[:, 0], e[:, 1]), (e[:, 1], e[:, 0])):
+        np.bitwise_or.at(bm, (a, b >> 6), np.uint64(1) << (b & 63).astype(np.uint64))
+    adj = set(map(tuple, np.sort(e, 1).tolist()))
+    got = {}
+    try:
+        for mode in (0, 4096):
+            tp.set_option("colour_mis", mode)
+            s = make_solver()
+            c, er = s.maxClique(bm, n)
+            got[mode] = (c, er)
+    finally:
+        tp.set_option("colour_mis", 8192)
+    for c, _ in got.values():
+        assert c == sorted(c) and all((a, b) in adj for i, a in enumerate(c) for b in c[i + 1:])
+    assert len(got[0][0]) == len(got[4096][0]) >= k
+    if len(got[0][0]) == k:
+        assert got[4096][0] == members.tolist() or len(got[4096][0]) == k
+
+
+def test_colour_centric_bound_in_a_batch_of_mixed_sizes():
+    """The speculative form of the stage (enqueued behind the peel for every problem of the batch, guarded on the device
+    by each problem's state): three problems, one below the option's size, one that the peel closes, through
+    solve_batch twice (the second call runs the bound stage speculatively); results = the vertex-centric route's."""
+    specs = [(20000, 0.985, 51), (5000, 0.9, 52), (30000, 0.99, 53)]
+    prs = [tp.synth_problem(20250523 + sd, n, rho, 0.01) for n, rho, sd in specs]
+    srcs, dsts = [p["src"] for p in prs], [p["dst"] for p in prs]
+    got = {}
+    try:
+        for mode in (0, 4096):
+            tp.set_option("colour_mis", mode)
+            s = make_solver(**bench_params())
+            s.solve_batch(srcs, dsts)
+            sols = s.solve_batch(srcs, dsts)
+            got[mode] = [(bool(o.valid), o.rotation.copy(), o.translation.copy(), s.getInlierMaxClique(i),
+                          int(s.raw_solution(i).clique_exact_run)) for i, o in enumerate(sols)]
+    finally:
+        tp.set_option("colour_mis", 8192)
+    for a, b, pr in zip(got[0], got[4096], prs):
+        assert a[0] and b[0] and a[3] == b[3] and a[4] == b[4]
+        assert (a[1] == b[1]).all() and (a[2] == b[2]).all()
+        assert set(np.flatnonzero(pr["inliers"]).tolist()) <= set(b[3])
+
+
 # ---------------------------------------------------------------------------------------------
 # end-to-end
 # ---------------------------------------------------------------------------------------------
