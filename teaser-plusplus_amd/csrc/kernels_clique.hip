@@ -2041,19 +2041,23 @@ __global__ __launch_bounds__(256) void root_prune_kernel(const ProbDesc* __restr
 //   bid    (a wave per 64-vertex bitmap word): load the word's column of NC, transpose it across the wave (64 x 64 bits,
 //          six butterfly stages), and every uncoloured vertex of the word picks the hash(v, round)-th free colour and
 //          joins that colour's bidder list;
-//   accept (a workgroup per colour): the colour's bidders in priority order; a bidder whose bit in NC[c] is clear is
-//          accepted and its row is OR-ed into NC[c] -- the lexicographically first maximal independent set of the
-//          bidders.  Candidates are taken sixteen at a time: their 16 x 16 mutual adjacency bits with one gather, the
-//          accepted ones' rows with one round of wide loads (a bitmap row is read ONCE in the whole stage: when its vertex
-//          is accepted).
-// About 45 % of the bidders are accepted per round: five or six rounds colour config 3 (the vertex-centric route: 16),
-// traffic = one sweep of the bitmap.  Every choice is a pure function of (v, round) and of the committed colours; a
-// colour with more than kMisBidders bidders in a round (the admission rate keeps the mean at 128) admits nobody in that
-// round, so the result does not depend on the order in which the lists were filled.
+//   accept (a workgroup per colour): the colour's bidders in priority order (largest degree first); a bidder whose bit
+//          in NC[c] is clear is accepted and its row is OR-ed into NC[c] -- the lexicographically first maximal
+//          independent set of the bidders.  Candidates are taken sixteen at a time: their 16 x 16 mutual adjacency bits
+//          with one gather, the accepted ones' rows with wide loads (a bitmap row is read ONCE in the whole stage: when
+//          its vertex is accepted).  Measured (profiles/r6d): the accept launches of config 3 move the 313 MB bitmap
+//          plus the gathers' lines in ~0.13 ms; larger batches (more gathered lines: 64 -> +40 %) and speculative row
+//          loads (rows of candidates that lose inside the batch: +45 %) are both slower -- the launches are bound by the
+//          bytes they move, not by their dependent round trips.
+// About 45 % of the bidders are accepted per round: five rounds colour config 3 (the vertex-centric route: 16), traffic =
+// one sweep of the bitmap; with the high-degree vertices in front nobody is left without a colour there.  Every choice
+// is a pure function of (v, round) and of the committed colours; a colour with more than kMisBidders bidders in a round
+// (the admission rate keeps the mean at 128) admits nobody in that round, so the result does not depend on the order in
+// which the lists were filled.
 // ------------------------------------------------------------------------------------------
 constexpr int kMisBidders = 256;  // per colour and round
 #ifndef TEASER_MIS_BATCH
-#define TEASER_MIS_BATCH 32
+#define TEASER_MIS_BATCH 16
 #endif
 constexpr int kMisBatch = TEASER_MIS_BATCH;  // candidates resolved per step of the accept kernel (<= 64)
 constexpr int kMisRounds = 6;
@@ -2301,16 +2305,18 @@ __global__ __launch_bounds__(256) void mis_accept_kernel(const ProbDesc* __restr
   const ProbDesc d = descs[p];
   if (!sel && colour_not_needed(states[p], d.n)) return;
   const int lbc = min(states[p].lb, mb.cap);
-  const int c = blockIdx.x;
-  if (c >= lbc) return;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  // (a workgroup per colour for one or a few problems; large batches -- the speculative form, where most slots return at
+  // once -- launch a looping grid)
+  for (int c = blockIdx.x; c < lbc; c += gridDim.x) {
   int32_t* bc = mb.bcount + (size_t)blockIdx.y * mb.cap + c;
   const int cnt = *bc;
-  if (cnt == 0) return;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (cnt == 0) continue;
   if (cnt > kMisBidders) {  // (the stored subset depends on timing: nobody is admitted, everybody bids again)
     if (t == 0) *bc = 0;
-    return;
+    continue;
   }
+  __syncthreads();  // (the previous colour's LDS state is no longer read)
   const int W = d.W;
   const uint64_t* bm = bitmap + d.bm_off;
   uint64_t* ncg = mb.nc + ((size_t)blockIdx.y * mb.cap + c) * mb.max_W;
@@ -2456,6 +2462,7 @@ __global__ __launch_bounds__(256) void mis_accept_kernel(const ProbDesc* __restr
     *bc = 0;
     if (won_total) atomicSub(&mb.ucount[4 * blockIdx.y], won_total);
   }
+  }
 }
 
 // whoever is still without a colour forms X
@@ -2553,7 +2560,7 @@ void launch_colour_bound(hipStream_t s, const ProbDesc* d_desc, const int32_t* d
     (void)hipMemsetAsync(mb.bcount, 0, (size_t)nsel * ((size_t)mb.cap * 4 + 16), s);
     uint64_t* unc = d_bits;
     const int max_W = (max_n + 63) / 64;
-    hipLaunchKernelGGL(mis_init_kernel, dim3(512, nsel), dim3(256), 0, s, d_desc, d_sel, d_bitmap, d_alive, d_clique, d_state,
+    hipLaunchKernelGGL(mis_init_kernel, dim3(nsel <= 4 ? 512 : 64, nsel), dim3(256), 0, s, d_desc, d_sel, d_bitmap, d_alive, d_clique, d_state,
                        d_colour, unc, mb);
     const size_t bid_lds = (size_t)mb.cap * kMisSlabPitch * 8;
     static DynLdsOptIn bid_optin;
@@ -2561,7 +2568,7 @@ void launch_colour_bound(hipStream_t s, const ProbDesc* d_desc, const int32_t* d
     const bool dbg = setting(S_K4_DEBUG) != 0;  // diagnostics only: survivors without a colour after every round, then a check of the colouring
     for (int r = 0; r < kMisRounds; ++r) {
       hipLaunchKernelGGL(mis_bid_kernel, dim3((max_W + kMisSlab - 1) / kMisSlab, nsel), dim3(256), bid_lds, s, d_desc, d_sel, d_state, unc, mb, r);
-      hipLaunchKernelGGL(mis_accept_kernel, dim3(mb.cap, nsel), dim3(256), 0, s, d_desc, d_sel, d_bitmap, d_state, d_colour,
+      hipLaunchKernelGGL(mis_accept_kernel, dim3(nsel <= 4 ? mb.cap : std::max(64, mb.cap / 8), nsel), dim3(256), 0, s, d_desc, d_sel, d_bitmap, d_state, d_colour,
                          unc, mb, r, d_deg);
       if (dbg) {
         int uc = -1;
