@@ -72,7 +72,8 @@ void launch_estimate_fused(hipStream_t, const ProbDesc*, int batch, const double
 }
 void launch_colour_bound(hipStream_t, const ProbDesc*, const int32_t*, int, int, const uint64_t*, const uint64_t*,
                          const int32_t*, ProbState*, int32_t*, int32_t*, int32_t*, int32_t*, int32_t*, int32_t*, int32_t*,
-                         uint64_t*, int64_t, int64_t, int) { ++g_stub_launches; }
+                         uint64_t*, int64_t, int64_t, int, void*, const int32_t*) { ++g_stub_launches; }
+int64_t colour_mis_bytes(int nsel, int max_n) { return 64 * (int64_t)nsel * ((max_n + 63) / 64 + 1); }
 void launch_exact_count(hipStream_t, const ProbDesc* dd, ExactProb* probs, int nprob, int, const uint64_t*, const uint64_t*,
                         const int32_t*, const ProbState* ds, const int32_t*, const int32_t*, uint64_t*, uint64_t*,
                         bool speculative) {
