@@ -35,7 +35,7 @@ SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_A
 SQ2="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA SQ_WAVES"
 LDS1="SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU"
 LDS2="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_WAVES SQ_BUSY_CYCLES"
-CLIQUE_KERNELS="greedy_small_kernel,degree_closure,exact_clique_kernel,colour_assign_kernel,colour_resolve_kernel,colour_round_kernel,colour_persistent_kernel,greedy_clique_kernel,peel_round_kernel,tail_fused_kernel"
+CLIQUE_KERNELS="mis_bid_kernel,mis_accept_kernel,mis_init_kernel,greedy_small_kernel,degree_closure,exact_clique_kernel,colour_assign_kernel,colour_resolve_kernel,colour_round_kernel,colour_persistent_kernel,greedy_clique_kernel,peel_round_kernel,tail_fused_kernel"
 
 prof() {  # prof <dir> <rocprofv3 args...> -- <cmd...>: rocprofv3 from /tmp, csv output into $OUT/<dir>
   local d=$1; shift

@@ -7,6 +7,7 @@
 
 #include <atomic>
 #include <mutex>
+#include <algorithm>
 #include <vector>
 
 #include "teaser_hip.h"
@@ -140,6 +141,7 @@ enum Setting {
   S_REFERENCE_SNAPSHOT, // 1: a handle behaves like the reference SNAPSHOT's binary, whose solve() never sees the caller's clique / graph fields (params_ is not stored: registration.h:830-908, registration.cc:574-583): PMC_EXACT + CHAIN + the default k-core threshold and time limit whatever was passed; read when a handle is created or reset TEASER_HIP_REFERENCE_SNAPSHOT
   S_TAIL_SKIP,         // TIMING PROBES ONLY (results are wrong): bit mask of stages NOT enqueued behind K1 -- 1 fix-up, 2 degree closure, 4 greedy / select / peel, 8 estimators, 16 K1 pre-pass (stale operands) TEASER_HIP_TAIL_SKIP
   S_COLOUR_MIS,        // > 0: problems of at least this many vertices run the colour-centric colouring bound (bit set per colour, independent-set rounds); 0: the vertex-centric rounds everywhere TEASER_HIP_COLOUR_MIS
+  S_COLOUR_MIS_ANY,    // 1: the colour-centric rounds whatever the ratio of vertices to palette (tests; by default they serve problems with n <= 128 x clique size: beyond, a round admits only a fraction of the vertices and six rounds do not reach everybody) TEASER_HIP_COLOUR_MIS_ANY
   S_COUNT
 };
 int64_t setting(Setting id);
@@ -253,6 +255,9 @@ inline int64_t colour_counts_bytes(int nsel) { return 4 * (int64_t)nsel * (kColo
 // colour-centric route (colour_mis): palette cap (a problem with a larger incumbent uses the first kMisMaxColours
 // colours only -- still a proper colouring) and the bytes of its arena for a launch of nsel problems of up to max_n vertices
 constexpr int kMisMaxColours = 1024;
+// the route serves a problem when a colour expects at most 128 bidders with EVERY vertex bidding (admission rate 1):
+// n <= 128 x min(lb, kMisMaxColours); colour_mis_any = 1 lifts the rule (tests)
+inline bool colour_mis_fits(int n, int lb) { return lb >= 2 && (int64_t)n <= 128 * (int64_t)std::min(lb, kMisMaxColours); }
 int64_t colour_mis_bytes(int nsel, int max_n);
 constexpr int kRootPruneCap = 512;   // leftover roots tested by root_prune_kernel (counts in d_tent)
 constexpr int kRootPruneSlices = 32; // workgroups per root

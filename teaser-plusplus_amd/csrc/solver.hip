@@ -87,6 +87,7 @@ const SettingRow kSettingRows[S_COUNT] = {
     {"reference_snapshot_semantics", "TEASER_HIP_REFERENCE_SNAPSHOT", 0, 0, 1},
     {"tail_skip", "TEASER_HIP_TAIL_SKIP", 0, 0, 31},
     {"colour_mis", "TEASER_HIP_COLOUR_MIS", 8192, 0, 65536},
+    {"colour_mis_any", "TEASER_HIP_COLOUR_MIS_ANY", 0, 0, 1},
 };
 struct SettingTable {
   std::atomic<int64_t> v[S_COUNT];
@@ -330,6 +331,7 @@ struct teaser_hip_solver {
   // ~40 launches come from the thread that enqueues everything else (several finisher threads launching at once cost
   // 40-60 us per launch, profiles/r5e).  TEASER_HIP_SPEC_BOUNDS=0 disables.
   bool spec_bounds_next = false;
+  bool spec_mis_fits = true;  // every problem the last batch left open fits the colour-centric rounds (colour_mis_fits)
   int last_unproven = 0;
   // The degree closure (kernels_heuristic.hip) decides the metric's workloads from the degrees alone; greedy / select /
   // peel are enqueued behind it all the same (their workgroups return at once for a decided problem: five launches of
@@ -743,6 +745,8 @@ int32_t close_clique_bounds(teaser_hip_solver* h, int batch, int64_t total_n, bo
   }
   h->colour_x.assign((size_t)batch, -1);
   h->last_unproven = (int)unproven.size();
+  h->spec_mis_fits = true;
+  for (int32_t b : unproven) h->spec_mis_fits = h->spec_mis_fits && colour_mis_fits(h->descs[(size_t)b].n, h->states[(size_t)b].lb);
   if (unproven.empty()) return TEASER_HIP_OK;
   int max_n = 0;
   for (int32_t b : unproven) max_n = std::max(max_n, h->descs[(size_t)b].n);
@@ -767,7 +771,9 @@ int32_t close_clique_bounds(teaser_hip_solver* h, int batch, int64_t total_n, bo
       HIPCHK(h, hipMemcpyAsync(h->c_sel.p, csel.data(), 4 * csel.size(), hipMemcpyHostToDevice, s));
       int cmax_n = 0;
       for (int32_t b : csel) cmax_n = std::max(cmax_n, h->descs[(size_t)b].n);
-      const bool mis = setting(S_COLOUR_MIS) > 0 && cmax_n >= setting(S_COLOUR_MIS) && cmax_n <= 65536;
+      bool mis = setting(S_COLOUR_MIS) > 0 && cmax_n >= setting(S_COLOUR_MIS) && cmax_n <= 65536;
+      if (mis && setting(S_COLOUR_MIS_ANY) == 0)  // (every selected problem must fit the colour-centric rounds)
+        for (int32_t b : csel) mis = mis && colour_mis_fits(h->descs[(size_t)b].n, h->states[(size_t)b].lb);
       if (mis) HIPCHK(h, h->c_mis.ensure((size_t)colour_mis_bytes((int)csel.size(), cmax_n)));
       launch_colour_bound(s, dd, h->c_sel.as<int32_t>(), (int)csel.size(), cmax_n,
                           h->d_bitmap.as<uint64_t>(), final_alive, h->d_clique.as<int32_t>(), ds,
@@ -996,7 +1002,10 @@ int32_t enqueue_bounds_speculative(teaser_hip_solver* h, int batch, int64_t tota
   HIPCHK(h, h->x_probs.ensure(sizeof(ExactProb) * (size_t)batch));
   HIPCHK(h, h->x_xbits.ensure(8 * tw));
   HIPCHK(h, h->pin_ep.ensure(sizeof(ExactProb) * (size_t)batch));
-  const bool mis = setting(S_COLOUR_MIS) > 0 && h->max_n >= setting(S_COLOUR_MIS) && h->max_n <= 65536;
+  bool mis = setting(S_COLOUR_MIS) > 0 && h->max_n >= setting(S_COLOUR_MIS) && h->max_n <= 65536;
+  // (the host does not know this batch's cliques yet: the open problems of the PREVIOUS batch -- the reason the stage is
+  // enqueued speculatively at all -- stand in for them)
+  if (mis && setting(S_COLOUR_MIS_ANY) == 0) mis = h->spec_mis_fits;
   if (mis) HIPCHK(h, h->c_mis.ensure((size_t)colour_mis_bytes(batch, h->max_n)));
   {
     StageScope sc(h, ST_COLOUR);
@@ -1792,6 +1801,7 @@ int32_t enqueue_on_lane(teaser_hip_solver* h, int idx, int32_t ticket, const dou
   lane->params = h->params;
   lane->profiling = h->profiling;
   lane->spec_bounds_next = h->spec_bounds_next;
+  lane->spec_mis_fits = h->spec_mis_fits;
   lane->job.off.assign(pt_off, pt_off + batch);
   lane->job.n.assign(n, n + batch);
   lane->job.d_src = d_src;
@@ -1977,6 +1987,7 @@ int32_t wait_impl(teaser_hip_solver* h, int32_t ticket, teaser_solution_c* out) 
                                                                              : finish_lane_job(lane, out);
   if (rc != TEASER_HIP_OK) h->err = lane->err;
   h->spec_bounds_next = rc == TEASER_HIP_OK && lane->last_unproven > 0;
+  h->spec_mis_fits = lane->spec_mis_fits;
   profile_end(lane);
   h->prof = lane->prof;
   lane->job.busy = false;

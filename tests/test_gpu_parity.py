@@ -799,11 +799,14 @@ def _sparse_graph_with_planted_clique(rng, n, avg_deg, k):
 
 
 @pytest.mark.parametrize("n,avg_deg,k", [(9000, 40, 24), (12000, 90, 22), (20000, 60, 12)])
-def test_colour_centric_bound_on_supplied_graphs(n, avg_deg, k):
+def test_colour_centric_bound_on_supplied_graphs(n, avg_deg, k, capfd):
     """The colour-centric bound through findMaxClique on graphs whose colouring is NOT a formality: (a) palette ample, the
     bound closes; (b) palette short by a few colours, the survivors without a colour are the roots of the exact search;
     (c) palette far too small, most survivors are roots.  Both routes must return a maximum clique of the same size
-    (a valid clique containing the planted one when that is the unique maximum)."""
+    (a valid clique containing the planted one when that is the unique maximum).  These graphs have far more vertices
+    than 128 x clique size, where the product keeps the vertex-centric rounds (a round then admits a fraction of the
+    vertices only): colour_mis_any = 1 sends them through the colour-centric ones all the same, and the diagnostics
+    pass must have seen a proper colouring."""
     rng = np.random.default_rng(1000 + n)
     e, members = _sparse_graph_with_planted_clique(rng, n, avg_deg, k)
     bm = np.zeros((n, (n + 63) // 64), dtype=np.uint64)
@@ -814,12 +817,18 @@ def test_colour_centric_bound_on_supplied_graphs(n, avg_deg, k):
     try:
         for mode in (0, 4096):
             tp.set_option("colour_mis", mode)
+            tp.set_option("colour_mis_any", 1 if mode else 0)
+            tp.set_option("k4_debug", 1 if mode else 0)
             s = make_solver()
+            capfd.readouterr()
             c, er = s.maxClique(bm, n)
-            got[mode] = (c, er)
+            got[mode] = (c, er, capfd.readouterr().err)
     finally:
         tp.set_option("colour_mis", 8192)
-    for c, _ in got.values():
+        tp.set_option("colour_mis_any", 0)
+        tp.set_option("k4_debug", 0)
+    assert "colour_mis verify" in got[4096][2] and " 0 same-colour adjacencies" in got[4096][2], got[4096][2][-400:]
+    for c, _, _ in got.values():
         assert c == sorted(c) and all((a, b) in adj for i, a in enumerate(c) for b in c[i + 1:])
     assert len(got[0][0]) == len(got[4096][0]) >= k
     if len(got[0][0]) == k:
