@@ -136,3 +136,27 @@ def test_set_option_validates_names_and_ranges():
     # the keyword-only device: Params followed by a positional argument is refused loudly (round-5 advice)
     with pytest.raises(TypeError, match="device"):
         tp.RobustRegistrationSolver._params_from_ctor_args((tp.RobustRegistrationSolver.Params(), 0), {})
+
+
+def test_every_documented_option_exists_with_its_default():
+    """INTEGRATION.md's settings table against the library's: every option a row names is accepted with the default the
+    row states (a renamed or dropped option fails here; the call also leaves the table at its defaults), and the options
+    this round added check their ranges."""
+    L = tp.lib()
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    table = text[text.index("| option | env | default | meaning |"):]
+    table = table[:table.index("\n\n")]
+    seen = set()
+    for line in table.splitlines()[2:]:
+        cols = [c.strip() for c in line.strip().strip("|").split("|")]
+        names = re.findall(r"`([a-z0-9_]+)`", cols[0])
+        defaults = [int(x) for x in re.findall(r"-?\d+", cols[2].replace("\u2212", "-").replace(" ", ""))]
+        assert names and defaults, line[:80]
+        if len(defaults) == 1:
+            defaults = defaults * len(names)
+        assert len(defaults) == len(names), (names, defaults)
+        for name, default in zip(names, defaults):
+            assert L.teaser_hip_set_option(None, name.encode(), default) == 0, (name, default)
+            seen.add(name)
+    assert len(seen) >= 30 and {"colour_mis", "colour_mis_any", "colour_persistent", "deg_closure", "scale_hull"} <= seen, sorted(seen)
+    assert L.teaser_hip_set_option(None, b"colour_mis", 65537) != 0 and L.teaser_hip_set_option(None, b"colour_mis_any", 2) != 0
