@@ -2389,7 +2389,7 @@ __global__ __launch_bounds__(256) void mis_accept_kernel(const ProbDesc* __restr
 #pragma unroll
         for (int q = 0; q < kGrp; ++q) {
           const int b = (t % kTpc) * kPpt + g0 + q;
-          const bool on = a < ncand && b < ncand && a != b;
+          const bool on = a < ncand && b < a;  // (only the candidates IN FRONT of a decide about a: half the gathered lines)
           ubv[q] = on ? cand[b] : -1;
           wd[q] = on ? rowa[ubv[q] >> 6] : 0ull;
         }
