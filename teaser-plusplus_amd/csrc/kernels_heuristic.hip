@@ -199,7 +199,106 @@ __device__ __forceinline__ int greedy_one_start(
     // the give-up decision is uniform, and whatever this round computed is discarded)
     const int reach = csize + pc;
     bool hopeless = false;
-    for (int w = wave; w < W && !hopeless; w += kGreedyWaves) {
+    // The candidates as a LIST (in the compact matrix's LDS, unused in this phase): a wave then streams four (256-thread form: two) candidates'
+    // rows at a time wherever they sit.  Walking P word by word (the loop below, kept for sets too large to list) a wave
+    // finds one candidate per word when |P| is a few hundred among 50 000 vertices -- one row, one dependent round trip
+    // at a time: 163 us for the 660 rows of the one start in sixteen that needs this round at N = 50 000, which was the
+    // kernel's duration.
+    constexpr int kListCap = kCap * kCapStride * 2;  // ints in A
+    const bool listed = pc <= kListCap;
+    if (listed) {
+      int* clist = reinterpret_cast<int*>(A);
+      {
+        const int wpt = (W + kGreedyThreads - 1) / kGreedyThreads;
+        const int w0 = tid * wpt, w1 = min(W, w0 + wpt);
+        int mycnt = 0;
+        for (int w = w0; w < w1; ++w) mycnt += __popcll(P[w]);
+        wcnt[tid] = mycnt;
+        for (int w = tid; w < W; w += kGreedyThreads) U[w] = 0ull;
+        __syncthreads();
+        if (wave == 0) {  // exclusive scan over kGreedyThreads entries (kGreedyWaves per lane)
+          constexpr int kPer = kGreedyWaves;
+          int a[kPer], tot = 0;
+#pragma unroll
+          for (int k = 0; k < kPer; ++k) {
+            a[k] = wcnt[kPer * lane + k];
+            tot += a[k];
+          }
+          int incl = tot;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+          }
+          int ex = incl - tot;
+#pragma unroll
+          for (int k = 0; k < kPer; ++k) {
+            wcnt[kPer * lane + k] = ex;
+            ex += a[k];
+          }
+        }
+        __syncthreads();
+        int pos = wcnt[tid];
+        for (int w = w0; w < w1; ++w) {
+          uint64_t bits = P[w];
+          while (bits) {
+            clist[pos++] = w * 64 + __builtin_ctzll(bits);
+            bits &= bits - 1;
+          }
+        }
+        __syncthreads();
+      }
+      constexpr int kStreamRows = kGreedyThreads >= 512 ? 4 : 2;  // (the 256-thread form runs beside K1: its register count stays)
+      for (int i0 = wave * kStreamRows; i0 < pc && !hopeless; i0 += kGreedyWaves * kStreamRows) {
+        if (__hip_atomic_load(&st->heu_best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > reach) {
+          hopeless = true;
+          break;
+        }
+        int vv[kStreamRows];
+        bool on[kStreamRows];
+        const uint64_t* rr[kStreamRows];
+#pragma unroll
+        for (int q = 0; q < kStreamRows; ++q) {
+          on[q] = i0 + q < pc;
+          vv[q] = clist[on[q] ? i0 + q : i0];
+          rr[q] = bm + (int64_t)vv[q] * W;
+        }
+        int cc[kStreamRows];
+#pragma unroll
+        for (int q = 0; q < kStreamRows; ++q) cc[q] = 0;
+        for (int x0 = 0; x0 < W; x0 += 64 * 8) {
+          uint64_t ra[kStreamRows][8];
+#pragma unroll
+          for (int q = 0; q < kStreamRows; ++q)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const int x = x0 + 64 * j + lane;
+              ra[q][j] = (on[q] && x < W) ? rr[q][x] : 0ull;
+            }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int x = x0 + 64 * j + lane;
+            const uint64_t m = x < W ? P[x] : 0ull;
+#pragma unroll
+            for (int q = 0; q < kStreamRows; ++q) cc[q] += __popcll(ra[q][j] & m);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < kStreamRows; ++q) cc[q] = wave_sum_i(cc[q]);
+#pragma unroll
+        for (int q = 0; q < kStreamRows; ++q) {
+          if (!on[q]) continue;
+          if (cc[q] == pc - 1) {
+            if (lane == 0) atomicOr(reinterpret_cast<unsigned long long*>(&U[vv[q] >> 6]), 1ull << (vv[q] & 63));
+          } else {
+            const unsigned long long kk =
+                ((unsigned long long)(unsigned int)(cc[q] + 1) << 32) | (0xffffffffu - (unsigned int)vv[q]);
+            bestk = kk > bestk ? kk : bestk;
+          }
+        }
+      }
+    }
+    for (int w = wave; w < W && !hopeless && !listed; w += kGreedyWaves) {
       uint64_t bits = P[w];
       uint64_t uni = 0;
       // TWO candidates' rows at a time, eight words of each in flight per lane before the first use (a plain
