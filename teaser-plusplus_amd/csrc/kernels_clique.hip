@@ -2038,13 +2038,13 @@ __global__ __launch_bounds__(256) void root_prune_kernel(const ProbDesc* __restr
 // 64-bit words in lock step: instruction-bound, 0.74 ms at N = 50 000).  Here the state is one bit set per COLOUR,
 //   NC[c] = union of the bitmap rows of the vertices that hold colour c      (lb x W words; 3 MB at N = 50 000),
 // so "colour c is free for v" is ONE bit, and a round is
-//   bid    (a wave per 64-vertex bitmap word): load the word's column of NC, transpose it across the wave (64 x 64 bits,
-//          six butterfly stages), and every uncoloured vertex of the word picks the hash(v, round)-th free colour and
-//          joins that colour's bidder list;
+//   bid    (a wave per 64-vertex bitmap word; a workgroup stages its four words' slab of NC in LDS): the word's column
+//          of NC is transposed across the wave (64 x 64 bits, six butterfly stages), and every uncoloured vertex of the
+//          word picks the hash(v, round)-th free colour and joins that colour's bidder list;
 //   accept (a workgroup per colour): the colour's bidders in priority order (largest degree first); a bidder whose bit
 //          in NC[c] is clear is accepted and its row is OR-ed into NC[c] -- the lexicographically first maximal
-//          independent set of the bidders.  Candidates are taken sixteen at a time: their 16 x 16 mutual adjacency bits
-//          with one gather, the accepted ones' rows with wide loads (a bitmap row is read ONCE in the whole stage: when
+//          independent set of the bidders.  Candidates are taken sixteen at a time: the adjacency bits of every one to
+//          those in front of it with one gather, the accepted ones' rows with wide loads (a bitmap row is read ONCE in the whole stage: when
 //          its vertex is accepted).  Measured (profiles/r6d): the accept launches of config 3 move the 313 MB bitmap
 //          plus the gathers' lines in ~0.13 ms; larger batches (more gathered lines: 64 -> +40 %) and speculative row
 //          loads (rows of candidates that lose inside the batch: +45 %) are both slower -- the launches are bound by the
